@@ -1,0 +1,106 @@
+"""CPU: pins oracle/rtfs_oracle.py against vectors captured from the reference itself
+(oracle/make_golden.py).  Everything but the SRU cell is the reference's own code in those
+vectors; the SRU arithmetic is the oracle's (third-party package absent -> parity unpinned)."""
+import numpy as np
+import pytest
+
+from oracle import rtfs_oracle as O
+from oracle.params import make_inputs, make_state_dict
+from tests.util import check_probe, load_golden, rand, rel_err, spec_R4
+
+TOL = 2e-5  # fp32 reference vs float64-accumulating oracle
+
+SD = make_state_dict(spec_R4(), 0)
+BLK = O._sub(SD, "refinement_module.audio_net.blocks")
+VBLK = O._sub(SD, "refinement_module.video_net.blocks")
+CELL = O._sub(SD, "refinement_module.crossmodal_fusion.fusion_module.audio_lstm")
+
+
+def test_encoder():
+    a0, _ = O.stft_encoder(rand((2, 2048), 101, 0.07), O._sub(SD, "encoder"))
+    check_probe(load_golden("mod_encoder"), "out", a0, TOL)
+
+
+def test_audio_bn():
+    y = O.conv_norm_act(rand((2, 256, 9, 129), 102), O._sub(SD, "audio_bottleneck"), pre_norm="gLN", pre_act="ReLU")
+    check_probe(load_golden("mod_audio_bn"), "out", y, TOL)
+
+
+@pytest.mark.parametrize("name,idx,dim", [("mod_dualpath_f", 0, 4), ("mod_dualpath_t", 1, 3)])
+def test_dualpath(name, idx, dim):
+    y = O.dualpath_rnn(rand((2, 64, 12, 64), 103), O._sub(BLK, f"globalatt.{idx}"), dim)
+    check_probe(load_golden(name), "out", y, TOL)
+
+
+def test_dualpath_min_and_short():
+    y = O.dualpath_rnn(rand((1, 64, 8, 64), 113), O._sub(BLK, "globalatt.1"), 3)
+    check_probe(load_golden("mod_dualpath_t_min"), "out", y, TOL)
+    with pytest.raises(ValueError):  # reference: nn.Unfold raises for a sweep axis < kernel_size
+        O.dualpath_rnn(rand((1, 64, 5, 64), 1), O._sub(BLK, "globalatt.1"), 3)
+
+
+def test_mhsa2d():
+    y = O.mhsa2d(rand((2, 64, 12, 64), 103), O._sub(BLK, "globalatt.2"))
+    check_probe(load_golden("mod_mhsa2d"), "out", y, TOL)
+
+
+def test_tfar():
+    glo = rand((2, 64, 8, 64), 105)
+    y = O.injection_multi_sum(rand((2, 64, 17, 129), 104), glo, O._sub(BLK, "fusion_layers.0"))
+    check_probe(load_golden("mod_tfar_up"), "out", y, TOL)
+    y = O.injection_multi_sum(rand((2, 64, 8, 64), 106), glo, O._sub(BLK, "fusion_layers.1"))
+    check_probe(load_golden("mod_tfar_same"), "out", y, TOL)
+
+
+def test_caf():
+    y = O.caf(rand((2, 256, 17, 129), 107), rand((2, 512, 7), 108), CELL)
+    check_probe(load_golden("mod_caf"), "out", y, TOL)
+
+
+@pytest.mark.parametrize("name,tv,seed", [("mod_vp50", 50, 109), ("mod_vp7", 7, 110)])
+def test_vp_block(name, tv, seed):
+    y = O.vp_block(rand((2, 512, tv), seed), VBLK)
+    check_probe(load_golden(name), "out", y, TOL)
+
+
+def test_s3():
+    y = O.s3_mask(rand((2, 256, 9, 129), 111), rand((2, 256, 9, 129), 112), O._sub(SD, "mask_generator"))
+    check_probe(load_golden("mod_s3"), "out", y, TOL)
+
+
+def test_decoder():
+    y = O.stft_decoder(rand((2, 1, 256, 17, 129), 114, 0.3), O._sub(SD, "decoder"), 2048)
+    check_probe(load_golden("mod_decoder"), "out", y, TOL)
+
+
+def test_rtfs_block_with_internals():
+    g = load_golden("mod_rtfs_block")
+    out, ints = O.rtfs_block(rand((1, 256, 17, 129), 115), BLK, return_internals=True)
+    for k in ["residual", "x_enc", "d0", "d1", "g_f", "g_t", "g_att", "xf0", "xf1"]:
+        check_probe(g, k, ints[k], TOL, "block.")
+    check_probe(g, "out", out, TOL)
+
+
+@pytest.mark.parametrize("name,R,B,L,Tv,seed", [
+    ("e2e_R4_L4096_B2", 4, 2, 4096, 7, 1),
+    ("e2e_R4_L5000_B3", 4, 3, 5000, 8, 3),
+    ("e2e_R6_L8000_B2", 6, 2, 8000, 13, 5),
+    ("e2e_R12_L8000_B1", 12, 1, 8000, 13, 4),
+])
+def test_end_to_end(name, R, B, L, Tv, seed):
+    g = load_golden(name)
+    wav, emb = make_inputs(B, L, Tv, seed)
+    out, ints = O.avnet_forward(wav, emb, SD, repeats=R, return_internals=True)
+    for k in ["a0", "a1", "refined", "sep"]:
+        check_probe(g, k, ints[k], 5 * TOL if R <= 6 else 2e-4, name + ".")
+    e = rel_err(out, g["out"])
+    assert e <= (5 * TOL if R <= 6 else 2e-4), f"{name}: out rel err {e:.3e}"
+
+
+@pytest.mark.slow
+def test_end_to_end_full_size_2s():
+    g = load_golden("e2e_R4_L32000_B1")
+    wav, emb = make_inputs(1, 32000, 50, 2)
+    out = O.avnet_forward(wav, emb, SD, repeats=4)
+    e = rel_err(out, g["out"])
+    assert e <= 1e-4, f"2 s end-to-end rel err {e:.3e}"
