@@ -1,0 +1,121 @@
+/* rtfs_amd.h -- C ABI of the MI355X-native RTFS-Net separator forward pass (librtfs_amd.so).
+ *
+ * The reference (SutirthaChakraborty/RTFS-Net) has no FFI of its own: its hot path is the Python
+ * nn.Module tree under AVNet.forward (src/models/tdavnet.py:86-97) plus ONE third-party native
+ * operator, sru.SRU (src/models/layers/rnn_layers.py:99-105,150).  Each entry point below is what a
+ * binding for one of those modules / that operator calls; the comment on each names the reference
+ * interface it replaces.  INTEGRATION.md shows the ctypes stubs a maintainer would add.
+ *
+ * Conventions (all entry points):
+ *   - raw DEVICE pointers, float32, contiguous row-major, reference layouts:
+ *       spectrogram-shaped tensors (B, C, T, F) with F fastest; waveforms (B, L); lip embedding (B, 512, Tv)
+ *   - `pack` = that module's parameters as ONE contiguous device buffer laid out as documented in
+ *     rtfs-net_amd/packing.py (every tensor padded to a multiple of 64 floats, 1x1 weights stored
+ *     transposed [cin][cout]); rtfs_pack_floats(kind) returns the expected length
+ *   - caller allocates outputs and the workspace (size from the matching *_workspace_bytes query);
+ *     kernels are enqueued on `stream` (a hipStream_t passed as void*), never synchronise, never
+ *     allocate, never call back; workspace contents are scratch
+ *   - return 0 on success; <0 on error: -1 bad shape, -2 workspace too small, -3 launch failure, -4 bad argument
+ *   - eval-mode semantics (BatchNorm running statistics, no dropout); re-entrant, stateless.
+ * F must satisfy F/2 == 64 wherever a block / attention is involved (the reference's n_freqs: 64 ties
+ * LayerNormalization4D's parameters to 64 compressed frequency bins, config/lrs2_RTFSNet_4_layer.yaml:68).
+ */
+#ifndef RTFS_AMD_H
+#define RTFS_AMD_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum rtfs_pack_kind {
+    RTFS_PACK_ENCODER = 0,
+    RTFS_PACK_AUDIO_BN = 1,
+    RTFS_PACK_BLOCK = 2,
+    RTFS_PACK_DUALPATH = 3,
+    RTFS_PACK_ATTENTION = 4,
+    RTFS_PACK_TFAR = 5,
+    RTFS_PACK_CAF = 6,
+    RTFS_PACK_S3 = 7,
+    RTFS_PACK_DECODER = 8
+};
+
+/* library / build identification: returns "rtfs_amd <version> gfx950" */
+const char* rtfs_version(void);
+/* number of floats in a parameter pack of the given kind */
+size_t rtfs_pack_floats(int kind);
+/* frames of the STFT for a waveform of L samples: 1 + L/128 */
+int rtfs_num_frames(int L);
+
+/* STFTEncoder.forward (src/models/TDAVNet/encoder.py:161-175): wav (B,L) -> a0 (B,256,T,129).
+ * workspace holds the (B,2,T,129) spectrogram.  If stats != NULL it receives (B,2) doubles
+ * = (sum, sum of squares) of a0 per sample (consumed by the audio bottleneck's gLN). */
+size_t rtfs_stft_encoder_workspace_bytes(int B, int L);
+int rtfs_stft_encoder_f32(const float* wav, const float* pack, float* a0, double* stats, int B, int L, void* ws,
+                          size_t ws_bytes, void* stream);
+
+/* audio_bottleneck = ConvNormAct(gLN -> ReLU -> Conv2d 1x1 256->256) (tdavnet.py:59,89;
+ * layers/conv_layers.py:65-129).  stats: (B,2) doubles of x as produced by the encoder, or NULL to
+ * have them computed here (needs the workspace). */
+size_t rtfs_audio_bottleneck_workspace_bytes(int B);
+int rtfs_audio_bottleneck_f32(const float* x, const double* stats, const float* pack, float* out, int B, int T, int F,
+                              void* ws, size_t ws_bytes, void* stream);
+
+/* RTFS block = TDANetBlock.forward, is2d, upsampling_depth 2, globalatt = [DualPathRNN(F), DualPathRNN(T),
+ * MultiHeadSelfAttention2D] (src/models/separators/tdanet.py:104-131).  x_res may be NULL; otherwise the block
+ * input is x + x_res (RefinementModule's residual, refinement_module.py:51,60). */
+size_t rtfs_block_workspace_bytes(int B, int T, int F);
+int rtfs_block_f32(const float* x, const float* x_res, const float* pack, float* out, int B, int T, int F, void* ws,
+                   size_t ws_bytes, void* stream);
+
+/* DualPathRNN.forward with rnn_type SRU, kernel 8, stride 1, 4 layers, bidirectional, hidden 32
+ * (src/models/layers/rnn_layers.py:136-162).  x, out (B,64,T,F); dim = 4 sweeps along F, 3 along T. */
+size_t rtfs_dualpath_workspace_bytes(int B, int T, int F);
+int rtfs_dualpath_sru_f32(const float* x, const float* pack, float* out, int B, int T, int F, int dim, void* ws,
+                          size_t ws_bytes, void* stream);
+
+/* MultiHeadSelfAttention2D.forward, 4 heads, hid_chan 4, dim 3 (src/models/layers/attention.py:149-189). x (B,64,T,64). */
+size_t rtfs_tf_attention_workspace_bytes(int B, int T);
+int rtfs_tf_attention_f32(const float* x, const float* pack, float* out, int B, int T, void* ws, size_t ws_bytes,
+                          void* stream);
+
+/* InjectionMultiSum.forward (TFAR, src/models/layers/fusion.py:54-69): local (B,64,H,W), global (B,64,Hg,Wg). */
+size_t rtfs_tfar_workspace_bytes(int B, int H, int W, int Hg, int Wg);
+int rtfs_tfar_f32(const float* local, const float* global, const float* pack, float* out, int B, int H, int W, int Hg,
+                  int Wg, void* ws, size_t ws_bytes, void* stream);
+
+/* CAF = ATTNFusion.forward with video_fusion False -> ATTNFusionCell (src/models/TDAVNet/fusion.py:204-212,
+ * src/models/layers/fusion.py:252-274): audio (B,256,T,F), video (B,512,Tv) -> fused audio. */
+size_t rtfs_caf_workspace_bytes(int B, int Tv);
+int rtfs_caf_f32(const float* audio, const float* video, const float* pack, float* out, int B, int T, int F, int Tv,
+                 void* ws, size_t ws_bytes, void* stream);
+
+/* S^3 = MaskGenerator.forward with RI_split, n_src 1 (src/models/TDAVNet/mask_generator.py:67-99):
+ * refined, a0 (B,256,T,F) -> separated embedding (B,1,256,T,F). */
+int rtfs_s3_mask_f32(const float* refined, const float* a0, const float* pack, float* out, int B, int T, int F,
+                     void* stream);
+
+/* STFTDecoder.forward (src/models/TDAVNet/decoder.py:110-132): x (B,1,256,T,129) -> wav (B,1,L). */
+size_t rtfs_istft_decoder_workspace_bytes(int B, int T);
+int rtfs_istft_decoder_f32(const float* x, const float* pack, float* wav, int B, int T, int L, void* ws, size_t ws_bytes,
+                           void* stream);
+
+/* The whole separator, AVNet.forward minus the (tiny, 0.004 GMAC) video-side VP block whose output the caller
+ * passes in (src/models/tdavnet.py:86-97, refinement_module.py:45-62):
+ *   encoder -> audio bottleneck -> block -> CAF(video_vp) -> (repeats-1) x block(+a1) -> S^3 -> decoder.
+ * packs: encoder, audio_bn, block, caf, s3, decoder.  wav (B,L), video_vp (B,512,Tv) -> out (B,1,L). */
+size_t rtfs_separator_workspace_bytes(int B, int L, int Tv);
+int rtfs_separator_forward_f32(const float* wav, const float* video_vp, const float* pack_enc, const float* pack_bn,
+                               const float* pack_block, const float* pack_caf, const float* pack_s3,
+                               const float* pack_dec, float* out, int B, int L, int Tv, int repeats, void* ws,
+                               size_t ws_bytes, void* stream);
+
+/* Operator-level seam: sru.SRU(input_size=512, hidden_size=32, num_layers=4, bidirectional=True).forward
+ * (call site src/models/layers/rnn_layers.py:150; third-party asappresearch `sru`, v2 recurrence).
+ * x (L,N,512) -> h (L,N,64).  pack = the DUALPATH pack (only its SRU part is read). */
+size_t rtfs_sru_workspace_bytes(int L, int N);
+int rtfs_sru_f32(const float* x, const float* pack, float* h, int L, int N, void* ws, size_t ws_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,95 @@
+"""ctypes binding of librtfs_amd.so (the C ABI declared in include/rtfs_amd.h).
+
+There is no fallback: if the shared library is missing the import of any hot-path module raises,
+and every call checks that its tensors live on a HIP device.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librtfs_amd.so")
+
+PACK_ENCODER, PACK_AUDIO_BN, PACK_BLOCK, PACK_DUALPATH, PACK_ATTENTION, PACK_TFAR, PACK_CAF, PACK_S3, PACK_DECODER = range(9)
+
+_ERR = {-1: "bad shape", -2: "workspace too small", -3: "kernel launch failure", -4: "bad argument"}
+
+_p, _i, _z = C.c_void_p, C.c_int, C.c_size_t
+# name -> (restype, argtypes); must list every symbol of include/rtfs_amd.h
+SIGNATURES = {
+    "rtfs_version": (C.c_char_p, []),
+    "rtfs_pack_floats": (_z, [_i]),
+    "rtfs_num_frames": (_i, [_i]),
+    "rtfs_stft_encoder_workspace_bytes": (_z, [_i, _i]),
+    "rtfs_stft_encoder_f32": (_i, [_p, _p, _p, _p, _i, _i, _p, _z, _p]),
+    "rtfs_audio_bottleneck_workspace_bytes": (_z, [_i]),
+    "rtfs_audio_bottleneck_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _z, _p]),
+    "rtfs_block_workspace_bytes": (_z, [_i, _i, _i]),
+    "rtfs_block_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _z, _p]),
+    "rtfs_dualpath_workspace_bytes": (_z, [_i, _i, _i]),
+    "rtfs_dualpath_sru_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _z, _p]),
+    "rtfs_tf_attention_workspace_bytes": (_z, [_i, _i]),
+    "rtfs_tf_attention_f32": (_i, [_p, _p, _p, _i, _i, _p, _z, _p]),
+    "rtfs_tfar_workspace_bytes": (_z, [_i, _i, _i, _i, _i]),
+    "rtfs_tfar_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _z, _p]),
+    "rtfs_caf_workspace_bytes": (_z, [_i, _i]),
+    "rtfs_caf_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _z, _p]),
+    "rtfs_s3_mask_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
+    "rtfs_istft_decoder_workspace_bytes": (_z, [_i, _i]),
+    "rtfs_istft_decoder_f32": (_i, [_p, _p, _p, _i, _i, _i, _p, _z, _p]),
+    "rtfs_separator_workspace_bytes": (_z, [_i, _i, _i]),
+    "rtfs_separator_forward_f32": (_i, [_p] * 9 + [_i, _i, _i, _i, _p, _z, _p]),
+    "rtfs_sru_workspace_bytes": (_z, [_i, _i]),
+    "rtfs_sru_f32": (_i, [_p, _p, _p, _i, _i, _p, _z, _p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load librtfs_amd.so once; raise (never fall back) when it is absent or incomplete."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build it with `make -C rtfs-net_amd/csrc` (or __graft_entry__.build()); "
+            "the RTFS-Net MI355X path has no non-HIP fallback"
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(code: int, what: str):
+    if code != 0:
+        raise RuntimeError(f"{what} failed: {_ERR.get(code, code)}")
+
+
+def ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream_of(t: torch.Tensor):
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def need_gpu(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("rtfs_net_amd kernels run on the MI355X only: got a CPU tensor (there is no CPU fallback)")
+        if t.dtype != torch.float32:
+            raise RuntimeError(f"rtfs_net_amd kernels are float32; got {t.dtype}")
+
+
+def workspace(nbytes: int, device):
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)

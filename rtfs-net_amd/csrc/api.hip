@@ -1,0 +1,763 @@
+// C-ABI layer: parameter-pack layouts, workspace carving and the launch sequences of each module.
+// See include/rtfs_amd.h for the contract and the reference interfaces each entry point replaces.
+#include "../../include/rtfs_amd.h"
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int NF = 129;   // STFT bins (n_fft 256)
+constexpr int CA = 256;   // audio feature channels
+constexpr int CH = 64;    // block hidden channels
+constexpr int FQ = 64;    // compressed frequency bins (n_freqs)
+
+// ---------------------------------------------------------------- parameter packs
+// A pack is a flat float buffer; every tensor starts on a 64-float boundary.  The order below is the
+// contract with rtfs-net_amd/packing.py.
+struct Cursor {
+    const float* p;
+    size_t off = 0;
+    explicit Cursor(const float* base) : p(base) {}
+    const float* take(size_t n) {
+        const float* r = p ? p + off : nullptr;
+        off += (n + 63) / 64 * 64;
+        return r;
+    }
+};
+
+struct EncPack {
+    const float* w;  // (256, 18)
+    explicit EncPack(Cursor& c) { w = c.take(CA * 18); }
+};
+struct BnPack {
+    const float *gamma, *beta, *wt, *bias;
+    explicit BnPack(Cursor& c) {
+        gamma = c.take(CA);
+        beta = c.take(CA);
+        wt = c.take(CA * CA);
+        bias = c.take(CA);
+    }
+};
+struct DpPack {
+    const float *ln_g, *ln_b, *W0, *Wl, *wc, *bias, *Wt, *bt;
+    explicit DpPack(Cursor& c) {
+        ln_g = c.take(CH);
+        ln_b = c.take(CH);
+        W0 = c.take(512 * 256);
+        Wl = c.take(3 * 64 * 256);
+        wc = c.take(4 * 128);
+        bias = c.take(4 * 128);
+        Wt = c.take(512 * 64);
+        bt = c.take(CH);
+    }
+};
+struct AttnPack {
+    const float *qkv_wt, *qkv_b, *qkv_slope, *qkv_gamma, *qkv_beta, *proj_wt, *proj_b, *proj_slope, *proj_gamma, *proj_beta;
+    explicit AttnPack(Cursor& c) {
+        qkv_wt = c.take(64 * 96);
+        qkv_b = c.take(96);
+        qkv_slope = c.take(12);
+        qkv_gamma = c.take(96 * FQ);
+        qkv_beta = c.take(96 * FQ);
+        proj_wt = c.take(64 * 64);
+        proj_b = c.take(64);
+        proj_slope = c.take(1);
+        proj_gamma = c.take(64 * FQ);
+        proj_beta = c.take(64 * FQ);
+    }
+};
+struct TfarPack {  // InjectionMultiSum: local_embedding, global_embedding, global_gate
+    const float *loc_w, *loc_g, *loc_b, *emb_w, *emb_g, *emb_b, *gate_w, *gate_g, *gate_b;
+    explicit TfarPack(Cursor& c) {
+        loc_w = c.take(CH * 16);
+        loc_g = c.take(CH);
+        loc_b = c.take(CH);
+        emb_w = c.take(CH * 16);
+        emb_g = c.take(CH);
+        emb_b = c.take(CH);
+        gate_w = c.take(CH * 16);
+        gate_g = c.take(CH);
+        gate_b = c.take(CH);
+    }
+};
+struct BlockPack {
+    const float *gw, *gb, *gslope, *proj_wt, *proj_b;
+    const float *ds0_w, *ds0_b, *ds0_g, *ds0_be, *ds1_w, *ds1_b, *ds1_g, *ds1_be;
+    DpPack dpF, dpT;
+    AttnPack attn;
+    TfarPack fus0, fus1, cat0;
+    const float *res_wt, *res_b;
+    static BlockPack make(Cursor& c) {
+        const float* gw = c.take(CA);
+        const float* gb = c.take(CA);
+        const float* gs = c.take(1);
+        const float* pw = c.take(CA * CH);
+        const float* pb = c.take(CH);
+        const float* d[8];
+        for (int i = 0; i < 2; ++i) {
+            d[4 * i] = c.take(CH * 16);
+            d[4 * i + 1] = c.take(CH);
+            d[4 * i + 2] = c.take(CH);
+            d[4 * i + 3] = c.take(CH);
+        }
+        DpPack f(c), t(c);
+        AttnPack at(c);
+        TfarPack f0(c), f1(c), c0(c);
+        const float* rw = c.take(CH * CA);
+        const float* rb = c.take(CA);
+        return BlockPack{gw, gb, gs, pw, pb, d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7], f, t, at, f0, f1, c0, rw, rb};
+    }
+};
+struct CafPack {
+    const float *w_key, *bn_key, *w_val, *bn_val, *w_att, *b_att, *g_att, *be_att, *w_resize, *b_resize, *g_resize, *be_resize;
+    explicit CafPack(Cursor& c) {
+        w_key = c.take(CA);
+        bn_key = c.take(4 * CA);
+        w_val = c.take(CA);
+        bn_val = c.take(4 * CA);
+        w_att = c.take(1024 * 2);
+        b_att = c.take(1024);
+        g_att = c.take(1024);
+        be_att = c.take(1024);
+        w_resize = c.take(CA * 2);
+        b_resize = c.take(CA);
+        g_resize = c.take(CA);
+        be_resize = c.take(CA);
+    }
+};
+struct S3Pack {
+    const float *slope, *wt, *bias;
+    explicit S3Pack(Cursor& c) {
+        slope = c.take(1);
+        wt = c.take(CA * CA);
+        bias = c.take(CA);
+    }
+};
+struct DecPack {
+    const float* wt;  // (256, 32): 18 tap maps (o*3+dt)*3+df, zero padded to 32
+    explicit DecPack(Cursor& c) { wt = c.take(CA * 32); }
+};
+
+// ---------------------------------------------------------------- workspace carving
+struct Arena {
+    char* base;
+    size_t off = 0, cap;
+    Arena(void* b, size_t c) : base((char*)b), cap(c) {}
+    template <class T>
+    T* take(size_t n) {
+        off = align_up(off, 256);
+        T* r = base ? (T*)(base + off) : nullptr;
+        off += n * sizeof(T);
+        return r;
+    }
+    bool ok() const { return off <= cap; }
+};
+
+#define CHECK(expr)                  \
+    do {                             \
+        int _e = (expr);             \
+        if (_e != RTFS_OK) return _e; \
+    } while (0)
+
+inline hipStream_t S(void* s) { return (hipStream_t)s; }
+
+// ---------------------------------------------------------------- dual path
+DpArgs dp_args(const DpPack& p, const float* x, float* out, int R, int Ls, size_t bstride, size_t rstride, size_t cstride) {
+    DpArgs a;
+    a.x = x;
+    a.out = out;
+    a.R = R;
+    a.Ls = Ls;
+    a.bstride = bstride;
+    a.rstride = rstride;
+    a.cstride = cstride;
+    a.ln_gamma = p.ln_g;
+    a.ln_beta = p.ln_b;
+    a.W0 = p.W0;
+    a.Wl = p.Wl;
+    a.wc = p.wc;
+    a.bias = p.bias;
+    a.Wt = p.Wt;
+    a.bt = p.bt;
+    return a;
+}
+
+// x, out (B,64,T,F).  dim 4: sequences along F, rows (b,t).  dim 3: along T via two tiled transposes.
+int dualpath(const DpPack& p, const float* x, float* out, int B, int T, int F, int dim, float* tA, float* tB, hipStream_t st) {
+    const size_t plane = (size_t)T * F;
+    if (dim == 4) {
+        RTFS_RETURN_IF(F < 8 || F > 250, RTFS_ERR_SHAPE);
+        return launch_dualpath(dp_args(p, x, out, T, F, CH * plane, F, plane), B * T, st);
+    }
+    RTFS_RETURN_IF(T < 8 || T > 250, RTFS_ERR_SHAPE);
+    CHECK(launch_transpose(x, tA, B * CH, T, F, st));
+    CHECK(launch_dualpath(dp_args(p, tA, tB, F, T, CH * plane, T, plane), B * F, st));
+    return launch_transpose(tB, out, B * CH, F, T, st);
+}
+
+// ---------------------------------------------------------------- attention
+int attention(const AttnPack& p, const float* x, float* out, int B, int T, float* q, float* k, float* v, float* o, hipStream_t st) {
+    RowCanArgs a;
+    a.x = x;
+    a.wt = p.qkv_wt;
+    a.bias = p.qkv_b;
+    a.slope = p.qkv_slope;
+    a.gamma = p.qkv_gamma;
+    a.beta = p.qkv_beta;
+    a.ngroups = 12;
+    // channel order: Q_h (4 each), K_h (4 each), V_h (16 each)
+    for (int g = 0; g <= 12; ++g) a.group_start[g] = g <= 8 ? 4 * g : 32 + 16 * (g - 8);
+    for (int g = 0; g < 12; ++g)
+        for (int o_ = a.group_start[g]; o_ < a.group_start[g + 1]; ++o_) a.group_of[o_] = (unsigned char)g;
+    a.T = T;
+    a.q = q;
+    a.k = k;
+    a.v = v;
+    CHECK(launch_row_can_qkv(a, B, st));
+    AttnArgs c;
+    c.q = q;
+    c.k = k;
+    c.v = v;
+    c.out = o;
+    c.T = T;
+    c.scale = 1.0f / 16.0f;  // 1/sqrt(E*F) = 1/sqrt(4*64)
+    CHECK(launch_attn_core(c, B, st));
+    RowCanArgs r;
+    r.x = o;
+    r.wt = p.proj_wt;
+    r.bias = p.proj_b;
+    r.slope = p.proj_slope;
+    r.gamma = p.proj_gamma;
+    r.beta = p.proj_beta;
+    r.ngroups = 1;
+    r.group_start[0] = 0;
+    r.group_start[1] = 64;
+    r.T = T;
+    r.res = x;
+    r.out = out;
+    return launch_row_can_proj(r, B, st);
+}
+
+// ---------------------------------------------------------------- RTFS block
+struct BlockWs {
+    float *residual, *x_enc, *c0, *xf0, *expanded;                       // full resolution
+    float *c1, *p0, *g, *gF, *tA, *tB, *gT, *gA, *q, *k, *v, *o;         // compressed resolution
+    float *E0, *G0, *E1, *G1, *L1, *xf1, *E2, *G2;
+    double* stats;  // 11 slots x (B,2)
+    static constexpr int NSTAT = 11;
+    enum { S_C0, S_C1, S_E0, S_G0, S_E1, S_G1, S_L1, S_E2, S_G2, S_L0, S_L2 };
+    BlockWs(Arena& a, int B, int T, int F) {
+        const size_t P = (size_t)T * F, Pg = (size_t)(T / 2) * (F / 2);
+        residual = a.take<float>(B * CA * P);
+        x_enc = a.take<float>(B * CH * P);
+        c0 = a.take<float>(B * CH * P);
+        xf0 = a.take<float>(B * CH * P);
+        expanded = a.take<float>(B * CH * P);
+        float** gs[] = {&c1, &p0, &g, &gF, &tA, &tB, &gT, &gA, &v, &o, &E0, &G0, &E1, &G1, &L1, &xf1, &E2, &G2};
+        for (float** s : gs) *s = a.take<float>(B * CH * Pg);
+        q = a.take<float>(B * CH * Pg / 4);
+        k = a.take<float>(B * CH * Pg / 4);
+        stats = a.take<double>((size_t)NSTAT * B * 2);
+    }
+    double* st(int slot, int B) const { return stats ? stats + (size_t)slot * B * 2 : nullptr; }
+};
+
+int block_forward(const BlockPack& p, const float* x, const float* x_res, float* out, int B, int T, int F, BlockWs& w, hipStream_t st) {
+    const int Tp = T / 2, Fp = F / 2;
+    const int P = T * F, Pg = Tp * Fp;
+    const double icF = 1.0 / ((double)CH * P), icG = 1.0 / ((double)CH * Pg);
+    typedef BlockWs W;
+    if (hipMemsetAsync(w.stats, 0, sizeof(double) * W::NSTAT * B * 2, st) != hipSuccess) return RTFS_ERR_LAUNCH;
+
+    {  // 1. gateway (dw 1x1 + PReLU) -> residual; projection 1x1 256->64 -> x_enc          tdanet.py:106-107
+        PwArgs a;
+        a.x = x;
+        a.x2 = x_res;
+        a.res_out = w.residual;
+        a.wt = p.proj_wt;
+        a.bias = p.proj_b;
+        a.out = w.x_enc;
+        a.gw = p.gw;
+        a.gb = p.gb;
+        a.slope = p.gslope;
+        a.P = P;
+        CHECK(launch_pw_gateway_proj(a, B, st));
+    }
+    {  // 2. downsample[0]: dw 4x4 s1 + bias -> c0 (pre-gLN) + stats                         tdanet.py:110
+        DwArgs a;
+        a.x = w.x_enc;
+        a.w[0] = p.ds0_w;
+        a.bias[0] = p.ds0_b;
+        a.out[0] = w.c0;
+        a.stats_out[0] = w.st(W::S_C0, B);
+        a.C = CH; a.H = T; a.W = F; a.TH = 8;
+        CHECK(launch_dw_s1(a, 1, false, 0, B, st));
+    }
+    {  // 3. downsample[1] on d0 = gLN(c0): dw 4x4 s2 -> c1 + stats; p0 = adaptive_avg_pool2d(d0)   tdanet.py:111-116
+        DwArgs a;
+        a.x = w.c0;
+        a.in_stats = w.st(W::S_C0, B); a.in_inv_count = icF; a.in_gamma = p.ds0_g; a.in_beta = p.ds0_be;
+        a.w[0] = p.ds1_w;
+        a.bias[0] = p.ds1_b;
+        a.out[0] = w.c1;
+        a.out[1] = w.p0;
+        a.stats_out[0] = w.st(W::S_C1, B);
+        a.C = CH; a.H = T; a.W = F; a.Hg = Tp; a.Wg = Fp; a.TH = 8;
+        CHECK(launch_dw_s2_pool(a, B, st));
+    }
+    // 4. g = pool(d0) + d1
+    CHECK(launch_g_form(w.p0, w.c1, w.st(W::S_C1, B), icG, p.ds1_g, p.ds1_be, w.g, B, CH, Pg, st));
+    // 5-8. dual-path sweeps along F then T                                                  yaml layer_1 / layer_2
+    CHECK(dualpath(p.dpF, w.g, w.gF, B, Tp, Fp, 4, w.tA, w.tB, st));
+    CHECK(dualpath(p.dpT, w.gF, w.gT, B, Tp, Fp, 3, w.tA, w.tB, st));
+    // 9. TF self-attention                                                                  yaml layer_3
+    CHECK(attention(p.attn, w.gT, w.gA, B, Tp, w.q, w.k, w.v, w.o, st));
+    {  // 10. the four G-level convs on the attention output (fusion 0/1: global_embedding, global_gate)
+        DwArgs a;
+        a.x = w.gA;
+        a.w[0] = p.fus0.emb_w; a.w[1] = p.fus0.gate_w; a.w[2] = p.fus1.emb_w; a.w[3] = p.fus1.gate_w;
+        a.out[0] = w.E0; a.out[1] = w.G0; a.out[2] = w.E1; a.out[3] = w.G1;
+        a.stats_out[0] = w.st(W::S_E0, B); a.stats_out[1] = w.st(W::S_G0, B);
+        a.stats_out[2] = w.st(W::S_E1, B); a.stats_out[3] = w.st(W::S_G1, B);
+        a.C = CH; a.H = Tp; a.W = Fp; a.TH = 16;
+        CHECK(launch_dw_s1(a, 4, false, 0, B, st));
+    }
+    {  // 11. fusion 1 local_embedding on d1 = gLN(c1)
+        DwArgs a;
+        a.x = w.c1;
+        a.in_stats = w.st(W::S_C1, B); a.in_inv_count = icG; a.in_gamma = p.ds1_g; a.in_beta = p.ds1_be;
+        a.w[0] = p.fus1.loc_w;
+        a.out[0] = w.L1;
+        a.stats_out[0] = w.st(W::S_L1, B);
+        a.C = CH; a.H = Tp; a.W = Fp; a.TH = 16;
+        CHECK(launch_dw_s1(a, 1, true, 0, B, st));
+    }
+    {  // 12. xf1 = gLN(L1) * sigmoid(gLN(G1)) + gLN(E1)                                      fusion.py:62-67
+        GCombineArgs a;
+        a.l = w.L1; a.gate = w.G1; a.emb = w.E1;
+        a.l_stats = w.st(W::S_L1, B); a.gate_stats = w.st(W::S_G1, B); a.emb_stats = w.st(W::S_E1, B);
+        a.l_gamma = p.fus1.loc_g; a.l_beta = p.fus1.loc_b;
+        a.gate_gamma = p.fus1.gate_g; a.gate_beta = p.fus1.gate_b;
+        a.emb_gamma = p.fus1.emb_g; a.emb_beta = p.fus1.emb_b;
+        a.inv_count = icG;
+        a.out = w.xf1;
+        a.C = CH; a.HW = Pg;
+        CHECK(launch_g_combine(a, B, st));
+    }
+    {  // 13. concat layer's global convs on xf1
+        DwArgs a;
+        a.x = w.xf1;
+        a.w[0] = p.cat0.emb_w; a.w[1] = p.cat0.gate_w;
+        a.out[0] = w.E2; a.out[1] = w.G2;
+        a.stats_out[0] = w.st(W::S_E2, B); a.stats_out[1] = w.st(W::S_G2, B);
+        a.C = CH; a.H = Tp; a.W = Fp; a.TH = 16;
+        CHECK(launch_dw_s1(a, 2, false, 0, B, st));
+    }
+    DwArgs d0in;  // common: read d0 = gLN(c0) at full resolution
+    d0in.x = w.c0;
+    d0in.in_stats = w.st(W::S_C0, B); d0in.in_inv_count = icF; d0in.in_gamma = p.ds0_g; d0in.in_beta = p.ds0_be;
+    d0in.C = CH; d0in.H = T; d0in.W = F; d0in.TH = 8; d0in.Hg = Tp; d0in.Wg = Fp;
+    {  // 14. fusion 0 local_embedding conv on d0: statistics only
+        DwArgs a = d0in;
+        a.w[0] = p.fus0.loc_w;
+        a.stats_out[0] = w.st(W::S_L0, B);
+        CHECK(launch_dw_s1(a, 1, true, 1, B, st));
+    }
+    {  // 15. xf0 = gLN(conv(d0)) * sigmoid(gLN(G0))^ + gLN(E0)^                              fusion.py:58-67
+        DwArgs a = d0in;
+        a.w[0] = p.fus0.loc_w;
+        a.loc_stats = w.st(W::S_L0, B); a.loc_inv_count = icF; a.loc_gamma = p.fus0.loc_g; a.loc_beta = p.fus0.loc_b;
+        a.gate = w.G0; a.gate_stats = w.st(W::S_G0, B); a.gate_gamma = p.fus0.gate_g; a.gate_beta = p.fus0.gate_b;
+        a.emb = w.E0; a.emb_stats = w.st(W::S_E0, B); a.emb_gamma = p.fus0.emb_g; a.emb_beta = p.fus0.emb_b;
+        a.g_inv_count = icG;
+        a.out[0] = w.xf0;
+        CHECK(launch_dw_s1(a, 1, true, 2, B, st));
+    }
+    DwArgs xin;  // common: read xf0
+    xin.x = w.xf0;
+    xin.C = CH; xin.H = T; xin.W = F; xin.TH = 8; xin.Hg = Tp; xin.Wg = Fp;
+    {  // 16. concat layer local_embedding conv on xf0: statistics only
+        DwArgs a = xin;
+        a.w[0] = p.cat0.loc_w;
+        a.stats_out[0] = w.st(W::S_L2, B);
+        CHECK(launch_dw_s1(a, 1, false, 1, B, st));
+    }
+    {  // 17. expanded = InjectionMultiSum(xf0, xf1) + d0                                     tdanet.py:125
+        DwArgs a = xin;
+        a.w[0] = p.cat0.loc_w;
+        a.loc_stats = w.st(W::S_L2, B); a.loc_inv_count = icF; a.loc_gamma = p.cat0.loc_g; a.loc_beta = p.cat0.loc_b;
+        a.gate = w.G2; a.gate_stats = w.st(W::S_G2, B); a.gate_gamma = p.cat0.gate_g; a.gate_beta = p.cat0.gate_b;
+        a.emb = w.E2; a.emb_stats = w.st(W::S_E2, B); a.emb_gamma = p.cat0.emb_g; a.emb_beta = p.cat0.emb_b;
+        a.g_inv_count = icG;
+        a.addend = w.c0; a.add_stats = w.st(W::S_C0, B); a.add_inv_count = icF; a.add_gamma = p.ds0_g; a.add_beta = p.ds0_be;
+        a.out[0] = w.expanded;
+        CHECK(launch_dw_s1(a, 1, false, 2, B, st));
+    }
+    {  // 18. out = residual_conv(expanded) + residual                                        tdanet.py:129
+        PwArgs a;
+        a.x = w.expanded;
+        a.wt = p.res_wt;
+        a.bias = p.res_b;
+        a.aux = w.residual;
+        a.out = out;
+        a.P = P;
+        CHECK(launch_pw_residual(a, B, st));
+    }
+    return RTFS_OK;
+}
+
+int audio_bn(const BnPack& p, const float* x, const double* stats, float* out, int B, int P, hipStream_t st) {
+    PwArgs a;
+    a.x = x;
+    a.wt = p.wt;
+    a.bias = p.bias;
+    a.out = out;
+    a.stats = stats;
+    a.inv_count = 1.0 / ((double)CA * P);
+    a.gamma = p.gamma;
+    a.beta = p.beta;
+    a.P = P;
+    return launch_pw_audio_bn(a, B, st);
+}
+
+CafArgs caf_args(const CafPack& p, const float* audio, const float* video, float* out, float* r, float* att, int T, int F, int Tv) {
+    CafArgs a;
+    a.audio = audio; a.video = video; a.out = out; a.r_out = r; a.att_out = att;
+    a.T = T; a.F = F; a.Tv = Tv;
+    a.w_key = p.w_key; a.bn_key = p.bn_key; a.w_val = p.w_val; a.bn_val = p.bn_val;
+    a.w_att = p.w_att; a.b_att = p.b_att; a.g_att = p.g_att; a.be_att = p.be_att;
+    a.w_resize = p.w_resize; a.b_resize = p.b_resize; a.g_resize = p.g_resize; a.be_resize = p.be_resize;
+    return a;
+}
+
+int s3_mask(const S3Pack& p, const float* refined, const float* a0, float* out, int B, int P, hipStream_t st) {
+    PwArgs a;
+    a.x = refined;
+    a.wt = p.wt;
+    a.bias = p.bias;
+    a.aux = a0;
+    a.out = out;
+    a.slope = p.slope;
+    a.P = P;
+    return launch_pw_s3(a, B, st);
+}
+
+int decoder(const DecPack& p, const float* x, float* wav, float* z, int B, int T, int L, hipStream_t st) {
+    PwArgs a;
+    a.x = x;
+    a.wt = p.wt;
+    a.out = z;
+    a.P = T * NF;
+    a.cout_live = 18;
+    CHECK(launch_pw_dec_taps(a, B, st));
+    return launch_dec_istft(z, wav, B, T, NF, L, (size_t)T * NF, (size_t)18 * T * NF, st);
+}
+
+template <class PackT>
+size_t pack_size() {
+    Cursor c(nullptr);
+    PackT p(c);
+    (void)p;
+    return c.off;
+}
+
+bool shape_ok_block(int B, int T, int F) { return B >= 1 && F / 2 == FQ && T / 2 >= 8 && T / 2 <= 250; }
+
+}  // namespace
+
+extern "C" {
+
+const char* rtfs_version(void) { return "rtfs_amd 0.1 gfx950"; }
+
+int rtfs_num_frames(int L) { return 1 + L / 128; }
+
+size_t rtfs_pack_floats(int kind) {
+    switch (kind) {
+        case RTFS_PACK_ENCODER: return pack_size<EncPack>();
+        case RTFS_PACK_AUDIO_BN: return pack_size<BnPack>();
+        case RTFS_PACK_BLOCK: {
+            Cursor c(nullptr);
+            BlockPack::make(c);
+            return c.off;
+        }
+        case RTFS_PACK_DUALPATH: return pack_size<DpPack>();
+        case RTFS_PACK_ATTENTION: return pack_size<AttnPack>();
+        case RTFS_PACK_TFAR: return pack_size<TfarPack>();
+        case RTFS_PACK_CAF: return pack_size<CafPack>();
+        case RTFS_PACK_S3: return pack_size<S3Pack>();
+        case RTFS_PACK_DECODER: return pack_size<DecPack>();
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------ encoder
+size_t rtfs_stft_encoder_workspace_bytes(int B, int L) { return (size_t)B * 2 * rtfs_num_frames(L) * NF * sizeof(float) + 256; }
+
+int rtfs_stft_encoder_f32(const float* wav, const float* pack, float* a0, double* stats, int B, int L, void* ws, size_t ws_bytes, void* stream) {
+    RTFS_RETURN_IF(!wav || !pack || !a0 || B < 1 || L <= 128, RTFS_ERR_ARG);
+    const int T = rtfs_num_frames(L);
+    Arena ar(ws, ws_bytes);
+    float* spec = ar.take<float>((size_t)B * 2 * T * NF);
+    RTFS_RETURN_IF(!ws || !ar.ok(), RTFS_ERR_WORKSPACE);
+    Cursor c(pack);
+    EncPack p(c);
+    if (stats && hipMemsetAsync(stats, 0, sizeof(double) * 2 * B, S(stream)) != hipSuccess) return RTFS_ERR_LAUNCH;
+    CHECK(launch_stft(wav, spec, B, L, T, S(stream)));
+    return launch_enc_conv(spec, p.w, a0, stats, B, CA, T, NF, (size_t)T * NF, (size_t)CA * T * NF, S(stream));
+}
+
+// ------------------------------------------------------------ audio bottleneck
+size_t rtfs_audio_bottleneck_workspace_bytes(int B) { return sizeof(double) * 2 * B + 256; }
+
+int rtfs_audio_bottleneck_f32(const float* x, const double* stats, const float* pack, float* out, int B, int T, int F, void* ws, size_t ws_bytes, void* stream) {
+    RTFS_RETURN_IF(!x || !pack || !out || B < 1 || T < 1 || F < 1, RTFS_ERR_ARG);
+    Cursor c(pack);
+    BnPack p(c);
+    if (!stats) {
+        Arena ar(ws, ws_bytes);
+        double* s = ar.take<double>(2 * B);
+        RTFS_RETURN_IF(!ws || !ar.ok(), RTFS_ERR_WORKSPACE);
+        if (hipMemsetAsync(s, 0, sizeof(double) * 2 * B, S(stream)) != hipSuccess) return RTFS_ERR_LAUNCH;
+        CHECK(launch_stats(x, s, B, (size_t)CA * T * F, S(stream)));
+        stats = s;
+    }
+    return audio_bn(p, x, stats, out, B, T * F, S(stream));
+}
+
+// ------------------------------------------------------------ RTFS block
+size_t rtfs_block_workspace_bytes(int B, int T, int F) {
+    Arena ar(nullptr, 0);
+    BlockWs w(ar, B, T, F);
+    return ar.off + 256;
+}
+
+int rtfs_block_f32(const float* x, const float* x_res, const float* pack, float* out, int B, int T, int F, void* ws, size_t ws_bytes, void* stream) {
+    RTFS_RETURN_IF(!x || !pack || !out, RTFS_ERR_ARG);
+    RTFS_RETURN_IF(!shape_ok_block(B, T, F), RTFS_ERR_SHAPE);
+    Arena ar(ws, ws_bytes);
+    BlockWs w(ar, B, T, F);
+    RTFS_RETURN_IF(!ws || !ar.ok(), RTFS_ERR_WORKSPACE);
+    Cursor c(pack);
+    BlockPack p = BlockPack::make(c);
+    return block_forward(p, x, x_res, out, B, T, F, w, S(stream));
+}
+
+// ------------------------------------------------------------ dual path
+size_t rtfs_dualpath_workspace_bytes(int B, int T, int F) { return 2 * ((size_t)B * CH * T * F * sizeof(float) + 256); }
+
+int rtfs_dualpath_sru_f32(const float* x, const float* pack, float* out, int B, int T, int F, int dim, void* ws, size_t ws_bytes, void* stream) {
+    RTFS_RETURN_IF(!x || !pack || !out || B < 1 || (dim != 3 && dim != 4), RTFS_ERR_ARG);
+    Arena ar(ws, ws_bytes);
+    float* tA = ar.take<float>((size_t)B * CH * T * F);
+    float* tB = ar.take<float>((size_t)B * CH * T * F);
+    RTFS_RETURN_IF(dim == 3 && (!ws || !ar.ok()), RTFS_ERR_WORKSPACE);
+    Cursor c(pack);
+    DpPack p(c);
+    return dualpath(p, x, out, B, T, F, dim, tA, tB, S(stream));
+}
+
+// ------------------------------------------------------------ TF attention
+size_t rtfs_tf_attention_workspace_bytes(int B, int T) { return (size_t)B * T * (4 * 256 + 4 * 256 + 4 * 1024 + 64 * FQ) * sizeof(float) + 4 * 256; }
+
+int rtfs_tf_attention_f32(const float* x, const float* pack, float* out, int B, int T, void* ws, size_t ws_bytes, void* stream) {
+    RTFS_RETURN_IF(!x || !pack || !out || B < 1, RTFS_ERR_ARG);
+    RTFS_RETURN_IF(T < 1 || T > 256, RTFS_ERR_SHAPE);
+    Arena ar(ws, ws_bytes);
+    float* q = ar.take<float>((size_t)B * 4 * T * 256);
+    float* k = ar.take<float>((size_t)B * 4 * T * 256);
+    float* v = ar.take<float>((size_t)B * 4 * T * 1024);
+    float* o = ar.take<float>((size_t)B * 64 * T * FQ);
+    RTFS_RETURN_IF(!ws || !ar.ok(), RTFS_ERR_WORKSPACE);
+    Cursor c(pack);
+    AttnPack p(c);
+    return attention(p, x, out, B, T, q, k, v, o, S(stream));
+}
+
+// ------------------------------------------------------------ TFAR
+size_t rtfs_tfar_workspace_bytes(int B, int H, int W, int Hg, int Wg) {
+    return 3 * ((size_t)B * CH * (size_t)(H * W > Hg * Wg ? Hg * Wg : H * W) * sizeof(float) + 256) + 3 * 2 * B * sizeof(double) + 256;
+}
+
+int rtfs_tfar_f32(const float* local, const float* global, const float* pack, float* out, int B, int H, int W, int Hg, int Wg, void* ws, size_t ws_bytes, void* stream) {
+    RTFS_RETURN_IF(!local || !global || !pack || !out || B < 1, RTFS_ERR_ARG);
+    const bool up = (size_t)H * W > (size_t)Hg * Wg;
+    RTFS_RETURN_IF(!up && (H != Hg || W != Wg), RTFS_ERR_SHAPE);  // the path only ever has equal-size or larger local maps
+    Arena ar(ws, ws_bytes);
+    const size_t ng = (size_t)B * CH * Hg * Wg;
+    float* E = ar.take<float>(ng);
+    float* G = ar.take<float>(ng);
+    float* Lc = ar.take<float>(ng);
+    double* st = ar.take<double>(3 * 2 * B);
+    RTFS_RETURN_IF(!ws || !ar.ok(), RTFS_ERR_WORKSPACE);
+    Cursor c(pack);
+    TfarPack p(c);
+    hipStream_t s = S(stream);
+    if (hipMemsetAsync(st, 0, sizeof(double) * 6 * B, s) != hipSuccess) return RTFS_ERR_LAUNCH;
+    double *stE = st, *stG = st + 2 * B, *stL = st + 4 * B;
+    const double icG = 1.0 / ((double)CH * Hg * Wg), icL = 1.0 / ((double)CH * H * W);
+    {
+        DwArgs a;
+        a.x = global;
+        a.w[0] = p.emb_w; a.w[1] = p.gate_w;
+        a.out[0] = E; a.out[1] = G;
+        a.stats_out[0] = stE; a.stats_out[1] = stG;
+        a.C = CH; a.H = Hg; a.W = Wg; a.TH = 16;
+        CHECK(launch_dw_s1(a, 2, false, 0, B, s));
+    }
+    if (up) {
+        DwArgs a;
+        a.x = local;
+        a.w[0] = p.loc_w;
+        a.C = CH; a.H = H; a.W = W; a.TH = 8; a.Hg = Hg; a.Wg = Wg;
+        a.stats_out[0] = stL;
+        CHECK(launch_dw_s1(a, 1, false, 1, B, s));
+        a.stats_out[0] = nullptr;
+        a.loc_stats = stL; a.loc_inv_count = icL; a.loc_gamma = p.loc_g; a.loc_beta = p.loc_b;
+        a.gate = G; a.gate_stats = stG; a.gate_gamma = p.gate_g; a.gate_beta = p.gate_b;
+        a.emb = E; a.emb_stats = stE; a.emb_gamma = p.emb_g; a.emb_beta = p.emb_b;
+        a.g_inv_count = icG;
+        a.out[0] = out;
+        return launch_dw_s1(a, 1, false, 2, B, s);
+    }
+    {
+        DwArgs a;
+        a.x = local;
+        a.w[0] = p.loc_w;
+        a.out[0] = Lc;
+        a.stats_out[0] = stL;
+        a.C = CH; a.H = H; a.W = W; a.TH = 16;
+        CHECK(launch_dw_s1(a, 1, false, 0, B, s));
+    }
+    GCombineArgs a;
+    a.l = Lc; a.gate = G; a.emb = E;
+    a.l_stats = stL; a.gate_stats = stG; a.emb_stats = stE;
+    a.l_gamma = p.loc_g; a.l_beta = p.loc_b; a.gate_gamma = p.gate_g; a.gate_beta = p.gate_b; a.emb_gamma = p.emb_g; a.emb_beta = p.emb_b;
+    a.inv_count = icG;
+    a.out = out;
+    a.C = CH; a.HW = H * W;
+    return launch_g_combine(a, B, s);
+}
+
+// ------------------------------------------------------------ CAF
+size_t rtfs_caf_workspace_bytes(int B, int Tv) { return 2 * ((size_t)B * CA * Tv * sizeof(float) + 256); }
+
+int rtfs_caf_f32(const float* audio, const float* video, const float* pack, float* out, int B, int T, int F, int Tv, void* ws, size_t ws_bytes, void* stream) {
+    RTFS_RETURN_IF(!audio || !video || !pack || !out || B < 1 || T < 1 || F < 1 || Tv < 1, RTFS_ERR_ARG);
+    Arena ar(ws, ws_bytes);
+    float* r = ar.take<float>((size_t)B * CA * Tv);
+    float* att = ar.take<float>((size_t)B * CA * Tv);
+    RTFS_RETURN_IF(!ws || !ar.ok(), RTFS_ERR_WORKSPACE);
+    Cursor c(pack);
+    CafPack p(c);
+    CafArgs a = caf_args(p, audio, video, out, r, att, T, F, Tv);
+    CHECK(launch_caf_video(a, B, S(stream)));
+    return launch_caf_apply(a, B, S(stream));
+}
+
+// ------------------------------------------------------------ S^3
+int rtfs_s3_mask_f32(const float* refined, const float* a0, const float* pack, float* out, int B, int T, int F, void* stream) {
+    RTFS_RETURN_IF(!refined || !a0 || !pack || !out || B < 1 || T < 1 || F < 1, RTFS_ERR_ARG);
+    Cursor c(pack);
+    S3Pack p(c);
+    return s3_mask(p, refined, a0, out, B, T * F, S(stream));
+}
+
+// ------------------------------------------------------------ decoder
+size_t rtfs_istft_decoder_workspace_bytes(int B, int T) { return (size_t)B * 18 * T * NF * sizeof(float) + 256; }
+
+int rtfs_istft_decoder_f32(const float* x, const float* pack, float* wav, int B, int T, int L, void* ws, size_t ws_bytes, void* stream) {
+    RTFS_RETURN_IF(!x || !pack || !wav || B < 1 || T < 1 || L < 1, RTFS_ERR_ARG);
+    RTFS_RETURN_IF(L > 128 * T + 127, RTFS_ERR_SHAPE);  // every output sample needs at least one frame
+    Arena ar(ws, ws_bytes);
+    float* z = ar.take<float>((size_t)B * 18 * T * NF);
+    RTFS_RETURN_IF(!ws || !ar.ok(), RTFS_ERR_WORKSPACE);
+    Cursor c(pack);
+    DecPack p(c);
+    return decoder(p, x, wav, z, B, T, L, S(stream));
+}
+
+// ------------------------------------------------------------ whole separator
+namespace {
+struct SepWs {
+    float *spec, *a0, *a1, *cur, *nxt, *r, *att, *z;
+    double* st0;
+    BlockWs blk;
+    SepWs(Arena& a, int B, int T, int Tv)
+        : spec(a.take<float>((size_t)B * 2 * T * NF)),
+          a0(a.take<float>((size_t)B * CA * T * NF)),
+          a1(a.take<float>((size_t)B * CA * T * NF)),
+          cur(a.take<float>((size_t)B * CA * T * NF)),
+          nxt(a.take<float>((size_t)B * CA * T * NF)),
+          r(a.take<float>((size_t)B * CA * Tv)),
+          att(a.take<float>((size_t)B * CA * Tv)),
+          z(a.take<float>((size_t)B * 18 * T * NF)),
+          st0(a.take<double>(2 * B)),
+          blk(a, B, T, NF) {}
+};
+}  // namespace
+
+size_t rtfs_separator_workspace_bytes(int B, int L, int Tv) {
+    Arena ar(nullptr, 0);
+    SepWs w(ar, B, rtfs_num_frames(L), Tv);
+    return ar.off + 256;
+}
+
+int rtfs_separator_forward_f32(const float* wav, const float* video_vp, const float* pack_enc, const float* pack_bn, const float* pack_block,
+                               const float* pack_caf, const float* pack_s3, const float* pack_dec, float* out, int B, int L, int Tv,
+                               int repeats, void* ws, size_t ws_bytes, void* stream) {
+    RTFS_RETURN_IF(!wav || !video_vp || !pack_enc || !pack_bn || !pack_block || !pack_caf || !pack_s3 || !pack_dec || !out, RTFS_ERR_ARG);
+    RTFS_RETURN_IF(B < 1 || L <= 128 || Tv < 1 || repeats < 1, RTFS_ERR_ARG);
+    const int T = rtfs_num_frames(L);
+    RTFS_RETURN_IF(!shape_ok_block(B, T, NF), RTFS_ERR_SHAPE);
+    Arena ar(ws, ws_bytes);
+    SepWs w(ar, B, T, Tv);
+    RTFS_RETURN_IF(!ws || !ar.ok(), RTFS_ERR_WORKSPACE);
+    hipStream_t st = S(stream);
+    Cursor ce(pack_enc), cb(pack_bn), ck(pack_block), cc(pack_caf), cs(pack_s3), cd(pack_dec);
+    EncPack pe(ce);
+    BnPack pb(cb);
+    BlockPack pk = BlockPack::make(ck);
+    CafPack pc(cc);
+    S3Pack ps(cs);
+    DecPack pd(cd);
+    const int P = T * NF;
+    if (hipMemsetAsync(w.st0, 0, sizeof(double) * 2 * B, st) != hipSuccess) return RTFS_ERR_LAUNCH;
+    CHECK(launch_stft(wav, w.spec, B, L, T, st));
+    CHECK(launch_enc_conv(w.spec, pe.w, w.a0, w.st0, B, CA, T, NF, (size_t)P, (size_t)CA * P, st));
+    CHECK(audio_bn(pb, w.a0, w.st0, w.a1, B, P, st));
+    // refinement_module.py:45-62: block(a1); CAF; then (repeats-1) x block(audio + a1), shared weights
+    CHECK(block_forward(pk, w.a1, nullptr, w.cur, B, T, NF, w.blk, st));
+    {
+        CafArgs a = caf_args(pc, w.cur, video_vp, w.nxt, w.r, w.att, T, NF, Tv);
+        CHECK(launch_caf_video(a, B, st));
+        CHECK(launch_caf_apply(a, B, st));
+    }
+    float *cur = w.nxt, *nxt = w.cur;
+    for (int i = 1; i < repeats; ++i) {
+        CHECK(block_forward(pk, cur, w.a1, nxt, B, T, NF, w.blk, st));
+        float* t = cur;
+        cur = nxt;
+        nxt = t;
+    }
+    CHECK(s3_mask(ps, cur, w.a0, nxt, B, P, st));
+    return decoder(pd, nxt, out, w.z, B, T, L, st);
+}
+
+// ------------------------------------------------------------ stand-alone SRU operator
+size_t rtfs_sru_workspace_bytes(int L, int N) {
+    (void)L;
+    (void)N;
+    return 256;
+}
+
+int rtfs_sru_f32(const float* x, const float* pack, float* h, int L, int N, void* ws, size_t ws_bytes, void* stream) {
+    (void)ws;
+    (void)ws_bytes;
+    RTFS_RETURN_IF(!x || !pack || !h || L < 1 || N < 1, RTFS_ERR_ARG);
+    RTFS_RETURN_IF(L > 243, RTFS_ERR_SHAPE);
+    Cursor c(pack);
+    DpPack p(c);
+    return launch_sru_standalone(x, h, L, N, p.W0, p.Wl, p.wc, p.bias, S(stream));
+}
+
+}  // extern "C"

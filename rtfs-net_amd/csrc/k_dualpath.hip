@@ -1,0 +1,203 @@
+// Fused dual-path SRU sweep (the hot loop of the RTFS block).
+// Restates DualPathRNN.forward (reference src/models/layers/rnn_layers.py:136-162) with the
+// third-party sru.SRU cell (call site rnn_layers.py:99-105,150; upstream v2 recurrence):
+//   LN over channels -> Unfold(k=8) -> 4 stacked bidirectional SRU layers (hidden 32)
+//   -> ConvTranspose1d(64->64, k=8) + bias -> + un-normalised input.
+// One workgroup (4 waves) owns one sequence end to end; nothing but the input row and the
+// output row touches HBM: the unfolded (L,512) matrix is never built (it is an addressing mode
+// of the normalised row in LDS), U = X.W lives 32 time-steps at a time in LDS, and the hidden
+// sequences ping-pong between two LDS buffers.
+//   LDS: bufA [64][Ls] (normalised row, later hidden ping [L][65]) | bufB hidden pong [L][65] | U [32][256]
+//   GEMMs: v_mfma_f32_32x32x2_f32 (exact f32).  Waves 0,1 produce the forward direction's 128
+//   U columns, waves 2,3 the backward direction's; both directions run on a common "virtual
+//   time" tau (backward reads position L-1-tau), so one wave scans both directions at once
+//   (lanes 0-31 forward j, lanes 32-63 backward j).
+#include "common.h"
+#include "kernels.h"
+
+#define DP_C 64     // channels of the sequence
+#define DP_K 8      // unfold / conv-transpose kernel
+#define DP_HS 65    // padded row stride of the hidden buffers (bank-conflict-free column reads)
+
+// STANDALONE = the bare sru.SRU operator: x (L,N,512) -> h (L,N,64); no LayerNorm / unfold / ConvTranspose
+// (a.Ls carries L+7 so the buffer arithmetic is shared, a.R carries N).
+template <bool STANDALONE>
+__global__ __launch_bounds__(256) void dualpath_sru_kernel(DpArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int Ls = a.Ls, L = Ls - DP_K + 1;
+    const int szA = (DP_C * Ls + 3) & ~3, szB = (L * DP_HS + 3) & ~3;
+    float* bufA = lds;
+    float* bufB = lds + szA;
+    float* U = bufB + szB;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = blockIdx.x;
+    const size_t base = STANDALONE ? 0 : (size_t)(n / a.R) * a.bstride + (size_t)(n % a.R) * a.rstride;
+
+    // ---- 1. load the row, LayerNorm over channels per position (normalizations.py:33-37)
+    for (int idx = tid; !STANDALONE && idx < DP_C * Ls; idx += 256) {
+        const int c = idx / Ls, s = idx - c * Ls;
+        bufA[idx] = a.x[base + (size_t)c * a.cstride + s];
+    }
+    __syncthreads();
+    for (int s = tid; !STANDALONE && s < Ls; s += 256) {
+        float mean = 0.f;
+        for (int c = 0; c < DP_C; ++c) mean += bufA[c * Ls + s];
+        mean *= (1.0f / DP_C);
+        float var = 0.f;
+        for (int c = 0; c < DP_C; ++c) {
+            const float d = bufA[c * Ls + s] - mean;
+            var = fmaf(d, d, var);
+        }
+        const float rstd = 1.0f / sqrtf(var * (1.0f / DP_C) + RTFS_EPS);
+        for (int c = 0; c < DP_C; ++c) bufA[c * Ls + s] = fmaf((bufA[c * Ls + s] - mean) * rstd, a.ln_gamma[c], a.ln_beta[c]);
+    }
+    __syncthreads();
+
+    // ---- 2. four SRU layers
+    const int dir = wave >> 1;         // GEMM role of this wave
+    const int col0 = wave * 64;        // its 64 U columns: (dir*32 + j)*4 + m
+    const int nT = (L + 31) >> 5;
+    for (int layer = 0; layer < 4; ++layer) {
+        const float* hin = (layer & 1) ? bufB : bufA;  // layer 0: the normalised row in bufA
+        float* hout = (layer & 1) ? bufA : bufB;
+        float cstate = 0.f;  // wave 0: c_{t-1} of (dir = lane>>5, j = lane&31)
+        const float vf = a.wc[layer * 128 + lane], vr = a.wc[layer * 128 + 64 + lane];
+        const float bf = a.bias[layer * 128 + lane], br = a.bias[layer * 128 + 64 + lane];
+        for (int tile = 0; tile < nT; ++tile) {
+            // -- GEMM: U[tau_local][col] for this wave's direction and 64 columns
+            int tau = tile * 32 + (lane & 31);
+            tau = tau < L ? tau : L - 1;
+            const int pos = dir ? (L - 1 - tau) : tau;
+            f32x16 acc0, acc1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+            if (layer == 0) {
+                const float* w = a.W0 + col0 + (lane & 31);
+#pragma unroll 8
+                for (int k0 = 0; k0 < DP_C * DP_K; k0 += 2) {
+                    const int k = k0 + (lane >> 5);
+                    const float av = STANDALONE ? a.x[((size_t)pos * a.R + n) * (DP_C * DP_K) + k]
+                                                : hin[(k >> 3) * Ls + pos + (k & 7)];  // unfold: feature c*8+kk = xn[c][l+kk]
+                    const float b0 = w[(size_t)k * 256], b1 = w[(size_t)k * 256 + 32];
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, acc1, 0, 0, 0);
+                }
+            } else {
+                const float* w = a.Wl + (size_t)(layer - 1) * DP_C * 256 + col0 + (lane & 31);
+#pragma unroll 8
+                for (int k0 = 0; k0 < DP_C; k0 += 2) {
+                    const int k = k0 + (lane >> 5);
+                    const float av = hin[pos * DP_HS + k];
+                    const float b0 = w[(size_t)k * 256], b1 = w[(size_t)k * 256 + 32];
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, acc1, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                U[row * 256 + col0 + (lane & 31)] = acc0[r];
+                U[row * 256 + col0 + 32 + (lane & 31)] = acc1[r];
+            }
+            __syncthreads();
+            // -- scan 32 steps of both directions (wave 0; lane = dir*32 + j)
+            if (wave == 0) {
+                const int sdir = lane >> 5;
+                const int steps = min(32, L - tile * 32);
+                for (int i = 0; i < steps; ++i) {
+                    const int t = tile * 32 + i;
+                    const int p = sdir ? (L - 1 - t) : t;
+                    const f32x4 u = *reinterpret_cast<const f32x4*>(&U[i * 256 + lane * 4]);
+                    const float f = sigmoidf_(u[1] + vf * cstate + bf);
+                    const float r = sigmoidf_(u[2] + vr * cstate + br);
+                    cstate = u[0] + (cstate - u[0]) * f;
+                    const float xp = layer == 0 ? u[3] : hin[p * DP_HS + lane];
+                    hout[p * DP_HS + lane] = xp + (cstate - xp) * r;
+                }
+            }
+            __syncthreads();
+        }
+    }
+
+    if (STANDALONE) {
+        for (int idx = tid; idx < L * 64; idx += 256) a.out[((size_t)(idx >> 6) * a.R + n) * 64 + (idx & 63)] = bufA[(idx >> 6) * DP_HS + (idx & 63)];
+        return;
+    }
+    // ---- 3. ConvTranspose1d(64->64, k=8) + bias + residual, computed transposed (M = co, N = position)
+    //      y[co][t] = bt[co] + sum_{kk,ci} Wt[kk*64+ci][co] * H[t-kk][ci]      (H = bufA, layer 3 output)
+    {
+        const float* H = bufA;
+        const int mt = wave & 1;
+        const int nNt = (Ls + 31) >> 5;
+        const float* w = a.Wt + mt * 32 + (lane & 31);
+        for (int q = (wave >> 1); q < nNt; q += 4) {
+            const int q1 = q + 2;  // second position tile handled in the same pass (shares the weight loads)
+            const int t0 = q * 32 + (lane & 31), t1 = q1 * 32 + (lane & 31);
+            f32x16 acc0, acc1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+#pragma unroll 8
+            for (int k0 = 0; k0 < DP_C * DP_K; k0 += 2) {
+                const int k = k0 + (lane >> 5);
+                const int kk = k >> 6, ci = k & 63;
+                const float av = w[(size_t)k * DP_C];
+                const int s0 = t0 - kk, s1 = t1 - kk;
+                const float b0 = (s0 >= 0 && s0 < L) ? H[s0 * DP_HS + ci] : 0.f;
+                const float b1 = (q1 < nNt && s1 >= 0 && s1 < L) ? H[s1 * DP_HS + ci] : 0.f;
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, acc1, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const float bb = a.bt[co];
+                const size_t o = base + (size_t)co * a.cstride;
+                if (t0 < Ls) a.out[o + t0] = acc0[r] + bb + a.x[o + t0];
+                if (q1 < nNt && t1 < Ls) a.out[o + t1] = acc1[r] + bb + a.x[o + t1];
+            }
+        }
+    }
+}
+
+size_t dualpath_lds_bytes(int Ls) {
+    const int L = Ls - DP_K + 1;
+    const size_t szA = (DP_C * Ls + 3) & ~3, szB = (L * DP_HS + 3) & ~3;
+    return (szA + szB + 32 * 256) * sizeof(float);
+}
+
+int launch_dualpath(const DpArgs& a, int nseq, hipStream_t st) {
+    if (a.Ls < DP_K || a.Ls > 250) return RTFS_ERR_SHAPE;
+    const size_t lds = dualpath_lds_bytes(a.Ls);
+    static size_t configured = 0;
+    if (lds > configured) {
+        if (hipFuncSetAttribute((const void*)dualpath_sru_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return RTFS_ERR_LAUNCH;
+        configured = lds;
+    }
+    hipLaunchKernelGGL(dualpath_sru_kernel<false>, dim3(nseq), dim3(256), lds, st, a);
+    return rtfs_launch_status();
+}
+
+int launch_sru_standalone(const float* x, float* h, int L, int N, const float* W0, const float* Wl, const float* wc,
+                          const float* bias, hipStream_t st) {
+    if (L < 1 || L > 243) return RTFS_ERR_SHAPE;
+    DpArgs a;
+    a.x = x;
+    a.out = h;
+    a.R = N;
+    a.Ls = L + DP_K - 1;
+    a.W0 = W0;
+    a.Wl = Wl;
+    a.wc = wc;
+    a.bias = bias;
+    const size_t lds = dualpath_lds_bytes(a.Ls);
+    static size_t configured = 0;
+    if (lds > configured) {
+        if (hipFuncSetAttribute((const void*)dualpath_sru_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return RTFS_ERR_LAUNCH;
+        configured = lds;
+    }
+    hipLaunchKernelGGL(dualpath_sru_kernel<true>, dim3(N), dim3(256), lds, st, a);
+    return rtfs_launch_status();
+}

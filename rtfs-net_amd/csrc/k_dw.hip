@@ -1,0 +1,255 @@
+// Depthwise 4x4 convolution family + the G-level elementwise glue of the RTFS block.
+// Reference modules restated here:
+//   downsample_layers[0] (dw 4x4 s1 'same' +bias -> gLN)          separators/tdanet.py:59-74,110
+//   downsample_layers[1] (dw 4x4 s2 pad 1 +bias -> gLN)           separators/tdanet.py:111-112
+//   adaptive_avg_pool2d sum                                        separators/tdanet.py:115-116
+//   InjectionMultiSum (TFAR): three dw 4x4 'same' no-bias + gLN    layers/fusion.py:24-69
+// gLN (GroupNorm(1,C)) needs per-sample statistics of a conv's whole output, so every conv here
+// writes (or only accumulates) its pre-norm output plus (sum, sumsq) in f64; the consumer folds
+// mean/rstd/gamma/beta into one FMA at load time (gln_fold).  Zero padding is applied to the
+// *normalised* input, i.e. out-of-image taps contribute 0, not `shift`.
+#include "common.h"
+#include "kernels.h"
+
+// ---------------------------------------------------------------- stride-1 'same' 4x4 (pad lo 1, hi 2)
+// MODE 0: write pre-norm outputs + stats.  MODE 1: stats only.  MODE 2: TFAR apply:
+//   out = gLN_loc(conv(x)) * sigmoid(gLN_gate(G_gate)^) + gLN_emb(G_emb)^ [+ gLN_add(addend)]
+// where ^ is legacy nearest up-sampling from (Hg, Wg) to (H, W).
+template <int NCONV, bool IN_AFFINE, int MODE>
+__global__ __launch_bounds__(256) void dw_s1_kernel(DwArgs a) {
+    extern __shared__ float tile[];  // (TH+3) x (W+3)
+    __shared__ double red[8];
+    const int H = a.H, W = a.W, C = a.C, TH = a.TH;
+    const int c = blockIdx.y, b = blockIdx.z;
+    const int r0 = blockIdx.x * TH;
+    const int TW = W + 3;
+    const size_t plane = ((size_t)b * C + c) * H * W;
+    float isc = 1.f, ish = 0.f;
+    if (IN_AFFINE) gln_fold(a.in_stats + 2 * b, a.in_inv_count, a.in_gamma[c], a.in_beta[c], isc, ish);
+    for (int idx = threadIdx.x; idx < (TH + 3) * TW; idx += 256) {
+        const int rr = idx / TW, cc = idx % TW;
+        const int t = r0 + rr - 1, f = cc - 1;
+        float v = 0.f;
+        if (t >= 0 && t < H && f >= 0 && f < W) {
+            v = a.x[plane + (size_t)t * W + f];
+            if (IN_AFFINE) v = fmaf(v, isc, ish);
+        }
+        tile[idx] = v;
+    }
+    float wgt[NCONV][16];
+    float bia[NCONV];
+#pragma unroll
+    for (int n = 0; n < NCONV; ++n) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) wgt[n][j] = a.w[n][c * 16 + j];
+        bia[n] = a.bias[n] ? a.bias[n][c] : 0.f;
+    }
+    // MODE 2 folds
+    float lsc = 1.f, lsh = 0.f, gsc = 1.f, gsh = 0.f, esc = 1.f, esh = 0.f, asc = 1.f, ash = 0.f;
+    size_t gplane = 0;
+    if (MODE == 2) {
+        gln_fold(a.loc_stats + 2 * b, a.loc_inv_count, a.loc_gamma[c], a.loc_beta[c], lsc, lsh);
+        gln_fold(a.gate_stats + 2 * b, a.g_inv_count, a.gate_gamma[c], a.gate_beta[c], gsc, gsh);
+        gln_fold(a.emb_stats + 2 * b, a.g_inv_count, a.emb_gamma[c], a.emb_beta[c], esc, esh);
+        if (a.addend) gln_fold(a.add_stats + 2 * b, a.add_inv_count, a.add_gamma[c], a.add_beta[c], asc, ash);
+        gplane = ((size_t)b * C + c) * a.Hg * a.Wg;
+    }
+    __syncthreads();
+    float s[NCONV], ss[NCONV];
+#pragma unroll
+    for (int n = 0; n < NCONV; ++n) s[n] = ss[n] = 0.f;
+    const int rows = min(TH, H - r0);
+    for (int idx = threadIdx.x; idx < rows * W; idx += 256) {
+        const int rr = idx / W, f = idx % W;
+        float v[16];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[i * 4 + j] = tile[(rr + i) * TW + f + j];
+        const size_t o = plane + (size_t)(r0 + rr) * W + f;
+#pragma unroll
+        for (int n = 0; n < NCONV; ++n) {
+            float acc = bia[n];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc = fmaf(v[j], wgt[n][j], acc);
+            if (MODE == 0) a.out[n][o] = acc;
+            if (MODE != 2) {
+                s[n] += acc;
+                ss[n] = fmaf(acc, acc, ss[n]);
+            } else {
+                const int tg = nearest_src(r0 + rr, a.Hg, H), fg = nearest_src(f, a.Wg, W);
+                const size_t go = gplane + (size_t)tg * a.Wg + fg;
+                const float gate = sigmoidf_(fmaf(a.gate[go], gsc, gsh));
+                const float emb = fmaf(a.emb[go], esc, esh);
+                float y = fmaf(fmaf(acc, lsc, lsh), gate, emb);
+                if (a.addend) y += fmaf(a.addend[o], asc, ash);
+                a.out[0][o] = y;
+            }
+        }
+    }
+    if (MODE != 2) {
+#pragma unroll
+        for (int n = 0; n < NCONV; ++n) {
+            block_stats_atomic(s[n], ss[n], red, a.stats_out[n] + 2 * b);
+            __syncthreads();
+        }
+    }
+}
+
+// ---------------------------------------------------------------- stride-2 pad-1 4x4 + adaptive average pool
+// Reads d0 = gLN(c0) through the fold; writes c1 (pre-norm conv output, +stats) and p0 = adaptive_avg_pool2d(d0)
+// at the conv's output resolution (Ho = H/2, Wo = W/2).  The pool window of output (i,j) is
+// rows [floor(i*H/Ho), ceil((i+1)*H/Ho)) which always lies inside the conv window [2i-1, 2i+3).
+__global__ __launch_bounds__(256) void dw_s2_pool_kernel(DwArgs a) {
+    extern __shared__ float tile[];  // (2*TH+2) x (W+2)
+    __shared__ double red[8];
+    const int H = a.H, W = a.W, C = a.C, TH = a.TH, Ho = a.Hg, Wo = a.Wg;
+    const int c = blockIdx.y, b = blockIdx.z;
+    const int i0 = blockIdx.x * TH;
+    const int TW = W + 2, TR = 2 * TH + 2;
+    const size_t plane = ((size_t)b * C + c) * H * W;
+    float isc, ish;
+    gln_fold(a.in_stats + 2 * b, a.in_inv_count, a.in_gamma[c], a.in_beta[c], isc, ish);
+    for (int idx = threadIdx.x; idx < TR * TW; idx += 256) {
+        const int rr = idx / TW, cc = idx % TW;
+        const int t = 2 * i0 - 1 + rr, f = cc - 1;
+        float v = 0.f;
+        if (t >= 0 && t < H && f >= 0 && f < W) v = fmaf(a.x[plane + (size_t)t * W + f], isc, ish);
+        tile[idx] = v;
+    }
+    float wgt[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) wgt[j] = a.w[0][c * 16 + j];
+    const float bia = a.bias[0][c];
+    __syncthreads();
+    float s = 0.f, ss = 0.f;
+    const int rows = min(TH, Ho - i0);
+    const size_t oplane = ((size_t)b * C + c) * Ho * Wo;
+    for (int idx = threadIdx.x; idx < rows * Wo; idx += 256) {
+        const int ii = idx / Wo, j = idx % Wo;
+        const int i = i0 + ii;
+        float acc = bia;
+        // pool window in image coordinates
+        const int ts = (int)(((long long)i * H) / Ho), te = (int)(((long long)(i + 1) * H + Ho - 1) / Ho);
+        const int fs = (int)(((long long)j * W) / Wo), fe = (int)(((long long)(j + 1) * W + Wo - 1) / Wo);
+        float pool = 0.f;
+#pragma unroll
+        for (int di = 0; di < 4; ++di)
+#pragma unroll
+            for (int dj = 0; dj < 4; ++dj) {
+                const float v = tile[(2 * ii + di) * TW + 2 * j + dj];
+                acc = fmaf(v, wgt[di * 4 + dj], acc);
+                const int t = 2 * i - 1 + di, f = 2 * j - 1 + dj;
+                if (t >= ts && t < te && f >= fs && f < fe) pool += v;
+            }
+        pool /= (float)((te - ts) * (fe - fs));
+        const size_t o = oplane + (size_t)i * Wo + j;
+        a.out[0][o] = acc;
+        a.out[1][o] = pool;
+        s += acc;
+        ss = fmaf(acc, acc, ss);
+    }
+    block_stats_atomic(s, ss, red, a.stats_out[0] + 2 * b);
+}
+
+// ---------------------------------------------------------------- G-level elementwise glue
+// g = p0 + gLN(c1)           (global pooling sum, tdanet.py:116)
+__global__ __launch_bounds__(256) void g_form_kernel(const float* __restrict__ p0, const float* __restrict__ c1,
+                                                     const double* __restrict__ st1, double inv_count,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     float* __restrict__ g, int C, int HW) {
+    const int c = blockIdx.y, b = blockIdx.z;
+    float sc, sh;
+    gln_fold(st1 + 2 * b, inv_count, gamma[c], beta[c], sc, sh);
+    const size_t base = ((size_t)b * C + c) * HW;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) g[base + i] = p0[base + i] + fmaf(c1[base + i], sc, sh);
+}
+
+// xf1 = gLN(l) * sigmoid(gLN(gate)) + gLN(emb)     (same-size InjectionMultiSum, fusion.py:62-67)
+__global__ __launch_bounds__(256) void g_combine_kernel(GCombineArgs a) {
+    const int c = blockIdx.y, b = blockIdx.z;
+    float lsc, lsh, gsc, gsh, esc, esh;
+    gln_fold(a.l_stats + 2 * b, a.inv_count, a.l_gamma[c], a.l_beta[c], lsc, lsh);
+    gln_fold(a.gate_stats + 2 * b, a.inv_count, a.gate_gamma[c], a.gate_beta[c], gsc, gsh);
+    gln_fold(a.emb_stats + 2 * b, a.inv_count, a.emb_gamma[c], a.emb_beta[c], esc, esh);
+    const size_t base = ((size_t)b * a.C + c) * a.HW;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < a.HW; i += gridDim.x * 256)
+        a.out[base + i] = fmaf(fmaf(a.l[base + i], lsc, lsh), sigmoidf_(fmaf(a.gate[base + i], gsc, gsh)), fmaf(a.emb[base + i], esc, esh));
+}
+
+// (N, H, W) -> (N, W, H) through a padded 32x32 LDS tile.
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W) {
+    __shared__ float t[32][33];
+    const size_t base = (size_t)blockIdx.z * H * W;
+    const int w0 = blockIdx.x * 32, h0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8)
+        if (h0 + r < H && w0 + tx < W) t[r][tx] = x[base + (size_t)(h0 + r) * W + w0 + tx];
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8)
+        if (w0 + r < W && h0 + tx < H) y[base + (size_t)(w0 + r) * H + h0 + tx] = t[tx][r];
+}
+
+// stats of an arbitrary (B, N) tensor (used when a module is called stand-alone)
+__global__ __launch_bounds__(256) void stats_kernel(const float* __restrict__ x, double* __restrict__ stats, size_t N) {
+    __shared__ double red[8];
+    const int b = blockIdx.y;
+    float s = 0.f, ss = 0.f;
+    const float* xb = x + (size_t)b * N;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < N; i += (size_t)gridDim.x * 256) {
+        const float v = xb[i];
+        s += v;
+        ss = fmaf(v, v, ss);
+    }
+    block_stats_atomic(s, ss, red, stats + 2 * b);
+}
+
+// ---------------------------------------------------------------- launchers
+template <int NCONV, bool IN_AFFINE, int MODE>
+static int launch_dw_s1_t(const DwArgs& a, int B, hipStream_t st) {
+    const size_t lds = (size_t)(a.TH + 3) * (a.W + 3) * sizeof(float);
+    hipLaunchKernelGGL((dw_s1_kernel<NCONV, IN_AFFINE, MODE>), dim3(cdiv(a.H, a.TH), a.C, B), dim3(256), lds, st, a);
+    return rtfs_launch_status();
+}
+
+int launch_dw_s1(const DwArgs& a, int nconv, bool in_affine, int mode, int B, hipStream_t st) {
+    if (mode == 0 && nconv == 1 && !in_affine) return launch_dw_s1_t<1, false, 0>(a, B, st);
+    if (mode == 0 && nconv == 1 && in_affine) return launch_dw_s1_t<1, true, 0>(a, B, st);
+    if (mode == 0 && nconv == 2 && !in_affine) return launch_dw_s1_t<2, false, 0>(a, B, st);
+    if (mode == 0 && nconv == 4 && !in_affine) return launch_dw_s1_t<4, false, 0>(a, B, st);
+    if (mode == 0 && nconv == 3 && !in_affine) return launch_dw_s1_t<3, false, 0>(a, B, st);
+    if (mode == 1 && nconv == 1 && in_affine) return launch_dw_s1_t<1, true, 1>(a, B, st);
+    if (mode == 1 && nconv == 1 && !in_affine) return launch_dw_s1_t<1, false, 1>(a, B, st);
+    if (mode == 2 && nconv == 1 && in_affine) return launch_dw_s1_t<1, true, 2>(a, B, st);
+    if (mode == 2 && nconv == 1 && !in_affine) return launch_dw_s1_t<1, false, 2>(a, B, st);
+    return RTFS_ERR_ARG;
+}
+
+int launch_dw_s2_pool(const DwArgs& a, int B, hipStream_t st) {
+    const size_t lds = (size_t)(2 * a.TH + 2) * (a.W + 2) * sizeof(float);
+    hipLaunchKernelGGL(dw_s2_pool_kernel, dim3(cdiv(a.Hg, a.TH), a.C, B), dim3(256), lds, st, a);
+    return rtfs_launch_status();
+}
+
+int launch_g_form(const float* p0, const float* c1, const double* st1, double inv_count, const float* gamma,
+                  const float* beta, float* g, int B, int C, int HW, hipStream_t st) {
+    hipLaunchKernelGGL(g_form_kernel, dim3(cdiv(HW, 256 * 4), C, B), dim3(256), 0, st, p0, c1, st1, inv_count, gamma, beta, g, C, HW);
+    return rtfs_launch_status();
+}
+
+int launch_g_combine(const GCombineArgs& a, int B, hipStream_t st) {
+    hipLaunchKernelGGL(g_combine_kernel, dim3(cdiv(a.HW, 256 * 4), a.C, B), dim3(256), 0, st, a);
+    return rtfs_launch_status();
+}
+
+int launch_transpose(const float* x, float* y, int N, int H, int W, hipStream_t st) {
+    hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(W, 32), cdiv(H, 32), N), dim3(256), 0, st, x, y, H, W);
+    return rtfs_launch_status();
+}
+
+int launch_stats(const float* x, double* stats, int B, size_t N, hipStream_t st) {
+    int gx = (int)((N + 256 * 16 - 1) / (256 * 16));
+    gx = gx < 1 ? 1 : (gx > 1024 ? 1024 : gx);
+    hipLaunchKernelGGL(stats_kernel, dim3(gx, B), dim3(256), 0, st, x, stats, N);
+    return rtfs_launch_status();
+}

@@ -1,0 +1,163 @@
+// STFT encoder / iSTFT decoder kernels (gfx950).
+//   stft_kernel        reference TDAVNet/encoder.py:164-172  (torch.stft + stack(re,im).transpose)
+//   enc_conv_kernel    reference TDAVNet/encoder.py:146-157,173 (Conv2d 2->C 3x3 'same', no bias) + gLN stats of its output
+//   dec_shift_sum_istft reference TDAVNet/decoder.py:117-128   (tail of ConvTranspose2d + torch.istft)
+#include "common.h"
+#include "kernels.h"
+
+#define NFFT 256
+#define HOP 128
+#define NBIN 129
+
+// One workgroup per (frame t, batch b): 256 threads.  Direct 256-point real DFT with an exact
+// table of cos/sin(2*pi*k/256) built in LDS (angle index reduced mod 256 in integers, so the
+// bin indexing is exact).  Output spec (B,2,T,F): [b][0][t][f] = Re, [b][1][t][f] = Im.
+__global__ __launch_bounds__(256) void stft_kernel(const float* __restrict__ wav, float* __restrict__ spec, int L, int T) {
+    __shared__ float xw[NFFT];
+    __shared__ float ct[NFFT];
+    __shared__ float st[NFFT];
+    const int t = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    {
+        float s, c;
+        sincospif((float)tid * (1.0f / 128.0f), &s, &c);
+        ct[tid] = c;
+        st[tid] = s;
+        int n = t * HOP + tid - NFFT / 2;  // index into the un-padded signal
+        if (n < 0) n = -n;                 // reflect (no edge repeat)
+        if (n >= L) n = 2 * (L - 1) - n;
+        n = n < 0 ? 0 : n;
+        const float w = 0.5f - 0.5f * cospif((float)tid * (1.0f / 128.0f));  // periodic Hann
+        xw[tid] = wav[(size_t)b * L + n] * w;
+    }
+    __syncthreads();
+    if (tid < NBIN) {
+        float re = 0.f, im = 0.f;
+#pragma unroll 8
+        for (int n = 0; n < NFFT; ++n) {
+            const int k = (tid * n) & (NFFT - 1);
+            const float x = xw[n];
+            re = fmaf(x, ct[k], re);
+            im = fmaf(-x, st[k], im);
+        }
+        const size_t plane = (size_t)T * NBIN;
+        spec[((size_t)b * 2 + 0) * plane + (size_t)t * NBIN + tid] = re;
+        spec[((size_t)b * 2 + 1) * plane + (size_t)t * NBIN + tid] = im;
+    }
+}
+
+// Conv2d(2 -> C, 3x3, 'same', no bias) over spec (B,2,T,F) -> a0 (B,C,T,F) with channel stride cs.
+// One thread per pixel keeps its 18 taps in registers and walks the C output channels; the
+// weights are wave-uniform (scalar loads).  Also accumulates (sum, sumsq) of a0 per sample.
+__global__ __launch_bounds__(256) void enc_conv_kernel(const float* __restrict__ spec, const float* __restrict__ w,
+                                                       float* __restrict__ a0, double* __restrict__ stats, int C, int T,
+                                                       int F, size_t cs, size_t bs) {
+    __shared__ double red[8];
+    const int P = T * F;
+    const int b = blockIdx.y;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    float tap[18];
+    const bool live = p < P;
+    {
+        const int t = live ? p / F : 0, f = live ? p % F : 0;
+#pragma unroll
+        for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+            for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+                for (int df = 0; df < 3; ++df) {
+                    const int tt = t + dt - 1, ff = f + df - 1;
+                    const bool ok = live && tt >= 0 && tt < T && ff >= 0 && ff < F;
+                    tap[ci * 9 + dt * 3 + df] = ok ? spec[((size_t)b * 2 + ci) * P + (size_t)tt * F + ff] : 0.f;
+                }
+    }
+    float s = 0.f, ss = 0.f;
+    float* out = a0 + (size_t)b * bs + p;
+    for (int c = 0; c < C; ++c) {
+        const float* wc = w + c * 18;
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < 18; ++j) acc = fmaf(tap[j], wc[j], acc);
+        if (live) {
+            out[(size_t)c * cs] = acc;
+            s += acc;
+            ss = fmaf(acc, acc, ss);
+        }
+    }
+    if (stats) block_stats_atomic(s, ss, red, stats + 2 * b);
+}
+
+// Tail of the decoder.  z (B,18,T,F) holds the per-tap pointwise products
+//   z[b][(o*3+dt)*3+df][t][f] = sum_c x[b][c][t][f] * Wdec[c][o][dt][df]
+// ConvTranspose2d(pad 1): y[o][t][f] = sum_{dt,df} z[o,dt,df][t+1-dt][f+1-df].
+// Then torch.istft: frame-wise irfft(256) * hann, overlap-add, / sum(w^2), drop 128, keep L.
+// One workgroup per hop-block s of 128 output samples: the two frames that overlap it are
+// t0 = s (second half, m = 128 + n) and t1 = s + 1 (first half, m = n).
+__global__ __launch_bounds__(128) void dec_shift_sum_istft_kernel(const float* __restrict__ z, float* __restrict__ wav,
+                                                                  int T, int F, int L, size_t zcs, size_t zbs) {
+    __shared__ float re[2][NBIN];
+    __shared__ float im[2][NBIN];
+    __shared__ float ct[NFFT];
+    __shared__ float st[NFFT];
+    const int s = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    for (int k = tid; k < NFFT; k += 128) {
+        float sn, cs;
+        sincospif((float)k * (1.0f / 128.0f), &sn, &cs);
+        ct[k] = cs;
+        st[k] = sn;
+    }
+    for (int idx = tid; idx < 2 * 2 * NBIN; idx += 128) {
+        const int fr = idx / (2 * NBIN), o = (idx / NBIN) & 1, f = idx % NBIN;
+        const int t = s + fr;
+        float acc = 0.f;
+        if (t < T) {
+#pragma unroll
+            for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+                for (int df = 0; df < 3; ++df) {
+                    const int tt = t + 1 - dt, ff = f + 1 - df;
+                    if (tt >= 0 && tt < T && ff >= 0 && ff < F)
+                        acc += z[(size_t)b * zbs + (size_t)((o * 3 + dt) * 3 + df) * zcs + (size_t)tt * F + ff];
+                }
+        }
+        (o == 0 ? re : im)[fr][f] = acc;
+    }
+    __syncthreads();
+    const int n = s * HOP + tid;  // output sample
+    if (n >= L) return;
+    float num = 0.f, env = 0.f;
+#pragma unroll
+    for (int fr = 0; fr < 2; ++fr) {
+        const int t = s + fr;
+        if (t >= T) continue;
+        const int m = fr == 0 ? tid + HOP : tid;  // sample index inside the frame
+        // irfft: bins 0 and 128 contribute their real part only
+        float acc = re[fr][0] + ((m & 1) ? -re[fr][128] : re[fr][128]);
+        float a2 = 0.f;
+        for (int f = 1; f < 128; ++f) {
+            const int k = (f * m) & (NFFT - 1);
+            a2 = fmaf(re[fr][f], ct[k], a2);
+            a2 = fmaf(-im[fr][f], st[k], a2);
+        }
+        acc = (acc + 2.f * a2) * (1.0f / NFFT);
+        const float w = 0.5f - 0.5f * cospif((float)m * (1.0f / 128.0f));
+        num = fmaf(acc, w, num);
+        env = fmaf(w, w, env);
+    }
+    wav[(size_t)b * L + n] = num / env;
+}
+
+int launch_stft(const float* wav, float* spec, int B, int L, int T, hipStream_t st) {
+    hipLaunchKernelGGL(stft_kernel, dim3(T, B), dim3(256), 0, st, wav, spec, L, T);
+    return rtfs_launch_status();
+}
+
+int launch_enc_conv(const float* spec, const float* w, float* a0, double* stats, int B, int C, int T, int F, size_t cs,
+                    size_t bs, hipStream_t st) {
+    hipLaunchKernelGGL(enc_conv_kernel, dim3(cdiv(T * F, 256), B), dim3(256), 0, st, spec, w, a0, stats, C, T, F, cs, bs);
+    return rtfs_launch_status();
+}
+
+int launch_dec_istft(const float* z, float* wav, int B, int T, int F, int L, size_t zcs, size_t zbs, hipStream_t st) {
+    hipLaunchKernelGGL(dec_shift_sum_istft_kernel, dim3(cdiv(L, HOP), B), dim3(128), 0, st, z, wav, T, F, L, zcs, zbs);
+    return rtfs_launch_status();
+}

@@ -1,0 +1,150 @@
+// Internal (C++) launch interface between the C-ABI layer (api.hip) and the kernel files.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+struct PwArgs {
+    const float* x = nullptr;     // (B, CIN, P)
+    const float* x2 = nullptr;    // optional second addend (gateway: the bottleneck residual a1)
+    float* res_out = nullptr;     // gateway: PReLU(dw1x1(x [+x2])) written through, (B, CIN, P)
+    const float* wt = nullptr;    // (CIN, COUT) transposed 1x1 weight
+    const float* bias = nullptr;  // (COUT)
+    const float* aux = nullptr;   // EPI_BIAS_RES: residual (B,COUT,P); EPI_S3: encoder output a0 (B,COUT,P)
+    float* out = nullptr;         // (B, COUT, P)
+    const double* stats = nullptr;  // PRO_GLN_RELU: (B,2) sum / sumsq of x
+    double inv_count = 0;
+    const float* gamma = nullptr;
+    const float* beta = nullptr;
+    const float* gw = nullptr;  // gateway depthwise scale (CIN)
+    const float* gb = nullptr;  // gateway depthwise bias (CIN)
+    const float* slope = nullptr;  // PReLU slope (1)
+    int P = 0;
+    int cout_live = 0;  // EPI_TAPS: number of real output channels
+};
+
+int launch_stft(const float* wav, float* spec, int B, int L, int T, hipStream_t st);
+int launch_enc_conv(const float* spec, const float* w, float* a0, double* stats, int B, int C, int T, int F, size_t cs,
+                    size_t bs, hipStream_t st);
+int launch_dec_istft(const float* z, float* wav, int B, int T, int F, int L, size_t zcs, size_t zbs, hipStream_t st);
+
+int launch_pw_audio_bn(const PwArgs& a, int B, hipStream_t st);
+int launch_pw_gateway_proj(const PwArgs& a, int B, hipStream_t st);
+int launch_pw_residual(const PwArgs& a, int B, hipStream_t st);
+int launch_pw_s3(const PwArgs& a, int B, hipStream_t st);
+int launch_pw_dec_taps(const PwArgs& a, int B, hipStream_t st);
+
+// Depthwise 4x4 family.  Tensors are (B, C, H, W) contiguous.
+struct DwArgs {
+    const float* x = nullptr;
+    // input fold (IN_AFFINE): x is a pre-norm conv output, its gLN is applied at load time
+    const double* in_stats = nullptr;
+    double in_inv_count = 0;
+    const float* in_gamma = nullptr;
+    const float* in_beta = nullptr;
+    const float* w[4] = {nullptr, nullptr, nullptr, nullptr};     // (C,16) each
+    const float* bias[4] = {nullptr, nullptr, nullptr, nullptr};  // (C) or null
+    float* out[4] = {nullptr, nullptr, nullptr, nullptr};
+    double* stats_out[4] = {nullptr, nullptr, nullptr, nullptr};  // (B,2) each
+    int C = 0, H = 0, W = 0, TH = 8;
+    // MODE 2 (TFAR apply) / stride-2 kernel: the low-resolution side
+    int Hg = 0, Wg = 0;
+    const double* loc_stats = nullptr;
+    double loc_inv_count = 0;
+    const float* loc_gamma = nullptr;
+    const float* loc_beta = nullptr;
+    const float* gate = nullptr;
+    const double* gate_stats = nullptr;
+    const float* gate_gamma = nullptr;
+    const float* gate_beta = nullptr;
+    const float* emb = nullptr;
+    const double* emb_stats = nullptr;
+    const float* emb_gamma = nullptr;
+    const float* emb_beta = nullptr;
+    double g_inv_count = 0;
+    const float* addend = nullptr;  // optional "+ d0" (pre-norm c0 with its fold)
+    const double* add_stats = nullptr;
+    double add_inv_count = 0;
+    const float* add_gamma = nullptr;
+    const float* add_beta = nullptr;
+};
+
+struct GCombineArgs {
+    const float *l, *gate, *emb;
+    const double *l_stats, *gate_stats, *emb_stats;
+    const float *l_gamma, *l_beta, *gate_gamma, *gate_beta, *emb_gamma, *emb_beta;
+    double inv_count;
+    float* out;
+    int C, HW;
+};
+
+int launch_dw_s1(const DwArgs& a, int nconv, bool in_affine, int mode, int B, hipStream_t st);
+int launch_dw_s2_pool(const DwArgs& a, int B, hipStream_t st);
+int launch_g_form(const float* p0, const float* c1, const double* st1, double inv_count, const float* gamma,
+                  const float* beta, float* g, int B, int C, int HW, hipStream_t st);
+int launch_g_combine(const GCombineArgs& a, int B, hipStream_t st);
+int launch_transpose(const float* x, float* y, int N, int H, int W, hipStream_t st);
+int launch_stats(const float* x, double* stats, int B, size_t N, hipStream_t st);
+
+// Fused dual-path SRU sweep.  Sequence n = (b, row): element (c, s) at
+//   x[(n / R) * bstride + (n % R) * rstride + c * cstride + s],  s = 0..Ls-1 contiguous.
+struct DpArgs {
+    const float* x = nullptr;
+    float* out = nullptr;
+    int R = 0, Ls = 0;
+    size_t bstride = 0, rstride = 0, cstride = 0;
+    const float* ln_gamma = nullptr;  // (64)
+    const float* ln_beta = nullptr;   // (64)
+    const float* W0 = nullptr;        // (512, 256)  layer-0 projection, column (dir*32+j)*4+m
+    const float* Wl = nullptr;        // 3 x (64, 256) layers 1-3, k=3 columns padded to 4 (m=3 zero)
+    const float* wc = nullptr;        // 4 x (128)   [v_f(dir,j) | v_r(dir,j)]
+    const float* bias = nullptr;      // 4 x (128)   [b_f | b_r]
+    const float* Wt = nullptr;        // (512 = kk*64+ci, 64 co)  ConvTranspose1d weight, re-ordered
+    const float* bt = nullptr;        // (64)
+};
+size_t dualpath_lds_bytes(int Ls);
+int launch_dualpath(const DpArgs& a, int nseq, hipStream_t st);
+int launch_sru_standalone(const float* x, float* h, int L, int N, const float* W0, const float* Wl, const float* wc,
+                          const float* bias, hipStream_t st);
+
+// TF attention
+struct RowCanArgs {
+    const float* x = nullptr;      // (B,64,T,64)
+    const float* wt = nullptr;     // (64, NOUT) transposed 1x1 weights of every ConvActNorm in the call
+    const float* bias = nullptr;   // (NOUT)
+    const float* slope = nullptr;  // (ngroups) PReLU slope of each ConvActNorm
+    const float* gamma = nullptr;  // (NOUT, 64)
+    const float* beta = nullptr;   // (NOUT, 64)
+    int ngroups = 0;
+    int group_start[13] = {0};     // channel range of each LayerNorm group
+    unsigned char group_of[96] = {0};
+    int T = 0;
+    float *q = nullptr, *k = nullptr, *v = nullptr;  // NOUT == 96
+    const float* res = nullptr;                       // NOUT == 64: residual
+    float* out = nullptr;
+};
+struct AttnArgs {
+    const float *q = nullptr, *k = nullptr, *v = nullptr;
+    float* out = nullptr;  // (B,64,T,64), channel = head*16 + c
+    int T = 0;
+    float scale = 0.f;
+};
+int launch_row_can_qkv(const RowCanArgs& a, int B, hipStream_t st);
+int launch_row_can_proj(const RowCanArgs& a, int B, hipStream_t st);
+int launch_attn_core(const AttnArgs& a, int B, hipStream_t st);
+size_t attn_core_lds_bytes(int T);
+
+// CAF
+struct CafArgs {
+    const float* audio = nullptr;  // (B,256,T,F)
+    const float* video = nullptr;  // (B,512,Tv)
+    float* out = nullptr;          // (B,256,T,F)
+    float* r_out = nullptr;        // (B,256,Tv) workspace: resize(video)
+    float* att_out = nullptr;      // (B,256,Tv) workspace: softmax attention
+    int T = 0, F = 0, Tv = 0;
+    const float *w_key = nullptr, *bn_key = nullptr;  // (256), (4,256) = [weight | bias | running_mean | running_var]
+    const float *w_val = nullptr, *bn_val = nullptr;
+    const float *w_att = nullptr, *b_att = nullptr, *g_att = nullptr, *be_att = nullptr;          // (1024,2),(1024)x3
+    const float *w_resize = nullptr, *b_resize = nullptr, *g_resize = nullptr, *be_resize = nullptr;  // (256,2),(256)x3
+};
+int launch_caf_video(const CafArgs& a, int B, hipStream_t st);
+int launch_caf_apply(const CafArgs& a, int B, hipStream_t st);

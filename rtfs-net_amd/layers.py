@@ -1,0 +1,467 @@
+"""Layer-level mirror of the reference's ``src/models/layers`` for the RTFS-Net path.
+
+Same class names, constructor keywords and parameter / buffer names as the reference (so
+``state_dict`` keys line up), but the audio-path modules do no arithmetic in Python: their
+``forward`` hands raw device pointers to ``librtfs_amd.so``.  Only the 0.004-GMAC video-side
+(1-D) modules keep a stock-torch-op ``forward``.
+
+reference files: layers/conv_layers.py, normalizations.py, activations.py, rnn_layers.py,
+attention.py, fusion.py.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib, packing
+
+EPS = 1e-5
+
+
+# ----------------------------------------------------------------------------- pack cache
+class PackedModule(nn.Module):
+    """Caches the flat parameter pack of a module; rebuilt when any tensor is replaced, moved or
+    modified in place (tracked through data_ptr + _version)."""
+
+    _pack_fn = None  # staticmethod(packing.pack_*) set by subclasses
+
+    def _state_tensors(self):
+        return self.state_dict(keep_vars=True)
+
+    def pack(self) -> torch.Tensor:
+        sd = self._state_tensors()
+        key = tuple((v.data_ptr(), v._version) for v in sd.values())
+        if getattr(self, "_pack_key", None) != key:
+            with torch.no_grad():
+                pk = type(self)._pack_fn(sd)
+            object.__setattr__(self, "_pack_buf", pk)
+            object.__setattr__(self, "_pack_key", key)
+        return self._pack_buf
+
+    def _guard(self, *tensors):
+        _lib.need_gpu(*tensors)
+        if self.training:
+            raise RuntimeError(
+                f"{type(self).__name__}: only the eval-mode forward is implemented on the MI355X path "
+                "(call .eval(); the backward pass is not built yet)"
+            )
+
+
+# ----------------------------------------------------------------------------- normalisations / activations
+class GlobalLayerNorm(nn.Module):
+    """gLN = GroupNorm(1, C) (reference normalizations.py:8-17); parameter keys ``norm.weight/bias``."""
+
+    def __init__(self, num_channels: int = 1, eps: float = EPS):
+        super().__init__()
+        self.num_channels, self.eps = num_channels, eps
+        self.norm = nn.GroupNorm(1, num_channels, eps=eps)
+
+    def forward(self, x):
+        return self.norm(x)
+
+
+class LayerNormalization4D(nn.Module):
+    """Reference normalizations.py:20-41: gamma/beta of shape (1, C, 1, F); statistics over C when F == 1,
+    over (C, F) otherwise."""
+
+    def __init__(self, input_dimension, eps: float = EPS):
+        super().__init__()
+        c, f = input_dimension
+        self.dim = (1, 3) if f > 1 else (1,)
+        self.gamma = nn.Parameter(torch.ones(1, c, 1, f))
+        self.beta = nn.Parameter(torch.zeros(1, c, 1, f))
+        self.eps = eps
+
+    def forward(self, x):
+        mu = x.mean(dim=self.dim, keepdim=True)
+        sd = torch.sqrt(x.var(dim=self.dim, unbiased=False, keepdim=True) + self.eps)
+        return (x - mu) / sd * self.gamma + self.beta
+
+
+gLN = GlobalLayerNorm
+LN4d = LayerNormalization4D
+_LOCAL_NORMS = {"gLN": GlobalLayerNorm, "GlobalLayerNorm": GlobalLayerNorm, "LayerNormalization4D": LayerNormalization4D, "LN4d": LayerNormalization4D}
+
+
+def norm_class(identifier):
+    if identifier is None:
+        return nn.Identity
+    if callable(identifier):
+        return identifier
+    if isinstance(identifier, str):
+        cls = getattr(nn, identifier, None) or _LOCAL_NORMS.get(identifier)
+        if cls is not None:
+            return cls
+    raise ValueError("Could not interpret normalization identifier: " + str(identifier))
+
+
+def act_class(identifier):
+    if identifier is None:
+        return nn.Identity
+    if callable(identifier):
+        return identifier
+    if isinstance(identifier, str) and hasattr(nn, identifier):
+        return getattr(nn, identifier)
+    raise ValueError("Could not interpret activation identifier: " + str(identifier))
+
+
+# ----------------------------------------------------------------------------- conv holders
+def _config_of(module):
+    return {k: v for k, v in module.__dict__.items() if not k.startswith("_") and k != "training" and not callable(v)}
+
+
+class ConvNormAct(nn.Module):
+    """Parameter holder with the reference's layout ``full_layer = Sequential(pre_norm, pre_act, conv, norm, act)``
+    (conv_layers.py:65-129), hence keys ``full_layer.{0,2,3,4}.*``.  kernel_size <= 0 makes every stage an
+    Identity and out_chan = in_chan."""
+
+    def __init__(self, in_chan=1, out_chan=1, kernel_size=-1, stride=1, groups=1, dilation=1, padding=None,
+                 pre_norm_type=None, pre_act_type=None, norm_type=None, act_type=None, xavier_init=False, bias=True,
+                 is2d=False, *args, **kwargs):
+        super().__init__()
+        self.in_chan = in_chan
+        self.out_chan = out_chan if kernel_size > 0 else in_chan
+        self.kernel_size, self.stride, self.groups, self.dilation = kernel_size, stride, groups, dilation
+        self.pre_norm_type, self.pre_act_type, self.norm_type, self.act_type = pre_norm_type, pre_act_type, norm_type, act_type
+        self.xavier_init, self.bias = xavier_init, bias
+        self.padding = padding
+        if self.padding is None:
+            self.padding = dilation * (kernel_size - 1) // 2 if stride > 1 else "same"
+        stages = [norm_class(pre_norm_type)(in_chan), act_class(pre_act_type)()]
+        if kernel_size > 0:
+            conv = (nn.Conv2d if is2d else nn.Conv1d)(in_chan, self.out_chan, kernel_size, stride=stride, padding=self.padding,
+                                                      dilation=dilation, groups=groups, bias=bias)
+            if xavier_init:
+                nn.init.xavier_uniform_(conv.weight)
+        else:
+            conv = nn.Identity()
+        stages += [conv, norm_class(norm_type)(self.out_chan), act_class(act_type)()]
+        self.full_layer = nn.Sequential(*stages)
+
+    def forward(self, x):
+        return self.full_layer(x)
+
+    def get_config(self):
+        return _config_of(self)
+
+
+class ConvActNorm(nn.Module):
+    """conv -> act -> norm (conv_layers.py:142-215); keys ``conv.*``, ``act.weight``, ``norm.gamma/beta``."""
+
+    def __init__(self, in_chan=1, out_chan=1, kernel_size=-1, stride=1, groups=1, dilation=1, padding=None, norm_type=None,
+                 act_type=None, n_freqs=-1, xavier_init=False, bias=True, is2d=False, *args, **kwargs):
+        super().__init__()
+        self.in_chan, self.out_chan, self.kernel_size, self.stride = in_chan, out_chan, kernel_size, stride
+        self.groups, self.dilation, self.norm_type, self.act_type, self.n_freqs = groups, dilation, norm_type, act_type, n_freqs
+        self.xavier_init, self.bias = xavier_init, bias
+        self.padding = (0 if stride > 1 else "same") if padding is None else padding
+        if kernel_size > 0:
+            self.conv = (nn.Conv2d if is2d else nn.Conv1d)(in_chan, out_chan, kernel_size, stride=stride, padding=self.padding,
+                                                           dilation=dilation, groups=groups, bias=bias)
+            if xavier_init:
+                nn.init.xavier_uniform_(self.conv.weight)
+        else:
+            self.conv = nn.Identity()
+        self.act = act_class(act_type)()
+        self.norm = norm_class(norm_type)((out_chan, n_freqs) if norm_type == "LayerNormalization4D" else out_chan)
+
+    def forward(self, x):
+        return self.norm(self.act(self.conv(x)))
+
+    def get_config(self):
+        return _config_of(self)
+
+
+class FeedForwardNetwork(nn.Module):
+    """Video-side FFN (conv_layers.py:218-259): 1x1 -> dw conv + ReLU -> 1x1, gLN after the 1x1s, + input."""
+
+    def __init__(self, in_chan, hid_chan, kernel_size=5, norm_type="gLN", act_type="ReLU", dropout=0, is2d=False, *args, **kwargs):
+        super().__init__()
+        self.in_chan, self.hid_chan, self.kernel_size = in_chan, hid_chan, kernel_size
+        self.norm_type, self.act_type, self.dropout, self.is2d = norm_type, act_type, dropout, is2d
+        self.encoder = ConvNormAct(in_chan, hid_chan, 1, norm_type=norm_type, bias=False, is2d=is2d)
+        self.refiner = ConvNormAct(hid_chan, hid_chan, kernel_size, groups=hid_chan, act_type=act_type, is2d=is2d)
+        self.decoder = ConvNormAct(hid_chan, in_chan, 1, norm_type=norm_type, bias=False, is2d=is2d)
+        self.dropout_layer = nn.Identity()  # DropPath: identity in eval, the only supported mode
+
+    def forward(self, x):
+        return self.decoder(self.refiner(self.encoder(x))) + x
+
+
+# ----------------------------------------------------------------------------- SRU operator
+class SRUCell(nn.Module):
+    """Parameters of one upstream ``sru.SRUCell`` (names weight / weight_c / bias)."""
+
+    def __init__(self, input_size, hidden_size, bidirectional=True):
+        super().__init__()
+        out = hidden_size * (2 if bidirectional else 1)
+        k = 4 if input_size != out else 3
+        self.input_size, self.hidden_size, self.num_matrices = input_size, hidden_size, k
+        self.weight = nn.Parameter(torch.empty(input_size, out * k))
+        self.weight_c = nn.Parameter(torch.empty(2 * out))
+        self.bias = nn.Parameter(torch.zeros(2 * out))
+        self.reset_parameters()
+
+    @torch.no_grad()
+    def reset_parameters(self):
+        # upstream v2 defaults: weight ~ U(+-sqrt(3/in)), gate columns and weight_c scaled by sqrt(0.5), bias 0
+        lim = (3.0 / self.input_size) ** 0.5
+        self.weight.uniform_(-lim, lim)
+        w = self.weight.view(self.input_size, -1, self.num_matrices)
+        w[:, :, 1].mul_(0.5 ** 0.5)
+        w[:, :, 2].mul_(0.5 ** 0.5)
+        self.weight_c.uniform_(-(3.0 ** 0.5), 3.0 ** 0.5).mul_(0.5 ** 0.5)
+        self.bias.zero_()
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        state_dict.pop(prefix + "scale_x", None)  # upstream buffer; rescale is off at the reference call site
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
+
+def _sru_pack(sd):
+    """A DUALPATH pack whose SRU part is filled and the rest zero (what rtfs_sru_f32 reads)."""
+    full = {"norm.gamma": sd["rnn_lst.0.weight"].new_zeros(64), "norm.beta": sd["rnn_lst.0.weight"].new_zeros(64),
+            "linear.weight": sd["rnn_lst.0.weight"].new_zeros(64, 64, 8), "linear.bias": sd["rnn_lst.0.weight"].new_zeros(64)}
+    full.update({"rnn." + k: v for k, v in sd.items()})
+    return packing.pack_dualpath(full)
+
+
+class SRU(PackedModule):
+    """Drop-in for ``sru.SRU(input_size=512, hidden_size=32, num_layers=4, bidirectional=True)`` as called at
+    reference rnn_layers.py:99-105,150: forward(x (L,N,512)) -> (h (L,N,64), None)."""
+
+    _pack_fn = staticmethod(_sru_pack)
+
+    def __init__(self, input_size, hidden_size, num_layers=2, bidirectional=False, **kwargs):
+        super().__init__()
+        if not (input_size == 512 and hidden_size == 32 and num_layers == 4 and bidirectional):
+            raise ValueError("the MI355X SRU kernel is built for input 512, hidden 32, 4 layers, bidirectional")
+        self.input_size, self.hidden_size, self.num_layers, self.bidirectional = input_size, hidden_size, num_layers, bidirectional
+        self.rnn_lst = nn.ModuleList([SRUCell(input_size if i == 0 else 2 * hidden_size, hidden_size, True) for i in range(num_layers)])
+
+    def forward(self, x):
+        self._guard(x)
+        lib = _lib.load()
+        x = x.contiguous()
+        L, N, _ = x.shape
+        h = torch.empty(L, N, 64, device=x.device, dtype=torch.float32)
+        ws = _lib.workspace(lib.rtfs_sru_workspace_bytes(L, N), x.device)
+        _lib.check(lib.rtfs_sru_f32(_lib.ptr(x), _lib.ptr(self.pack()), _lib.ptr(h), L, N, _lib.ptr(ws), ws.numel(), _lib.stream_of(x)), "rtfs_sru_f32")
+        return h, None
+
+
+# ----------------------------------------------------------------------------- dual-path RNN
+class DualPathRNN(PackedModule):
+    """reference rnn_layers.py:62-162 with rnn_type SRU.  x (B,64,T,F) -> same shape."""
+
+    _pack_fn = staticmethod(packing.pack_dualpath)
+
+    def __init__(self, in_chan, hid_chan, dim, kernel_size=8, stride=1, rnn_type="LSTM", num_layers=1,
+                 norm_type="LayerNormalization4D", act_type="Tanh", bidirectional=True, apply_ffn=False, *args, **kwargs):
+        super().__init__()
+        if not (rnn_type == "SRU" and in_chan == 64 and hid_chan == 32 and kernel_size == 8 and stride == 1 and num_layers == 4
+                and bidirectional and norm_type == "LayerNormalization4D" and not apply_ffn and dim in (3, 4)):
+            raise ValueError("MI355X DualPathRNN supports the RTFS-Net yaml configuration only "
+                             "(SRU, in 64, hid 32, kernel 8, stride 1, 4 layers, bidirectional, LN4D)")
+        self.in_chan, self.hid_chan, self.dim, self.kernel_size, self.stride = in_chan, hid_chan, dim, kernel_size, stride
+        self.rnn_type, self.num_layers, self.norm_type, self.act_type = rnn_type, num_layers, norm_type, act_type
+        self.bidirectional, self.apply_ffn = bidirectional, apply_ffn
+        self.num_direction = 2
+        self.unfolded_chan = in_chan * kernel_size
+        self.rnn_out_chan = hid_chan * 2
+        self.norm = LayerNormalization4D((in_chan, 1))
+        self.rnn = SRU(self.unfolded_chan, hid_chan, num_layers=num_layers, bidirectional=True)
+        self.linear = nn.ConvTranspose1d(self.rnn_out_chan, in_chan, kernel_size, stride=stride)
+
+    def forward(self, x):
+        self._guard(x)
+        lib = _lib.load()
+        x = x.contiguous()
+        B, C, T, Fq = x.shape
+        if (T if self.dim == 3 else Fq) < self.kernel_size:
+            raise ValueError(f"sweep axis shorter than kernel_size {self.kernel_size}")  # nn.Unfold raises in the reference
+        out = torch.empty_like(x)
+        ws = _lib.workspace(lib.rtfs_dualpath_workspace_bytes(B, T, Fq), x.device)
+        _lib.check(lib.rtfs_dualpath_sru_f32(_lib.ptr(x), _lib.ptr(self.pack()), _lib.ptr(out), B, T, Fq, self.dim, _lib.ptr(ws),
+                                             ws.numel(), _lib.stream_of(x)), "rtfs_dualpath_sru_f32")
+        return out
+
+
+# ----------------------------------------------------------------------------- TF self-attention
+class MultiHeadSelfAttention2D(PackedModule):
+    """reference attention.py:76-189 (4 heads, hid_chan 4, n_freqs 64, dim 3)."""
+
+    _pack_fn = staticmethod(packing.pack_attention)
+
+    def __init__(self, in_chan, n_freqs, n_head=4, hid_chan=4, act_type="PReLU", norm_type="LayerNormalization4D", dim=3, *args, **kwargs):
+        super().__init__()
+        if not (in_chan == 64 and n_freqs == 64 and n_head == 4 and hid_chan == 4 and act_type == "PReLU"
+                and norm_type == "LayerNormalization4D" and dim == 3):
+            raise ValueError("MI355X MultiHeadSelfAttention2D supports in_chan 64, n_freqs 64, 4 heads, hid_chan 4, dim 3")
+        self.in_chan, self.n_freqs, self.n_head, self.hid_chan = in_chan, n_freqs, n_head, hid_chan
+        self.act_type, self.norm_type, self.dim = act_type, norm_type, dim
+        mk = lambda oc: ConvActNorm(in_chan, oc, 1, act_type=act_type, norm_type=norm_type, n_freqs=n_freqs, is2d=True)
+        self.Queries = nn.ModuleList([mk(hid_chan) for _ in range(n_head)])
+        self.Keys = nn.ModuleList([mk(hid_chan) for _ in range(n_head)])
+        self.Values = nn.ModuleList([mk(in_chan // n_head) for _ in range(n_head)])
+        self.attn_concat_proj = mk(in_chan)
+
+    def forward(self, x):
+        self._guard(x)
+        lib = _lib.load()
+        x = x.contiguous()
+        B, C, T, Fq = x.shape
+        if C != 64 or Fq != 64:
+            raise ValueError("expected (B, 64, T, 64)")
+        out = torch.empty_like(x)
+        ws = _lib.workspace(lib.rtfs_tf_attention_workspace_bytes(B, T), x.device)
+        _lib.check(lib.rtfs_tf_attention_f32(_lib.ptr(x), _lib.ptr(self.pack()), _lib.ptr(out), B, T, _lib.ptr(ws), ws.numel(),
+                                             _lib.stream_of(x)), "rtfs_tf_attention_f32")
+        return out
+
+
+# ----------------------------------------------------------------------------- TFAR
+class InjectionMultiSum(PackedModule):
+    """reference layers/fusion.py:9-69.  2-D (audio) instances run on the HIP path; 1-D (video) ones on torch ops."""
+
+    _pack_fn = staticmethod(packing.pack_tfar)
+
+    def __init__(self, in_chan, kernel_size, norm_type="gLN", is2d=False, *args, **kwargs):
+        super().__init__()
+        self.in_chan, self.kernel_size, self.norm_type, self.is2d = in_chan, kernel_size, norm_type, is2d
+        mk = lambda act=None: ConvNormAct(in_chan, in_chan, kernel_size, groups=in_chan, norm_type=norm_type, act_type=act, bias=False, is2d=is2d)
+        self.local_embedding = mk()
+        self.global_embedding = mk()
+        self.global_gate = mk("Sigmoid")
+
+    def forward(self, local_features, global_features):
+        if not self.is2d:
+            return self._forward_1d(local_features, global_features)
+        self._guard(local_features, global_features)
+        if self.in_chan != 64 or self.kernel_size != 4 or self.norm_type != "gLN":
+            raise ValueError("MI355X TFAR kernel: in_chan 64, kernel 4, gLN")
+        lib = _lib.load()
+        loc, glo = local_features.contiguous(), global_features.contiguous()
+        B, _, H, W = loc.shape
+        Hg, Wg = glo.shape[-2:]
+        out = torch.empty_like(loc)
+        ws = _lib.workspace(lib.rtfs_tfar_workspace_bytes(B, H, W, Hg, Wg), loc.device)
+        _lib.check(lib.rtfs_tfar_f32(_lib.ptr(loc), _lib.ptr(glo), _lib.ptr(self.pack()), _lib.ptr(out), B, H, W, Hg, Wg, _lib.ptr(ws),
+                                     ws.numel(), _lib.stream_of(loc)), "rtfs_tfar_f32")
+        return out
+
+    def _forward_1d(self, loc, glo):
+        n_new, n_old = loc.shape[-1], glo.shape[-1]
+        le = self.local_embedding(loc)
+        if n_new > n_old:
+            ge = F.interpolate(self.global_embedding(glo), size=n_new, mode="nearest")
+            gate = F.interpolate(self.global_gate(glo), size=n_new, mode="nearest")
+        else:
+            gi = F.interpolate(glo, size=n_new, mode="nearest")
+            ge, gate = self.global_embedding(gi), self.global_gate(gi)
+        return le * gate + ge
+
+
+# ----------------------------------------------------------------------------- CAF cell
+class ATTNFusionCell(PackedModule):
+    """reference layers/fusion.py:194-274 (the CAF block's arithmetic)."""
+
+    _pack_fn = staticmethod(packing.pack_caf)
+
+    def __init__(self, in_chan_a, in_chan_b, kernel_size=1, is2d=False, *args, **kwargs):
+        super().__init__()
+        self.in_chan_a, self.in_chan_b, self.kernel_size, self.is2d = in_chan_a, in_chan_b, kernel_size, is2d
+        bn = "BatchNorm2d" if is2d else "BatchNorm1d"
+        self.key_embed = ConvNormAct(in_chan_a, in_chan_a, 1, groups=in_chan_a, norm_type=bn, act_type="ReLU", bias=False, is2d=is2d)
+        self.value_embed = ConvNormAct(in_chan_a, in_chan_a, 1, groups=in_chan_a, norm_type=bn, bias=False, is2d=is2d)
+        self.attention_embed = ConvNormAct(in_chan_b, kernel_size * in_chan_a, 1, groups=in_chan_a, norm_type="gLN")
+        self.resize = ConvNormAct(in_chan_b, in_chan_a, 1, groups=in_chan_a, norm_type="gLN")
+
+    def forward(self, tensor_a, tensor_b):
+        self._guard(tensor_a, tensor_b)
+        if not (self.is2d and self.in_chan_a == 256 and self.in_chan_b == 512 and self.kernel_size == 4):
+            raise ValueError("MI355X CAF kernel: audio 256 ch (2-D), video 512 ch, kernel_size 4")
+        lib = _lib.load()
+        a, v = tensor_a.contiguous(), tensor_b.contiguous()
+        B, _, T, Fq = a.shape
+        Tv = v.shape[-1]
+        out = torch.empty_like(a)
+        ws = _lib.workspace(lib.rtfs_caf_workspace_bytes(B, Tv), a.device)
+        _lib.check(lib.rtfs_caf_f32(_lib.ptr(a), _lib.ptr(v), _lib.ptr(self.pack()), _lib.ptr(out), B, T, Fq, Tv, _lib.ptr(ws), ws.numel(),
+                                    _lib.stream_of(a)), "rtfs_caf_f32")
+        return out
+
+
+# ----------------------------------------------------------------------------- video-side attention (torch ops)
+class PositionalEncoding(nn.Module):
+    """reference attention.py:9-25: sinusoidal table kept as the persistent buffer ``pe`` (1, max_len, C)."""
+
+    def __init__(self, channels, max_len=10000, *args, **kwargs):
+        super().__init__()
+        self.channels, self.max_len = channels, max_len
+        pos = torch.arange(0, max_len).unsqueeze(1).float()
+        div = torch.exp(torch.arange(0, channels, 2).float() * -(torch.log(torch.tensor(max_len).float()) / channels))
+        pe = torch.zeros(max_len, channels)
+        pe[:, 0::2] = torch.sin(pos * div)
+        pe[:, 1::2] = torch.cos(pos * div)
+        self.register_buffer("pe", pe.unsqueeze(0))
+
+    def forward(self, x):
+        return x + self.pe[:, : x.size(1)]
+
+
+class MultiHeadSelfAttention(nn.Module):
+    """reference attention.py:28-73 (eval mode: dropout / DropPath are identities)."""
+
+    def __init__(self, in_chan, n_head=8, dropout=0.1, positional_encoding=True, batch_first=True, *args, **kwargs):
+        super().__init__()
+        assert in_chan % n_head == 0, f"In channels: {in_chan} must be divisible by the number of heads: {n_head}"
+        self.in_chan, self.n_head, self.dropout, self.positional_encoding, self.batch_first = in_chan, n_head, dropout, positional_encoding, batch_first
+        self.norm1 = nn.LayerNorm(in_chan)
+        self.pos_enc = PositionalEncoding(in_chan) if positional_encoding else nn.Identity()
+        self.attention = nn.MultiheadAttention(in_chan, n_head, dropout, batch_first=batch_first)
+        self.dropout_layer = nn.Dropout(dropout)
+        self.norm2 = nn.LayerNorm(in_chan)
+        self.drop_path_layer = nn.Identity()
+
+    def forward(self, x):
+        res = x
+        y = x.transpose(1, 2) if self.batch_first else x
+        y = self.pos_enc(self.norm1(y))
+        y = self.norm2(self.dropout_layer(self.attention(y, y, y, need_weights=False)[0]) + y)
+        if self.batch_first:
+            y = y.transpose(2, 1)
+        return y + res
+
+
+class GlobalAttention(nn.Module):
+    """reference attention.py:192-220: MHSA followed by the FFN."""
+
+    def __init__(self, in_chan, hid_chan=None, ffn_name="FeedForwardNetwork", kernel_size=5, n_head=8, dropout=0.1, pos_enc=True, *args, **kwargs):
+        super().__init__()
+        self.in_chan = in_chan
+        self.hid_chan = hid_chan if hid_chan is not None else 2 * in_chan
+        self.ffn_name, self.kernel_size, self.n_head, self.dropout, self.pos_enc = ffn_name, kernel_size, n_head, dropout, pos_enc
+        self.MHSA = MultiHeadSelfAttention(in_chan, n_head, dropout, pos_enc)
+        self.FFN = get(ffn_name)(in_chan, self.hid_chan, kernel_size, dropout=dropout)
+
+    def forward(self, x):
+        return self.FFN(self.MHSA(x))
+
+
+_REGISTRY = {c.__name__: c for c in (ConvNormAct, ConvActNorm, FeedForwardNetwork, DualPathRNN, MultiHeadSelfAttention2D,
+                                     MultiHeadSelfAttention, GlobalAttention, InjectionMultiSum, ATTNFusionCell)}
+
+
+def get(identifier):
+    """String -> layer class, like reference layers/__init__.py:19-30 (RTFS-Net path classes only)."""
+    if identifier is None:
+        return nn.Identity
+    if callable(identifier):
+        return identifier
+    if isinstance(identifier, str) and identifier in _REGISTRY:
+        return _REGISTRY[identifier]
+    raise ValueError("Could not interpret normalization identifier: " + str(identifier))

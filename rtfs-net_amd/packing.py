@@ -1,0 +1,127 @@
+"""Parameter packs: the flat float32 device buffers the C ABI reads (layout contract with
+``csrc/api.hip``; every tensor padded to a multiple of 64 floats, 1x1 weights stored [cin][cout]).
+
+Each ``pack_*`` takes a mapping ``name -> tensor`` with the reference's ``state_dict`` key names
+*relative to the module it packs* (e.g. ``full_layer.2.weight``), so the same functions serve live
+``nn.Module`` parameters and loaded checkpoints.
+"""
+from __future__ import annotations
+
+import torch
+
+ALIGN = 64
+
+
+def _sub(sd, prefix):
+    p = prefix + "."
+    return {k[len(p):]: v for k, v in sd.items() if k.startswith(p)}
+
+
+def _cat(tensors):
+    out = []
+    for t in tensors:
+        t = t.detach().to(torch.float32).reshape(-1)
+        pad = (-t.numel()) % ALIGN
+        if pad:
+            t = torch.cat([t, t.new_zeros(pad)])
+        out.append(t)
+    return torch.cat(out).contiguous()
+
+
+def pack_encoder(sd):
+    """STFTEncoder: conv.full_layer.2.weight (256,2,3,3) -> (256,18)."""
+    return _cat([sd["conv.full_layer.2.weight"].reshape(256, 18)])
+
+
+def pack_audio_bn(sd):
+    w = sd["full_layer.2.weight"].reshape(256, 256)
+    return _cat([sd["full_layer.0.norm.weight"], sd["full_layer.0.norm.bias"], w.t(), sd["full_layer.2.bias"]])
+
+
+def _dualpath_parts(sd):
+    parts = [sd["norm.gamma"].reshape(64), sd["norm.beta"].reshape(64), sd["rnn.rnn_lst.0.weight"]]
+    wl = []
+    for i in (1, 2, 3):
+        w = sd[f"rnn.rnn_lst.{i}.weight"].reshape(64, 64, 3)  # (in, dir*32+j, m)
+        wl.append(torch.cat([w, w.new_zeros(64, 64, 1)], 2).reshape(64, 256))
+    parts.append(torch.stack(wl))
+    parts.append(torch.stack([sd[f"rnn.rnn_lst.{i}.weight_c"] for i in range(4)]))
+    parts.append(torch.stack([sd[f"rnn.rnn_lst.{i}.bias"] for i in range(4)]))
+    parts.append(sd["linear.weight"].permute(2, 0, 1).reshape(512, 64))  # (ci,co,k) -> (k*64+ci, co)
+    parts.append(sd["linear.bias"])
+    return parts
+
+
+def pack_dualpath(sd):
+    return _cat(_dualpath_parts(sd))
+
+
+def _attention_parts(sd):
+    names = [f"Queries.{h}" for h in range(4)] + [f"Keys.{h}" for h in range(4)] + [f"Values.{h}" for h in range(4)]
+    w = torch.cat([sd[n + ".conv.weight"].reshape(-1, 64) for n in names])  # (96,64)
+    b = torch.cat([sd[n + ".conv.bias"] for n in names])
+    slope = torch.cat([sd[n + ".act.weight"].reshape(1) for n in names])
+    gamma = torch.cat([sd[n + ".norm.gamma"].reshape(-1, 64) for n in names])
+    beta = torch.cat([sd[n + ".norm.beta"].reshape(-1, 64) for n in names])
+    p = "attn_concat_proj"
+    return [w.t(), b, slope, gamma, beta, sd[p + ".conv.weight"].reshape(64, 64).t(), sd[p + ".conv.bias"],
+            sd[p + ".act.weight"].reshape(1), sd[p + ".norm.gamma"].reshape(64, 64), sd[p + ".norm.beta"].reshape(64, 64)]
+
+
+def pack_attention(sd):
+    return _cat(_attention_parts(sd))
+
+
+def _tfar_parts(sd):
+    parts = []
+    for n in ("local_embedding", "global_embedding", "global_gate"):
+        parts += [sd[n + ".full_layer.2.weight"].reshape(64, 16), sd[n + ".full_layer.3.norm.weight"], sd[n + ".full_layer.3.norm.bias"]]
+    return parts
+
+
+def pack_tfar(sd):
+    return _cat(_tfar_parts(sd))
+
+
+def pack_block(sd):
+    """TDANetBlock (2-D, depth 2) with globalatt = [DualPathRNN, DualPathRNN, MultiHeadSelfAttention2D]."""
+    parts = [sd["gateway.full_layer.2.weight"].reshape(256), sd["gateway.full_layer.2.bias"], sd["gateway.full_layer.4.weight"].reshape(1),
+             sd["projection.full_layer.2.weight"].reshape(64, 256).t(), sd["projection.full_layer.2.bias"]]
+    for i in (0, 1):
+        p = f"downsample_layers.{i}.full_layer."
+        parts += [sd[p + "2.weight"].reshape(64, 16), sd[p + "2.bias"], sd[p + "3.norm.weight"], sd[p + "3.norm.bias"]]
+    parts += _dualpath_parts(_sub(sd, "globalatt.0"))
+    parts += _dualpath_parts(_sub(sd, "globalatt.1"))
+    parts += _attention_parts(_sub(sd, "globalatt.2"))
+    parts += _tfar_parts(_sub(sd, "fusion_layers.0"))
+    parts += _tfar_parts(_sub(sd, "fusion_layers.1"))
+    parts += _tfar_parts(_sub(sd, "concat_layers.0"))
+    parts += [sd["residual_conv.full_layer.2.weight"].reshape(256, 64).t(), sd["residual_conv.full_layer.2.bias"]]
+    return _cat(parts)
+
+
+def pack_caf(sd):
+    """ATTNFusionCell (audio_lstm)."""
+    def bn(n):
+        p = n + ".full_layer.3."
+        return torch.stack([sd[p + "weight"], sd[p + "bias"], sd[p + "running_mean"], sd[p + "running_var"]])
+    return _cat([
+        sd["key_embed.full_layer.2.weight"].reshape(256), bn("key_embed"),
+        sd["value_embed.full_layer.2.weight"].reshape(256), bn("value_embed"),
+        sd["attention_embed.full_layer.2.weight"].reshape(1024, 2), sd["attention_embed.full_layer.2.bias"],
+        sd["attention_embed.full_layer.3.norm.weight"], sd["attention_embed.full_layer.3.norm.bias"],
+        sd["resize.full_layer.2.weight"].reshape(256, 2), sd["resize.full_layer.2.bias"],
+        sd["resize.full_layer.3.norm.weight"], sd["resize.full_layer.3.norm.bias"],
+    ])
+
+
+def pack_s3(sd):
+    """MaskGenerator: mask_generator = Sequential(PReLU, ConvNormAct(1x1, ReLU))."""
+    return _cat([sd["mask_generator.0.weight"].reshape(1), sd["mask_generator.1.full_layer.2.weight"].reshape(256, 256).t(),
+                 sd["mask_generator.1.full_layer.2.bias"]])
+
+
+def pack_decoder(sd):
+    """STFTDecoder: ConvTranspose2d weight (256,2,3,3) -> 18 per-tap 1x1 maps, zero padded to 32."""
+    w = sd["decoder.weight"].reshape(256, 18)
+    return _cat([torch.cat([w, w.new_zeros(256, 14)], 1)])

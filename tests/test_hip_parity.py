@@ -1,0 +1,246 @@
+"""GPU parity: the HIP path (through the C ABI via the nn.Module mirror) vs the CPU oracle on the same
+seeded inputs, and vs the golden vectors captured from the reference.  Tolerance: the north_star's
+1e-4 relative (fp32), read as max|got-ref| / max|ref| per tensor."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import rtfs_oracle as O
+from oracle.params import make_inputs, make_state_dict
+from tests.util import check_probe, l2_rel, load_golden, rand, rel_err, spec_R4
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+SD = make_state_dict(spec_R4(), 0)
+BLK = O._sub(SD, "refinement_module.audio_net.blocks")
+CELL = O._sub(SD, "refinement_module.crossmodal_fusion.fusion_module.audio_lstm")
+
+
+def _conf(repeats=4):
+    import copy
+    from tests.test_host import RTFS4_AUDIONET
+    c = copy.deepcopy(RTFS4_AUDIONET)
+    c["audio_params"]["repeats"] = repeats
+    return c
+
+
+_MODELS = {}
+
+
+def model(repeats=4):
+    import rtfs_net_amd as R
+    if repeats not in _MODELS:
+        m = R.AVNet(print_macs=False, **_conf(repeats))
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in SD.items()})
+        _MODELS[repeats] = m.cuda().eval()
+    return _MODELS[repeats]
+
+
+def dev(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).cuda()
+
+
+def host(t):
+    torch.cuda.synchronize()
+    return t.detach().cpu().numpy()
+
+
+def close(name, got, ref, tol=TOL):
+    e, l2 = rel_err(got, ref), l2_rel(got, ref)
+    print(f"[parity] {name}: max-rel {e:.3e}  l2-rel {l2:.3e}  shape {tuple(np.shape(ref))}")
+    assert np.isfinite(np.asarray(got)).all(), f"{name}: non-finite output"
+    assert e <= tol, f"{name}: rel err {e:.3e} > {tol:.1e}"
+
+
+def test_library_loaded_is_hip():
+    from rtfs_net_amd import _lib
+    lib = _lib.load()
+    assert b"gfx950" in lib.rtfs_version()
+
+
+def test_encoder():
+    m = model()
+    x = rand((2, 2048), 101, 0.07)
+    a0 = host(m.encoder(dev(x)))
+    ref, _ = O.stft_encoder(x, O._sub(SD, "encoder"))
+    close("encoder", a0, ref)
+    check_probe(load_golden("mod_encoder"), "out", a0, TOL)
+
+
+def test_encoder_stats_and_ragged_length():
+    m = model()
+    x = rand((3, 5000), 7, 0.07)
+    a0, st = m.encoder(dev(x), return_stats=True)
+    a0, st = host(a0), host(st)
+    ref, _ = O.stft_encoder(x, O._sub(SD, "encoder"))
+    close("encoder L=5000", a0, ref)
+    want = np.stack([ref.reshape(3, -1).astype(np.float64).sum(1), (ref.reshape(3, -1).astype(np.float64) ** 2).sum(1)], 1)
+    assert np.allclose(st[:, 1], want[:, 1], rtol=1e-5)
+    assert np.allclose(st[:, 0], want[:, 0], rtol=1e-3, atol=1e-3 * np.abs(ref).sum() / 3 * 1e-3)
+
+
+def test_audio_bn():
+    m = model()
+    x = rand((2, 256, 9, 129), 102)
+    y = host(m.audio_bottleneck(dev(x)))
+    close("audio_bn", y, O.conv_norm_act(x, O._sub(SD, "audio_bottleneck"), pre_norm="gLN", pre_act="ReLU"))
+    check_probe(load_golden("mod_audio_bn"), "out", y, TOL)
+
+
+@pytest.mark.parametrize("name,idx,dim,shape,seed", [
+    ("mod_dualpath_f", 0, 4, (2, 64, 12, 64), 103),
+    ("mod_dualpath_t", 1, 3, (2, 64, 12, 64), 103),
+    ("mod_dualpath_t_min", 1, 3, (1, 64, 8, 64), 113),
+])
+def test_dualpath(name, idx, dim, shape, seed):
+    m = model()
+    x = rand(shape, seed)
+    y = host(m.refinement_module.audio_net.blocks.globalatt[idx](dev(x)))
+    close(name, y, O.dualpath_rnn(x, O._sub(BLK, f"globalatt.{idx}"), dim))
+    check_probe(load_golden(name), "out", y, TOL)
+
+
+@pytest.mark.parametrize("dim,shape", [(4, (1, 64, 125, 64)), (3, (1, 64, 125, 64)), (3, (1, 64, 250, 64)), (4, (2, 64, 9, 64)), (3, (3, 64, 37, 64))])
+def test_dualpath_full_size_rows(dim, shape):
+    """2 s (T'=125) and 4 s (T'=250) sweep lengths, odd tile remainders."""
+    m = model()
+    x = rand(shape, 11 + dim)
+    idx = 0 if dim == 4 else 1
+    y = host(m.refinement_module.audio_net.blocks.globalatt[idx](dev(x)))
+    close(f"dualpath dim{dim} {shape}", y, O.dualpath_rnn(x, O._sub(BLK, f"globalatt.{idx}"), dim))
+
+
+def test_dualpath_short_axis_raises():
+    m = model()
+    with pytest.raises(ValueError):
+        m.refinement_module.audio_net.blocks.globalatt[1](dev(rand((1, 64, 5, 64), 1)))
+
+
+def test_sru_operator():
+    """Operator-level seam: sru.SRU.forward(x (L,N,512)) -> (h (L,N,64), c)."""
+    m = model()
+    sru = m.refinement_module.audio_net.blocks.globalatt[0].rnn
+    x = rand((19, 5, 512), 21)
+    h, _ = sru(dev(x))
+    p = O._sub(BLK, "globalatt.0")
+    close("sru operator", host(h), O.sru_forward(x, O._sru_layers(p)))
+
+
+@pytest.mark.parametrize("shape,seed", [((2, 64, 12, 64), 103), ((1, 64, 125, 64), 5), ((1, 64, 250, 64), 6), ((2, 64, 33, 64), 8)])
+def test_mhsa2d(shape, seed):
+    m = model()
+    x = rand(shape, seed)
+    y = host(m.refinement_module.audio_net.blocks.globalatt[2](dev(x)))
+    close(f"mhsa2d {shape}", y, O.mhsa2d(x, O._sub(BLK, "globalatt.2")))
+    if seed == 103:
+        check_probe(load_golden("mod_mhsa2d"), "out", y, TOL)
+
+
+def test_tfar():
+    m = model()
+    blk = m.refinement_module.audio_net.blocks
+    glo = rand((2, 64, 8, 64), 105)
+    loc = rand((2, 64, 17, 129), 104)
+    y = host(blk.fusion_layers[0](dev(loc), dev(glo)))
+    close("tfar up", y, O.injection_multi_sum(loc, glo, O._sub(BLK, "fusion_layers.0")))
+    check_probe(load_golden("mod_tfar_up"), "out", y, TOL)
+    loc = rand((2, 64, 8, 64), 106)
+    y = host(blk.fusion_layers[1](dev(loc), dev(glo)))
+    close("tfar same", y, O.injection_multi_sum(loc, glo, O._sub(BLK, "fusion_layers.1")))
+    check_probe(load_golden("mod_tfar_same"), "out", y, TOL)
+
+
+def test_caf():
+    m = model()
+    a, v = rand((2, 256, 17, 129), 107), rand((2, 512, 7), 108)
+    y, v2 = m.refinement_module.crossmodal_fusion.fusion_module(dev(a), dev(v))
+    y = host(y)
+    close("caf", y, O.caf(a, v, CELL))
+    check_probe(load_golden("mod_caf"), "out", y, TOL)
+
+
+@pytest.mark.parametrize("name,tv,seed", [("mod_vp50", 50, 109), ("mod_vp7", 7, 110)])
+def test_vp_block(name, tv, seed):
+    m = model()
+    v = rand((2, 512, tv), seed)
+    y = host(m.refinement_module.video_net.blocks(dev(v)))
+    check_probe(load_golden(name), "out", y, TOL)
+
+
+def test_s3():
+    m = model()
+    r, a0 = rand((2, 256, 9, 129), 111), rand((2, 256, 9, 129), 112)
+    y = host(m.mask_generator(dev(r), dev(a0)))
+    close("s3", y, O.s3_mask(r, a0, O._sub(SD, "mask_generator")))
+    check_probe(load_golden("mod_s3"), "out", y, TOL)
+
+
+def test_decoder():
+    m = model()
+    x = rand((2, 1, 256, 17, 129), 114, 0.3)
+    y = host(m.decoder(dev(x), torch.Size([2, 2048])))
+    close("decoder", y, O.stft_decoder(x, O._sub(SD, "decoder"), 2048))
+    check_probe(load_golden("mod_decoder"), "out", y, TOL)
+
+
+def test_rtfs_block():
+    m = model()
+    x = rand((1, 256, 17, 129), 115)
+    y = host(m.refinement_module.audio_net.blocks(dev(x)))
+    close("rtfs block", y, O.rtfs_block(x, BLK))
+    check_probe(load_golden("mod_rtfs_block"), "out", y, TOL)
+
+
+def test_rtfs_block_with_residual_input_and_batch():
+    m = model()
+    x, r = rand((3, 256, 20, 129), 31), rand((3, 256, 20, 129), 32)
+    y = host(m.refinement_module.audio_net.blocks(dev(x), dev(r)))
+    close("rtfs block(x + res)", y, O.rtfs_block(x + r, BLK))
+
+
+@pytest.mark.parametrize("name,R,B,L,Tv,seed", [
+    ("e2e_R4_L4096_B2", 4, 2, 4096, 7, 1),
+    ("e2e_R4_L5000_B3", 4, 3, 5000, 8, 3),
+    ("e2e_R6_L8000_B2", 6, 2, 8000, 13, 5),
+    ("e2e_R12_L8000_B1", 12, 1, 8000, 13, 4),
+    ("e2e_R4_L32000_B1", 4, 1, 32000, 50, 2),
+])
+@pytest.mark.parametrize("fused", [True, False])
+def test_end_to_end_vs_golden(name, R, B, L, Tv, seed, fused):
+    g = load_golden(name)
+    m = model(R)
+    m.fused = fused
+    wav, emb = make_inputs(B, L, Tv, seed)
+    try:
+        out = host(m(dev(wav), dev(emb)))
+    finally:
+        m.fused = True
+    tol = TOL if R <= 6 else 5e-4  # 12 un-trained repeats amplify rounding ~45x (oracle vs reference: 2e-4 bound)
+    close(f"{name} fused={fused}", out, g["out"], tol)
+
+
+def test_input_rank_variants_match():
+    m = model()
+    wav, emb = make_inputs(1, 4096, 7, 9)
+    a = host(m(dev(wav), dev(emb)))
+    b = host(m(dev(wav[0]), dev(emb)))
+    c = host(m(dev(wav[:, None, :]), dev(emb)))
+    assert a.shape == (1, 1, 4096) and np.array_equal(a, b) and np.array_equal(a, c)
+
+
+def test_batch_independence_property():
+    """Size-independent property at bench batch size: every mixture of a batch separates exactly as it does alone
+    (all norms are per-sample in eval mode)."""
+    m = model()
+    wav, emb = make_inputs(4, 8000, 13, 12)
+    full = host(m(dev(wav), dev(emb)))
+    for i in (0, 3):
+        one = host(m(dev(wav[i:i + 1]), dev(emb[i:i + 1])))
+        assert rel_err(full[i:i + 1], one) <= 2e-6
+
+
+def test_cpu_tensor_rejected():
+    m = model()
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 4096), torch.zeros(1, 512, 7))
