@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""Throughput benchmark of the MI355X-native RTFS-Net separator forward.
+
+  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+Metric (BASELINE.json): mixtures/s of the RTFS-Net-4 forward on synthetic 2 s @16 kHz 2-speaker mixtures with
+dummy lip embeddings, batch 32 per GPU (configs[1]); inputs and weights are resident in HBM before the timed
+region.  One "step" = one forward over one batch.  Weak scaling: every rank runs its own batch, there is no
+data-path collective (utterances are independent in the forward).  Rank 0 prints ONE JSON line that also carries
+  roofline      the fused dual-path sweep kernel: algorithmic bytes (20*L*N*64 per SRU layer, 4 layers per
+                launch) / its launch duration measured live with HIP events on the launch stream, vs 8 TB/s HBM
+  cpu_baseline  the CPU oracle (oracle/rtfs_oracle.py, numpy) timed on this box's host cores on a bounded sample.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md); ~6300 GB/s achievable
+
+
+def audionet_config(repeats):
+    import copy
+    from tests.test_host import RTFS4_AUDIONET
+    c = copy.deepcopy(RTFS4_AUDIONET)
+    c["audio_params"]["repeats"] = repeats
+    return c
+
+
+def sweep_bytes(seq_len, n_seq):
+    """Algorithmic bytes of one dual-path launch at the reference's op boundary."""
+    return 20.0 * (seq_len - 7) * n_seq * 64 * 4
+
+
+def cpu_baseline(repeats, seconds_budget=25.0):
+    from threadpoolctl import threadpool_info
+    from oracle import rtfs_oracle as O
+    from oracle.params import load_spec, make_inputs, make_state_dict
+    sd = make_state_dict(load_spec("state_spec_R4.json"), 0)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        wav, emb = make_inputs(1, 32000, 50, n)
+        O.avnet_forward(wav, emb, sd, repeats=repeats)
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt + dt / n > seconds_budget or n >= 8:
+            break
+    threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+    return {"value": round(n / dt, 4), "unit": "mixtures/s", "cores": int(threads), "kind": "port",
+            "sample": f"{n} x (1 mixture, 2 s @16 kHz, RTFS-Net-{repeats}) through the numpy CPU oracle, {dt:.1f} s, "
+                      f"BLAS threads {threads} of {os.cpu_count()} host cpus"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="mixtures per GPU per step")
+    ap.add_argument("--repeats", type=int, default=4, help="RTFS-Net-R")
+    ap.add_argument("--seconds", type=float, default=2.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with `python -m torch.distributed.run --nproc-per-node N bench.py ...`")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    import rtfs_net_amd as R
+    from rtfs_net_amd import _lib
+    lib = _lib.load()
+
+    torch.manual_seed(0)  # random-init weights of the named architecture (no checkpoints offline)
+    model = R.AVNet(print_macs=False, **audionet_config(args.repeats)).to(dev).eval()
+    B, L = args.batch, int(args.seconds * 16000)
+    Tv = int(args.seconds * 25)
+    g = torch.Generator().manual_seed(1234 + rank)
+    s1 = torch.randn(B, L, generator=g) * 0.05
+    s2 = torch.randn(B, L, generator=g) * 0.05
+    wav = (s1 + s2).to(dev)
+    emb = torch.randn(B, 512, Tv, generator=g).to(dev)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            out = model(wav, emb)
+        barrier()
+        lib.rtfs_sweep_timing_enable(1)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = model(wav, emb)
+        barrier()
+        dt = time.perf_counter() - t0
+    assert bool(torch.isfinite(out).all())
+
+    # per-launch durations of the dominant kernel, recorded during the timed region
+    cap = 4096
+    ms = (ctypes.c_float * cap)()
+    ls = (ctypes.c_int * cap)()
+    ns = (ctypes.c_int * cap)()
+    n_ev = lib.rtfs_sweep_timing_collect(ms, ls, ns, cap)
+    lib.rtfs_sweep_timing_enable(0)
+
+    if dist is not None:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank == 0:
+        total_bytes = sum(sweep_bytes(ls[i], ns[i]) for i in range(n_ev))
+        total_ms = sum(ms[i] for i in range(n_ev))
+        achieved = total_bytes / (total_ms * 1e-3) / 1e9 if n_ev > 0 and total_ms > 0 else None
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "sweep_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("batch") == B and tj.get("repeats") == args.repeats and tj.get("seconds") == args.seconds:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        res = {
+            "metric": "mixtures/sec forward (2 s@16 kHz, 2-spk) RTFS-Net-4",
+            "value": round(world * B * args.steps / dt, 3),
+            "unit": "mixtures/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"RTFS-Net-{args.repeats} forward, batch {B}/GPU, {args.seconds:g} s @16 kHz 2-speaker mixtures "
+                                   f"+ dummy lip embeddings (B,512,{Tv}), random-init weights, eval",
+                       "per_gpu_batch": B, "global_batch": B * world, "samples": L, "parallelism": f"dp{world} (no data-path collective)"},
+            "roofline": {
+                "kernel": "dualpath_sru_kernel (fused LN + unfold-GEMM + 4x bi-SRU scan + ConvTranspose1d + residual)",
+                "bound": "hbm",
+                "achieved": None if achieved is None else round(achieved, 2),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": traffic,
+                "launches_timed": int(n_ev),
+                "avg_launch_ms": None if n_ev <= 0 else round(total_ms / n_ev, 4),
+                "algorithmic_bytes_per_launch": None if n_ev <= 0 else round(total_bytes / n_ev),
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(args.repeats)
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -115,6 +115,14 @@ int rtfs_separator_forward_f32(const float* wav, const float* video_vp, const fl
 size_t rtfs_sru_workspace_bytes(int L, int N);
 int rtfs_sru_f32(const float* x, const float* pack, float* h, int L, int N, void* ws, size_t ws_bytes, void* stream);
 
+/* Measurement hook (bench.py roofline leg; no reference counterpart).  While enabled, every launch of the fused
+ * dual-path sweep kernel is bracketed by HIP events recorded on the stream it is launched on.  collect() waits for
+ * the recorded launches (host-side, call it outside any timed region / graph capture), writes per-launch
+ * milliseconds + sequence length + sequence count (HOST pointers, up to cap entries), clears the log and returns the
+ * number of entries (or <0 on error). */
+int rtfs_sweep_timing_enable(int on);
+int rtfs_sweep_timing_collect(float* ms, int* seq_len, int* n_seq, int cap);
+
 #ifdef __cplusplus
 }
 #endif

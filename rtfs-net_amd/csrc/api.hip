@@ -760,4 +760,12 @@ int rtfs_sru_f32(const float* x, const float* pack, float* h, int L, int N, void
     return launch_sru_standalone(x, h, L, N, p.W0, p.Wl, p.wc, p.bias, S(stream));
 }
 
+// ------------------------------------------------------------ measurement hook
+int rtfs_sweep_timing_enable(int on) { return dualpath_timing_enable(on); }
+
+int rtfs_sweep_timing_collect(float* ms, int* seq_len, int* n_seq, int cap) {
+    RTFS_RETURN_IF(!ms || !seq_len || !n_seq || cap < 1, RTFS_ERR_ARG);
+    return dualpath_timing_collect(ms, seq_len, n_seq, cap);
+}
+
 }  // extern "C"

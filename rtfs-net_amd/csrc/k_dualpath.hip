@@ -160,6 +160,52 @@ __global__ __launch_bounds__(256) void dualpath_sru_kernel(DpArgs a) {
     }
 }
 
+// ---- optional per-launch timing of the sweep kernel (HIP events on the launch stream; bench.py's roofline leg)
+namespace {
+constexpr int TIMING_CAP = 4096;
+struct TimingSlot {
+    hipEvent_t beg, end;
+    int Ls, nseq;
+};
+TimingSlot g_slots[TIMING_CAP];
+int g_nslots = 0, g_nalloc = 0;
+bool g_timing = false;
+}  // namespace
+
+int dualpath_timing_enable(int on) {
+    g_timing = on != 0;
+    g_nslots = 0;
+    return RTFS_OK;
+}
+
+int dualpath_timing_collect(float* ms, int* ls, int* nseq, int cap) {
+    int n = 0;
+    for (int i = 0; i < g_nslots && n < cap; ++i) {
+        if (hipEventSynchronize(g_slots[i].end) != hipSuccess) return RTFS_ERR_LAUNCH;
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, g_slots[i].beg, g_slots[i].end) != hipSuccess) return RTFS_ERR_LAUNCH;
+        ms[n] = t;
+        ls[n] = g_slots[i].Ls;
+        nseq[n] = g_slots[i].nseq;
+        ++n;
+    }
+    g_nslots = 0;
+    return n;
+}
+
+static TimingSlot* timing_begin(int Ls, int nseq, hipStream_t st) {
+    if (!g_timing || g_nslots >= TIMING_CAP) return nullptr;
+    if (g_nslots >= g_nalloc) {
+        if (hipEventCreate(&g_slots[g_nalloc].beg) != hipSuccess || hipEventCreate(&g_slots[g_nalloc].end) != hipSuccess) return nullptr;
+        ++g_nalloc;
+    }
+    TimingSlot* s = &g_slots[g_nslots++];
+    s->Ls = Ls;
+    s->nseq = nseq;
+    (void)hipEventRecord(s->beg, st);
+    return s;
+}
+
 size_t dualpath_lds_bytes(int Ls) {
     const int L = Ls - DP_K + 1;
     const size_t szA = (DP_C * Ls + 3) & ~3, szB = (L * DP_HS + 3) & ~3;
@@ -175,7 +221,9 @@ int launch_dualpath(const DpArgs& a, int nseq, hipStream_t st) {
             return RTFS_ERR_LAUNCH;
         configured = lds;
     }
+    TimingSlot* slot = timing_begin(a.Ls, nseq, st);
     hipLaunchKernelGGL(dualpath_sru_kernel<false>, dim3(nseq), dim3(256), lds, st, a);
+    if (slot) (void)hipEventRecord(slot->end, st);
     return rtfs_launch_status();
 }
 

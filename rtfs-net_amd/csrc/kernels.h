@@ -148,3 +148,5 @@ struct CafArgs {
 };
 int launch_caf_video(const CafArgs& a, int B, hipStream_t st);
 int launch_caf_apply(const CafArgs& a, int B, hipStream_t st);
+int dualpath_timing_enable(int on);
+int dualpath_timing_collect(float* ms, int* ls, int* nseq, int cap);
