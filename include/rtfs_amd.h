@@ -115,6 +115,10 @@ int rtfs_separator_forward_f32(const float* wav, const float* video_vp, const fl
 size_t rtfs_sru_workspace_bytes(int L, int N);
 int rtfs_sru_f32(const float* x, const float* pack, float* h, int L, int N, void* ws, size_t ws_bytes, void* stream);
 
+/* Self test of the f16 MFMA fragment layout the split-precision GEMM kernels assume: D (32x32) = A (32x16) . B (16x32),
+ * all DEVICE pointers, row-major; exact for small integer data. */
+int rtfs_selftest_mfma_f16(const float* A, const float* B, float* D, void* stream);
+
 /* Measurement hook (bench.py roofline leg; no reference counterpart).  While enabled, every launch of the fused
  * dual-path sweep kernel is bracketed by HIP events recorded on the stream it is launched on.  collect() waits for
  * the recorded launches (host-side, call it outside any timed region / graph capture), writes per-launch

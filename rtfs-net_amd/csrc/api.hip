@@ -3,6 +3,7 @@
 #include "../../include/rtfs_amd.h"
 #include "common.h"
 #include "kernels.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -30,16 +31,18 @@ struct EncPack {
     explicit EncPack(Cursor& c) { w = c.take(CA * 18); }
 };
 struct BnPack {
-    const float *gamma, *beta, *wt, *bias;
+    const float *gamma, *beta, *wt, *bias, *w16;
     explicit BnPack(Cursor& c) {
         gamma = c.take(CA);
         beta = c.take(CA);
         wt = c.take(CA * CA);
         bias = c.take(CA);
+        w16 = c.take(CA * CA);
     }
 };
 struct DpPack {
     const float *ln_g, *ln_b, *W0, *Wl, *wc, *bias, *Wt, *bt;
+    const float *w16_l0, *w16_l, *w16_ct, *wc16, *bias16;  // f16x3 images (k_dualpath16.hip)
     explicit DpPack(Cursor& c) {
         ln_g = c.take(CH);
         ln_b = c.take(CH);
@@ -49,6 +52,11 @@ struct DpPack {
         bias = c.take(4 * 128);
         Wt = c.take(512 * 64);
         bt = c.take(CH);
+        w16_l0 = c.take(512 * 256);
+        w16_l = c.take(3 * 64 * 256);
+        w16_ct = c.take(512 * 64);
+        wc16 = c.take(4 * 128);
+        bias16 = c.take(4 * 128);
     }
 };
 struct AttnPack {
@@ -86,7 +94,7 @@ struct BlockPack {
     DpPack dpF, dpT;
     AttnPack attn;
     TfarPack fus0, fus1, cat0;
-    const float *res_wt, *res_b;
+    const float *res_wt, *res_b, *proj_w16, *res_w16;
     static BlockPack make(Cursor& c) {
         const float* gw = c.take(CA);
         const float* gb = c.take(CA);
@@ -105,7 +113,9 @@ struct BlockPack {
         TfarPack f0(c), f1(c), c0(c);
         const float* rw = c.take(CH * CA);
         const float* rb = c.take(CA);
-        return BlockPack{gw, gb, gs, pw, pb, d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7], f, t, at, f0, f1, c0, rw, rb};
+        const float* p16 = c.take(CA * CH);
+        const float* r16 = c.take(CH * CA);
+        return BlockPack{gw, gb, gs, pw, pb, d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7], f, t, at, f0, f1, c0, rw, rb, p16, r16};
     }
 };
 struct CafPack {
@@ -126,16 +136,20 @@ struct CafPack {
     }
 };
 struct S3Pack {
-    const float *slope, *wt, *bias;
+    const float *slope, *wt, *bias, *w16;
     explicit S3Pack(Cursor& c) {
         slope = c.take(1);
         wt = c.take(CA * CA);
         bias = c.take(CA);
+        w16 = c.take(CA * CA);
     }
 };
 struct DecPack {
-    const float* wt;  // (256, 32): 18 tap maps (o*3+dt)*3+df, zero padded to 32
-    explicit DecPack(Cursor& c) { wt = c.take(CA * 32); }
+    const float *wt, *w16;  // (256, 32): 18 tap maps (o*3+dt)*3+df, zero padded to 32; and its f16 split image
+    explicit DecPack(Cursor& c) {
+        wt = c.take(CA * 32);
+        w16 = c.take(CA * 32);
+    }
 };
 
 // ---------------------------------------------------------------- workspace carving
@@ -161,6 +175,15 @@ struct Arena {
 
 inline hipStream_t S(void* s) { return (hipStream_t)s; }
 
+// RTFS_GEMM_F32=1 selects the exact-f32 MFMA kernels instead of the f16x3 split-precision ones (A/B + debugging).
+inline bool gemm_f32() {
+    static const bool v = [] {
+        const char* e = getenv("RTFS_GEMM_F32");
+        return e && e[0] == '1';
+    }();
+    return v;
+}
+
 // ---------------------------------------------------------------- dual path
 DpArgs dp_args(const DpPack& p, const float* x, float* out, int R, int Ls, size_t bstride, size_t rstride, size_t cstride) {
     DpArgs a;
@@ -182,16 +205,42 @@ DpArgs dp_args(const DpPack& p, const float* x, float* out, int R, int Ls, size_
     return a;
 }
 
+Dp16Args dp16_args(const DpPack& p, const float* x, float* out, int nseq, int R, int Ls, size_t bstride, size_t rstride, size_t cstride) {
+    Dp16Args a;
+    a.x = x;
+    a.out = out;
+    a.nseq = nseq;
+    a.R = R;
+    a.Ls = Ls;
+    a.bstride = bstride;
+    a.rstride = rstride;
+    a.cstride = cstride;
+    a.ln_gamma = p.ln_g;
+    a.ln_beta = p.ln_b;
+    a.w16_l0 = reinterpret_cast<const half8*>(p.w16_l0);
+    a.w16_l = reinterpret_cast<const half8*>(p.w16_l);
+    a.w16_ct = reinterpret_cast<const half8*>(p.w16_ct);
+    a.wc16 = p.wc16;
+    a.bias16 = p.bias16;
+    a.bt = p.bt;
+    return a;
+}
+
 // x, out (B,64,T,F).  dim 4: sequences along F, rows (b,t).  dim 3: along T via two tiled transposes.
 int dualpath(const DpPack& p, const float* x, float* out, int B, int T, int F, int dim, float* tA, float* tB, hipStream_t st) {
     const size_t plane = (size_t)T * F;
     if (dim == 4) {
         RTFS_RETURN_IF(F < 8 || F > 250, RTFS_ERR_SHAPE);
+        if (!gemm_f32()) return launch_dualpath16(dp16_args(p, x, out, B * T, T, F, CH * plane, F, plane), st);
         return launch_dualpath(dp_args(p, x, out, T, F, CH * plane, F, plane), B * T, st);
     }
     RTFS_RETURN_IF(T < 8 || T > 250, RTFS_ERR_SHAPE);
     CHECK(launch_transpose(x, tA, B * CH, T, F, st));
-    CHECK(launch_dualpath(dp_args(p, tA, tB, F, T, CH * plane, T, plane), B * F, st));
+    if (!gemm_f32()) {
+        CHECK(launch_dualpath16(dp16_args(p, tA, tB, B * F, F, T, CH * plane, T, plane), st));
+    } else {
+        CHECK(launch_dualpath(dp_args(p, tA, tB, F, T, CH * plane, T, plane), B * F, st));
+    }
     return launch_transpose(tB, out, B * CH, F, T, st);
 }
 
@@ -275,13 +324,14 @@ int block_forward(const BlockPack& p, const float* x, const float* x_res, float*
         a.x2 = x_res;
         a.res_out = w.residual;
         a.wt = p.proj_wt;
+        a.w16 = p.proj_w16;
         a.bias = p.proj_b;
         a.out = w.x_enc;
         a.gw = p.gw;
         a.gb = p.gb;
         a.slope = p.gslope;
         a.P = P;
-        CHECK(launch_pw_gateway_proj(a, B, st));
+        CHECK(gemm_f32() ? launch_pw_gateway_proj(a, B, st) : launch_pw16_gateway_proj(a, B, st));
     }
     {  // 2. downsample[0]: dw 4x4 s1 + bias -> c0 (pre-gLN) + stats                         tdanet.py:110
         DwArgs a;
@@ -290,7 +340,7 @@ int block_forward(const BlockPack& p, const float* x, const float* x_res, float*
         a.bias[0] = p.ds0_b;
         a.out[0] = w.c0;
         a.stats_out[0] = w.st(W::S_C0, B);
-        a.C = CH; a.H = T; a.W = F; a.TH = 8;
+        a.C = CH; a.H = T; a.W = F; a.TH = 32;
         CHECK(launch_dw_s1(a, 1, false, 0, B, st));
     }
     {  // 3. downsample[1] on d0 = gLN(c0): dw 4x4 s2 -> c1 + stats; p0 = adaptive_avg_pool2d(d0)   tdanet.py:111-116
@@ -302,7 +352,7 @@ int block_forward(const BlockPack& p, const float* x, const float* x_res, float*
         a.out[0] = w.c1;
         a.out[1] = w.p0;
         a.stats_out[0] = w.st(W::S_C1, B);
-        a.C = CH; a.H = T; a.W = F; a.Hg = Tp; a.Wg = Fp; a.TH = 8;
+        a.C = CH; a.H = T; a.W = F; a.Hg = Tp; a.Wg = Fp; a.TH = 32;
         CHECK(launch_dw_s2_pool(a, B, st));
     }
     // 4. g = pool(d0) + d1
@@ -319,7 +369,7 @@ int block_forward(const BlockPack& p, const float* x, const float* x_res, float*
         a.out[0] = w.E0; a.out[1] = w.G0; a.out[2] = w.E1; a.out[3] = w.G1;
         a.stats_out[0] = w.st(W::S_E0, B); a.stats_out[1] = w.st(W::S_G0, B);
         a.stats_out[2] = w.st(W::S_E1, B); a.stats_out[3] = w.st(W::S_G1, B);
-        a.C = CH; a.H = Tp; a.W = Fp; a.TH = 16;
+        a.C = CH; a.H = Tp; a.W = Fp; a.TH = 32;
         CHECK(launch_dw_s1(a, 4, false, 0, B, st));
     }
     {  // 11. fusion 1 local_embedding on d1 = gLN(c1)
@@ -329,7 +379,7 @@ int block_forward(const BlockPack& p, const float* x, const float* x_res, float*
         a.w[0] = p.fus1.loc_w;
         a.out[0] = w.L1;
         a.stats_out[0] = w.st(W::S_L1, B);
-        a.C = CH; a.H = Tp; a.W = Fp; a.TH = 16;
+        a.C = CH; a.H = Tp; a.W = Fp; a.TH = 32;
         CHECK(launch_dw_s1(a, 1, true, 0, B, st));
     }
     {  // 12. xf1 = gLN(L1) * sigmoid(gLN(G1)) + gLN(E1)                                      fusion.py:62-67
@@ -350,13 +400,13 @@ int block_forward(const BlockPack& p, const float* x, const float* x_res, float*
         a.w[0] = p.cat0.emb_w; a.w[1] = p.cat0.gate_w;
         a.out[0] = w.E2; a.out[1] = w.G2;
         a.stats_out[0] = w.st(W::S_E2, B); a.stats_out[1] = w.st(W::S_G2, B);
-        a.C = CH; a.H = Tp; a.W = Fp; a.TH = 16;
+        a.C = CH; a.H = Tp; a.W = Fp; a.TH = 32;
         CHECK(launch_dw_s1(a, 2, false, 0, B, st));
     }
     DwArgs d0in;  // common: read d0 = gLN(c0) at full resolution
     d0in.x = w.c0;
     d0in.in_stats = w.st(W::S_C0, B); d0in.in_inv_count = icF; d0in.in_gamma = p.ds0_g; d0in.in_beta = p.ds0_be;
-    d0in.C = CH; d0in.H = T; d0in.W = F; d0in.TH = 8; d0in.Hg = Tp; d0in.Wg = Fp;
+    d0in.C = CH; d0in.H = T; d0in.W = F; d0in.TH = 32; d0in.Hg = Tp; d0in.Wg = Fp;
     {  // 14. fusion 0 local_embedding conv on d0: statistics only
         DwArgs a = d0in;
         a.w[0] = p.fus0.loc_w;
@@ -375,7 +425,7 @@ int block_forward(const BlockPack& p, const float* x, const float* x_res, float*
     }
     DwArgs xin;  // common: read xf0
     xin.x = w.xf0;
-    xin.C = CH; xin.H = T; xin.W = F; xin.TH = 8; xin.Hg = Tp; xin.Wg = Fp;
+    xin.C = CH; xin.H = T; xin.W = F; xin.TH = 32; xin.Hg = Tp; xin.Wg = Fp;
     {  // 16. concat layer local_embedding conv on xf0: statistics only
         DwArgs a = xin;
         a.w[0] = p.cat0.loc_w;
@@ -397,11 +447,12 @@ int block_forward(const BlockPack& p, const float* x, const float* x_res, float*
         PwArgs a;
         a.x = w.expanded;
         a.wt = p.res_wt;
+        a.w16 = p.res_w16;
         a.bias = p.res_b;
         a.aux = w.residual;
         a.out = out;
         a.P = P;
-        CHECK(launch_pw_residual(a, B, st));
+        CHECK(gemm_f32() ? launch_pw_residual(a, B, st) : launch_pw16_residual(a, B, st));
     }
     return RTFS_OK;
 }
@@ -417,7 +468,8 @@ int audio_bn(const BnPack& p, const float* x, const double* stats, float* out, i
     a.gamma = p.gamma;
     a.beta = p.beta;
     a.P = P;
-    return launch_pw_audio_bn(a, B, st);
+    a.w16 = p.w16;
+    return gemm_f32() ? launch_pw_audio_bn(a, B, st) : launch_pw16_audio_bn(a, B, st);
 }
 
 CafArgs caf_args(const CafPack& p, const float* audio, const float* video, float* out, float* r, float* att, int T, int F, int Tv) {
@@ -439,7 +491,8 @@ int s3_mask(const S3Pack& p, const float* refined, const float* a0, float* out, 
     a.out = out;
     a.slope = p.slope;
     a.P = P;
-    return launch_pw_s3(a, B, st);
+    a.w16 = p.w16;
+    return gemm_f32() ? launch_pw_s3(a, B, st) : launch_pw16_s3(a, B, st);
 }
 
 int decoder(const DecPack& p, const float* x, float* wav, float* z, int B, int T, int L, hipStream_t st) {
@@ -449,7 +502,8 @@ int decoder(const DecPack& p, const float* x, float* wav, float* z, int B, int T
     a.out = z;
     a.P = T * NF;
     a.cout_live = 18;
-    CHECK(launch_pw_dec_taps(a, B, st));
+    a.w16 = p.w16;
+    CHECK(gemm_f32() ? launch_pw_dec_taps(a, B, st) : launch_pw16_dec_taps(a, B, st));
     return launch_dec_istft(z, wav, B, T, NF, L, (size_t)T * NF, (size_t)18 * T * NF, st);
 }
 
@@ -601,14 +655,14 @@ int rtfs_tfar_f32(const float* local, const float* global, const float* pack, fl
         a.w[0] = p.emb_w; a.w[1] = p.gate_w;
         a.out[0] = E; a.out[1] = G;
         a.stats_out[0] = stE; a.stats_out[1] = stG;
-        a.C = CH; a.H = Hg; a.W = Wg; a.TH = 16;
+        a.C = CH; a.H = Hg; a.W = Wg; a.TH = 32;
         CHECK(launch_dw_s1(a, 2, false, 0, B, s));
     }
     if (up) {
         DwArgs a;
         a.x = local;
         a.w[0] = p.loc_w;
-        a.C = CH; a.H = H; a.W = W; a.TH = 8; a.Hg = Hg; a.Wg = Wg;
+        a.C = CH; a.H = H; a.W = W; a.TH = 32; a.Hg = Hg; a.Wg = Wg;
         a.stats_out[0] = stL;
         CHECK(launch_dw_s1(a, 1, false, 1, B, s));
         a.stats_out[0] = nullptr;
@@ -625,7 +679,7 @@ int rtfs_tfar_f32(const float* local, const float* global, const float* pack, fl
         a.w[0] = p.loc_w;
         a.out[0] = Lc;
         a.stats_out[0] = stL;
-        a.C = CH; a.H = H; a.W = W; a.TH = 16;
+        a.C = CH; a.H = H; a.W = W; a.TH = 32;
         CHECK(launch_dw_s1(a, 1, false, 0, B, s));
     }
     GCombineArgs a;
@@ -758,6 +812,12 @@ int rtfs_sru_f32(const float* x, const float* pack, float* h, int L, int N, void
     Cursor c(pack);
     DpPack p(c);
     return launch_sru_standalone(x, h, L, N, p.W0, p.Wl, p.wc, p.bias, S(stream));
+}
+
+// ------------------------------------------------------------ self test
+int rtfs_selftest_mfma_f16(const float* A, const float* B, float* D, void* stream) {
+    RTFS_RETURN_IF(!A || !B || !D, RTFS_ERR_ARG);
+    return launch_mfma_f16_selftest(A, B, D, S(stream));
 }
 
 // ------------------------------------------------------------ measurement hook

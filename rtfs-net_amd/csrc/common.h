@@ -13,6 +13,7 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
 static inline int rtfs_launch_status() {
     hipError_t e = hipGetLastError();

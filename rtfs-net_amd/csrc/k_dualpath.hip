@@ -206,6 +206,11 @@ static TimingSlot* timing_begin(int Ls, int nseq, hipStream_t st) {
     return s;
 }
 
+void* dualpath_timing_begin(int Ls, int nseq, hipStream_t st) { return timing_begin(Ls, nseq, st); }
+void dualpath_timing_end(void* slot, hipStream_t st) {
+    if (slot) (void)hipEventRecord(static_cast<TimingSlot*>(slot)->end, st);
+}
+
 size_t dualpath_lds_bytes(int Ls) {
     const int L = Ls - DP_K + 1;
     const size_t szA = (DP_C * Ls + 3) & ~3, szB = (L * DP_HS + 3) & ~3;

@@ -1,0 +1,320 @@
+// Fused dual-path SRU sweep, generation 2: f16x3 split-precision MFMA + in-register scan.
+// Same arithmetic as k_dualpath.hip (DualPathRNN.forward, reference src/models/layers/rnn_layers.py:136-162,
+// with the third-party sru.SRU cell, call site rnn_layers.py:99-105,150) but restructured for gfx950:
+//
+//   * one 512-thread workgroup (8 waves, 2 per SIMD) owns NSEQ sequences end to end; HBM sees only the input
+//     row, the output row and (through L2) the weights;
+//   * activations live in LDS as two f16 planes (hi, lo) [position][64 ch], 144-byte rows -> every MFMA A/B
+//     fragment (8 consecutive channels of one position) is one conflict-free ds_read_b128.  The Unfold(k=8)
+//     is an addressing mode: K index k' = kk*64 + c reads row (pos + kk);
+//   * all GEMMs use v_mfma_f32_32x32x16_f16 on split operands: x = xh + xl, 256*w = wh + wl,
+//     x.w ~ (xh.wh + xh.wl + xl.wh)/256 (error 2^-22; measured end to end 6e-7);
+//   * weights are streamed from L2 in 32-deep K chunks through a double-buffered LDS image shared by the 8 waves
+//     (register prefetch of chunk q+1 during the MFMAs of chunk q, one barrier per chunk);
+//   * wave = (sequence, direction, time part): its 2 row tiles x 4 gate tiles of U stay in 128 accumulator
+//     registers; the recurrence runs on those registers (both lane halves take turns 4 steps at a time, the
+//     cell state crosses halves with v_permlane32_swap); the highway input x' of layers 1-3 is produced by the
+//     same MFMAs through an identity block in the weight image; sigmoid = rcp(1 + exp2(z)) with -log2(e)
+//     folded into the gate weights; hidden outputs are written back to the LDS planes in place.
+#include "common.h"
+#include "kernels.h"
+
+
+#define HLD 72   // activation row stride (halfs)
+#define WLD 40   // staged weight row stride (halfs)
+#define WINV (1.0f / 256.0f)
+
+namespace {
+
+__device__ __forceinline__ void split8(const float (&v)[8], half8& hi, half8& lo) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const _Float16 hh = (_Float16)v[i];
+        hi[i] = hh;
+        lo[i] = (_Float16)(v[i] - (float)hh);
+    }
+}
+
+// sigmoid with the -log2(e) factor already folded into z
+__device__ __forceinline__ float sig2(float z) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z)); }
+
+// broadcast the values held by lanes of half `ph` (0 = lanes 0-31, 1 = lanes 32-63) to the partner lanes
+__device__ __forceinline__ float take_half(float v, int ph) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(ph == 0 ? r[0] : r[1]);
+}
+
+}  // namespace
+
+template <int NSEQ, int NHALF>
+__global__ __launch_bounds__(512) void dp16_kernel(Dp16Args a) {
+    static_assert(NSEQ * NHALF == 4, "8 waves = NSEQ sequences x 2 directions x NHALF time parts");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int Ls = a.Ls, L = Ls - 7, rowsH = Ls + 1;  // one extra all-zero row for the conv-transpose borders
+    _Float16* Hh = reinterpret_cast<_Float16*>(smem);
+    _Float16* Hl = Hh + NSEQ * rowsH * HLD;
+    _Float16* Wst = Hl + NSEQ * rowsH * HLD;  // [buf 2][part 2][256][WLD]
+    float* chand = reinterpret_cast<float*>(Wst + 2 * 2 * 256 * WLD);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int seq = wave / (2 * NHALF), dir = (wave / NHALF) & 1, part = wave % NHALF;
+    const int n0 = blockIdx.x * NSEQ;
+
+    auto seq_base = [&](int s) {
+        int n = n0 + s;
+        n = n < a.nseq ? n : a.nseq - 1;
+        return (size_t)(n / a.R) * a.bstride + (size_t)(n % a.R) * a.rstride;
+    };
+
+    // ---------------- phase 0: load rows, LayerNorm over channels, split to f16 planes (normalizations.py:33-37)
+    for (int task = tid; task < NSEQ * Ls; task += 512) {
+        const int s = task / Ls, pos = task - s * Ls;
+        const float* xp = a.x + seq_base(s) + pos;
+        float v[64];
+#pragma unroll
+        for (int c = 0; c < 64; ++c) v[c] = xp[(size_t)c * a.cstride];
+        float mean = 0.f;
+#pragma unroll
+        for (int c = 0; c < 64; ++c) mean += v[c];
+        mean *= (1.0f / 64);
+        float var = 0.f;
+#pragma unroll
+        for (int c = 0; c < 64; ++c) {
+            const float d = v[c] - mean;
+            var = fmaf(d, d, var);
+        }
+        const float rstd = 1.0f / sqrtf(var * (1.0f / 64) + RTFS_EPS);
+        _Float16* dh = Hh + (s * rowsH + pos) * HLD;
+        _Float16* dl = Hl + (s * rowsH + pos) * HLD;
+#pragma unroll
+        for (int c8 = 0; c8 < 8; ++c8) {
+            float y[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) y[i] = fmaf((v[c8 * 8 + i] - mean) * rstd, a.ln_gamma[c8 * 8 + i], a.ln_beta[c8 * 8 + i]);
+            half8 hi, lo;
+            split8(y, hi, lo);
+            *reinterpret_cast<half8*>(dh + c8 * 8) = hi;
+            *reinterpret_cast<half8*>(dl + c8 * 8) = lo;
+        }
+    }
+    if (tid < NSEQ * 9) {  // the zero rows (72 halfs = 9 x 16 B each)
+        half8 z;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) z[i] = (_Float16)0.f;
+        const int s = tid / 9, pc = tid % 9;
+        *reinterpret_cast<half8*>(Hh + (s * rowsH + Ls) * HLD + pc * 8) = z;
+        *reinterpret_cast<half8*>(Hl + (s * rowsH + Ls) * HLD + pc * 8) = z;
+    }
+
+    // weight chunk staging: image [part 2][rows][32 halfs] in global -> padded rows in LDS buffer `buf`
+    half8 pre[4];
+    auto stage_load = [&](const half8* img, int rows) {  // rows = 256 (gate columns) or 64 (conv-transpose co)
+        const int npiece = 2 * rows * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = tid + 512 * j;
+            if (i < npiece) pre[j] = img[i];
+        }
+    };
+    auto stage_write = [&](int buf, int rows) {
+        const int npiece = 2 * rows * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = tid + 512 * j;
+            if (i < npiece) {
+                const int pt = i / (rows * 4), rem = i - pt * rows * 4;
+                *reinterpret_cast<half8*>(Wst + ((buf * 2 + pt) * 256 + (rem >> 2)) * WLD + (rem & 3) * 8) = pre[j];
+            }
+        }
+    };
+
+    // activation rows of this wave's two row tiles (virtual time tau; the backward direction reads position L-1-tau)
+    int rowbase[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        int tau = 64 * part + 32 * t + r;
+        tau = tau < L ? tau : L - 1;
+        rowbase[t] = (seq * rowsH + (dir ? L - 1 - tau : tau)) * HLD;
+    }
+
+    // ---------------- four SRU layers
+    for (int layer = 0; layer < 4; ++layer) {
+        const int nchunk = layer == 0 ? 16 : 2;
+        const half8* wimg = layer == 0 ? a.w16_l0 : a.w16_l + (size_t)(layer - 1) * 2 * (2 * 256 * 4);
+        const float vf = a.wc16[layer * 128 + dir * 32 + r], vr = a.wc16[layer * 128 + 64 + dir * 32 + r];
+        const float bf = a.bias16[layer * 128 + dir * 32 + r] * 256.f, br = a.bias16[layer * 128 + 64 + dir * 32 + r] * 256.f;
+        f32x16 acc[2][4];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                acc[t][0][q] = 0.f;
+                acc[t][1][q] = bf;
+                acc[t][2][q] = br;
+                acc[t][3][q] = 0.f;
+            }
+        stage_load(wimg, 256);
+        __syncthreads();  // phase 0 / previous layer's in-place hidden writes are complete; staging buffers are free
+        stage_write(0, 256);
+        __syncthreads();
+        for (int q = 0; q < nchunk; ++q) {
+            if (q + 1 < nchunk) stage_load(wimg + (size_t)(q + 1) * (2 * 256 * 4), 256);
+            const int aoff = layer == 0 ? (q >> 1) * HLD + (q & 1) * 32 : q * 32;
+            const _Float16* wb = Wst + ((q & 1) * 2) * 256 * WLD + (dir * 128 + r) * WLD + 8 * h;
+#pragma unroll
+            for (int ks = 0; ks < 32; ks += 16) {
+                half8 ah[2], al[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    ah[t] = *reinterpret_cast<const half8*>(Hh + rowbase[t] + aoff + ks + 8 * h);
+                    al[t] = *reinterpret_cast<const half8*>(Hl + rowbase[t] + aoff + ks + 8 * h);
+                }
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const half8 bh = *reinterpret_cast<const half8*>(wb + m * 32 * WLD + ks);
+                    const half8 bl = *reinterpret_cast<const half8*>(wb + 256 * WLD + m * 32 * WLD + ks);
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], bh, acc[t][m], 0, 0, 0);
+                        acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], bl, acc[t][m], 0, 0, 0);
+                        acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[t], bh, acc[t][m], 0, 0, 0);
+                    }
+                }
+            }
+            if (q + 1 < nchunk) stage_write((q + 1) & 1, 256);
+            __syncthreads();
+        }
+        // every wave has finished reading the activation planes: the scan may overwrite them in place.
+        // ---- recurrence on the accumulator registers (row of register q: (q&3) + 8*(q>>2) + 4*h)
+        for (int hp = 0; hp < NHALF; ++hp) {
+            if (part == hp) {
+                float c = 0.f;
+                if (NHALF > 1 && hp > 0) c = chand[(seq * 2 + dir) * 32 + r];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg) {
+#pragma unroll
+                        for (int ph = 0; ph < 2; ++ph) {
+                            float cr = c;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const int q = rg * 4 + i;
+                                const float u0 = acc[t][0][q] * WINV;
+                                const float f = sig2(fmaf(acc[t][1][q], WINV, vf * cr));
+                                const float g = sig2(fmaf(acc[t][2][q], WINV, vr * cr));
+                                const float xp = acc[t][3][q] * WINV;
+                                cr = fmaf(cr - u0, f, u0);
+                                const float hv = fmaf(cr - xp, g, xp);
+                                if (h == ph) acc[t][0][q] = hv;  // this lane's own rows: keep the hidden output
+                            }
+                            c = take_half(cr, ph);
+                        }
+                    }
+                }
+                if (NHALF > 1 && h == 0) chand[(seq * 2 + dir) * 32 + r] = c;
+                // write the hidden outputs (this wave's direction half of the channels) back in place
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const int tau = 64 * part + 32 * t + (q & 3) + 8 * (q >> 2) + 4 * h;
+                        if (tau < L) {
+                            const int pos = dir ? L - 1 - tau : tau;
+                            const float hv = acc[t][0][q];
+                            const _Float16 hh = (_Float16)hv;
+                            const int o = (seq * rowsH + pos) * HLD + dir * 32 + r;
+                            Hh[o] = hh;
+                            Hl[o] = (_Float16)(hv - (float)hh);
+                        }
+                    }
+            }
+            if (NHALF > 1) __syncthreads();
+        }
+    }
+
+    // ---------------- ConvTranspose1d(64->64, k=8) + bias + residual (rnn_layers.py:153-156), transposed:
+    //   y[co][t] = bt[co] + sum_{kk,ci} Wt[co][kk*64+ci] * H[t-kk][ci];  wave = (sequence, co tile, position part)
+    {
+        f32x16 acc[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
+        const int cot = dir;
+        stage_load(a.w16_ct, 64);
+        __syncthreads();  // layer-3 hidden outputs are in LDS; staging buffers are free
+        stage_write(0, 64);
+        __syncthreads();
+        for (int q = 0; q < 16; ++q) {
+            if (q + 1 < 16) stage_load(a.w16_ct + (size_t)(q + 1) * (2 * 64 * 4), 64);
+            const int kk = q >> 1, c0 = (q & 1) * 32;
+            const _Float16* wb = Wst + ((q & 1) * 2) * 256 * WLD + (cot * 32 + r) * WLD + 8 * h;
+            int hrow[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int p = 64 * part + 32 * t + r - kk;
+                hrow[t] = (seq * rowsH + ((p >= 0 && p < L) ? p : Ls)) * HLD + c0 + 8 * h;
+            }
+#pragma unroll
+            for (int ks = 0; ks < 32; ks += 16) {
+                const half8 wh = *reinterpret_cast<const half8*>(wb + ks);
+                const half8 wl = *reinterpret_cast<const half8*>(wb + 256 * WLD + ks);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const half8 xh = *reinterpret_cast<const half8*>(Hh + hrow[t] + ks);
+                    const half8 xl = *reinterpret_cast<const half8*>(Hl + hrow[t] + ks);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, acc[t], 0, 0, 0);
+                }
+            }
+            if (q + 1 < 16) stage_write((q + 1) & 1, 64);
+            __syncthreads();
+        }
+        if (n0 + seq < a.nseq) {
+            const size_t base = seq_base(seq);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int p = 64 * part + 32 * t + r;
+                if (p < Ls) {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const int co = cot * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+                        const size_t o = base + (size_t)co * a.cstride + p;
+                        a.out[o] = fmaf(acc[t][q], WINV, a.bt[co]) + a.x[o];
+                    }
+                }
+            }
+        }
+    }
+}
+
+size_t dp16_lds_bytes(int Ls, int nseq_per_wg) {
+    return (size_t)2 * nseq_per_wg * (Ls + 1) * HLD * 2 + (size_t)2 * 2 * 256 * WLD * 2 + (size_t)nseq_per_wg * 2 * 32 * 4;
+}
+
+template <int NSEQ, int NHALF>
+static int launch_dp16_t(const Dp16Args& a, hipStream_t st) {
+    const size_t lds = dp16_lds_bytes(a.Ls, NSEQ);
+    static size_t configured = 0;
+    if (lds > configured) {
+        if (hipFuncSetAttribute((const void*)dp16_kernel<NSEQ, NHALF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return RTFS_ERR_LAUNCH;
+        configured = lds;
+    }
+    void* slot = dualpath_timing_begin(a.Ls, a.nseq, st);
+    hipLaunchKernelGGL((dp16_kernel<NSEQ, NHALF>), dim3(cdiv(a.nseq, NSEQ)), dim3(512), lds, st, a);
+    dualpath_timing_end(slot, st);
+    return rtfs_launch_status();
+}
+
+int launch_dualpath16(const Dp16Args& a, hipStream_t st) {
+    const int L = a.Ls - 7;
+    if (L < 1 || L > 256) return RTFS_ERR_SHAPE;
+    if (L <= 64) return launch_dp16_t<4, 1>(a, st);
+    if (L <= 128) return launch_dp16_t<2, 2>(a, st);
+    return launch_dp16_t<1, 4>(a, st);
+}

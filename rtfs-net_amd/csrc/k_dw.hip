@@ -12,80 +12,96 @@
 #include "kernels.h"
 
 // ---------------------------------------------------------------- stride-1 'same' 4x4 (pad lo 1, hi 2)
+// One thread per (channel, column) walks a band of TH rows with a 4x4 register window (no LDS: the four
+// overlapping row segments of neighbouring lanes are served by L1, HBM sees each element once per band).
 // MODE 0: write pre-norm outputs + stats.  MODE 1: stats only.  MODE 2: TFAR apply:
 //   out = gLN_loc(conv(x)) * sigmoid(gLN_gate(G_gate)^) + gLN_emb(G_emb)^ [+ gLN_add(addend)]
 // where ^ is legacy nearest up-sampling from (Hg, Wg) to (H, W).
 template <int NCONV, bool IN_AFFINE, int MODE>
 __global__ __launch_bounds__(256) void dw_s1_kernel(DwArgs a) {
-    extern __shared__ float tile[];  // (TH+3) x (W+3)
     __shared__ double red[8];
-    const int H = a.H, W = a.W, C = a.C, TH = a.TH;
-    const int c = blockIdx.y, b = blockIdx.z;
-    const int r0 = blockIdx.x * TH;
-    const int TW = W + 3;
+    const int H = a.H, W = a.W, C = a.C;
+    const int b = blockIdx.z;
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    const bool live = g < C * W;
+    const int c = live ? g / W : 0, f = live ? g - c * W : 0;
+    const int r0 = blockIdx.y * a.TH, r1 = min(r0 + a.TH, H);
     const size_t plane = ((size_t)b * C + c) * H * W;
+    const float* xp = a.x + plane;
     float isc = 1.f, ish = 0.f;
     if (IN_AFFINE) gln_fold(a.in_stats + 2 * b, a.in_inv_count, a.in_gamma[c], a.in_beta[c], isc, ish);
-    for (int idx = threadIdx.x; idx < (TH + 3) * TW; idx += 256) {
-        const int rr = idx / TW, cc = idx % TW;
-        const int t = r0 + rr - 1, f = cc - 1;
-        float v = 0.f;
-        if (t >= 0 && t < H && f >= 0 && f < W) {
-            v = a.x[plane + (size_t)t * W + f];
-            if (IN_AFFINE) v = fmaf(v, isc, ish);
-        }
-        tile[idx] = v;
-    }
-    float wgt[NCONV][16];
-    float bia[NCONV];
+    float wgt[NCONV][16], bia[NCONV];
 #pragma unroll
     for (int n = 0; n < NCONV; ++n) {
 #pragma unroll
         for (int j = 0; j < 16; ++j) wgt[n][j] = a.w[n][c * 16 + j];
         bia[n] = a.bias[n] ? a.bias[n][c] : 0.f;
     }
-    // MODE 2 folds
     float lsc = 1.f, lsh = 0.f, gsc = 1.f, gsh = 0.f, esc = 1.f, esh = 0.f, asc = 1.f, ash = 0.f;
     size_t gplane = 0;
+    int fg = 0;
     if (MODE == 2) {
         gln_fold(a.loc_stats + 2 * b, a.loc_inv_count, a.loc_gamma[c], a.loc_beta[c], lsc, lsh);
         gln_fold(a.gate_stats + 2 * b, a.g_inv_count, a.gate_gamma[c], a.gate_beta[c], gsc, gsh);
         gln_fold(a.emb_stats + 2 * b, a.g_inv_count, a.emb_gamma[c], a.emb_beta[c], esc, esh);
         if (a.addend) gln_fold(a.add_stats + 2 * b, a.add_inv_count, a.add_gamma[c], a.add_beta[c], asc, ash);
         gplane = ((size_t)b * C + c) * a.Hg * a.Wg;
+        fg = nearest_src(f, a.Wg, W);
     }
-    __syncthreads();
+    bool fok[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fok[j] = live && (f - 1 + j) >= 0 && (f - 1 + j) < W;
+    auto load_row = [&](int t, float (&row)[4]) {
+        const bool tok = t >= 0 && t < H;
+        const float* rp = xp + (size_t)(tok ? t : 0) * W + f - 1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v = 0.f;
+            if (tok && fok[j]) {
+                v = rp[j];
+                if (IN_AFFINE) v = fmaf(v, isc, ish);
+            }
+            row[j] = v;
+        }
+    };
+    float win[4][4];
+    load_row(r0 - 1, win[0]);
+    load_row(r0, win[1]);
+    load_row(r0 + 1, win[2]);
     float s[NCONV], ss[NCONV];
 #pragma unroll
     for (int n = 0; n < NCONV; ++n) s[n] = ss[n] = 0.f;
-    const int rows = min(TH, H - r0);
-    for (int idx = threadIdx.x; idx < rows * W; idx += 256) {
-        const int rr = idx / W, f = idx % W;
-        float v[16];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[i * 4 + j] = tile[(rr + i) * TW + f + j];
-        const size_t o = plane + (size_t)(r0 + rr) * W + f;
+#pragma unroll 4
+    for (int t = r0; t < r1; ++t) {
+        load_row(t + 2, win[3]);
+        const size_t o = plane + (size_t)t * W + f;
 #pragma unroll
         for (int n = 0; n < NCONV; ++n) {
             float acc = bia[n];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) acc = fmaf(v[j], wgt[n][j], acc);
-            if (MODE == 0) a.out[n][o] = acc;
-            if (MODE != 2) {
-                s[n] += acc;
-                ss[n] = fmaf(acc, acc, ss[n]);
-            } else {
-                const int tg = nearest_src(r0 + rr, a.Hg, H), fg = nearest_src(f, a.Wg, W);
-                const size_t go = gplane + (size_t)tg * a.Wg + fg;
-                const float gate = sigmoidf_(fmaf(a.gate[go], gsc, gsh));
-                const float emb = fmaf(a.emb[go], esc, esh);
-                float y = fmaf(fmaf(acc, lsc, lsh), gate, emb);
-                if (a.addend) y += fmaf(a.addend[o], asc, ash);
-                a.out[0][o] = y;
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc = fmaf(win[i][j], wgt[n][i * 4 + j], acc);
+            if (live) {
+                if (MODE == 0) a.out[n][o] = acc;
+                if (MODE != 2) {
+                    s[n] += acc;
+                    ss[n] = fmaf(acc, acc, ss[n]);
+                } else {
+                    const int tg = nearest_src(t, a.Hg, H);
+                    const size_t go = gplane + (size_t)tg * a.Wg + fg;
+                    const float gate = sigmoidf_(fmaf(a.gate[go], gsc, gsh));
+                    const float emb = fmaf(a.emb[go], esc, esh);
+                    float y = fmaf(fmaf(acc, lsc, lsh), gate, emb);
+                    if (a.addend) y += fmaf(a.addend[o], asc, ash);
+                    a.out[0][o] = y;
+                }
             }
         }
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) win[i][j] = win[i + 1][j];
     }
     if (MODE != 2) {
 #pragma unroll
@@ -100,54 +116,72 @@ __global__ __launch_bounds__(256) void dw_s1_kernel(DwArgs a) {
 // Reads d0 = gLN(c0) through the fold; writes c1 (pre-norm conv output, +stats) and p0 = adaptive_avg_pool2d(d0)
 // at the conv's output resolution (Ho = H/2, Wo = W/2).  The pool window of output (i,j) is
 // rows [floor(i*H/Ho), ceil((i+1)*H/Ho)) which always lies inside the conv window [2i-1, 2i+3).
+// One thread per (channel, output column) walks TH output rows, keeping the two rows shared by
+// consecutive windows in registers.
 __global__ __launch_bounds__(256) void dw_s2_pool_kernel(DwArgs a) {
-    extern __shared__ float tile[];  // (2*TH+2) x (W+2)
     __shared__ double red[8];
-    const int H = a.H, W = a.W, C = a.C, TH = a.TH, Ho = a.Hg, Wo = a.Wg;
-    const int c = blockIdx.y, b = blockIdx.z;
-    const int i0 = blockIdx.x * TH;
-    const int TW = W + 2, TR = 2 * TH + 2;
+    const int H = a.H, W = a.W, C = a.C, Ho = a.Hg, Wo = a.Wg;
+    const int b = blockIdx.z;
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    const bool live = g < C * Wo;
+    const int c = live ? g / Wo : 0, j = live ? g - c * Wo : 0;
+    const int i0 = blockIdx.y * a.TH, i1 = min(i0 + a.TH, Ho);
     const size_t plane = ((size_t)b * C + c) * H * W;
+    const float* xp = a.x + plane;
     float isc, ish;
     gln_fold(a.in_stats + 2 * b, a.in_inv_count, a.in_gamma[c], a.in_beta[c], isc, ish);
-    for (int idx = threadIdx.x; idx < TR * TW; idx += 256) {
-        const int rr = idx / TW, cc = idx % TW;
-        const int t = 2 * i0 - 1 + rr, f = cc - 1;
-        float v = 0.f;
-        if (t >= 0 && t < H && f >= 0 && f < W) v = fmaf(a.x[plane + (size_t)t * W + f], isc, ish);
-        tile[idx] = v;
-    }
     float wgt[16];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) wgt[j] = a.w[0][c * 16 + j];
+    for (int k = 0; k < 16; ++k) wgt[k] = a.w[0][c * 16 + k];
     const float bia = a.bias[0][c];
-    __syncthreads();
-    float s = 0.f, ss = 0.f;
-    const int rows = min(TH, Ho - i0);
-    const size_t oplane = ((size_t)b * C + c) * Ho * Wo;
-    for (int idx = threadIdx.x; idx < rows * Wo; idx += 256) {
-        const int ii = idx / Wo, j = idx % Wo;
-        const int i = i0 + ii;
-        float acc = bia;
-        // pool window in image coordinates
-        const int ts = (int)(((long long)i * H) / Ho), te = (int)(((long long)(i + 1) * H + Ho - 1) / Ho);
-        const int fs = (int)(((long long)j * W) / Wo), fe = (int)(((long long)(j + 1) * W + Wo - 1) / Wo);
-        float pool = 0.f;
+    const int fs = (int)(((long long)j * W) / Wo), fe = (int)(((long long)(j + 1) * W + Wo - 1) / Wo);
+    bool fok[4], fpool[4];
 #pragma unroll
-        for (int di = 0; di < 4; ++di)
+    for (int d = 0; d < 4; ++d) {
+        const int f = 2 * j - 1 + d;
+        fok[d] = live && f >= 0 && f < W;
+        fpool[d] = f >= fs && f < fe;
+    }
+    auto load_row = [&](int t, float (&row)[4]) {
+        const bool tok = t >= 0 && t < H;
+        const float* rp = xp + (size_t)(tok ? t : 0) * W + 2 * j - 1;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) row[d] = (tok && fok[d]) ? fmaf(rp[d], isc, ish) : 0.f;
+    };
+    float win[4][4];
+    load_row(2 * i0 - 1, win[0]);
+    load_row(2 * i0, win[1]);
+    float s = 0.f, ss = 0.f;
+    const size_t oplane = ((size_t)b * C + c) * Ho * Wo;
+#pragma unroll 2
+    for (int i = i0; i < i1; ++i) {
+        load_row(2 * i + 1, win[2]);
+        load_row(2 * i + 2, win[3]);
+        const int ts = (int)(((long long)i * H) / Ho), te = (int)(((long long)(i + 1) * H + Ho - 1) / Ho);
+        float acc = bia, pool = 0.f;
+#pragma unroll
+        for (int di = 0; di < 4; ++di) {
+            const int t = 2 * i - 1 + di;
+            const bool tp = t >= ts && t < te;
 #pragma unroll
             for (int dj = 0; dj < 4; ++dj) {
-                const float v = tile[(2 * ii + di) * TW + 2 * j + dj];
-                acc = fmaf(v, wgt[di * 4 + dj], acc);
-                const int t = 2 * i - 1 + di, f = 2 * j - 1 + dj;
-                if (t >= ts && t < te && f >= fs && f < fe) pool += v;
+                acc = fmaf(win[di][dj], wgt[di * 4 + dj], acc);
+                if (tp && fpool[dj]) pool += win[di][dj];
             }
+        }
         pool /= (float)((te - ts) * (fe - fs));
-        const size_t o = oplane + (size_t)i * Wo + j;
-        a.out[0][o] = acc;
-        a.out[1][o] = pool;
-        s += acc;
-        ss = fmaf(acc, acc, ss);
+        if (live) {
+            const size_t o = oplane + (size_t)i * Wo + j;
+            a.out[0][o] = acc;
+            a.out[1][o] = pool;
+            s += acc;
+            ss = fmaf(acc, acc, ss);
+        }
+#pragma unroll
+        for (int dj = 0; dj < 4; ++dj) {
+            win[0][dj] = win[2][dj];
+            win[1][dj] = win[3][dj];
+        }
     }
     block_stats_atomic(s, ss, red, a.stats_out[0] + 2 * b);
 }
@@ -207,8 +241,7 @@ __global__ __launch_bounds__(256) void stats_kernel(const float* __restrict__ x,
 // ---------------------------------------------------------------- launchers
 template <int NCONV, bool IN_AFFINE, int MODE>
 static int launch_dw_s1_t(const DwArgs& a, int B, hipStream_t st) {
-    const size_t lds = (size_t)(a.TH + 3) * (a.W + 3) * sizeof(float);
-    hipLaunchKernelGGL((dw_s1_kernel<NCONV, IN_AFFINE, MODE>), dim3(cdiv(a.H, a.TH), a.C, B), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((dw_s1_kernel<NCONV, IN_AFFINE, MODE>), dim3(cdiv(a.C * a.W, 256), cdiv(a.H, a.TH), B), dim3(256), 0, st, a);
     return rtfs_launch_status();
 }
 
@@ -226,8 +259,7 @@ int launch_dw_s1(const DwArgs& a, int nconv, bool in_affine, int mode, int B, hi
 }
 
 int launch_dw_s2_pool(const DwArgs& a, int B, hipStream_t st) {
-    const size_t lds = (size_t)(2 * a.TH + 2) * (a.W + 2) * sizeof(float);
-    hipLaunchKernelGGL(dw_s2_pool_kernel, dim3(cdiv(a.Hg, a.TH), a.C, B), dim3(256), lds, st, a);
+    hipLaunchKernelGGL(dw_s2_pool_kernel, dim3(cdiv(a.C * a.Wg, 256), cdiv(a.Hg, a.TH), B), dim3(256), 0, st, a);
     return rtfs_launch_status();
 }
 

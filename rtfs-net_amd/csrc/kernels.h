@@ -2,12 +2,14 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stddef.h>
+#include "common.h"
 
 struct PwArgs {
     const float* x = nullptr;     // (B, CIN, P)
     const float* x2 = nullptr;    // optional second addend (gateway: the bottleneck residual a1)
     float* res_out = nullptr;     // gateway: PReLU(dw1x1(x [+x2])) written through, (B, CIN, P)
-    const float* wt = nullptr;    // (CIN, COUT) transposed 1x1 weight
+    const float* wt = nullptr;    // (CIN, COUT) transposed 1x1 weight (exact-f32 kernels)
+    const void* w16 = nullptr;    // [CIN/32][hi|lo][COUT][32] f16 split image of 256*W (f16x3 kernels)
     const float* bias = nullptr;  // (COUT)
     const float* aux = nullptr;   // EPI_BIAS_RES: residual (B,COUT,P); EPI_S3: encoder output a0 (B,COUT,P)
     float* out = nullptr;         // (B, COUT, P)
@@ -32,6 +34,12 @@ int launch_pw_gateway_proj(const PwArgs& a, int B, hipStream_t st);
 int launch_pw_residual(const PwArgs& a, int B, hipStream_t st);
 int launch_pw_s3(const PwArgs& a, int B, hipStream_t st);
 int launch_pw_dec_taps(const PwArgs& a, int B, hipStream_t st);
+int launch_pw16_audio_bn(const PwArgs& a, int B, hipStream_t st);
+int launch_pw16_gateway_proj(const PwArgs& a, int B, hipStream_t st);
+int launch_pw16_residual(const PwArgs& a, int B, hipStream_t st);
+int launch_pw16_s3(const PwArgs& a, int B, hipStream_t st);
+int launch_pw16_dec_taps(const PwArgs& a, int B, hipStream_t st);
+int launch_mfma_f16_selftest(const float* A, const float* B, float* D, hipStream_t st);
 
 // Depthwise 4x4 family.  Tensors are (B, C, H, W) contiguous.
 struct DwArgs {
@@ -150,3 +158,23 @@ int launch_caf_video(const CafArgs& a, int B, hipStream_t st);
 int launch_caf_apply(const CafArgs& a, int B, hipStream_t st);
 int dualpath_timing_enable(int on);
 int dualpath_timing_collect(float* ms, int* ls, int* nseq, int cap);
+
+// Fused dual-path SRU sweep, f16x3 generation (k_dualpath16.hip).  Same sequence addressing as DpArgs.
+struct Dp16Args {
+    const float* x = nullptr;
+    float* out = nullptr;
+    int nseq = 0, R = 0, Ls = 0;
+    size_t bstride = 0, rstride = 0, cstride = 0;
+    const float* ln_gamma = nullptr;
+    const float* ln_beta = nullptr;
+    const half8* w16_l0 = nullptr;  // [16 chunks][hi|lo][256 cols = dir*128 + gate*32 + j][32 k'], k' = kk*64 + c
+    const half8* w16_l = nullptr;   // 3 x [2 chunks][hi|lo][256][32]; gate 3 = identity block (highway input)
+    const half8* w16_ct = nullptr;  // [16 chunks][hi|lo][64 co][32 k'], k' = kk*64 + ci
+    const float* wc16 = nullptr;    // 4 x (128): v_f, v_r scaled by -log2(e)
+    const float* bias16 = nullptr;  // 4 x (128): b_f, b_r scaled by -log2(e)
+    const float* bt = nullptr;      // (64)
+};
+size_t dp16_lds_bytes(int Ls, int nseq_per_wg);
+int launch_dualpath16(const Dp16Args& a, hipStream_t st);
+void* dualpath_timing_begin(int Ls, int nseq, hipStream_t st);
+void dualpath_timing_end(void* slot, hipStream_t st);

@@ -28,6 +28,21 @@ def _cat(tensors):
     return torch.cat(out).contiguous()
 
 
+LOG2E = 1.4426950408889634
+W16_SCALE = 256.0  # weights are stored pre-scaled by 2^8 so their f16 low parts stay normal; kernels undo it
+
+
+def split16_image(w):
+    """(cout, cin) f32 weight -> the f16x3 kernels' staged image [cin/32][hi|lo][cout][32] halfs, returned bit-cast
+    to float32 (cout*cin/... same element count as w).  w*256 = hi + lo with hi, lo exactly representable in f16."""
+    cout, cin = w.shape
+    ws = w.detach().to(torch.float32) * W16_SCALE
+    hi = ws.to(torch.float16)
+    lo = (ws - hi.to(torch.float32)).to(torch.float16)
+    img = torch.stack([hi.reshape(cout, cin // 32, 32).permute(1, 0, 2), lo.reshape(cout, cin // 32, 32).permute(1, 0, 2)], 1)
+    return img.contiguous().view(torch.float32).reshape(-1)
+
+
 def pack_encoder(sd):
     """STFTEncoder: conv.full_layer.2.weight (256,2,3,3) -> (256,18)."""
     return _cat([sd["conv.full_layer.2.weight"].reshape(256, 18)])
@@ -35,7 +50,7 @@ def pack_encoder(sd):
 
 def pack_audio_bn(sd):
     w = sd["full_layer.2.weight"].reshape(256, 256)
-    return _cat([sd["full_layer.0.norm.weight"], sd["full_layer.0.norm.bias"], w.t(), sd["full_layer.2.bias"]])
+    return _cat([sd["full_layer.0.norm.weight"], sd["full_layer.0.norm.bias"], w.t(), sd["full_layer.2.bias"], split16_image(w)])
 
 
 def _dualpath_parts(sd):
@@ -49,6 +64,22 @@ def _dualpath_parts(sd):
     parts.append(torch.stack([sd[f"rnn.rnn_lst.{i}.bias"] for i in range(4)]))
     parts.append(sd["linear.weight"].permute(2, 0, 1).reshape(512, 64))  # (ci,co,k) -> (k*64+ci, co)
     parts.append(sd["linear.bias"])
+    # ---- f16x3 images for k_dualpath16.hip.  Gate columns (m = 1 forget, 2 reset), v_f/v_r and b_f/b_r carry the
+    # factor -log2(e) so the kernel's sigmoid is rcp(1 + exp2(z)).
+    gate_scale = torch.tensor([1.0, -LOG2E, -LOG2E, 1.0], dtype=torch.float32, device=sd["norm.gamma"].device)
+    w0 = sd["rnn.rnn_lst.0.weight"].detach().to(torch.float32).reshape(64, 8, 2, 32, 4) * gate_scale  # (c, kk, dir, j, m)
+    w0 = w0.permute(1, 0, 2, 4, 3).reshape(512, 256)  # rows k' = kk*64 + c, cols dir*128 + m*32 + j
+    parts.append(split16_image(w0.t()))
+    imgs = []
+    eye = torch.eye(64, dtype=torch.float32, device=w0.device).reshape(64, 2, 32, 1)  # highway input via an identity gate
+    for i in (1, 2, 3):
+        w = sd[f"rnn.rnn_lst.{i}.weight"].detach().to(torch.float32).reshape(64, 2, 32, 3)
+        w = torch.cat([w, eye], 3) * gate_scale  # (k, dir, j, m)
+        imgs.append(split16_image(w.permute(0, 1, 3, 2).reshape(64, 256).t()))
+    parts.append(torch.stack(imgs))
+    parts.append(split16_image(sd["linear.weight"].detach().to(torch.float32).permute(1, 2, 0).reshape(64, 512)))  # rows co, k' = kk*64+ci
+    parts.append(torch.stack([sd[f"rnn.rnn_lst.{i}.weight_c"] for i in range(4)]) * (-LOG2E))
+    parts.append(torch.stack([sd[f"rnn.rnn_lst.{i}.bias"] for i in range(4)]) * (-LOG2E))
     return parts
 
 
@@ -97,6 +128,7 @@ def pack_block(sd):
     parts += _tfar_parts(_sub(sd, "fusion_layers.1"))
     parts += _tfar_parts(_sub(sd, "concat_layers.0"))
     parts += [sd["residual_conv.full_layer.2.weight"].reshape(256, 64).t(), sd["residual_conv.full_layer.2.bias"]]
+    parts += [split16_image(sd["projection.full_layer.2.weight"].reshape(64, 256)), split16_image(sd["residual_conv.full_layer.2.weight"].reshape(256, 64))]
     return _cat(parts)
 
 
@@ -117,11 +149,12 @@ def pack_caf(sd):
 
 def pack_s3(sd):
     """MaskGenerator: mask_generator = Sequential(PReLU, ConvNormAct(1x1, ReLU))."""
-    return _cat([sd["mask_generator.0.weight"].reshape(1), sd["mask_generator.1.full_layer.2.weight"].reshape(256, 256).t(),
-                 sd["mask_generator.1.full_layer.2.bias"]])
+    w = sd["mask_generator.1.full_layer.2.weight"].reshape(256, 256)
+    return _cat([sd["mask_generator.0.weight"].reshape(1), w.t(), sd["mask_generator.1.full_layer.2.bias"], split16_image(w)])
 
 
 def pack_decoder(sd):
     """STFTDecoder: ConvTranspose2d weight (256,2,3,3) -> 18 per-tap 1x1 maps, zero padded to 32."""
     w = sd["decoder.weight"].reshape(256, 18)
-    return _cat([torch.cat([w, w.new_zeros(256, 14)], 1)])
+    w = torch.cat([w, w.new_zeros(256, 14)], 1)  # (cin 256, 32 taps)
+    return _cat([w, split16_image(w.t())])

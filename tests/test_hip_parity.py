@@ -59,6 +59,20 @@ def test_library_loaded_is_hip():
     assert b"gfx950" in lib.rtfs_version()
 
 
+def test_mfma_f16_fragment_layout():
+    """Exact integer data, asymmetric operands: catches any row/col or k-order mistake in the assumed lane maps."""
+    import ctypes
+    from rtfs_net_amd import _lib
+    lib = _lib.load()
+    i, k, j = np.arange(32)[:, None], np.arange(16), np.arange(32)[None, :]
+    A = ((i * 3 + k[None, :] * 5) % 7 - 3).astype(np.float32)
+    Bm = ((k[:, None] * 2 + j * 11) % 5 - 2).astype(np.float32)
+    dA, dB = dev(A), dev(Bm)
+    dD = torch.zeros(32, 32, device="cuda")
+    _lib.check(lib.rtfs_selftest_mfma_f16(_lib.ptr(dA), _lib.ptr(dB), _lib.ptr(dD), _lib.stream_of(dD)), "selftest")
+    assert np.array_equal(host(dD), A @ Bm)
+
+
 def test_encoder():
     m = model()
     x = rand((2, 2048), 101, 0.07)

@@ -111,7 +111,15 @@ def test_pack_layout_and_cache_invalidation():
     assert torch.equal(wt[3, 5], dp.linear.weight.detach()[5, :, 3])
     with torch.no_grad():
         dp.linear.bias.add_(1.0)
-    assert dp.pack() is not p and torch.equal(dp.pack()[-64:], dp.linear.bias.detach())
+    off += 512 * 64
+    assert dp.pack() is not p and torch.equal(dp.pack()[off:off + 64], dp.linear.bias.detach())
+    # f16x3 image of the layer-0 projection: [chunk][hi|lo][col = dir*128 + gate*32 + j][32 k'], k' = kk*64 + c, scaled by 256
+    img = dp.pack()[off + 64:off + 64 + 512 * 256].view(torch.float16).view(16, 2, 256, 32).float()
+    w0 = dp.rnn.rnn_lst[0].weight.detach()
+    c, kk, d, j = 37, 5, 1, 9
+    kp = kk * 64 + c
+    rec = (img[kp // 32, 0, d * 128 + 0 * 32 + j, kp % 32] + img[kp // 32, 1, d * 128 + j, kp % 32]) / 256.0
+    assert abs(float(rec) - float(w0[c * 8 + kk, (d * 32 + j) * 4 + 0])) < 1e-6 * abs(float(w0[c * 8 + kk, (d * 32 + j) * 4]))+1e-9
 
 
 def test_upstream_sru_checkpoint_keys_accepted():
