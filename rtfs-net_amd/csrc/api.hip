@@ -331,7 +331,7 @@ int block_forward(const BlockPack& p, const float* x, const float* x_res, float*
         a.gb = p.gb;
         a.slope = p.gslope;
         a.P = P;
-        CHECK(gemm_f32() ? launch_pw_gateway_proj(a, B, st) : launch_pw16_gateway_proj(a, B, st));
+        CHECK(gemm_f32() ? launch_pw_gateway_proj(a, B, st) : launch_pws_gateway_proj(a, B, st));
     }
     {  // 2. downsample[0]: dw 4x4 s1 + bias -> c0 (pre-gLN) + stats                         tdanet.py:110
         DwArgs a;
@@ -452,7 +452,7 @@ int block_forward(const BlockPack& p, const float* x, const float* x_res, float*
         a.aux = w.residual;
         a.out = out;
         a.P = P;
-        CHECK(gemm_f32() ? launch_pw_residual(a, B, st) : launch_pw16_residual(a, B, st));
+        CHECK(gemm_f32() ? launch_pw_residual(a, B, st) : launch_pws_residual(a, B, st));
     }
     return RTFS_OK;
 }

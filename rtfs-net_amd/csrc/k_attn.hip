@@ -101,7 +101,8 @@ __global__ __launch_bounds__(256) void attn_core_kernel(AttnArgs a) {
         }
         for (int idx = tid; idx < NK * 64; idx += 256) {
             const int j = idx >> 6, k = idx & 63;
-            Ks[j * 65 + k] = j < T ? K[(size_t)j * 256 + kc + k] : 0.f;
+            const float kv = K[(size_t)min(j, T - 1) * 256 + kc + k];
+            Ks[j * 65 + k] = j < T ? kv : 0.f;
         }
         __syncthreads();
 #pragma unroll 4

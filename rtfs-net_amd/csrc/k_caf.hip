@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void caf_video_kernel(CafArgs a) {
     for (int t = 0; t < Tv; ++t) ao[t] *= inv;
 }
 
-__global__ __launch_bounds__(256) void caf_apply_kernel(CafArgs a) {
+__device__ __forceinline__ void caf_apply_body(const CafArgs& a, const float* __restrict__ AUDIO, float* __restrict__ OUT) {
     const int c = blockIdx.y, b = blockIdx.z;
     const int T = a.T, F = a.F, Tv = a.Tv;
     const float ks = a.w_key[c] * a.bn_key[c] / sqrtf(a.bn_key[768 + c] + RTFS_EPS);
@@ -93,10 +93,12 @@ __global__ __launch_bounds__(256) void caf_apply_kernel(CafArgs a) {
     for (int p = blockIdx.x * 256 + threadIdx.x; p < T * F; p += gridDim.x * 256) {
         const int t = p / F;
         const int tv = nearest_src(t, Tv, T);
-        const float x = a.audio[plane + p];
-        a.out[plane + p] = fmaf(fmaxf(fmaf(x, ks, kb), 0.f), r[tv], at[tv] * fmaf(x, vs, vb));
+        const float x = AUDIO[plane + p];
+        OUT[plane + p] = fmaf(fmaxf(fmaf(x, ks, kb), 0.f), r[tv], at[tv] * fmaf(x, vs, vb));
     }
 }
+
+__global__ __launch_bounds__(256) void caf_apply_kernel(CafArgs a) { caf_apply_body(a, a.audio, a.out); }
 
 int launch_caf_video(const CafArgs& a, int B, hipStream_t st) {
     hipLaunchKernelGGL(caf_video_kernel, dim3(B), dim3(256), 0, st, a);

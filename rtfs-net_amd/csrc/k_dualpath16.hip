@@ -18,6 +18,7 @@
 //     folded into the gate weights; hidden outputs are written back to the LDS planes in place.
 #include "common.h"
 #include "kernels.h"
+#include <type_traits>
 
 
 #define HLD 72   // activation row stride (halfs)
@@ -110,25 +111,24 @@ __global__ __launch_bounds__(512) void dp16_kernel(Dp16Args a) {
 
     // weight chunk staging: image [part 2][rows][32 halfs] in global -> padded rows in LDS buffer `buf`
     half8 pre[4];
-    auto stage_load = [&](const half8* img, int rows) {  // rows = 256 (gate columns) or 64 (conv-transpose co)
-        const int npiece = 2 * rows * 4;
+    auto stage_load = [&](const half8* __restrict__ img, auto rows_c) {  // rows = 256 (gate columns) or 64 (conv-transpose co)
+        constexpr int rows = decltype(rows_c)::value;
+        constexpr int npiece = 2 * rows * 4;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < (npiece + 511) / 512; ++j) pre[j] = img[tid + 512 * j];
+    };
+    auto stage_write = [&](int buf, auto rows_c) {
+        constexpr int rows = decltype(rows_c)::value;
+        constexpr int npiece = 2 * rows * 4;
+#pragma unroll
+        for (int j = 0; j < (npiece + 511) / 512; ++j) {
             const int i = tid + 512 * j;
-            if (i < npiece) pre[j] = img[i];
+            const int pt = i / (rows * 4), rem = i - pt * rows * 4;
+            *reinterpret_cast<half8*>(Wst + ((buf * 2 + pt) * 256 + (rem >> 2)) * WLD + (rem & 3) * 8) = pre[j];
         }
     };
-    auto stage_write = [&](int buf, int rows) {
-        const int npiece = 2 * rows * 4;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int i = tid + 512 * j;
-            if (i < npiece) {
-                const int pt = i / (rows * 4), rem = i - pt * rows * 4;
-                *reinterpret_cast<half8*>(Wst + ((buf * 2 + pt) * 256 + (rem >> 2)) * WLD + (rem & 3) * 8) = pre[j];
-            }
-        }
-    };
+    const std::integral_constant<int, 256> R256;
+    const std::integral_constant<int, 64> R64;
 
     // activation rows of this wave's two row tiles (virtual time tau; the backward direction reads position L-1-tau)
     int rowbase[2];
@@ -155,12 +155,12 @@ __global__ __launch_bounds__(512) void dp16_kernel(Dp16Args a) {
                 acc[t][2][q] = br;
                 acc[t][3][q] = 0.f;
             }
-        stage_load(wimg, 256);
+        stage_load(wimg, R256);
         __syncthreads();  // phase 0 / previous layer's in-place hidden writes are complete; staging buffers are free
-        stage_write(0, 256);
+        stage_write(0, R256);
         __syncthreads();
         for (int q = 0; q < nchunk; ++q) {
-            if (q + 1 < nchunk) stage_load(wimg + (size_t)(q + 1) * (2 * 256 * 4), 256);
+            if (q + 1 < nchunk) stage_load(wimg + (size_t)(q + 1) * (2 * 256 * 4), R256);
             const int aoff = layer == 0 ? (q >> 1) * HLD + (q & 1) * 32 : q * 32;
             const _Float16* wb = Wst + ((q & 1) * 2) * 256 * WLD + (dir * 128 + r) * WLD + 8 * h;
 #pragma unroll
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(512) void dp16_kernel(Dp16Args a) {
                     }
                 }
             }
-            if (q + 1 < nchunk) stage_write((q + 1) & 1, 256);
+            if (q + 1 < nchunk) stage_write((q + 1) & 1, R256);
             __syncthreads();
         }
         // every wave has finished reading the activation planes: the scan may overwrite them in place.
@@ -244,12 +244,12 @@ __global__ __launch_bounds__(512) void dp16_kernel(Dp16Args a) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
         const int cot = dir;
-        stage_load(a.w16_ct, 64);
+        stage_load(a.w16_ct, R64);
         __syncthreads();  // layer-3 hidden outputs are in LDS; staging buffers are free
-        stage_write(0, 64);
+        stage_write(0, R64);
         __syncthreads();
         for (int q = 0; q < 16; ++q) {
-            if (q + 1 < 16) stage_load(a.w16_ct + (size_t)(q + 1) * (2 * 64 * 4), 64);
+            if (q + 1 < 16) stage_load(a.w16_ct + (size_t)(q + 1) * (2 * 64 * 4), R64);
             const int kk = q >> 1, c0 = (q & 1) * 32;
             const _Float16* wb = Wst + ((q & 1) * 2) * 256 * WLD + (cot * 32 + r) * WLD + 8 * h;
             int hrow[2];
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(512) void dp16_kernel(Dp16Args a) {
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, acc[t], 0, 0, 0);
                 }
             }
-            if (q + 1 < 16) stage_write((q + 1) & 1, 64);
+            if (q + 1 < 16) stage_write((q + 1) & 1, R64);
             __syncthreads();
         }
         if (n0 + seq < a.nseq) {
@@ -280,11 +280,13 @@ __global__ __launch_bounds__(512) void dp16_kernel(Dp16Args a) {
             for (int t = 0; t < 2; ++t) {
                 const int p = 64 * part + 32 * t + r;
                 if (p < Ls) {
+                    float res[16];
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) res[q] = a.x[base + (size_t)(cot * 32 + (q & 3) + 8 * (q >> 2) + 4 * h) * a.cstride + p];
 #pragma unroll
                     for (int q = 0; q < 16; ++q) {
                         const int co = cot * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
-                        const size_t o = base + (size_t)co * a.cstride + p;
-                        a.out[o] = fmaf(acc[t][q], WINV, a.bt[co]) + a.x[o];
+                        a.out[base + (size_t)co * a.cstride + p] = fmaf(acc[t][q], WINV, a.bt[co]) + res[q];
                     }
                 }
             }

@@ -18,7 +18,9 @@
 //   out = gLN_loc(conv(x)) * sigmoid(gLN_gate(G_gate)^) + gLN_emb(G_emb)^ [+ gLN_add(addend)]
 // where ^ is legacy nearest up-sampling from (Hg, Wg) to (H, W).
 template <int NCONV, bool IN_AFFINE, int MODE>
-__global__ __launch_bounds__(256) void dw_s1_kernel(DwArgs a) {
+__device__ __forceinline__ void dw_s1_body(const DwArgs& a, const float* __restrict__ X, const float* __restrict__ GATE,
+                                           const float* __restrict__ EMB, const float* __restrict__ ADD, float* __restrict__ O0,
+                                           float* __restrict__ O1, float* __restrict__ O2, float* __restrict__ O3) {
     __shared__ double red[8];
     const int H = a.H, W = a.W, C = a.C;
     const int b = blockIdx.z;
@@ -27,7 +29,7 @@ __global__ __launch_bounds__(256) void dw_s1_kernel(DwArgs a) {
     const int c = live ? g / W : 0, f = live ? g - c * W : 0;
     const int r0 = blockIdx.y * a.TH, r1 = min(r0 + a.TH, H);
     const size_t plane = ((size_t)b * C + c) * H * W;
-    const float* xp = a.x + plane;
+    const float* __restrict__ xp = X + plane;
     float isc = 1.f, ish = 0.f;
     if (IN_AFFINE) gln_fold(a.in_stats + 2 * b, a.in_inv_count, a.in_gamma[c], a.in_beta[c], isc, ish);
     float wgt[NCONV][16], bia[NCONV];
@@ -49,19 +51,22 @@ __global__ __launch_bounds__(256) void dw_s1_kernel(DwArgs a) {
         fg = nearest_src(f, a.Wg, W);
     }
     bool fok[4];
+    int fcl[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) fok[j] = live && (f - 1 + j) >= 0 && (f - 1 + j) < W;
+    for (int j = 0; j < 4; ++j) {
+        const int ff = f - 1 + j;
+        fok[j] = live && ff >= 0 && ff < W;
+        fcl[j] = ff < 0 ? 0 : (ff < W ? ff : W - 1);
+    }
+    // unconditional loads from clamped addresses, zero-padding applied by select (no branch + wait per tap)
     auto load_row = [&](int t, float (&row)[4]) {
         const bool tok = t >= 0 && t < H;
-        const float* rp = xp + (size_t)(tok ? t : 0) * W + f - 1;
+        const float* __restrict__ rp = xp + (size_t)(t < 0 ? 0 : (t < H ? t : H - 1)) * W;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            float v = 0.f;
-            if (tok && fok[j]) {
-                v = rp[j];
-                if (IN_AFFINE) v = fmaf(v, isc, ish);
-            }
-            row[j] = v;
+            float v = rp[fcl[j]];
+            if (IN_AFFINE) v = fmaf(v, isc, ish);
+            row[j] = (tok && fok[j]) ? v : 0.f;
         }
     };
     float win[4][4];
@@ -83,18 +88,18 @@ __global__ __launch_bounds__(256) void dw_s1_kernel(DwArgs a) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc = fmaf(win[i][j], wgt[n][i * 4 + j], acc);
             if (live) {
-                if (MODE == 0) a.out[n][o] = acc;
+                if (MODE == 0) (n == 0 ? O0 : n == 1 ? O1 : n == 2 ? O2 : O3)[o] = acc;
                 if (MODE != 2) {
                     s[n] += acc;
                     ss[n] = fmaf(acc, acc, ss[n]);
                 } else {
                     const int tg = nearest_src(t, a.Hg, H);
                     const size_t go = gplane + (size_t)tg * a.Wg + fg;
-                    const float gate = sigmoidf_(fmaf(a.gate[go], gsc, gsh));
-                    const float emb = fmaf(a.emb[go], esc, esh);
+                    const float gate = sigmoidf_(fmaf(GATE[go], gsc, gsh));
+                    const float emb = fmaf(EMB[go], esc, esh);
                     float y = fmaf(fmaf(acc, lsc, lsh), gate, emb);
-                    if (a.addend) y += fmaf(a.addend[o], asc, ash);
-                    a.out[0][o] = y;
+                    if (ADD) y += fmaf(ADD[o], asc, ash);
+                    O0[o] = y;
                 }
             }
         }
@@ -112,13 +117,18 @@ __global__ __launch_bounds__(256) void dw_s1_kernel(DwArgs a) {
     }
 }
 
+template <int NCONV, bool IN_AFFINE, int MODE>
+__global__ __launch_bounds__(256) void dw_s1_kernel(DwArgs a) {
+    dw_s1_body<NCONV, IN_AFFINE, MODE>(a, a.x, a.gate, a.emb, a.addend, a.out[0], a.out[1], a.out[2], a.out[3]);
+}
+
 // ---------------------------------------------------------------- stride-2 pad-1 4x4 + adaptive average pool
 // Reads d0 = gLN(c0) through the fold; writes c1 (pre-norm conv output, +stats) and p0 = adaptive_avg_pool2d(d0)
 // at the conv's output resolution (Ho = H/2, Wo = W/2).  The pool window of output (i,j) is
 // rows [floor(i*H/Ho), ceil((i+1)*H/Ho)) which always lies inside the conv window [2i-1, 2i+3).
 // One thread per (channel, output column) walks TH output rows, keeping the two rows shared by
 // consecutive windows in registers.
-__global__ __launch_bounds__(256) void dw_s2_pool_kernel(DwArgs a) {
+__device__ __forceinline__ void dw_s2_pool_body(const DwArgs& a, const float* __restrict__ X, float* __restrict__ O0, float* __restrict__ O1) {
     __shared__ double red[8];
     const int H = a.H, W = a.W, C = a.C, Ho = a.Hg, Wo = a.Wg;
     const int b = blockIdx.z;
@@ -127,7 +137,7 @@ __global__ __launch_bounds__(256) void dw_s2_pool_kernel(DwArgs a) {
     const int c = live ? g / Wo : 0, j = live ? g - c * Wo : 0;
     const int i0 = blockIdx.y * a.TH, i1 = min(i0 + a.TH, Ho);
     const size_t plane = ((size_t)b * C + c) * H * W;
-    const float* xp = a.x + plane;
+    const float* __restrict__ xp = X + plane;
     float isc, ish;
     gln_fold(a.in_stats + 2 * b, a.in_inv_count, a.in_gamma[c], a.in_beta[c], isc, ish);
     float wgt[16];
@@ -136,17 +146,22 @@ __global__ __launch_bounds__(256) void dw_s2_pool_kernel(DwArgs a) {
     const float bia = a.bias[0][c];
     const int fs = (int)(((long long)j * W) / Wo), fe = (int)(((long long)(j + 1) * W + Wo - 1) / Wo);
     bool fok[4], fpool[4];
+    int fcl[4];
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
         const int f = 2 * j - 1 + d;
         fok[d] = live && f >= 0 && f < W;
         fpool[d] = f >= fs && f < fe;
+        fcl[d] = f < 0 ? 0 : (f < W ? f : W - 1);
     }
     auto load_row = [&](int t, float (&row)[4]) {
         const bool tok = t >= 0 && t < H;
-        const float* rp = xp + (size_t)(tok ? t : 0) * W + 2 * j - 1;
+        const float* __restrict__ rp = xp + (size_t)(t < 0 ? 0 : (t < H ? t : H - 1)) * W;
 #pragma unroll
-        for (int d = 0; d < 4; ++d) row[d] = (tok && fok[d]) ? fmaf(rp[d], isc, ish) : 0.f;
+        for (int d = 0; d < 4; ++d) {
+            const float v = fmaf(rp[fcl[d]], isc, ish);
+            row[d] = (tok && fok[d]) ? v : 0.f;
+        }
     };
     float win[4][4];
     load_row(2 * i0 - 1, win[0]);
@@ -172,8 +187,8 @@ __global__ __launch_bounds__(256) void dw_s2_pool_kernel(DwArgs a) {
         pool /= (float)((te - ts) * (fe - fs));
         if (live) {
             const size_t o = oplane + (size_t)i * Wo + j;
-            a.out[0][o] = acc;
-            a.out[1][o] = pool;
+            O0[o] = acc;
+            O1[o] = pool;
             s += acc;
             ss = fmaf(acc, acc, ss);
         }
@@ -185,6 +200,8 @@ __global__ __launch_bounds__(256) void dw_s2_pool_kernel(DwArgs a) {
     }
     block_stats_atomic(s, ss, red, a.stats_out[0] + 2 * b);
 }
+
+__global__ __launch_bounds__(256) void dw_s2_pool_kernel(DwArgs a) { dw_s2_pool_body(a, a.x, a.out[0], a.out[1]); }
 
 // ---------------------------------------------------------------- G-level elementwise glue
 // g = p0 + gLN(c1)           (global pooling sum, tdanet.py:116)

@@ -18,7 +18,8 @@ enum { EPI_BIAS = 0, EPI_BIAS_RES = 1, EPI_S3 = 2, EPI_TAPS = 3 };
 #define LDH 40  // padded row length in halfs (80 B)
 
 template <int CIN, int COUT, int PT, int WAVES_M, int PRO, int EPI>
-__global__ __launch_bounds__(256) void pw16_kernel(PwArgs a) {
+__device__ __forceinline__ void pw16_body(const PwArgs& a, const float* __restrict__ X, const float* __restrict__ X2,
+                                          float* __restrict__ RES, const float* __restrict__ AUX, float* __restrict__ OUT) {
     constexpr int WAVES_N = 4 / WAVES_M;
     constexpr int WM = COUT / 32 / WAVES_M;
     constexpr int WN = PT / 32 / WAVES_N;
@@ -62,23 +63,27 @@ __global__ __launch_bounds__(256) void pw16_kernel(PwArgs a) {
         for (int task = tid; task < PT * 4; task += 256) {
             const int pp = task % PT, gq = task / PT;
             const int p = p0 + pp;
+            const bool live = p < P;
+            const int pcl = live ? p : P - 1;  // loads are unconditional (clamped): no branch + wait per load
             half8 vh, vl;
+            float vv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) vv[i] = X[xb + (size_t)(c0 + gq * 8 + i) * P + pcl];
+            if (PRO == PRO_GATEWAY && X2) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) vv[i] += X2[xb + (size_t)(c0 + gq * 8 + i) * P + pcl];
+            }
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int ci = c0 + gq * 8 + i;
-                float v = 0.f;
-                if (p < P) {
-                    const size_t off = xb + (size_t)ci * P + p;
-                    v = a.x[off];
-                    if (PRO == PRO_GLN_RELU) {
-                        v = fmaxf(fmaf(v, sc[ci], sh[ci]), 0.f);
-                    } else if (PRO == PRO_GATEWAY) {
-                        if (a.x2) v += a.x2[off];
-                        v = preluf_(fmaf(v, sc[ci], sh[ci]), slope);
-                        a.res_out[off] = v;
-                    } else if (PRO == PRO_PRELU) {
-                        v = preluf_(v, slope);
-                    }
+                float v = vv[i];
+                if (PRO == PRO_GLN_RELU) {
+                    v = fmaxf(fmaf(v, sc[ci], sh[ci]), 0.f);
+                } else if (PRO == PRO_GATEWAY) {
+                    v = preluf_(fmaf(v, sc[ci], sh[ci]), slope);
+                    if (live) RES[xb + (size_t)ci * P + p] = v;
+                } else if (PRO == PRO_PRELU) {
+                    v = preluf_(v, slope);
                 }
                 const _Float16 hi = (_Float16)v;
                 vh[i] = hi;
@@ -138,25 +143,30 @@ __global__ __launch_bounds__(256) void pw16_kernel(PwArgs a) {
                 const float mr = fmaxf(fmaf(acc[0][n][q], WINV, a.bias[c]), 0.f);
                 const float mi = fmaxf(fmaf(acc[WM - 1][n][q], WINV, a.bias[c + 128]), 0.f);
                 const size_t o = ((size_t)b * COUT + c) * P + p;
-                const float er = a.aux[o], ei = a.aux[o + (size_t)128 * P];
-                a.out[o] = er * mr - ei * mi;
-                a.out[o + (size_t)128 * P] = er * mi + ei * mr;
+                const float er = AUX[o], ei = AUX[o + (size_t)128 * P];
+                OUT[o] = er * mr - ei * mi;
+                OUT[o + (size_t)128 * P] = er * mi + ei * mr;
             } else {
 #pragma unroll
                 for (int m = 0; m < WM; ++m) {
                     const int co = (wm + m * WAVES_M) * 32 + row;
                     if (EPI == EPI_TAPS) {
-                        if (co < a.cout_live) a.out[((size_t)b * a.cout_live + co) * P + p] = acc[m][n][q] * WINV;
+                        if (co < a.cout_live) OUT[((size_t)b * a.cout_live + co) * P + p] = acc[m][n][q] * WINV;
                     } else {
                         const size_t o = ((size_t)b * COUT + co) * P + p;
                         float v = fmaf(acc[m][n][q], WINV, a.bias[co]);
-                        if (EPI == EPI_BIAS_RES) v += a.aux[o];
-                        a.out[o] = v;
+                        if (EPI == EPI_BIAS_RES) v += AUX[o];
+                        OUT[o] = v;
                     }
                 }
             }
         }
     }
+}
+
+template <int CIN, int COUT, int PT, int WAVES_M, int PRO, int EPI>
+__global__ __launch_bounds__(256) void pw16_kernel(PwArgs a) {
+    pw16_body<CIN, COUT, PT, WAVES_M, PRO, EPI>(a, a.x, a.x2, a.res_out, a.aux, a.out);
 }
 
 template <int CIN, int COUT, int PT, int WAVES_M, int PRO, int EPI>

@@ -67,7 +67,9 @@ __global__ __launch_bounds__(256) void enc_conv_kernel(const float* __restrict__
                 for (int df = 0; df < 3; ++df) {
                     const int tt = t + dt - 1, ff = f + df - 1;
                     const bool ok = live && tt >= 0 && tt < T && ff >= 0 && ff < F;
-                    tap[ci * 9 + dt * 3 + df] = ok ? spec[((size_t)b * 2 + ci) * P + (size_t)tt * F + ff] : 0.f;
+                    const int tc = tt < 0 ? 0 : (tt < T ? tt : T - 1), fc = ff < 0 ? 0 : (ff < F ? ff : F - 1);
+                    const float v = spec[((size_t)b * 2 + ci) * P + (size_t)tc * F + fc];  // unconditional, clamped
+                    tap[ci * 9 + dt * 3 + df] = ok ? v : 0.f;
                 }
     }
     float s = 0.f, ss = 0.f;

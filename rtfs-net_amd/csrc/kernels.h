@@ -39,6 +39,8 @@ int launch_pw16_gateway_proj(const PwArgs& a, int B, hipStream_t st);
 int launch_pw16_residual(const PwArgs& a, int B, hipStream_t st);
 int launch_pw16_s3(const PwArgs& a, int B, hipStream_t st);
 int launch_pw16_dec_taps(const PwArgs& a, int B, hipStream_t st);
+int launch_pws_gateway_proj(const PwArgs& a, int B, hipStream_t st);
+int launch_pws_residual(const PwArgs& a, int B, hipStream_t st);
 int launch_mfma_f16_selftest(const float* A, const float* B, float* D, hipStream_t st);
 
 // Depthwise 4x4 family.  Tensors are (B, C, H, W) contiguous.
