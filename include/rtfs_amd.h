@@ -115,6 +115,11 @@ int rtfs_separator_forward_f32(const float* wav, const float* video_vp, const fl
 size_t rtfs_sru_workspace_bytes(int L, int N);
 int rtfs_sru_f32(const float* x, const float* pack, float* h, int L, int N, void* ws, size_t ws_bytes, void* stream);
 
+/* Diagnostic build of the dual-path sweep with s_memtime stamps at phase boundaries (profiling aid only).
+ * x, out: (B, 64, R, Ls) with sequences along the last axis; stamps: DEVICE u64 [ceil(B*R/seqs_per_wg)][16]. */
+int rtfs_debug_sweep_stamps(const float* x, const float* pack, float* out, int B, int R, int Ls, unsigned long long* stamps,
+                            void* stream);
+
 /* Self test of the f16 MFMA fragment layout the split-precision GEMM kernels assume: D (32x32) = A (32x16) . B (16x32),
  * all DEVICE pointers, row-major; exact for small integer data. */
 int rtfs_selftest_mfma_f16(const float* A, const float* B, float* D, void* stream);

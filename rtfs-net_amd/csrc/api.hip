@@ -814,6 +814,19 @@ int rtfs_sru_f32(const float* x, const float* pack, float* h, int L, int N, void
     return launch_sru_standalone(x, h, L, N, p.W0, p.Wl, p.wc, p.bias, S(stream));
 }
 
+// ------------------------------------------------------------ diagnostics
+// Runs the dual-path sweep (dim 4: along F, dim 3: x is already (B,64,F,T) transposed) in the phase-stamped
+// diagnostic build; stamps: DEVICE buffer of ceil(nseq/NSEQ) x 16 u64.  Not part of the product path.
+int rtfs_debug_sweep_stamps(const float* x, const float* pack, float* out, int B, int R, int Ls, unsigned long long* stamps, void* stream) {
+    RTFS_RETURN_IF(!x || !pack || !out || !stamps, RTFS_ERR_ARG);
+    Cursor c(pack);
+    DpPack p(c);
+    const size_t plane = (size_t)R * Ls;
+    Dp16Args a = dp16_args(p, x, out, B * R, R, Ls, CH * plane, Ls, plane);
+    a.stamps = stamps;
+    return launch_dualpath16(a, S(stream));
+}
+
 // ------------------------------------------------------------ self test
 int rtfs_selftest_mfma_f16(const float* A, const float* B, float* D, void* stream) {
     RTFS_RETURN_IF(!A || !B || !D, RTFS_ERR_ARG);

@@ -22,7 +22,8 @@
 
 
 #define HLD 72   // activation row stride (halfs)
-#define WLD 40   // staged weight row stride (halfs)
+#define WLD 40   // staged gate-weight row stride (halfs): 32 k + 8 pad
+#define CLD 72   // staged conv-transpose weight row stride (halfs): 64 k + 8 pad
 #define WINV (1.0f / 256.0f)
 
 namespace {
@@ -47,9 +48,17 @@ __device__ __forceinline__ float take_half(float v, int ph) {
 
 }  // namespace
 
-template <int NSEQ, int NHALF>
+// STAMP = diagnostic build: wave 0 of every workgroup records s_memtime at phase boundaries into a.stamps
+// ([workgroup][16] u64); never used by the product path.
+// PAIRED: the two lane halves of an MFMA tile (rows with bit 2 clear / set) carry two different sequences, 16 time
+// steps each, so accumulator register q of lane (h, j) is time step q of sequence (pair, h): the scan is a plain
+// loop over registers with every lane busy and no cross-lane traffic.  A wave then covers 32 time steps of a
+// sequence pair; NHALF = number of 32-step parts.  !PAIRED (4 s inputs, one sequence per workgroup): a wave covers
+// 64 steps of one sequence and the halves take turns (v_permlane32_swap hand-off every 4 steps).
+template <int NSEQ, int NHALF, bool PAIRED, bool STAMP = false>
 __global__ __launch_bounds__(512) void dp16_kernel(Dp16Args a) {
-    static_assert(NSEQ * NHALF == 4, "8 waves = NSEQ sequences x 2 directions x NHALF time parts");
+    static_assert((PAIRED ? NSEQ / 2 : NSEQ) * NHALF == 4, "8 waves = sequences (pairs) x 2 directions x NHALF time parts");
+    constexpr int STEPS = PAIRED ? 32 : 64;  // time steps covered by one wave
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int Ls = a.Ls, L = Ls - 7, rowsH = Ls + 1;  // one extra all-zero row for the conv-transpose borders
     _Float16* Hh = reinterpret_cast<_Float16*>(smem);
@@ -60,9 +69,25 @@ __global__ __launch_bounds__(512) void dp16_kernel(Dp16Args a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    const int seq = wave / (2 * NHALF), dir = (wave / NHALF) & 1, part = wave % NHALF;
+    const int grp = wave / (2 * NHALF), dir = (wave / NHALF) & 1, part = wave % NHALF;  // grp = sequence or pair
+    const int seq = PAIRED ? grp * 2 + h : grp;  // the sequence this LANE's accumulator rows / A-operand rows belong to
+    // conv-transpose roles (always one sequence per wave): sequence, co tile, 64-position part
+    constexpr int CPART = 4 / NSEQ;
+    const int cseq = wave / (2 * CPART), ccot = (wave / CPART) & 1, cpart = wave % CPART;
     const int n0 = blockIdx.x * NSEQ;
 
+    int nstamp = 0;
+    auto stamp = [&]() {
+        if (STAMP) {
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            if (tid == 0 && nstamp < 16) a.stamps[(size_t)blockIdx.x * 16 + nstamp] = t;
+            ++nstamp;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    stamp();  // 0: start
     auto seq_base = [&](int s) {
         int n = n0 + s;
         n = n < a.nseq ? n : a.nseq - 1;
@@ -111,20 +136,25 @@ __global__ __launch_bounds__(512) void dp16_kernel(Dp16Args a) {
 
     // weight chunk staging: image [part 2][rows][32 halfs] in global -> padded rows in LDS buffer `buf`
     half8 pre[4];
-    auto stage_load = [&](const half8* __restrict__ img, auto rows_c) {  // rows = 256 (gate columns) or 64 (conv-transpose co)
+    // rows_c = 256: gate chunk [hi|lo][256 cols][32 k] -> rows of WLD halfs;  64: conv-transpose chunk [hi|lo][64 co][64 k] -> rows of CLD
+    auto stage_load = [&](const half8* __restrict__ img, auto rows_c) {
         constexpr int rows = decltype(rows_c)::value;
-        constexpr int npiece = 2 * rows * 4;
+        constexpr int npiece = rows == 256 ? 2 * 256 * 4 : 2 * 64 * 8;
 #pragma unroll
-        for (int j = 0; j < (npiece + 511) / 512; ++j) pre[j] = img[tid + 512 * j];
+        for (int j = 0; j < npiece / 512; ++j) pre[j] = img[tid + 512 * j];
     };
     auto stage_write = [&](int buf, auto rows_c) {
         constexpr int rows = decltype(rows_c)::value;
-        constexpr int npiece = 2 * rows * 4;
+        constexpr int npiece = rows == 256 ? 2 * 256 * 4 : 2 * 64 * 8;
+        constexpr int ppr = rows == 256 ? 4 : 8;  // 16-byte pieces per row
 #pragma unroll
-        for (int j = 0; j < (npiece + 511) / 512; ++j) {
+        for (int j = 0; j < npiece / 512; ++j) {
             const int i = tid + 512 * j;
-            const int pt = i / (rows * 4), rem = i - pt * rows * 4;
-            *reinterpret_cast<half8*>(Wst + ((buf * 2 + pt) * 256 + (rem >> 2)) * WLD + (rem & 3) * 8) = pre[j];
+            const int pt = i / (rows * ppr), rem = i - pt * rows * ppr;
+            if (rows == 256)
+                *reinterpret_cast<half8*>(Wst + ((buf * 2 + pt) * 256 + rem / ppr) * WLD + (rem % ppr) * 8) = pre[j];
+            else
+                *reinterpret_cast<half8*>(Wst + buf * (2 * 64 * CLD) + (pt * 64 + rem / ppr) * CLD + (rem % ppr) * 8) = pre[j];
         }
     };
     const std::integral_constant<int, 256> R256;
@@ -134,11 +164,20 @@ __global__ __launch_bounds__(512) void dp16_kernel(Dp16Args a) {
     int rowbase[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-        int tau = 64 * part + 32 * t + r;
+        // A-operand row r of tile t: PAIRED -> sequence (pair, bit 2 of r), step (r&3) + 4*(r>>3); else step r
+        const int rs = PAIRED ? grp * 2 + ((r >> 2) & 1) : grp;
+        int tau = STEPS * part + (PAIRED ? 16 * t + (r & 3) + 4 * (r >> 3) : 32 * t + r);
         tau = tau < L ? tau : L - 1;
-        rowbase[t] = (seq * rowsH + (dir ? L - 1 - tau : tau)) * HLD;
+        rowbase[t] = (rs * rowsH + (dir ? L - 1 - tau : tau)) * HLD;
     }
 
+    stamp();  // 1: after load + LN issue (before first barrier)
+    // the weight chunks of all phases form one stream: chunk c+1 (or the next phase's chunk 0) is loaded into
+    // registers while chunk c is multiplied and written to the other LDS buffer before the barrier that ends chunk c.
+    stage_load(a.w16_l0, R256);
+    __syncthreads();  // phase 0 has filled the activation planes
+    stage_write(0, R256);
+    __syncthreads();
     // ---------------- four SRU layers
     for (int layer = 0; layer < 4; ++layer) {
         const int nchunk = layer == 0 ? 16 : 2;
@@ -155,12 +194,11 @@ __global__ __launch_bounds__(512) void dp16_kernel(Dp16Args a) {
                 acc[t][2][q] = br;
                 acc[t][3][q] = 0.f;
             }
-        stage_load(wimg, R256);
-        __syncthreads();  // phase 0 / previous layer's in-place hidden writes are complete; staging buffers are free
-        stage_write(0, R256);
-        __syncthreads();
         for (int q = 0; q < nchunk; ++q) {
-            if (q + 1 < nchunk) stage_load(wimg + (size_t)(q + 1) * (2 * 256 * 4), R256);
+            const bool last = q + 1 == nchunk;  // nchunk is even, so the next phase's chunk 0 lands in buffer 0
+            if (!last) stage_load(wimg + (size_t)(q + 1) * (2 * 256 * 4), R256);
+            else if (layer < 3) stage_load(a.w16_l + (size_t)layer * 2 * (2 * 256 * 4), R256);
+            else stage_load(a.w16_ct, R64);
             const int aoff = layer == 0 ? (q >> 1) * HLD + (q & 1) * 32 : q * 32;
             const _Float16* wb = Wst + ((q & 1) * 2) * 256 * WLD + (dir * 128 + r) * WLD + 8 * h;
 #pragma unroll
@@ -183,56 +221,87 @@ __global__ __launch_bounds__(512) void dp16_kernel(Dp16Args a) {
                     }
                 }
             }
-            if (q + 1 < nchunk) stage_write((q + 1) & 1, R256);
+            if (!last || layer < 3) stage_write((q + 1) & 1, R256);
+            else stage_write(0, R64);
             __syncthreads();
         }
+        stamp();  // 2,4,6,8: GEMM of layer done
         // every wave has finished reading the activation planes: the scan may overwrite them in place.
         // ---- recurrence on the accumulator registers (row of register q: (q&3) + 8*(q>>2) + 4*h)
         for (int hp = 0; hp < NHALF; ++hp) {
             if (part == hp) {
                 float c = 0.f;
                 if (NHALF > 1 && hp > 0) c = chand[(seq * 2 + dir) * 32 + r];
+                if (PAIRED) {
+                    // register q of tile t = time step 16t + q of this lane's own sequence
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
+                    for (int t = 0; t < 2; ++t)
 #pragma unroll
-                    for (int rg = 0; rg < 4; ++rg) {
+                        for (int q = 0; q < 16; ++q) {
+                            // everything that does not depend on c is computed off the recurrence chain
+                            const float u0 = acc[t][0][q] * WINV, p1 = acc[t][1][q] * WINV, p2 = acc[t][2][q] * WINV;
+                            const float xp = acc[t][3][q] * WINV;
+                            const float f = sig2(fmaf(vf, c, p1));
+                            const float g = sig2(fmaf(vr, c, p2));
+                            c = fmaf(c - u0, f, u0);
+                            acc[t][0][q] = fmaf(c - xp, g, xp);
+                            // keep the scheduler from hoisting the (chain-independent) scalings of all 32 steps at once
+                            if ((q & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+                        }
+                    if (NHALF > 1) chand[(seq * 2 + dir) * 32 + r] = c;
+                } else {
 #pragma unroll
-                        for (int ph = 0; ph < 2; ++ph) {
-                            float cr = c;
+                    for (int t = 0; t < 2; ++t) {
 #pragma unroll
-                            for (int i = 0; i < 4; ++i) {
-                                const int q = rg * 4 + i;
-                                const float u0 = acc[t][0][q] * WINV;
-                                const float f = sig2(fmaf(acc[t][1][q], WINV, vf * cr));
-                                const float g = sig2(fmaf(acc[t][2][q], WINV, vr * cr));
-                                const float xp = acc[t][3][q] * WINV;
-                                cr = fmaf(cr - u0, f, u0);
-                                const float hv = fmaf(cr - xp, g, xp);
-                                if (h == ph) acc[t][0][q] = hv;  // this lane's own rows: keep the hidden output
+                        for (int rg = 0; rg < 4; ++rg) {
+#pragma unroll
+                            for (int ph = 0; ph < 2; ++ph) {
+                                float cr = c;
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) {
+                                    const int q = rg * 4 + i;
+                                    const float u0 = acc[t][0][q] * WINV;
+                                    const float f = sig2(fmaf(acc[t][1][q], WINV, vf * cr));
+                                    const float g = sig2(fmaf(acc[t][2][q], WINV, vr * cr));
+                                    const float xp = acc[t][3][q] * WINV;
+                                    cr = fmaf(cr - u0, f, u0);
+                                    const float hv = fmaf(cr - xp, g, xp);
+                                    if (h == ph) acc[t][0][q] = hv;  // this lane's own rows: keep the hidden output
+                                }
+                                c = take_half(cr, ph);
                             }
-                            c = take_half(cr, ph);
                         }
                     }
+                    if (NHALF > 1 && h == 0) chand[(seq * 2 + dir) * 32 + r] = c;
                 }
-                if (NHALF > 1 && h == 0) chand[(seq * 2 + dir) * 32 + r] = c;
-                // write the hidden outputs (this wave's direction half of the channels) back in place
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) {
-                        const int tau = 64 * part + 32 * t + (q & 3) + 8 * (q >> 2) + 4 * h;
-                        if (tau < L) {
-                            const int pos = dir ? L - 1 - tau : tau;
-                            const float hv = acc[t][0][q];
-                            const _Float16 hh = (_Float16)hv;
-                            const int o = (seq * rowsH + pos) * HLD + dir * 32 + r;
-                            Hh[o] = hh;
-                            Hl[o] = (_Float16)(hv - (float)hh);
-                        }
-                    }
             }
-            if (NHALF > 1) __syncthreads();
+            if (NHALF > 1) __syncthreads();  // cell state published: the next time part starts while this one writes back
+            if (part == hp) {
+                // write the hidden outputs (this wave's direction half of the channels) back in place
+                {
+                    const int tau0 = STEPS * part;
+                    int o0 = (seq * rowsH + (dir ? L - 1 - tau0 : tau0)) * HLD + dir * 32 + r;
+                    asm volatile("" : "+v"(o0));  // opaque per layer: keeps 32 derived addresses from being hoisted + spilled
+                    const int ostep = dir ? -HLD : HLD;
+                    const int nvalid = L - tau0;
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) {
+                            const int idx = PAIRED ? 16 * t + q : 32 * t + (q & 3) + 8 * (q >> 2) + 4 * h;
+                            if (idx < nvalid) {
+                                const float hv = acc[t][0][q];
+                                const _Float16 hh = (_Float16)hv;
+                                const int o = o0 + idx * ostep;
+                                Hh[o] = hh;
+                                Hl[o] = (_Float16)(hv - (float)hh);
+                            }
+                        }
+                }
+            }
         }
+        __syncthreads();  // all hidden outputs of this layer are in the planes
+        stamp();  // 3,5,7,9: scan of layer done
     }
 
     // ---------------- ConvTranspose1d(64->64, k=8) + bias + residual (rnn_layers.py:153-156), transposed:
@@ -243,25 +312,21 @@ __global__ __launch_bounds__(512) void dp16_kernel(Dp16Args a) {
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
-        const int cot = dir;
-        stage_load(a.w16_ct, R64);
-        __syncthreads();  // layer-3 hidden outputs are in LDS; staging buffers are free
-        stage_write(0, R64);
-        __syncthreads();
-        for (int q = 0; q < 16; ++q) {
-            if (q + 1 < 16) stage_load(a.w16_ct + (size_t)(q + 1) * (2 * 64 * 4), R64);
-            const int kk = q >> 1, c0 = (q & 1) * 32;
-            const _Float16* wb = Wst + ((q & 1) * 2) * 256 * WLD + (cot * 32 + r) * WLD + 8 * h;
+        // chunk 0 is already staged; the barrier that ended the layer-3 scan ordered the hidden outputs.
+        // 8 chunks of 64 k' (one tap kk each): staged image [hi|lo][64 co][64 + 8 pad]
+        for (int q = 0; q < 8; ++q) {
+            if (q + 1 < 8) stage_load(a.w16_ct + (size_t)(q + 1) * (2 * 64 * 8), R64);
+            const _Float16* wb = Wst + (q & 1) * (2 * 64 * CLD) + (ccot * 32 + r) * CLD + 8 * h;
             int hrow[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                const int p = 64 * part + 32 * t + r - kk;
-                hrow[t] = (seq * rowsH + ((p >= 0 && p < L) ? p : Ls)) * HLD + c0 + 8 * h;
+                const int p = 64 * cpart + 32 * t + r - q;
+                hrow[t] = (cseq * rowsH + ((p >= 0 && p < L) ? p : Ls)) * HLD + 8 * h;
             }
 #pragma unroll
-            for (int ks = 0; ks < 32; ks += 16) {
+            for (int ks = 0; ks < 64; ks += 16) {
                 const half8 wh = *reinterpret_cast<const half8*>(wb + ks);
-                const half8 wl = *reinterpret_cast<const half8*>(wb + 256 * WLD + ks);
+                const half8 wl = *reinterpret_cast<const half8*>(wb + 64 * CLD + ks);
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     const half8 xh = *reinterpret_cast<const half8*>(Hh + hrow[t] + ks);
@@ -271,14 +336,16 @@ __global__ __launch_bounds__(512) void dp16_kernel(Dp16Args a) {
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, acc[t], 0, 0, 0);
                 }
             }
-            if (q + 1 < 16) stage_write((q + 1) & 1, R64);
+            if (q + 1 < 8) stage_write((q + 1) & 1, R64);
             __syncthreads();
         }
-        if (n0 + seq < a.nseq) {
-            const size_t base = seq_base(seq);
+        stamp();  // 10: conv-transpose GEMM done
+        if (n0 + cseq < a.nseq) {
+            const size_t base = seq_base(cseq);
+            const int cot = ccot;
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                const int p = 64 * part + 32 * t + r;
+                const int p = 64 * cpart + 32 * t + r;
                 if (p < Ls) {
                     float res[16];
 #pragma unroll
@@ -291,6 +358,7 @@ __global__ __launch_bounds__(512) void dp16_kernel(Dp16Args a) {
                 }
             }
         }
+        stamp();  // 11: end
     }
 }
 
@@ -298,17 +366,26 @@ size_t dp16_lds_bytes(int Ls, int nseq_per_wg) {
     return (size_t)2 * nseq_per_wg * (Ls + 1) * HLD * 2 + (size_t)2 * 2 * 256 * WLD * 2 + (size_t)nseq_per_wg * 2 * 32 * 4;
 }
 
-template <int NSEQ, int NHALF>
+template <int NSEQ, int NHALF, bool PAIRED>
+static int launch_dp16_stamp_t(const Dp16Args& a, hipStream_t st) {
+    const size_t lds = dp16_lds_bytes(a.Ls, NSEQ);
+    if (hipFuncSetAttribute((const void*)dp16_kernel<NSEQ, NHALF, PAIRED, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return RTFS_ERR_LAUNCH;
+    hipLaunchKernelGGL((dp16_kernel<NSEQ, NHALF, PAIRED, true>), dim3(cdiv(a.nseq, NSEQ)), dim3(512), lds, st, a);
+    return rtfs_launch_status();
+}
+
+template <int NSEQ, int NHALF, bool PAIRED>
 static int launch_dp16_t(const Dp16Args& a, hipStream_t st) {
     const size_t lds = dp16_lds_bytes(a.Ls, NSEQ);
     static size_t configured = 0;
     if (lds > configured) {
-        if (hipFuncSetAttribute((const void*)dp16_kernel<NSEQ, NHALF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)dp16_kernel<NSEQ, NHALF, PAIRED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return RTFS_ERR_LAUNCH;
         configured = lds;
     }
     void* slot = dualpath_timing_begin(a.Ls, a.nseq, st);
-    hipLaunchKernelGGL((dp16_kernel<NSEQ, NHALF>), dim3(cdiv(a.nseq, NSEQ)), dim3(512), lds, st, a);
+    hipLaunchKernelGGL((dp16_kernel<NSEQ, NHALF, PAIRED>), dim3(cdiv(a.nseq, NSEQ)), dim3(512), lds, st, a);
     dualpath_timing_end(slot, st);
     return rtfs_launch_status();
 }
@@ -316,7 +393,12 @@ static int launch_dp16_t(const Dp16Args& a, hipStream_t st) {
 int launch_dualpath16(const Dp16Args& a, hipStream_t st) {
     const int L = a.Ls - 7;
     if (L < 1 || L > 256) return RTFS_ERR_SHAPE;
-    if (L <= 64) return launch_dp16_t<4, 1>(a, st);
-    if (L <= 128) return launch_dp16_t<2, 2>(a, st);
-    return launch_dp16_t<1, 4>(a, st);
+    if (a.stamps) {
+        if (L <= 64) return launch_dp16_stamp_t<4, 2, true>(a, st);
+        if (L <= 128) return launch_dp16_stamp_t<2, 4, true>(a, st);
+        return launch_dp16_stamp_t<1, 4, false>(a, st);
+    }
+    if (L <= 64) return launch_dp16_t<4, 2, true>(a, st);    // 4 sequences: 2 pairs x 2 dirs x 2 parts of 32 steps
+    if (L <= 128) return launch_dp16_t<2, 4, true>(a, st);   // 2 sequences: 1 pair  x 2 dirs x 4 parts of 32 steps
+    return launch_dp16_t<1, 4, false>(a, st);                // 4 s inputs: 1 sequence x 2 dirs x 4 parts of 64 steps
 }

@@ -195,6 +195,8 @@ __global__ void mfma_f16_selftest_kernel(const float* __restrict__ A, const floa
     for (int q = 0; q < 16; ++q) acc[q] = 0.f;
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, acc, 0, 0, 0);
     for (int q = 0; q < 16; ++q) D[((q & 3) + 8 * (q >> 2) + 4 * h) * 32 + r] = acc[q];
+    // D[1024 ...]: f32 -> f16 -> f32 round trip of A (shows whether the conversion keeps f16 subnormals)
+    for (int j = 0; j < 8; ++j) D[1024 + r * 16 + 8 * h + j] = (float)av[j];
 }
 
 int launch_mfma_f16_selftest(const float* A, const float* B, float* D, hipStream_t st) {

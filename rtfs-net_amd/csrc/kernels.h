@@ -171,10 +171,11 @@ struct Dp16Args {
     const float* ln_beta = nullptr;
     const half8* w16_l0 = nullptr;  // [16 chunks][hi|lo][256 cols = dir*128 + gate*32 + j][32 k'], k' = kk*64 + c
     const half8* w16_l = nullptr;   // 3 x [2 chunks][hi|lo][256][32]; gate 3 = identity block (highway input)
-    const half8* w16_ct = nullptr;  // [16 chunks][hi|lo][64 co][32 k'], k' = kk*64 + ci
+    const half8* w16_ct = nullptr;  // [8 chunks][hi|lo][64 co][64 k'], k' = kk*64 + ci
     const float* wc16 = nullptr;    // 4 x (128): v_f, v_r scaled by -log2(e)
     const float* bias16 = nullptr;  // 4 x (128): b_f, b_r scaled by -log2(e)
     const float* bt = nullptr;      // (64)
+    unsigned long long* stamps = nullptr;  // diagnostic build only: [workgroups][16] s_memtime stamps
 };
 size_t dp16_lds_bytes(int Ls, int nseq_per_wg);
 int launch_dualpath16(const Dp16Args& a, hipStream_t st);

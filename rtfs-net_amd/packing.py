@@ -32,14 +32,14 @@ LOG2E = 1.4426950408889634
 W16_SCALE = 256.0  # weights are stored pre-scaled by 2^8 so their f16 low parts stay normal; kernels undo it
 
 
-def split16_image(w):
-    """(cout, cin) f32 weight -> the f16x3 kernels' staged image [cin/32][hi|lo][cout][32] halfs, returned bit-cast
-    to float32 (cout*cin/... same element count as w).  w*256 = hi + lo with hi, lo exactly representable in f16."""
+def split16_image(w, kc=32):
+    """(cout, cin) f32 weight -> the f16x3 kernels' staged image [cin/kc][hi|lo][cout][kc] halfs, returned bit-cast
+    to float32 (same element count as w).  w*256 = hi + lo with hi, lo exactly representable in f16."""
     cout, cin = w.shape
     ws = w.detach().to(torch.float32) * W16_SCALE
     hi = ws.to(torch.float16)
     lo = (ws - hi.to(torch.float32)).to(torch.float16)
-    img = torch.stack([hi.reshape(cout, cin // 32, 32).permute(1, 0, 2), lo.reshape(cout, cin // 32, 32).permute(1, 0, 2)], 1)
+    img = torch.stack([hi.reshape(cout, cin // kc, kc).permute(1, 0, 2), lo.reshape(cout, cin // kc, kc).permute(1, 0, 2)], 1)
     return img.contiguous().view(torch.float32).reshape(-1)
 
 
@@ -77,7 +77,7 @@ def _dualpath_parts(sd):
         w = torch.cat([w, eye], 3) * gate_scale  # (k, dir, j, m)
         imgs.append(split16_image(w.permute(0, 1, 3, 2).reshape(64, 256).t()))
     parts.append(torch.stack(imgs))
-    parts.append(split16_image(sd["linear.weight"].detach().to(torch.float32).permute(1, 2, 0).reshape(64, 512)))  # rows co, k' = kk*64+ci
+    parts.append(split16_image(sd["linear.weight"].detach().to(torch.float32).permute(1, 2, 0).reshape(64, 512), 64))  # rows co, k' = kk*64+ci
     parts.append(torch.stack([sd[f"rnn.rnn_lst.{i}.weight_c"] for i in range(4)]) * (-LOG2E))
     parts.append(torch.stack([sd[f"rnn.rnn_lst.{i}.bias"] for i in range(4)]) * (-LOG2E))
     return parts

@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Diagnostic: where does a dual-path sweep workgroup spend its cycles?  (GPU box only)"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import rtfs_net_amd as R
+from rtfs_net_amd import _lib
+from tests.test_host import RTFS4_AUDIONET
+import copy
+lib = _lib.load()
+torch.manual_seed(0)
+m = R.AVNet(print_macs=False, **copy.deepcopy(RTFS4_AUDIONET)).cuda().eval()
+blk = m.refinement_module.audio_net.blocks
+names = ["start", "load+LN", "L0 gemm", "L0 scan", "L1 gemm", "L1 scan", "L2 gemm", "L2 scan", "L3 gemm", "L3 scan", "convT gemm", "epilogue"]
+for label, dp, Rr, Ls, per in [("F-path", blk.globalatt[0], 125, 64, 4), ("T-path", blk.globalatt[1], 64, 125, 2)]:
+    B = 32
+    x = torch.randn(B, 64, Rr, Ls, device="cuda")
+    out = torch.empty_like(x)
+    nwg = (B * Rr + per - 1) // per
+    st = torch.zeros(nwg, 16, dtype=torch.int64, device="cuda")
+    for _ in range(2):
+        _lib.check(lib.rtfs_debug_sweep_stamps(_lib.ptr(x), _lib.ptr(dp.pack()), _lib.ptr(out), B, Rr, Ls, _lib.ptr(st), _lib.stream_of(x)), "stamps")
+    torch.cuda.synchronize()
+    s = st.cpu().numpy().astype(np.float64)
+    d = np.diff(s[:, :12], axis=1)
+    print(f"== {label}: {nwg} workgroups; cycles per phase (median / mean), total median {np.median(s[:,11]-s[:,0]):.0f}")
+    for i in range(11):
+        print(f"   {names[i+1]:12s} {np.median(d[:, i]):9.0f} {d[:, i].mean():9.0f}")
+    t0 = s[:, 0].min(); t1 = s[:, 11].max()
+    print(f"   kernel span {t1 - t0:.0f} ticks (s_memtime 100MHz?)")
