@@ -89,6 +89,12 @@ size_t rtfs_caf_workspace_bytes(int B, int Tv);
 int rtfs_caf_f32(const float* audio, const float* video, const float* pack, float* out, int B, int T, int F, int Tv,
                  void* ws, size_t ws_bytes, void* stream);
 
+/* VP block = the video-side 1-D TDANetBlock.forward (upsampling_depth 4, kernel 3, BatchNorm1d, GlobalAttention;
+ * src/models/separators/tdanet.py:104-131 with yaml video_params): video (B,512,Tv) -> (B,512,Tv), Tv <= 120.
+ * pack = rtfs-net_amd/packing.py:pack_vp (eval BatchNorm folded); rtfs_vp_pack_floats() returns its length. */
+size_t rtfs_vp_pack_floats(void);
+int rtfs_vp_block_f32(const float* video, const float* pack, float* out, int B, int Tv, void* stream);
+
 /* S^3 = MaskGenerator.forward with RI_split, n_src 1 (src/models/TDAVNet/mask_generator.py:67-99):
  * refined, a0 (B,256,T,F) -> separated embedding (B,1,256,T,F). */
 int rtfs_s3_mask_f32(const float* refined, const float* a0, const float* pack, float* out, int B, int T, int F,

@@ -37,6 +37,8 @@ SIGNATURES = {
     "rtfs_tfar_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _z, _p]),
     "rtfs_caf_workspace_bytes": (_z, [_i, _i]),
     "rtfs_caf_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _z, _p]),
+    "rtfs_vp_pack_floats": (_z, []),
+    "rtfs_vp_block_f32": (_i, [_p, _p, _p, _i, _i, _p]),
     "rtfs_s3_mask_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
     "rtfs_istft_decoder_workspace_bytes": (_z, [_i, _i]),
     "rtfs_istft_decoder_f32": (_i, [_p, _p, _p, _i, _i, _i, _p, _z, _p]),

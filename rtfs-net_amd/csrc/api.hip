@@ -708,6 +708,24 @@ int rtfs_caf_f32(const float* audio, const float* video, const float* pack, floa
     return launch_caf_apply(a, B, S(stream));
 }
 
+// ------------------------------------------------------------ VP block
+size_t rtfs_vp_pack_floats(void) {
+    size_t n = 0;
+    auto t = [&](size_t k) { n += (k + 63) / 64 * 64; };
+    t(512); t(512); t(1); t(512 * 64); t(64);
+    for (int i = 0; i < 4; ++i) { t(192); t(64); t(64); }
+    t(64); t(64); t(16 * 64); t(192 * 64); t(192); t(64 * 64); t(64); t(64); t(64);
+    t(128 * 64); t(128); t(128); t(128 * 3); t(128); t(64 * 128); t(64); t(64);
+    for (int i = 0; i < 7; ++i) for (int j = 0; j < 3; ++j) { t(192); t(64); t(64); }
+    t(64 * 512); t(512);
+    return n;
+}
+
+int rtfs_vp_block_f32(const float* video, const float* pack, float* out, int B, int Tv, void* stream) {
+    RTFS_RETURN_IF(!video || !pack || !out || B < 1, RTFS_ERR_ARG);
+    return launch_vp_block(video, pack, out, B, Tv, S(stream));
+}
+
 // ------------------------------------------------------------ S^3
 int rtfs_s3_mask_f32(const float* refined, const float* a0, const float* pack, float* out, int B, int T, int F, void* stream) {
     RTFS_RETURN_IF(!refined || !a0 || !pack || !out || B < 1 || T < 1 || F < 1, RTFS_ERR_ARG);

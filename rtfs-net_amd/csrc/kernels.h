@@ -181,3 +181,7 @@ size_t dp16_lds_bytes(int Ls, int nseq_per_wg);
 int launch_dualpath16(const Dp16Args& a, hipStream_t st);
 void* dualpath_timing_begin(int Ls, int nseq, hipStream_t st);
 void dualpath_timing_end(void* slot, hipStream_t st);
+
+// VP block (video 1-D TDANetBlock)
+size_t vp_lds_bytes(int Tv);
+int launch_vp_block(const float* video, const float* pack, float* out, int B, int Tv, hipStream_t st);

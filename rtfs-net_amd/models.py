@@ -149,9 +149,40 @@ class TDANetBlock(PackedModule):
                     and upsampling_depth == 2 and kinds == ["DualPathRNN", "DualPathRNN", "MultiHeadSelfAttention2D"] and dims == [4, 3, 3]):
                 raise ValueError("MI355X RTFS block supports the RTFS-Net yaml audio_params only")
 
+    def _vp_supported(self):
+        kinds = [type(m).__name__ for m in self.globalatt]
+        return (not self.is2d and self.in_chan == 512 and self.hid_chan == 64 and self.kernel_size == 3 and self.stride == 2
+                and self.norm_type == "BatchNorm1d" and self.act_type == "PReLU" and self.upsampling_depth == 4 and kinds == ["GlobalAttention"]
+                and self.globalatt[0].n_head == 8 and self.globalatt[0].kernel_size == 3 and self.globalatt[0].hid_chan == 128)
+
+    def pack_vp(self):
+        sd = self._state_tensors()
+        key = tuple((v.data_ptr(), v._version) for v in sd.values())
+        if getattr(self, "_vp_key", None) != key:
+            with torch.no_grad():
+                pk = packing.pack_vp(sd)
+            object.__setattr__(self, "_vp_buf", pk)
+            object.__setattr__(self, "_vp_key", key)
+        return self._vp_buf
+
+    def forward_vp(self, x):
+        """VP block on the fused HIP kernel (one workgroup per sample)."""
+        self._guard(x)
+        lib = _lib.load()
+        x = x.contiguous()
+        B, _, Tv = x.shape
+        out = torch.empty_like(x)
+        pk = self.pack_vp()
+        assert pk.numel() == lib.rtfs_vp_pack_floats()
+        _lib.check(lib.rtfs_vp_block_f32(_lib.ptr(x), _lib.ptr(pk), _lib.ptr(out), B, Tv, _lib.stream_of(x)), "rtfs_vp_block_f32")
+        return out
+
     def forward(self, x, x_res=None):
         if not self._hip:
-            return self._forward_1d(x if x_res is None else x + x_res)
+            x = x if x_res is None else x + x_res
+            if x.is_cuda and not self.training and self._vp_supported() and x.shape[-1] <= 120:
+                return self.forward_vp(x)
+            return self._forward_1d(x)
         self._guard(x, x_res)
         lib = _lib.load()
         x = x.contiguous()

@@ -158,3 +158,38 @@ def pack_decoder(sd):
     w = sd["decoder.weight"].reshape(256, 18)
     w = torch.cat([w, w.new_zeros(256, 14)], 1)  # (cin 256, 32 taps)
     return _cat([w, split16_image(w.t())])
+
+
+def _bn_fold(sd, prefix, conv_bias=None, eps=1e-5):
+    """Eval BatchNorm1d (and the conv bias in front of it) -> y = scale * conv + shift."""
+    scale = sd[prefix + ".weight"] / torch.sqrt(sd[prefix + ".running_var"] + eps)
+    shift = sd[prefix + ".bias"] - sd[prefix + ".running_mean"] * scale
+    if conv_bias is not None:
+        shift = shift + scale * conv_bias
+    return scale, shift
+
+
+def pack_vp(sd):
+    """Video TDANetBlock (1-D, depth 4, k 3, BatchNorm1d, GlobalAttention): order = csrc/k_vp.hip."""
+    parts = [sd["gateway.full_layer.2.weight"].reshape(512), sd["gateway.full_layer.2.bias"], sd["gateway.full_layer.4.weight"].reshape(1),
+             sd["projection.full_layer.2.weight"].reshape(64, 512).t(), sd["projection.full_layer.2.bias"]]
+    for i in range(4):
+        p = f"downsample_layers.{i}.full_layer."
+        sc, sh = _bn_fold(sd, p + "3", sd[p + "2.bias"])
+        parts += [sd[p + "2.weight"].reshape(64, 3), sc, sh]
+    m = "globalatt.0.MHSA."
+    parts += [sd[m + "norm1.weight"], sd[m + "norm1.bias"], sd[m + "pos_enc.pe"][0, :16], sd[m + "attention.in_proj_weight"],
+              sd[m + "attention.in_proj_bias"], sd[m + "attention.out_proj.weight"], sd[m + "attention.out_proj.bias"],
+              sd[m + "norm2.weight"], sd[m + "norm2.bias"]]
+    f = "globalatt.0.FFN."
+    parts += [sd[f + "encoder.full_layer.2.weight"].reshape(128, 64), sd[f + "encoder.full_layer.3.norm.weight"], sd[f + "encoder.full_layer.3.norm.bias"],
+              sd[f + "refiner.full_layer.2.weight"].reshape(128, 3), sd[f + "refiner.full_layer.2.bias"],
+              sd[f + "decoder.full_layer.2.weight"].reshape(64, 128), sd[f + "decoder.full_layer.3.norm.weight"], sd[f + "decoder.full_layer.3.norm.bias"]]
+    for grp, n in (("fusion_layers", 4), ("concat_layers", 3)):
+        for i in range(n):
+            for name in ("local_embedding", "global_embedding", "global_gate"):
+                p = f"{grp}.{i}.{name}.full_layer."
+                sc, sh = _bn_fold(sd, p + "3")
+                parts += [sd[p + "2.weight"].reshape(64, 3), sc, sh]
+    parts += [sd["residual_conv.full_layer.2.weight"].reshape(512, 64).t(), sd["residual_conv.full_layer.2.bias"]]
+    return _cat(parts)
