@@ -59,6 +59,27 @@ def cpu_baseline(repeats, seconds_budget=25.0):
                       f"BLAS threads {threads} of {os.cpu_count()} host cpus"}
 
 
+def rank_inputs(rank, B, L, Tv):
+    """Per-rank synthetic batch: s1, s2 ~ N(0, 0.05^2), mixture = s1 + s2, lip embedding ~ N(0, 1)."""
+    g = torch.Generator().manual_seed(1234 + rank)
+    s1 = torch.randn(B, L, generator=g) * 0.05
+    s2 = torch.randn(B, L, generator=g) * 0.05
+    return s1 + s2, torch.randn(B, 512, Tv, generator=g)
+
+
+def max_over_ranks(dt, dist, device):
+    """Whole-job time = the slowest rank's time."""
+    if dist is None:
+        return dt
+    tt = torch.tensor([dt], device=device, dtype=torch.float64)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    return float(tt.item())
+
+
+def throughput(world, B, steps, dt):
+    return world * B * steps / dt
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -94,11 +115,7 @@ def main():
     model = R.AVNet(print_macs=False, **audionet_config(args.repeats)).to(dev).eval()
     B, L = args.batch, int(args.seconds * 16000)
     Tv = int(args.seconds * 25)
-    g = torch.Generator().manual_seed(1234 + rank)
-    s1 = torch.randn(B, L, generator=g) * 0.05
-    s2 = torch.randn(B, L, generator=g) * 0.05
-    wav = (s1 + s2).to(dev)
-    emb = torch.randn(B, 512, Tv, generator=g).to(dev)
+    wav, emb = (t.to(dev) for t in rank_inputs(rank, B, L, Tv))
 
     def barrier():
         if dist is not None:
@@ -125,10 +142,7 @@ def main():
     n_ev = lib.rtfs_sweep_timing_collect(ms, ls, ns, cap)
     lib.rtfs_sweep_timing_enable(0)
 
-    if dist is not None:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt = max_over_ranks(dt, dist, dev)
 
     if rank == 0:
         total_bytes = sum(sweep_bytes(ls[i], ns[i]) for i in range(n_ev))
@@ -145,7 +159,7 @@ def main():
                 traffic = None
         res = {
             "metric": "mixtures/sec forward (2 s@16 kHz, 2-spk) RTFS-Net-4",
-            "value": round(world * B * args.steps / dt, 3),
+            "value": round(throughput(world, B, args.steps, dt), 3),
             "unit": "mixtures/s",
             "n_gpus": world,
             "steps": args.steps,
