@@ -77,7 +77,8 @@ __device__ __forceinline__ void gln_fold(const double* st, double inv_count, flo
     shift = (float)(beta - mean * rstd * gamma);
 }
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// v_exp_f32 + v_rcp_f32 (1 ulp each); saturates correctly: exp2(+inf) -> rcp(inf) = 0
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
 __device__ __forceinline__ float preluf_(float x, float a) { return x >= 0.f ? x : a * x; }
 
 // legacy 'nearest' source index: floor(dst * in / out)

@@ -122,6 +122,131 @@ __global__ __launch_bounds__(256) void dw_s1_kernel(DwArgs a) {
     dw_s1_body<NCONV, IN_AFFINE, MODE>(a, a.x, a.gate, a.emb, a.addend, a.out[0], a.out[1], a.out[2], a.out[3]);
 }
 
+// ---------------------------------------------------------------- packed variant for the full-resolution single-conv passes
+// The depthwise passes are VALU-bound (16 FMAs per output), so this variant halves the FMA instruction count with
+// v_pk_fma_f32: a thread owns TWO columns half a row apart (f and f + ceil(W/2)); their 4x4 windows are disjoint, so each
+// load fills one half of an operand pair and both columns' accumulators advance with one packed FMA per tap.
+// Zero padding: out-of-image COLUMNS are folded into per-lane weights (weight 0), out-of-image ROWS are selected to 0 only in
+// the first / last row band; the input gLN fold is applied to the result: conv(pad0(s*x+b)) = s*conv(pad0(x)) + b*sum(valid w).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <bool IN_AFFINE, int MODE>
+__device__ __forceinline__ void dw1p_body(const DwArgs& a, const float* __restrict__ X, const float* __restrict__ GATE,
+                                          const float* __restrict__ EMB, const float* __restrict__ ADD, float* __restrict__ OUT) {
+    __shared__ double red[8];
+    const int H = a.H, W = a.W, C = a.C;
+    const int half = (W + 1) >> 1;
+    const int b = blockIdx.z;
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    const bool live = g < C * half;
+    const int c = live ? g / half : 0, fa = live ? g - c * half : 0, fb = fa + half;
+    const bool liveb = live && fb < W;
+    const int r0 = blockIdx.y * a.TH, r1 = min(r0 + a.TH, H);
+    const size_t plane = ((size_t)b * C + c) * H * W;
+    const float* __restrict__ xp = X + plane;
+    float isc = 1.f, ish = 0.f;
+    if (IN_AFFINE) gln_fold(a.in_stats + 2 * b, a.in_inv_count, a.in_gamma[c], a.in_beta[c], isc, ish);
+    // per-lane weights with the column padding folded in; clamped column offsets
+    f32x2 wgt[16];
+    int ca[4], cb[4];
+    f32x2 rowsum[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rowsum[i] = f32x2{0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int xa = fa - 1 + j, xb = fb - 1 + j;
+        const bool oka = live && xa >= 0 && xa < W, okb = liveb && xb >= 0 && xb < W;
+        ca[j] = xa < 0 ? 0 : (xa < W ? xa : W - 1);
+        cb[j] = xb < 0 ? 0 : (xb < W ? xb : W - 1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float w = a.w[0][c * 16 + i * 4 + j];
+            wgt[i * 4 + j] = f32x2{oka ? w : 0.f, okb ? w : 0.f};
+            rowsum[i] += wgt[i * 4 + j];
+        }
+    }
+    const float bias = a.bias[0] ? a.bias[0][c] : 0.f;
+    float lsc = 1.f, lsh = 0.f, gsc = 1.f, gsh = 0.f, esc = 1.f, esh = 0.f, asc = 1.f, ash = 0.f;
+    size_t gplane = 0;
+    int fga = 0, fgb = 0;
+    if (MODE == 2) {
+        gln_fold(a.loc_stats + 2 * b, a.loc_inv_count, a.loc_gamma[c], a.loc_beta[c], lsc, lsh);
+        gln_fold(a.gate_stats + 2 * b, a.g_inv_count, a.gate_gamma[c], a.gate_beta[c], gsc, gsh);
+        gln_fold(a.emb_stats + 2 * b, a.g_inv_count, a.emb_gamma[c], a.emb_beta[c], esc, esh);
+        if (ADD) gln_fold(a.add_stats + 2 * b, a.add_inv_count, a.add_gamma[c], a.add_beta[c], asc, ash);
+        gplane = ((size_t)b * C + c) * a.Hg * a.Wg;
+        fga = nearest_src(fa, a.Wg, W);
+        fgb = nearest_src(fb < W ? fb : W - 1, a.Wg, W);
+    }
+    const bool border = r0 == 0 || r1 + 2 > H;  // block-uniform: only these bands ever see an out-of-image row
+    auto load_row = [&](int t, f32x2 (&row)[4]) {
+        const int tc = t < 0 ? 0 : (t < H ? t : H - 1);
+        const float* __restrict__ rp = xp + (size_t)tc * W;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) row[j] = f32x2{rp[ca[j]], rp[cb[j]]};
+        if (border && (t < 0 || t >= H)) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) row[j] = f32x2{0.f, 0.f};
+        }
+    };
+    f32x2 win[4][4];
+    load_row(r0 - 1, win[0]);
+    load_row(r0, win[1]);
+    load_row(r0 + 1, win[2]);
+    f32x2 s2 = {0.f, 0.f}, ss2 = {0.f, 0.f};
+    const f32x2 wv_full = rowsum[0] + rowsum[1] + rowsum[2] + rowsum[3];
+    const int fbc = fb < W ? fb : W - 1;
+#pragma unroll 2
+    for (int t = r0; t < r1; ++t) {
+        load_row(t + 2, win[3]);
+        f32x2 acc = {0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc = win[i][j] * wgt[i * 4 + j] + acc;
+        if (IN_AFFINE) {
+            f32x2 wv = wv_full;
+            if (border) {
+                if (t - 1 < 0) wv -= rowsum[0];
+                if (t + 1 >= H) wv -= rowsum[2];
+                if (t + 2 >= H) wv -= rowsum[3];
+            }
+            acc = acc * isc + wv * ish;
+        }
+        acc += bias;
+        const size_t oa = plane + (size_t)t * W + fa, ob = plane + (size_t)t * W + fbc;
+        if (MODE == 0) {
+            if (live) OUT[oa] = acc.x;
+            if (liveb) OUT[ob] = acc.y;
+        }
+        if (MODE != 2) {
+            const f32x2 m = {live ? 1.f : 0.f, liveb ? 1.f : 0.f};
+            const f32x2 am = acc * m;
+            s2 += am;
+            ss2 = am * am + ss2;
+        } else {
+            const int tg = nearest_src(t, a.Hg, H);
+            const size_t ga = gplane + (size_t)tg * a.Wg + fga, gb = gplane + (size_t)tg * a.Wg + fgb;
+            const f32x2 gate = {sigmoidf_(fmaf(GATE[ga], gsc, gsh)), sigmoidf_(fmaf(GATE[gb], gsc, gsh))};
+            const f32x2 emb = {fmaf(EMB[ga], esc, esh), fmaf(EMB[gb], esc, esh)};
+            f32x2 y = (acc * lsc + lsh) * gate + emb;
+            if (ADD) y += f32x2{fmaf(ADD[oa], asc, ash), fmaf(ADD[ob], asc, ash)};
+            if (live) OUT[oa] = y.x;
+            if (liveb) OUT[ob] = y.y;
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) win[i][j] = win[i + 1][j];
+    }
+    if (MODE != 2) block_stats_atomic(s2.x + s2.y, ss2.x + ss2.y, red, a.stats_out[0] + 2 * b);
+}
+
+template <bool IN_AFFINE, int MODE>
+__global__ __launch_bounds__(256) void dw1p_kernel(DwArgs a) {
+    dw1p_body<IN_AFFINE, MODE>(a, a.x, a.gate, a.emb, a.addend, a.out[0]);
+}
+
 // ---------------------------------------------------------------- stride-2 pad-1 4x4 + adaptive average pool
 // Reads d0 = gLN(c0) through the fold; writes c1 (pre-norm conv output, +stats) and p0 = adaptive_avg_pool2d(d0)
 // at the conv's output resolution (Ho = H/2, Wo = W/2).  The pool window of output (i,j) is
@@ -262,7 +387,19 @@ static int launch_dw_s1_t(const DwArgs& a, int B, hipStream_t st) {
     return rtfs_launch_status();
 }
 
+template <bool IN_AFFINE, int MODE>
+static int launch_dw1p_t(const DwArgs& a, int B, hipStream_t st) {
+    const int half = (a.W + 1) / 2;
+    hipLaunchKernelGGL((dw1p_kernel<IN_AFFINE, MODE>), dim3(cdiv(a.C * half, 256), cdiv(a.H, a.TH), B), dim3(256), 0, st, a);
+    return rtfs_launch_status();
+}
+
 int launch_dw_s1(const DwArgs& a, int nconv, bool in_affine, int mode, int B, hipStream_t st) {
+    if (nconv == 1 && a.W >= 96) {  // full-resolution passes: packed two-column variant
+        if (mode == 0) return in_affine ? launch_dw1p_t<true, 0>(a, B, st) : launch_dw1p_t<false, 0>(a, B, st);
+        if (mode == 1) return in_affine ? launch_dw1p_t<true, 1>(a, B, st) : launch_dw1p_t<false, 1>(a, B, st);
+        if (mode == 2) return in_affine ? launch_dw1p_t<true, 2>(a, B, st) : launch_dw1p_t<false, 2>(a, B, st);
+    }
     if (mode == 0 && nconv == 1 && !in_affine) return launch_dw_s1_t<1, false, 0>(a, B, st);
     if (mode == 0 && nconv == 1 && in_affine) return launch_dw_s1_t<1, true, 0>(a, B, st);
     if (mode == 0 && nconv == 2 && !in_affine) return launch_dw_s1_t<2, false, 0>(a, B, st);
