@@ -311,7 +311,8 @@ struct BlockWs {
     double* st(int slot, int B) const { return stats ? stats + (size_t)slot * B * 2 : nullptr; }
 };
 
-int block_forward(const BlockPack& p, const float* x, const float* x_res, float* out, int B, int T, int F, BlockWs& w, hipStream_t st) {
+int block_forward(const BlockPack& p, const float* x, const float* x_res, float* out, int B, int T, int F, BlockWs& w, hipStream_t st,
+                  const CafArgs* caf = nullptr) {
     const int Tp = T / 2, Fp = F / 2;
     const int P = T * F, Pg = Tp * Fp;
     const double icF = 1.0 / ((double)CH * P), icG = 1.0 / ((double)CH * Pg);
@@ -331,6 +332,11 @@ int block_forward(const BlockPack& p, const float* x, const float* x_res, float*
         a.gb = p.gb;
         a.slope = p.gslope;
         a.P = P;
+        if (caf && !gemm_f32()) {  // block input = CAF(x, video) + x_res, applied while streaming x (fused separator path)
+            a.caf_r = caf->r_out; a.caf_att = caf->att_out;
+            a.caf_w_key = caf->w_key; a.caf_bn_key = caf->bn_key; a.caf_w_val = caf->w_val; a.caf_bn_val = caf->bn_val;
+            a.caf_T = caf->T; a.caf_F = caf->F; a.caf_Tv = caf->Tv;
+        }
         CHECK(gemm_f32() ? launch_pw_gateway_proj(a, B, st) : launch_pws_gateway_proj(a, B, st));
     }
     {  // 2. downsample[0]: dw 4x4 s1 + bias -> c0 (pre-gLN) + stats                         tdanet.py:110
@@ -799,14 +805,18 @@ int rtfs_separator_forward_f32(const float* wav, const float* video_vp, const fl
     CHECK(audio_bn(pb, w.a0, w.st0, w.a1, B, P, st));
     // refinement_module.py:45-62: block(a1); CAF; then (repeats-1) x block(audio + a1), shared weights
     CHECK(block_forward(pk, w.a1, nullptr, w.cur, B, T, NF, w.blk, st));
-    {
-        CafArgs a = caf_args(pc, w.cur, video_vp, w.nxt, w.r, w.att, T, NF, Tv);
-        CHECK(launch_caf_video(a, B, st));
-        CHECK(launch_caf_apply(a, B, st));
+    CafArgs ca = caf_args(pc, w.cur, video_vp, w.nxt, w.r, w.att, T, NF, Tv);
+    CHECK(launch_caf_video(ca, B, st));
+    // with repeats > 1 the CAF's audio side is applied inside the next block's gateway kernel (one pass less over A256)
+    const bool fuse_caf = repeats > 1 && !gemm_f32();
+    float *cur = w.cur, *nxt = w.nxt;
+    if (!fuse_caf) {
+        CHECK(launch_caf_apply(ca, B, st));
+        cur = w.nxt;
+        nxt = w.cur;
     }
-    float *cur = w.nxt, *nxt = w.cur;
     for (int i = 1; i < repeats; ++i) {
-        CHECK(block_forward(pk, cur, w.a1, nxt, B, T, NF, w.blk, st));
+        CHECK(block_forward(pk, cur, w.a1, nxt, B, T, NF, w.blk, st, (i == 1 && fuse_caf) ? &ca : nullptr));
         float* t = cur;
         cur = nxt;
         nxt = t;

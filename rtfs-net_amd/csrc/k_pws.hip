@@ -14,7 +14,7 @@
 enum { PRO_NONE = 0, PRO_GATEWAY = 2 };
 enum { EPI_BIAS = 0, EPI_BIAS_RES = 1 };
 
-template <int CIN, int COUT, int PRO, int EPI, bool HAS_X2>
+template <int CIN, int COUT, int PRO, int EPI, bool HAS_X2, bool CAF>
 __device__ __forceinline__ void pws_body(const PwArgs& a, int ntiles, int tiles_per_sample, const float* __restrict__ X,
                                          const float* __restrict__ X2, float* __restrict__ RES, const float* __restrict__ AUX,
                                          float* __restrict__ OUT) {
@@ -28,6 +28,10 @@ __device__ __forceinline__ void pws_body(const PwArgs& a, int ntiles, int tiles_
     _Float16* Wl = Wh + COUT * LDW;
     float* gsc = reinterpret_cast<float*>(Wl + COUT * LDW);  // gateway scale / bias per input channel
     float* gsh = gsc + CIN;
+    float* cks = gsh + CIN;  // CAF: folded key / value embeddings (dw 1x1 . eval BatchNorm), layers/fusion.py:205-226
+    float* ckb = cks + (CAF ? CIN : 0);
+    float* cvs = ckb + (CAF ? CIN : 0);
+    float* cvb = cvs + (CAF ? CIN : 0);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -42,6 +46,14 @@ __device__ __forceinline__ void pws_body(const PwArgs& a, int ntiles, int tiles_
             for (int c = tid; c < CIN; c += 256) {
                 gsc[c] = a.gw[c];
                 gsh[c] = a.gb[c];
+                if (CAF) {
+                    const float sk = a.caf_bn_key[c] / sqrtf(a.caf_bn_key[3 * CIN + c] + RTFS_EPS);
+                    const float sv = a.caf_bn_val[c] / sqrtf(a.caf_bn_val[3 * CIN + c] + RTFS_EPS);
+                    cks[c] = a.caf_w_key[c] * sk;
+                    ckb[c] = a.caf_bn_key[CIN + c] - a.caf_bn_key[2 * CIN + c] * sk;
+                    cvs[c] = a.caf_w_val[c] * sv;
+                    cvb[c] = a.caf_bn_val[CIN + c] - a.caf_bn_val[2 * CIN + c] * sv;
+                }
             }
     }
     const float slope = PRO == PRO_GATEWAY ? a.slope[0] : 0.f;
@@ -54,6 +66,11 @@ __device__ __forceinline__ void pws_body(const PwArgs& a, int ntiles, int tiles_
         const int m0 = (wave % CSPLIT) * MTW;
         const bool live = p < P;
         const size_t xb = (size_t)b * CIN * P + (live ? p : P - 1);
+        size_t cafb = 0;
+        if (CAF) {  // nearest up-sampling of the video-side terms: tv = floor(t * Tv / T)
+            const int t = (live ? p : P - 1) / a.caf_F;
+            cafb = (size_t)b * CIN * a.caf_Tv + nearest_src(t, a.caf_Tv, a.caf_T);
+        }
         f32x16 acc[MTW];
 #pragma unroll
         for (int m = 0; m < MTW; ++m)
@@ -66,6 +83,11 @@ __device__ __forceinline__ void pws_body(const PwArgs& a, int ntiles, int tiles_
             for (int j = 0; j < 8; ++j) {
                 const size_t off = xb + (size_t)(ks + 8 * h + j) * P;
                 v[j] = X[off];  // dead lanes read a valid (clamped) pixel; nothing of theirs is stored
+                if (CAF) {
+                    const int ci = ks + 8 * h + j;
+                    const size_t co_ = cafb + (size_t)ci * a.caf_Tv;
+                    v[j] = fmaf(fmaxf(fmaf(v[j], cks[ci], ckb[ci]), 0.f), a.caf_r[co_], a.caf_att[co_] * fmaf(v[j], cvs[ci], cvb[ci]));
+                }
                 if (PRO == PRO_GATEWAY && HAS_X2) v[j] += X2[off];
             }
             if (PRO == PRO_GATEWAY) {
@@ -115,28 +137,29 @@ __device__ __forceinline__ void pws_body(const PwArgs& a, int ntiles, int tiles_
     }
 }
 
-template <int CIN, int COUT, int PRO, int EPI, bool HAS_X2>
+template <int CIN, int COUT, int PRO, int EPI, bool HAS_X2, bool CAF>
 __global__ __launch_bounds__(256, 2) void pws_kernel(PwArgs a, int ntiles, int tiles_per_sample) {
-    pws_body<CIN, COUT, PRO, EPI, HAS_X2>(a, ntiles, tiles_per_sample, a.x, a.x2, a.res_out, a.aux, a.out);
+    pws_body<CIN, COUT, PRO, EPI, HAS_X2, CAF>(a, ntiles, tiles_per_sample, a.x, a.x2, a.res_out, a.aux, a.out);
 }
 
-template <int CIN, int COUT, int PRO, int EPI, bool HAS_X2>
+template <int CIN, int COUT, int PRO, int EPI, bool HAS_X2, bool CAF = false>
 static int launch_pws_t(const PwArgs& a, int B, hipStream_t st) {
-    const size_t lds = (size_t)2 * COUT * (CIN + 8) * 2 + (size_t)2 * CIN * 4;
+    const size_t lds = (size_t)2 * COUT * (CIN + 8) * 2 + (size_t)(CAF ? 6 : 2) * CIN * 4;
     static bool configured = false;
     if (!configured) {
-        if (hipFuncSetAttribute((const void*)pws_kernel<CIN, COUT, PRO, EPI, HAS_X2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)pws_kernel<CIN, COUT, PRO, EPI, HAS_X2, CAF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return RTFS_ERR_LAUNCH;
         configured = true;
     }
     constexpr int PTB = 32 * (4 / (COUT / 32 > 4 ? COUT / 32 / 4 : 1));
     const int tps = cdiv(a.P, PTB), ntiles = tps * B;
     const int grid = ntiles < 512 ? ntiles : 512;  // 2 resident workgroups per CU
-    hipLaunchKernelGGL((pws_kernel<CIN, COUT, PRO, EPI, HAS_X2>), dim3(grid), dim3(256), lds, st, a, ntiles, tps);
+    hipLaunchKernelGGL((pws_kernel<CIN, COUT, PRO, EPI, HAS_X2, CAF>), dim3(grid), dim3(256), lds, st, a, ntiles, tps);
     return rtfs_launch_status();
 }
 
 int launch_pws_gateway_proj(const PwArgs& a, int B, hipStream_t st) {
+    if (a.caf_r) return a.x2 ? launch_pws_t<256, 64, PRO_GATEWAY, EPI_BIAS, true, true>(a, B, st) : RTFS_ERR_ARG;
     return a.x2 ? launch_pws_t<256, 64, PRO_GATEWAY, EPI_BIAS, true>(a, B, st) : launch_pws_t<256, 64, PRO_GATEWAY, EPI_BIAS, false>(a, B, st);
 }
 int launch_pws_residual(const PwArgs& a, int B, hipStream_t st) { return launch_pws_t<64, 256, PRO_NONE, EPI_BIAS_RES, false>(a, B, st); }

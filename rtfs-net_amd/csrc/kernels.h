@@ -22,6 +22,11 @@ struct PwArgs {
     const float* slope = nullptr;  // PReLU slope (1)
     int P = 0;
     int cout_live = 0;  // EPI_TAPS: number of real output channels
+    // optional CAF prologue of the gateway kernel (fused separator path): x <- CAF(x, video) before the residual add
+    const float* caf_r = nullptr;    // (B,256,Tv) resize(video)
+    const float* caf_att = nullptr;  // (B,256,Tv) softmax attention
+    const float *caf_w_key = nullptr, *caf_bn_key = nullptr, *caf_w_val = nullptr, *caf_bn_val = nullptr;
+    int caf_T = 0, caf_F = 0, caf_Tv = 0;
 };
 
 int launch_stft(const float* wav, float* spec, int B, int L, int T, hipStream_t st);
