@@ -17,10 +17,10 @@ enum { EPI_BIAS = 0, EPI_BIAS_RES = 1, EPI_S3 = 2, EPI_TAPS = 3 };
 #define KC 32
 #define LDH 40  // padded row length in halfs (80 B)
 
-template <int CIN, int COUT, int PT, int WAVES_M, int PRO, int EPI>
+template <int CIN, int COUT, int PT, int WAVES_M, int PRO, int EPI, int NT = 256>
 __device__ __forceinline__ void pw16_body(const PwArgs& a, const float* __restrict__ X, const float* __restrict__ X2,
                                           float* __restrict__ RES, const float* __restrict__ AUX, float* __restrict__ OUT) {
-    constexpr int WAVES_N = 4 / WAVES_M;
+    constexpr int WAVES_N = (NT / 64) / WAVES_M;
     constexpr int WM = COUT / 32 / WAVES_M;
     constexpr int WN = PT / 32 / WAVES_N;
     static_assert(WM >= 1 && WN >= 1 && CIN % KC == 0, "tile config");
@@ -40,9 +40,9 @@ __device__ __forceinline__ void pw16_body(const PwArgs& a, const float* __restri
     const size_t xb = (size_t)b * CIN * P;
 
     if (PRO == PRO_GLN_RELU) {
-        for (int c = tid; c < CIN; c += 256) gln_fold(a.stats + 2 * b, a.inv_count, a.gamma[c], a.beta[c], sc[c], sh[c]);
+        for (int c = tid; c < CIN; c += NT) gln_fold(a.stats + 2 * b, a.inv_count, a.gamma[c], a.beta[c], sc[c], sh[c]);
     } else if (PRO == PRO_GATEWAY) {
-        for (int c = tid; c < CIN; c += 256) {
+        for (int c = tid; c < CIN; c += NT) {
             sc[c] = a.gw[c];
             sh[c] = a.gb[c];
         }
@@ -60,7 +60,7 @@ __device__ __forceinline__ void pw16_body(const PwArgs& a, const float* __restri
     for (int c0 = 0; c0 < CIN; c0 += KC) {
         __syncthreads();
         // ---- stage X: each task = (pixel, group of 8 input channels) -> two 16-byte LDS rows pieces
-        for (int task = tid; task < PT * 4; task += 256) {
+        for (int task = tid; task < PT * 4; task += NT) {
             const int pp = task % PT, gq = task / PT;
             const int p = p0 + pp;
             const bool live = p < P;
@@ -95,7 +95,7 @@ __device__ __forceinline__ void pw16_body(const PwArgs& a, const float* __restri
         // ---- stage W: global image [chunk][hi|lo][co][32] halfs -> padded LDS rows
         {
             const half8* src = reinterpret_cast<const half8*>(a.w16) + (size_t)(c0 / KC) * 2 * COUT * 4;
-            for (int i = tid; i < COUT * 4; i += 256) {
+            for (int i = tid; i < COUT * 4; i += NT) {
                 const int co = i >> 2, part = i & 3;
                 *reinterpret_cast<half8*>(&Wh[co * LDH + part * 8]) = src[i];
                 *reinterpret_cast<half8*>(&Wl[co * LDH + part * 8]) = src[COUT * 4 + i];
@@ -164,21 +164,21 @@ __device__ __forceinline__ void pw16_body(const PwArgs& a, const float* __restri
     }
 }
 
-template <int CIN, int COUT, int PT, int WAVES_M, int PRO, int EPI>
-__global__ __launch_bounds__(256) void pw16_kernel(PwArgs a) {
-    pw16_body<CIN, COUT, PT, WAVES_M, PRO, EPI>(a, a.x, a.x2, a.res_out, a.aux, a.out);
+template <int CIN, int COUT, int PT, int WAVES_M, int PRO, int EPI, int NT>
+__global__ __launch_bounds__(NT) void pw16_kernel(PwArgs a) {
+    pw16_body<CIN, COUT, PT, WAVES_M, PRO, EPI, NT>(a, a.x, a.x2, a.res_out, a.aux, a.out);
 }
 
-template <int CIN, int COUT, int PT, int WAVES_M, int PRO, int EPI>
+template <int CIN, int COUT, int PT, int WAVES_M, int PRO, int EPI, int NT = 256>
 static int launch_pw16_t(const PwArgs& a, int B, hipStream_t st) {
-    hipLaunchKernelGGL((pw16_kernel<CIN, COUT, PT, WAVES_M, PRO, EPI>), dim3(cdiv(a.P, PT), B), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((pw16_kernel<CIN, COUT, PT, WAVES_M, PRO, EPI, NT>), dim3(cdiv(a.P, PT), B), dim3(NT), 0, st, a);
     return rtfs_launch_status();
 }
 
-int launch_pw16_audio_bn(const PwArgs& a, int B, hipStream_t st) { return launch_pw16_t<256, 256, 64, 4, PRO_GLN_RELU, EPI_BIAS>(a, B, st); }
+int launch_pw16_audio_bn(const PwArgs& a, int B, hipStream_t st) { return launch_pw16_t<256, 256, 128, 4, PRO_GLN_RELU, EPI_BIAS, 512>(a, B, st); }
 int launch_pw16_gateway_proj(const PwArgs& a, int B, hipStream_t st) { return launch_pw16_t<256, 64, 128, 2, PRO_GATEWAY, EPI_BIAS>(a, B, st); }
 int launch_pw16_residual(const PwArgs& a, int B, hipStream_t st) { return launch_pw16_t<64, 256, 64, 4, PRO_NONE, EPI_BIAS_RES>(a, B, st); }
-int launch_pw16_s3(const PwArgs& a, int B, hipStream_t st) { return launch_pw16_t<256, 256, 64, 4, PRO_PRELU, EPI_S3>(a, B, st); }
+int launch_pw16_s3(const PwArgs& a, int B, hipStream_t st) { return launch_pw16_t<256, 256, 128, 4, PRO_PRELU, EPI_S3, 512>(a, B, st); }
 int launch_pw16_dec_taps(const PwArgs& a, int B, hipStream_t st) { return launch_pw16_t<256, 32, 256, 1, PRO_NONE, EPI_TAPS>(a, B, st); }
 
 // ---------------------------------------------------------------- MFMA f16 fragment-layout self test
