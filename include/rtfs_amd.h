@@ -108,12 +108,15 @@ int rtfs_istft_decoder_f32(const float* x, const float* pack, float* wav, int B,
 /* The whole separator, AVNet.forward minus the (tiny, 0.004 GMAC) video-side VP block whose output the caller
  * passes in (src/models/tdavnet.py:86-97, refinement_module.py:45-62):
  *   encoder -> audio bottleneck -> block -> CAF(video_vp) -> (repeats-1) x block(+a1) -> S^3 -> decoder.
- * packs: encoder, audio_bn, block, caf, s3, decoder.  wav (B,L), video_vp (B,512,Tv) -> out (B,1,L). */
+ * packs: encoder, audio_bn, block, caf, s3, decoder.  wav (B,L), video_vp (B,512,Tv) -> out (B,1,L).
+ * video_ready: optional hipEvent_t (as void*, may be NULL) recorded by the caller after video_vp was produced on
+ * ANOTHER stream; the library makes `stream` wait for it right before the CAF block, so the VP block overlaps the
+ * encoder and the first RTFS block. */
 size_t rtfs_separator_workspace_bytes(int B, int L, int Tv);
 int rtfs_separator_forward_f32(const float* wav, const float* video_vp, const float* pack_enc, const float* pack_bn,
                                const float* pack_block, const float* pack_caf, const float* pack_s3,
                                const float* pack_dec, float* out, int B, int L, int Tv, int repeats, void* ws,
-                               size_t ws_bytes, void* stream);
+                               size_t ws_bytes, void* stream, void* video_ready);
 
 /* Operator-level seam: sru.SRU(input_size=512, hidden_size=32, num_layers=4, bidirectional=True).forward
  * (call site src/models/layers/rnn_layers.py:150; third-party asappresearch `sru`, v2 recurrence).

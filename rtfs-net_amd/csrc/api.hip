@@ -782,7 +782,7 @@ size_t rtfs_separator_workspace_bytes(int B, int L, int Tv) {
 
 int rtfs_separator_forward_f32(const float* wav, const float* video_vp, const float* pack_enc, const float* pack_bn, const float* pack_block,
                                const float* pack_caf, const float* pack_s3, const float* pack_dec, float* out, int B, int L, int Tv,
-                               int repeats, void* ws, size_t ws_bytes, void* stream) {
+                               int repeats, void* ws, size_t ws_bytes, void* stream, void* video_ready) {
     RTFS_RETURN_IF(!wav || !video_vp || !pack_enc || !pack_bn || !pack_block || !pack_caf || !pack_s3 || !pack_dec || !out, RTFS_ERR_ARG);
     RTFS_RETURN_IF(B < 1 || L <= 128 || Tv < 1 || repeats < 1, RTFS_ERR_ARG);
     const int T = rtfs_num_frames(L);
@@ -806,6 +806,7 @@ int rtfs_separator_forward_f32(const float* wav, const float* video_vp, const fl
     // refinement_module.py:45-62: block(a1); CAF; then (repeats-1) x block(audio + a1), shared weights
     CHECK(block_forward(pk, w.a1, nullptr, w.cur, B, T, NF, w.blk, st));
     CafArgs ca = caf_args(pc, w.cur, video_vp, w.nxt, w.r, w.att, T, NF, Tv);
+    if (video_ready && hipStreamWaitEvent(st, (hipEvent_t)video_ready, 0) != hipSuccess) return RTFS_ERR_LAUNCH;
     CHECK(launch_caf_video(ca, B, st));
     // with repeats > 1 the CAF's audio side is applied inside the next block's gateway kernel (one pass less over A256)
     const bool fuse_caf = repeats > 1 && !gemm_f32();

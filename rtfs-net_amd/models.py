@@ -8,6 +8,7 @@ arithmetic runs in ``librtfs_amd.so``.
 """
 from __future__ import annotations
 
+import ctypes
 import sys
 
 import torch
@@ -431,16 +432,32 @@ class AVNet(BaseAVModel):
         wav = wav.contiguous()
         B, L = wav.shape
         rm = self.refinement_module
-        vp = rm.video_net.get_block(0)(self.video_bottleneck(mouth_embedding)).contiguous()  # VP block (torch ops)
+        # VP block on a side stream: it only feeds the CAF block, so it overlaps the encoder and the first RTFS block
+        main = torch.cuda.current_stream(wav.device)
+        side = self._side_stream(wav.device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            vp = rm.video_net.get_block(0)(self.video_bottleneck(mouth_embedding)).contiguous()
+            ready = torch.cuda.Event()
+            ready.record(side)
+        vp.record_stream(main)
         Tv = vp.shape[-1]
         out = torch.empty(B, self.n_src, L, device=wav.device, dtype=torch.float32)
         ws = _lib.workspace(lib.rtfs_separator_workspace_bytes(B, L, Tv), wav.device)
         packs = [self.encoder.pack(), self.audio_bottleneck.pack(), rm.audio_net.get_block(0).pack(),
                  rm.crossmodal_fusion.get_fusion_block(0).audio_lstm.pack(), self.mask_generator.pack(), self.decoder.pack()]
         _lib.check(lib.rtfs_separator_forward_f32(_lib.ptr(wav), _lib.ptr(vp), *[_lib.ptr(p) for p in packs], _lib.ptr(out), B, L, Tv,
-                                                  int(self.audio_params["repeats"]), _lib.ptr(ws), ws.numel(), _lib.stream_of(wav)),
+                                                  int(self.audio_params["repeats"]), _lib.ptr(ws), ws.numel(), _lib.stream_of(wav),
+                                                  ctypes.c_void_p(ready.cuda_event)),
                    "rtfs_separator_forward_f32")
         return out
+
+    def _side_stream(self, device):
+        streams = self.__dict__.setdefault("_side_streams", {})
+        key = (device.type, device.index)
+        if key not in streams:
+            streams[key] = torch.cuda.Stream(device=device)
+        return streams[key]
 
     def forward_modular(self, audio_mixture, mouth_embedding=None):
         """Same result through the per-module entry points (the reference's own call sequence, tdavnet.py:86-97)."""
