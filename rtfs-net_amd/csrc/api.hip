@@ -94,7 +94,7 @@ struct BlockPack {
     DpPack dpF, dpT;
     AttnPack attn;
     TfarPack fus0, fus1, cat0;
-    const float *res_wt, *res_b, *proj_w16, *res_w16;
+    const float *res_wt, *res_b, *proj_w16, *res_w16, *proj_w16_perm;
     static BlockPack make(Cursor& c) {
         const float* gw = c.take(CA);
         const float* gb = c.take(CA);
@@ -115,7 +115,8 @@ struct BlockPack {
         const float* rb = c.take(CA);
         const float* p16 = c.take(CA * CH);
         const float* r16 = c.take(CH * CA);
-        return BlockPack{gw, gb, gs, pw, pb, d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7], f, t, at, f0, f1, c0, rw, rb, p16, r16};
+        const float* pp16 = c.take(CA * CH);
+        return BlockPack{gw, gb, gs, pw, pb, d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7], f, t, at, f0, f1, c0, rw, rb, p16, r16, pp16};
     }
 };
 struct CafPack {
@@ -311,14 +312,8 @@ struct BlockWs {
     double* st(int slot, int B) const { return stats ? stats + (size_t)slot * B * 2 : nullptr; }
 };
 
-int block_forward(const BlockPack& p, const float* x, const float* x_res, float* out, int B, int T, int F, BlockWs& w, hipStream_t st,
-                  const CafArgs* caf = nullptr) {
-    const int Tp = T / 2, Fp = F / 2;
-    const int P = T * F, Pg = Tp * Fp;
-    const double icF = 1.0 / ((double)CH * P), icG = 1.0 / ((double)CH * Pg);
-    typedef BlockWs W;
-    if (hipMemsetAsync(w.stats, 0, sizeof(double) * W::NSTAT * B * 2, st) != hipSuccess) return RTFS_ERR_LAUNCH;
-
+int block_head(const BlockPack& p, const float* x, const float* x_res, int B, int T, int F, BlockWs& w, hipStream_t st, const CafArgs* caf) {
+    const int P = T * F;
     {  // 1. gateway (dw 1x1 + PReLU) -> residual; projection 1x1 256->64 -> x_enc          tdanet.py:106-107
         PwArgs a;
         a.x = x;
@@ -339,6 +334,16 @@ int block_forward(const BlockPack& p, const float* x, const float* x_res, float*
         }
         CHECK(gemm_f32() ? launch_pw_gateway_proj(a, B, st) : launch_pws_gateway_proj(a, B, st));
     }
+    return RTFS_OK;
+}
+
+// steps 2-17: everything between the projection (x_enc, residual in the workspace) and `expanded`
+int block_body(const BlockPack& p, int B, int T, int F, BlockWs& w, hipStream_t st) {
+    const int Tp = T / 2, Fp = F / 2;
+    const int P = T * F, Pg = Tp * Fp;
+    const double icF = 1.0 / ((double)CH * P), icG = 1.0 / ((double)CH * Pg);
+    typedef BlockWs W;
+    if (hipMemsetAsync(w.stats, 0, sizeof(double) * W::NSTAT * B * 2, st) != hipSuccess) return RTFS_ERR_LAUNCH;
     {  // 2. downsample[0]: dw 4x4 s1 + bias -> c0 (pre-gLN) + stats                         tdanet.py:110
         DwArgs a;
         a.x = w.x_enc;
@@ -449,6 +454,11 @@ int block_forward(const BlockPack& p, const float* x, const float* x_res, float*
         a.out[0] = w.expanded;
         CHECK(launch_dw_s1(a, 1, false, 2, B, st));
     }
+    return RTFS_OK;
+}
+
+int block_tail(const BlockPack& p, float* out, int B, int T, int F, BlockWs& w, hipStream_t st) {
+    const int P = T * F;
     {  // 18. out = residual_conv(expanded) + residual                                        tdanet.py:129
         PwArgs a;
         a.x = w.expanded;
@@ -461,6 +471,36 @@ int block_forward(const BlockPack& p, const float* x, const float* x_res, float*
         CHECK(gemm_f32() ? launch_pw_residual(a, B, st) : launch_pws_residual(a, B, st));
     }
     return RTFS_OK;
+}
+
+int block_forward(const BlockPack& p, const float* x, const float* x_res, float* out, int B, int T, int F, BlockWs& w, hipStream_t st,
+                  const CafArgs* caf = nullptr) {
+    CHECK(block_head(p, x, x_res, B, T, F, w, st, caf));
+    CHECK(block_body(p, B, T, F, w, st));
+    return block_tail(p, out, B, T, F, w, st);
+}
+
+// block boundary of the fused separator: residual_conv(i) + [CAF] + a1 + gateway + projection(i+1) in one kernel
+int block_boundary(const BlockPack& p, const float* a1, int B, int T, int F, BlockWs& w, hipStream_t st, const CafArgs* caf) {
+    B2bArgs a;
+    a.x = w.expanded;
+    a.res = w.residual;
+    a.a1 = a1;
+    a.xenc = w.x_enc;
+    a.w1_16 = p.res_w16;
+    a.b1 = p.res_b;
+    a.w2_16 = p.proj_w16_perm;
+    a.bp = p.proj_b;
+    a.gw = p.gw;
+    a.gb = p.gb;
+    a.slope = p.gslope;
+    a.P = T * F;
+    if (caf) {
+        a.caf_r = caf->r_out; a.caf_att = caf->att_out;
+        a.caf_w_key = caf->w_key; a.caf_bn_key = caf->bn_key; a.caf_w_val = caf->w_val; a.caf_bn_val = caf->bn_val;
+        a.caf_T = caf->T; a.caf_F = caf->F; a.caf_Tv = caf->Tv;
+    }
+    return launch_pws_b2b(a, B, st);
 }
 
 int audio_bn(const BnPack& p, const float* x, const double* stats, float* out, int B, int P, hipStream_t st) {
@@ -804,23 +844,35 @@ int rtfs_separator_forward_f32(const float* wav, const float* video_vp, const fl
     CHECK(launch_enc_conv(w.spec, pe.w, w.a0, w.st0, B, CA, T, NF, (size_t)P, (size_t)CA * P, st));
     CHECK(audio_bn(pb, w.a0, w.st0, w.a1, B, P, st));
     // refinement_module.py:45-62: block(a1); CAF; then (repeats-1) x block(audio + a1), shared weights
-    CHECK(block_forward(pk, w.a1, nullptr, w.cur, B, T, NF, w.blk, st));
+    // refinement_module.py:45-62: block(a1); CAF; then (repeats-1) x block(audio + a1), shared weights.
     CafArgs ca = caf_args(pc, w.cur, video_vp, w.nxt, w.r, w.att, T, NF, Tv);
-    if (video_ready && hipStreamWaitEvent(st, (hipEvent_t)video_ready, 0) != hipSuccess) return RTFS_ERR_LAUNCH;
-    CHECK(launch_caf_video(ca, B, st));
-    // with repeats > 1 the CAF's audio side is applied inside the next block's gateway kernel (one pass less over A256)
-    const bool fuse_caf = repeats > 1 && !gemm_f32();
     float *cur = w.cur, *nxt = w.nxt;
-    if (!fuse_caf) {
+    if (gemm_f32() || repeats == 1) {  // unfused reference sequence (A/B path)
+        CHECK(block_forward(pk, w.a1, nullptr, w.cur, B, T, NF, w.blk, st));
+        if (video_ready && hipStreamWaitEvent(st, (hipEvent_t)video_ready, 0) != hipSuccess) return RTFS_ERR_LAUNCH;
+        CHECK(launch_caf_video(ca, B, st));
         CHECK(launch_caf_apply(ca, B, st));
         cur = w.nxt;
         nxt = w.cur;
-    }
-    for (int i = 1; i < repeats; ++i) {
-        CHECK(block_forward(pk, cur, w.a1, nxt, B, T, NF, w.blk, st, (i == 1 && fuse_caf) ? &ca : nullptr));
-        float* t = cur;
-        cur = nxt;
-        nxt = t;
+        for (int i = 1; i < repeats; ++i) {
+            CHECK(block_forward(pk, cur, w.a1, nxt, B, T, NF, w.blk, st));
+            float* t = cur;
+            cur = nxt;
+            nxt = t;
+        }
+    } else {
+        // block outputs between applications never reach HBM: the residual conv of block i, the CAF (after block 0),
+        // the "+ a1" and the gateway + projection of block i+1 run back to back in one kernel (block_boundary).
+        CHECK(block_head(pk, w.a1, nullptr, B, T, NF, w.blk, st, nullptr));
+        for (int i = 0; i < repeats; ++i) {
+            CHECK(block_body(pk, B, T, NF, w.blk, st));
+            if (i == 0) {
+                if (video_ready && hipStreamWaitEvent(st, (hipEvent_t)video_ready, 0) != hipSuccess) return RTFS_ERR_LAUNCH;
+                CHECK(launch_caf_video(ca, B, st));
+            }
+            if (i + 1 < repeats) CHECK(block_boundary(pk, w.a1, B, T, NF, w.blk, st, i == 0 ? &ca : nullptr));
+            else CHECK(block_tail(pk, cur, B, T, NF, w.blk, st));
+        }
     }
     CHECK(s3_mask(ps, cur, w.a0, nxt, B, P, st));
     return decoder(pd, nxt, out, w.z, B, T, L, st);

@@ -163,3 +163,180 @@ int launch_pws_gateway_proj(const PwArgs& a, int B, hipStream_t st) {
     return a.x2 ? launch_pws_t<256, 64, PRO_GATEWAY, EPI_BIAS, true>(a, B, st) : launch_pws_t<256, 64, PRO_GATEWAY, EPI_BIAS, false>(a, B, st);
 }
 int launch_pws_residual(const PwArgs& a, int B, hipStream_t st) { return launch_pws_t<64, 256, PRO_NONE, EPI_BIAS_RES, false>(a, B, st); }
+
+// ---------------------------------------------------------------- back-to-back block boundary
+// residual_conv of block i (64 -> 256, + residual_i) fused with the gateway + projection of block i+1
+// (input = out_i [CAF'ed after the first block] + a1; dw 1x1 + PReLU -> residual_{i+1}; 1x1 256 -> 64 -> x_enc_{i+1}):
+// out_i never goes to HBM.  Per wave (32 pixels): GEMM 1 leaves the 256 output channels of its pixels in 128
+// accumulator registers; the epilogue rewrites them in place as residual_{i+1}; converted to f16 hi/lo they are the B
+// operand of GEMM 2 *as they stand* -- registers 8s..8s+7 of co-tile m hold channels 32m+16s + (j&3) + 8(j>>2) + 4h,
+// so the projection weight image is stored with its K axis permuted to that order (packing.proj_perm).
+// Both weight matrices (141 KB of f16 hi/lo) stay resident in LDS; 8 waves per workgroup, no barriers in the loop.
+template <bool CAF>
+__device__ __forceinline__ void pws_b2b_body(const B2bArgs& a, int ntiles, int tiles_per_sample, const float* __restrict__ X,
+                                             float* __restrict__ RES, const float* __restrict__ A1, float* __restrict__ XENC) {
+    constexpr int L1 = 64 + 8, L2 = 256 + 8;
+    constexpr float WINV = 1.0f / 256.0f;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    _Float16* W1h = reinterpret_cast<_Float16*>(smem);  // [256][L1]
+    _Float16* W1l = W1h + 256 * L1;
+    _Float16* W2h = W1l + 256 * L1;                      // [64][L2], K permuted
+    _Float16* W2l = W2h + 64 * L2;
+    float* b1 = reinterpret_cast<float*>(W2l + 64 * L2);  // residual_conv bias (256)
+    float* gsc = b1 + 256;
+    float* gsh = gsc + 256;
+    float* cks = gsh + 256;
+    float* ckb = cks + (CAF ? 256 : 0);
+    float* cvs = ckb + (CAF ? 256 : 0);
+    float* cvb = cvs + (CAF ? 256 : 0);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    {
+        const half8* s1 = reinterpret_cast<const half8*>(a.w1_16);  // [2 chunks][hi|lo][256][32]
+        for (int i = tid; i < 2 * 2 * 256 * 4; i += 512) {
+            const int pc = i & 3, co = (i >> 2) & 255, part = (i >> 10) & 1, chunk = i >> 11;
+            *reinterpret_cast<half8*>((part ? W1l : W1h) + co * L1 + chunk * 32 + pc * 8) = s1[i];
+        }
+        const half8* s2 = reinterpret_cast<const half8*>(a.w2_16);  // [8 chunks][hi|lo][64][32]
+        for (int i = tid; i < 8 * 2 * 64 * 4; i += 512) {
+            const int pc = i & 3, co = (i >> 2) & 63, part = (i >> 8) & 1, chunk = i >> 9;
+            *reinterpret_cast<half8*>((part ? W2l : W2h) + co * L2 + chunk * 32 + pc * 8) = s2[i];
+        }
+        for (int c = tid; c < 256; c += 512) {
+            b1[c] = a.b1[c];
+            gsc[c] = a.gw[c];
+            gsh[c] = a.gb[c];
+            if (CAF) {
+                const float sk = a.caf_bn_key[c] / sqrtf(a.caf_bn_key[768 + c] + RTFS_EPS);
+                const float sv = a.caf_bn_val[c] / sqrtf(a.caf_bn_val[768 + c] + RTFS_EPS);
+                cks[c] = a.caf_w_key[c] * sk;
+                ckb[c] = a.caf_bn_key[256 + c] - a.caf_bn_key[512 + c] * sk;
+                cvs[c] = a.caf_w_val[c] * sv;
+                cvb[c] = a.caf_bn_val[256 + c] - a.caf_bn_val[512 + c] * sv;
+            }
+        }
+    }
+    const float slope = a.slope[0];
+    __syncthreads();
+    const int P = a.P;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int b = tile / tiles_per_sample;
+        const int p = (tile - b * tiles_per_sample) * 256 + wave * 32 + r;
+        const bool live = p < P;
+        const int pc_ = live ? p : P - 1;
+        unsigned cafb = 0;
+        if (CAF) cafb = (unsigned)(b * 256 * a.caf_Tv + nearest_src(pc_ / a.caf_F, a.caf_Tv, a.caf_T));
+        // ---- B fragments of GEMM 1 (expanded_i, 64 channels of this lane's pixel): loaded once per tile
+        half8 xh[4], xl[4];
+        {
+            // wave-uniform per-sample base + 32-bit lane offsets: one VGPR per address (saddr + voffset form)
+            const float* __restrict__ xs = X + (size_t)b * 64 * P;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = xs[(unsigned)((ks * 16 + 8 * h + j) * P + pc_)];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const _Float16 hi = (_Float16)v[j];
+                    xh[ks][j] = hi;
+                    xl[ks][j] = (_Float16)(v[j] - (float)hi);
+                }
+            }
+        }
+        f32x16 acc2[2];
+#pragma unroll
+        for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc2[m2][q] = 0.f;
+        float* __restrict__ ress = RES + (size_t)b * 256 * P;
+        const float* __restrict__ a1s = A1 + (size_t)b * 256 * P;
+        // ---- one output-channel tile of the residual conv at a time (a real loop: keeps one 16-register accumulator
+        //      and one 32-load group live): GEMM 1 tile -> epilogue 1 (-> residual_{i+1}) -> its two K steps of GEMM 2
+#pragma unroll 1
+        for (int m = 0; m < 8; ++m) {
+            const int cob = m * 32 + 4 * h;  // channel of accumulator register q: cob + (q&3) + 8*(q>>2)
+            float res[16], a1v[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const unsigned o = (unsigned)((cob + (q & 3) + 8 * (q >> 2)) * P + pc_);
+                res[q] = ress[o];
+                a1v[q] = a1s[o];
+            }
+            f32x16 acc1;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc1[q] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const half8 ah = *reinterpret_cast<const half8*>(W1h + (m * 32 + r) * L1 + ks * 16 + 8 * h);
+                const half8 al = *reinterpret_cast<const half8*>(W1l + (m * 32 + r) * L1 + ks * 16 + 8 * h);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xh[ks], acc1, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xl[ks], acc1, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, xh[ks], acc1, 0, 0, 0);
+            }
+            float rv[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int co = cob + (q & 3) + 8 * (q >> 2);
+                float y = fmaf(acc1[q], WINV, b1[co]) + res[q];  // out_i
+                if (CAF) {
+                    const unsigned ci = cafb + (unsigned)(co * a.caf_Tv);
+                    y = fmaf(fmaxf(fmaf(y, cks[co], ckb[co]), 0.f), a.caf_r[ci], a.caf_att[ci] * fmaf(y, cvs[co], cvb[co]));
+                }
+                y += a1v[q];
+                rv[q] = preluf_(fmaf(y, gsc[co], gsh[co]), slope);
+                if (live) ress[(unsigned)(co * P + pc_)] = rv[q];
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                half8 bh, bl;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const _Float16 hi = (_Float16)rv[8 * s + j];
+                    bh[j] = hi;
+                    bl[j] = (_Float16)(rv[8 * s + j] - (float)hi);
+                }
+                const int kk = (2 * m + s) * 16 + 8 * h;
+#pragma unroll
+                for (int m2 = 0; m2 < 2; ++m2) {
+                    const half8 ah = *reinterpret_cast<const half8*>(W2h + (m2 * 32 + r) * L2 + kk);
+                    const half8 al = *reinterpret_cast<const half8*>(W2l + (m2 * 32 + r) * L2 + kk);
+                    acc2[m2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc2[m2], 0, 0, 0);
+                    acc2[m2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc2[m2], 0, 0, 0);
+                    acc2[m2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc2[m2], 0, 0, 0);
+                }
+            }
+        }
+        if (live) {
+            float* __restrict__ xes = XENC + (size_t)b * 64 * P;
+#pragma unroll
+            for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int co = m2 * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+                    xes[(unsigned)(co * P + p)] = fmaf(acc2[m2][q], WINV, a.bp[co]);
+                }
+        }
+    }
+}
+
+template <bool CAF>
+__global__ __launch_bounds__(512) void pws_b2b_kernel(B2bArgs a, int ntiles, int tiles_per_sample) {
+    pws_b2b_body<CAF>(a, ntiles, tiles_per_sample, a.x, a.res, a.a1, a.xenc);
+}
+
+template <bool CAF>
+static int launch_b2b_t(const B2bArgs& a, int B, hipStream_t st) {
+    const size_t lds = (size_t)2 * 256 * 72 * 2 + (size_t)2 * 64 * 264 * 2 + (size_t)(CAF ? 7 : 3) * 256 * 4;
+    static bool configured = false;
+    if (!configured) {
+        if (hipFuncSetAttribute((const void*)pws_b2b_kernel<CAF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return RTFS_ERR_LAUNCH;
+        configured = true;
+    }
+    const int tps = cdiv(a.P, 256), ntiles = tps * B;
+    const int grid = ntiles < 256 ? ntiles : 256;  // one resident 8-wave workgroup per CU
+    hipLaunchKernelGGL((pws_b2b_kernel<CAF>), dim3(grid), dim3(512), lds, st, a, ntiles, tps);
+    return rtfs_launch_status();
+}
+
+int launch_pws_b2b(const B2bArgs& a, int B, hipStream_t st) { return a.caf_r ? launch_b2b_t<true>(a, B, st) : launch_b2b_t<false>(a, B, st); }

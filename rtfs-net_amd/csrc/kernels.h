@@ -44,6 +44,22 @@ int launch_pw16_gateway_proj(const PwArgs& a, int B, hipStream_t st);
 int launch_pw16_residual(const PwArgs& a, int B, hipStream_t st);
 int launch_pw16_s3(const PwArgs& a, int B, hipStream_t st);
 int launch_pw16_dec_taps(const PwArgs& a, int B, hipStream_t st);
+// block boundary: residual_conv(i) + gateway/projection(i+1) back to back (k_pws.hip)
+struct B2bArgs {
+    const float* x = nullptr;     // expanded_i (B,64,P)
+    float* res = nullptr;         // in: residual_i, out: residual_{i+1} (B,256,P), rewritten in place
+    const float* a1 = nullptr;    // bottleneck output (B,256,P), RefinementModule's residual
+    float* xenc = nullptr;        // x_enc_{i+1} (B,64,P)
+    const void* w1_16 = nullptr;  // residual_conv f16x3 image [2][hi|lo][256][32]
+    const float* b1 = nullptr;    // (256)
+    const void* w2_16 = nullptr;  // projection f16x3 image [8][hi|lo][64][32] with the K axis in accumulator order
+    const float* bp = nullptr;    // (64)
+    const float *gw = nullptr, *gb = nullptr, *slope = nullptr;
+    int P = 0;
+    const float *caf_r = nullptr, *caf_att = nullptr, *caf_w_key = nullptr, *caf_bn_key = nullptr, *caf_w_val = nullptr, *caf_bn_val = nullptr;
+    int caf_T = 0, caf_F = 0, caf_Tv = 0;
+};
+int launch_pws_b2b(const B2bArgs& a, int B, hipStream_t st);
 int launch_pws_gateway_proj(const PwArgs& a, int B, hipStream_t st);
 int launch_pws_residual(const PwArgs& a, int B, hipStream_t st);
 int launch_mfma_f16_selftest(const float* A, const float* B, float* D, hipStream_t st);

@@ -114,6 +114,18 @@ def pack_tfar(sd):
     return _cat(_tfar_parts(sd))
 
 
+def proj_perm():
+    """K order in which the back-to-back kernel feeds GEMM-1 accumulators to the projection GEMM: position
+    (2m+s)*16 + 8h + j holds channel 32m + 16s + (j&3) + 8(j>>2) + 4h  (m co-tile, s register octet, h lane half)."""
+    idx = []
+    for m in range(8):
+        for s_ in range(2):
+            for h in range(2):
+                for j in range(8):
+                    idx.append(32 * m + 16 * s_ + (j & 3) + 8 * (j >> 2) + 4 * h)
+    return idx
+
+
 def pack_block(sd):
     """TDANetBlock (2-D, depth 2) with globalatt = [DualPathRNN, DualPathRNN, MultiHeadSelfAttention2D]."""
     parts = [sd["gateway.full_layer.2.weight"].reshape(256), sd["gateway.full_layer.2.bias"], sd["gateway.full_layer.4.weight"].reshape(1),
@@ -128,7 +140,9 @@ def pack_block(sd):
     parts += _tfar_parts(_sub(sd, "fusion_layers.1"))
     parts += _tfar_parts(_sub(sd, "concat_layers.0"))
     parts += [sd["residual_conv.full_layer.2.weight"].reshape(256, 64).t(), sd["residual_conv.full_layer.2.bias"]]
-    parts += [split16_image(sd["projection.full_layer.2.weight"].reshape(64, 256)), split16_image(sd["residual_conv.full_layer.2.weight"].reshape(256, 64))]
+    wp = sd["projection.full_layer.2.weight"].reshape(64, 256)
+    parts += [split16_image(wp), split16_image(sd["residual_conv.full_layer.2.weight"].reshape(256, 64))]
+    parts += [split16_image(wp[:, torch.tensor(proj_perm(), device=wp.device)])]
     return _cat(parts)
 
 
