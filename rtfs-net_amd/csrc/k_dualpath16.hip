@@ -196,38 +196,72 @@ __global__ __launch_bounds__(512) void dp16_kernel(Dp16Args a) {
             }
         for (int q = 0; q < nchunk; ++q) {
             const bool last = q + 1 == nchunk;  // nchunk is even, so the next phase's chunk 0 lands in buffer 0
-            if (!last) stage_load(wimg + (size_t)(q + 1) * (2 * 256 * 4), R256);
-            else if (layer < 3) stage_load(a.w16_l + (size_t)layer * 2 * (2 * 256 * 4), R256);
-            else stage_load(a.w16_ct, R64);
+            // ONE unconditional load from a selected pointer: a load behind a branch is waited for at the join, which
+            // would serialise the prefetch in front of the MFMAs.  (The conv-transpose chunk only needs 2 of the 4 pieces.)
+            const half8* nextp = !last ? wimg + (size_t)(q + 1) * (2 * 256 * 4)
+                                       : (layer < 3 ? a.w16_l + (size_t)layer * 2 * (2 * 256 * 4) : a.w16_ct);
+            stage_load(nextp, R256);
             const int aoff = layer == 0 ? (q >> 1) * HLD + (q & 1) * 32 : q * 32;
             const _Float16* wb = Wst + ((q & 1) * 2) * 256 * WLD + (dir * 128 + r) * WLD + 8 * h;
+            // software-pipelined fragment reads: the LDS reads of gate tile (ks, m+1) are issued before the six MFMAs
+            // of (ks, m), so a wave never sits on an LDS round trip with the matrix pipe idle (sched_group_barrier pins
+            // the order: 2 DS reads, then 6 MFMAs)
+            {
+                half8 ah[2][2], al[2][2];  // [ks][tile]
 #pragma unroll
-            for (int ks = 0; ks < 32; ks += 16) {
-                half8 ah[2], al[2];
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    ah[t] = *reinterpret_cast<const half8*>(Hh + rowbase[t] + aoff + ks + 8 * h);
-                    al[t] = *reinterpret_cast<const half8*>(Hl + rowbase[t] + aoff + ks + 8 * h);
-                }
-#pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    const half8 bh = *reinterpret_cast<const half8*>(wb + m * 32 * WLD + ks);
-                    const half8 bl = *reinterpret_cast<const half8*>(wb + 256 * WLD + m * 32 * WLD + ks);
+                for (int k2 = 0; k2 < 2; ++k2)
 #pragma unroll
                     for (int t = 0; t < 2; ++t) {
-                        acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], bh, acc[t][m], 0, 0, 0);
-                        acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], bl, acc[t][m], 0, 0, 0);
-                        acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[t], bh, acc[t][m], 0, 0, 0);
+                        ah[k2][t] = *reinterpret_cast<const half8*>(Hh + rowbase[t] + aoff + 16 * k2 + 8 * h);
+                        al[k2][t] = *reinterpret_cast<const half8*>(Hl + rowbase[t] + aoff + 16 * k2 + 8 * h);
+                    }
+                half8 bh = *reinterpret_cast<const half8*>(wb);
+                half8 bl = *reinterpret_cast<const half8*>(wb + 256 * WLD);
+                __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);  // the 8 activation + 2 weight fragments above
+#pragma unroll
+                for (int step = 0; step < 8; ++step) {
+                    const int k2 = step >> 2, m = step & 3;
+                    half8 nh = bh, nl = bl;
+                    if (step < 7) {
+                        const int n2 = (step + 1) >> 2, nm = (step + 1) & 3;
+                        nh = *reinterpret_cast<const half8*>(wb + nm * 32 * WLD + 16 * n2);
+                        nl = *reinterpret_cast<const half8*>(wb + 256 * WLD + nm * 32 * WLD + 16 * n2);
+                    }
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[k2][t], bh, acc[t][m], 0, 0, 0);
+                        acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[k2][t], bl, acc[t][m], 0, 0, 0);
+                        acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[k2][t], bh, acc[t][m], 0, 0, 0);
+                    }
+                    if (step < 7) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // DS read x2 (next fragments) ...
+                    __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);                // ... in front of this step's 6 MFMAs
+                    bh = nh;
+                    bl = nl;
+                    if (step == 3) {
+                        // the next chunk (loaded into registers at the top of this iteration) goes to the other LDS buffer
+                        // under the second half of this chunk's MFMAs instead of after them
+                        if (!last || layer < 3) stage_write((q + 1) & 1, R256);
+                        else stage_write(0, R64);
+                        __builtin_amdgcn_sched_group_barrier(0x200, 4, 0);  // DS write x4
                     }
                 }
             }
-            if (!last || layer < 3) stage_write((q + 1) & 1, R256);
-            else stage_write(0, R64);
             __syncthreads();
         }
         stamp();  // 2,4,6,8: GEMM of layer done
         // every wave has finished reading the activation planes: the scan may overwrite them in place.
         // ---- recurrence on the accumulator registers (row of register q: (q&3) + 8*(q>>2) + 4*h)
+        if (PAIRED) {
+            // undo the 2^8 weight prescale on all 128 accumulators now, on every wave at once (independent work that
+            // packs into v_pk_mul_f32), so the serialised per-part recurrence below is the bare dependency chain
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) acc[t][m][q] *= WINV;
+            __builtin_amdgcn_sched_barrier(0);
+        }
         for (int hp = 0; hp < NHALF; ++hp) {
             if (part == hp) {
                 float c = 0.f;
@@ -238,15 +272,11 @@ __global__ __launch_bounds__(512) void dp16_kernel(Dp16Args a) {
                     for (int t = 0; t < 2; ++t)
 #pragma unroll
                         for (int q = 0; q < 16; ++q) {
-                            // everything that does not depend on c is computed off the recurrence chain
-                            const float u0 = acc[t][0][q] * WINV, p1 = acc[t][1][q] * WINV, p2 = acc[t][2][q] * WINV;
-                            const float xp = acc[t][3][q] * WINV;
-                            const float f = sig2(fmaf(vf, c, p1));
-                            const float g = sig2(fmaf(vr, c, p2));
+                            const float u0 = acc[t][0][q], xp = acc[t][3][q];
+                            const float f = sig2(fmaf(vf, c, acc[t][1][q]));
+                            const float g = sig2(fmaf(vr, c, acc[t][2][q]));
                             c = fmaf(c - u0, f, u0);
                             acc[t][0][q] = fmaf(c - xp, g, xp);
-                            // keep the scheduler from hoisting the (chain-independent) scalings of all 32 steps at once
-                            if ((q & 1) == 1) __builtin_amdgcn_sched_barrier(0);
                         }
                     if (NHALF > 1) chand[(seq * 2 + dir) * 32 + r] = c;
                 } else {
@@ -315,7 +345,7 @@ __global__ __launch_bounds__(512) void dp16_kernel(Dp16Args a) {
         // chunk 0 is already staged; the barrier that ended the layer-3 scan ordered the hidden outputs.
         // 8 chunks of 64 k' (one tap kk each): staged image [hi|lo][64 co][64 + 8 pad]
         for (int q = 0; q < 8; ++q) {
-            if (q + 1 < 8) stage_load(a.w16_ct + (size_t)(q + 1) * (2 * 64 * 8), R64);
+            stage_load(a.w16_ct + (size_t)(q + 1 < 8 ? q + 1 : 7) * (2 * 64 * 8), R64);  // unconditional (clamped)
             const _Float16* wb = Wst + (q & 1) * (2 * 64 * CLD) + (ccot * 32 + r) * CLD + 8 * h;
             int hrow[2];
 #pragma unroll
