@@ -158,7 +158,7 @@ def main():
             except Exception:
                 traffic = None
         res = {
-            "metric": "mixtures/sec forward (2 s@16 kHz, 2-spk) RTFS-Net-4",
+            "metric": f"mixtures/sec forward ({args.seconds:g} s@16 kHz, 2-spk) RTFS-Net-{args.repeats}",
             "value": round(throughput(world, B, args.steps, dt), 3),
             "unit": "mixtures/s",
             "n_gpus": world,

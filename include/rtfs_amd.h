@@ -36,7 +36,9 @@ enum rtfs_pack_kind {
     RTFS_PACK_TFAR = 5,
     RTFS_PACK_CAF = 6,
     RTFS_PACK_S3 = 7,
-    RTFS_PACK_DECODER = 8
+    RTFS_PACK_DECODER = 8,
+    RTFS_PACK_BLOCK_LSTM = 9,    /* RTFS block whose two DualPathRNN layers use rnn_type LSTM */
+    RTFS_PACK_DUALPATH_LSTM = 10
 };
 
 /* library / build identification: returns "rtfs_amd <version> gfx950" */
@@ -65,13 +67,18 @@ int rtfs_audio_bottleneck_f32(const float* x, const double* stats, const float* 
  * input is x + x_res (RefinementModule's residual, refinement_module.py:51,60). */
 size_t rtfs_block_workspace_bytes(int B, int T, int F);
 int rtfs_block_f32(const float* x, const float* x_res, const float* pack, float* out, int B, int T, int F, void* ws,
-                   size_t ws_bytes, void* stream);
+                   size_t ws_bytes, void* stream, int rnn_kind /* 0 = SRU pack, 1 = LSTM pack */);
 
 /* DualPathRNN.forward with rnn_type SRU, kernel 8, stride 1, 4 layers, bidirectional, hidden 32
  * (src/models/layers/rnn_layers.py:136-162).  x, out (B,64,T,F); dim = 4 sweeps along F, 3 along T. */
 size_t rtfs_dualpath_workspace_bytes(int B, int T, int F);
 int rtfs_dualpath_sru_f32(const float* x, const float* pack, float* out, int B, int T, int F, int dim, void* ws,
                           size_t ws_bytes, void* stream);
+
+/* The same module with rnn_type LSTM = nn.LSTM(512, 32, num_layers 4, bidirectional) (rnn_layers.py:116-122), the
+ * reference's stock-torch alternative cell; exact-f32 MFMA GEMMs + per-step recurrent term.  pack kind DUALPATH_LSTM. */
+int rtfs_dualpath_lstm_f32(const float* x, const float* pack, float* out, int B, int T, int F, int dim, void* ws,
+                           size_t ws_bytes, void* stream);
 
 /* MultiHeadSelfAttention2D.forward, 4 heads, hid_chan 4, dim 3 (src/models/layers/attention.py:149-189). x (B,64,T,64). */
 size_t rtfs_tf_attention_workspace_bytes(int B, int T);
@@ -116,7 +123,7 @@ size_t rtfs_separator_workspace_bytes(int B, int L, int Tv);
 int rtfs_separator_forward_f32(const float* wav, const float* video_vp, const float* pack_enc, const float* pack_bn,
                                const float* pack_block, const float* pack_caf, const float* pack_s3,
                                const float* pack_dec, float* out, int B, int L, int Tv, int repeats, void* ws,
-                               size_t ws_bytes, void* stream, void* video_ready);
+                               size_t ws_bytes, void* stream, void* video_ready, int rnn_kind /* 0 SRU, 1 LSTM block pack */);
 
 /* Operator-level seam: sru.SRU(input_size=512, hidden_size=32, num_layers=4, bidirectional=True).forward
  * (call site src/models/layers/rnn_layers.py:150; third-party asappresearch `sru`, v2 recurrence).

@@ -63,6 +63,11 @@ def make_param(name: str, shape, dtype: str, seed: int = 0) -> np.ndarray:
         return rs.uniform(0.1, 0.4, shape).astype(np.float32)
     if leaf == "weight_c":
         return rs.uniform(-1.0, 1.0, shape).astype(np.float32)
+    if "weight_hh_l" in leaf or "weight_ih_l" in leaf:  # nn.LSTM: (4*hidden, in)
+        a = math.sqrt(3.0 / shape[1])
+        return rs.uniform(-a, a, shape).astype(np.float32)
+    if "bias_ih_l" in leaf or "bias_hh_l" in leaf:
+        return rs.uniform(-0.3, 0.3, shape).astype(np.float32)
     if leaf in ("bias", "in_proj_bias"):
         lim = 0.5 if "rnn_lst" in name else 0.1
         return rs.uniform(-lim, lim, shape).astype(np.float32)

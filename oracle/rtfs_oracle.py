@@ -332,6 +332,34 @@ def sru_forward(x, layers):
     return h_in
 
 
+def lstm_forward(x, p: dict, num_layers=4, prefix="rnn."):
+    """Stacked bidirectional nn.LSTM (the reference's other DualPathRNN cell: rnn_layers.py:116-122 with
+    rnn_type LSTM; stock torch, so this function IS pinned by reference vectors).  x (L,N,Din) -> (L,N,2d).
+    Gate order in the weights: i, f, g, o;  c' = f*c + i*g;  h' = o*tanh(c')."""
+    L, N, _ = x.shape
+    h_in = x.astype(np.float64)
+    for layer in range(num_layers):
+        outs = []
+        for di, suf in enumerate(("", "_reverse")):
+            Wih = p[f"{prefix}weight_ih_l{layer}{suf}"].astype(np.float64)
+            Whh = p[f"{prefix}weight_hh_l{layer}{suf}"].astype(np.float64)
+            b = (p[f"{prefix}bias_ih_l{layer}{suf}"] + p[f"{prefix}bias_hh_l{layer}{suf}"]).astype(np.float64)
+            d = Whh.shape[1]
+            U = np.matmul(h_in.reshape(L * N, -1), Wih.T).reshape(L, N, 4 * d) + b
+            h = np.zeros((N, d))
+            c = np.zeros((N, d))
+            out = np.empty((L, N, d))
+            for t in (range(L) if di == 0 else range(L - 1, -1, -1)):
+                g = U[t] + h @ Whh.T
+                i_, f_, g_, o_ = g[:, :d], g[:, d:2 * d], g[:, 2 * d:3 * d], g[:, 3 * d:]
+                c = 1.0 / (1.0 + np.exp(-f_)) * c + 1.0 / (1.0 + np.exp(-i_)) * np.tanh(g_)
+                h = 1.0 / (1.0 + np.exp(-o_)) * np.tanh(c)
+                out[t] = h
+            outs.append(out)
+        h_in = np.concatenate(outs, -1)
+    return h_in.astype(f32)
+
+
 def _sru_layers(p: dict, prefix="rnn.rnn_lst"):
     out = []
     i = 0
@@ -360,7 +388,10 @@ def dualpath_rnn(x, p: dict, dim: int, kernel_size=8):
     # nn.Unfold((k,1)): feature index c*k + kk, value seq[:, c, l+kk]
     unf = np.stack([seq[:, :, kk:kk + Lr] for kk in range(kernel_size)], 2)  # N,C,k,L
     unf = unf.reshape(B * nF, C * kernel_size, Lr).transpose(2, 0, 1)  # L,N,C*k
-    h = sru_forward(np.ascontiguousarray(unf), _sru_layers(p))  # L,N,2d
+    if "rnn.weight_ih_l0" in p:  # rnn_type LSTM
+        h = lstm_forward(np.ascontiguousarray(unf), p)
+    else:
+        h = sru_forward(np.ascontiguousarray(unf), _sru_layers(p))  # L,N,2d
     hh = h.transpose(1, 2, 0)  # N,2d,L
     Wt = p["linear.weight"]  # (Cin=2d, Cout=C, k)
     y = np.zeros((B * nF, C, nT), np.float64)

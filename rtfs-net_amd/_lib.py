@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librtfs_amd.so")
 
-PACK_ENCODER, PACK_AUDIO_BN, PACK_BLOCK, PACK_DUALPATH, PACK_ATTENTION, PACK_TFAR, PACK_CAF, PACK_S3, PACK_DECODER = range(9)
+PACK_ENCODER, PACK_AUDIO_BN, PACK_BLOCK, PACK_DUALPATH, PACK_ATTENTION, PACK_TFAR, PACK_CAF, PACK_S3, PACK_DECODER, PACK_BLOCK_LSTM, PACK_DUALPATH_LSTM = range(11)
 
 _ERR = {-1: "bad shape", -2: "workspace too small", -3: "kernel launch failure", -4: "bad argument"}
 
@@ -28,9 +28,10 @@ SIGNATURES = {
     "rtfs_audio_bottleneck_workspace_bytes": (_z, [_i]),
     "rtfs_audio_bottleneck_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _z, _p]),
     "rtfs_block_workspace_bytes": (_z, [_i, _i, _i]),
-    "rtfs_block_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _z, _p]),
+    "rtfs_block_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _z, _p, _i]),
     "rtfs_dualpath_workspace_bytes": (_z, [_i, _i, _i]),
     "rtfs_dualpath_sru_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _z, _p]),
+    "rtfs_dualpath_lstm_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _z, _p]),
     "rtfs_tf_attention_workspace_bytes": (_z, [_i, _i]),
     "rtfs_tf_attention_f32": (_i, [_p, _p, _p, _i, _i, _p, _z, _p]),
     "rtfs_tfar_workspace_bytes": (_z, [_i, _i, _i, _i, _i]),
@@ -43,7 +44,7 @@ SIGNATURES = {
     "rtfs_istft_decoder_workspace_bytes": (_z, [_i, _i]),
     "rtfs_istft_decoder_f32": (_i, [_p, _p, _p, _i, _i, _i, _p, _z, _p]),
     "rtfs_separator_workspace_bytes": (_z, [_i, _i, _i]),
-    "rtfs_separator_forward_f32": (_i, [_p] * 9 + [_i, _i, _i, _i, _p, _z, _p, _p]),
+    "rtfs_separator_forward_f32": (_i, [_p] * 9 + [_i, _i, _i, _i, _p, _z, _p, _p, _i]),
     "rtfs_sru_workspace_bytes": (_z, [_i, _i]),
     "rtfs_sru_f32": (_i, [_p, _p, _p, _i, _i, _p, _z, _p]),
     "rtfs_debug_sweep_stamps": (_i, [_p, _p, _p, _i, _i, _i, _p, _p]),

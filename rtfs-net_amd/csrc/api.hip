@@ -41,11 +41,21 @@ struct BnPack {
     }
 };
 struct DpPack {
-    const float *ln_g, *ln_b, *W0, *Wl, *wc, *bias, *Wt, *bt;
-    const float *w16_l0, *w16_l, *w16_ct, *wc16, *bias16;  // f16x3 images (k_dualpath16.hip)
-    explicit DpPack(Cursor& c) {
+    const float *ln_g, *ln_b, *W0, *Wl, *wc = nullptr, *bias, *Wt, *bt;
+    const float *w16_l0 = nullptr, *w16_l = nullptr, *w16_ct = nullptr, *wc16 = nullptr, *bias16 = nullptr;  // f16x3 images (k_dualpath16.hip)
+    const float* whh = nullptr;  // LSTM cell only
+    explicit DpPack(Cursor& c, int rnn_kind = 0) {
         ln_g = c.take(CH);
         ln_b = c.take(CH);
+        if (rnn_kind == 1) {  // nn.LSTM(512, 32, 4 layers, bidirectional): order = packing._dualpath_lstm_parts
+            W0 = c.take(512 * 256);
+            Wl = c.take(3 * 64 * 256);
+            bias = c.take(4 * 256);
+            whh = c.take(4 * 2 * 32 * 128);
+            Wt = c.take(512 * 64);
+            bt = c.take(CH);
+            return;
+        }
         W0 = c.take(512 * 256);
         Wl = c.take(3 * 64 * 256);
         wc = c.take(4 * 128);
@@ -95,7 +105,7 @@ struct BlockPack {
     AttnPack attn;
     TfarPack fus0, fus1, cat0;
     const float *res_wt, *res_b, *proj_w16, *res_w16, *proj_w16_perm;
-    static BlockPack make(Cursor& c) {
+    static BlockPack make(Cursor& c, int rnn_kind = 0) {
         const float* gw = c.take(CA);
         const float* gb = c.take(CA);
         const float* gs = c.take(1);
@@ -108,7 +118,7 @@ struct BlockPack {
             d[4 * i + 2] = c.take(CH);
             d[4 * i + 3] = c.take(CH);
         }
-        DpPack f(c), t(c);
+        DpPack f(c, rnn_kind), t(c, rnn_kind);
         AttnPack at(c);
         TfarPack f0(c), f1(c), c0(c);
         const float* rw = c.take(CH * CA);
@@ -203,6 +213,7 @@ DpArgs dp_args(const DpPack& p, const float* x, float* out, int R, int Ls, size_
     a.bias = p.bias;
     a.Wt = p.Wt;
     a.bt = p.bt;
+    a.whh = p.whh;
     return a;
 }
 
@@ -232,12 +243,12 @@ int dualpath(const DpPack& p, const float* x, float* out, int B, int T, int F, i
     const size_t plane = (size_t)T * F;
     if (dim == 4) {
         RTFS_RETURN_IF(F < 8 || F > 250, RTFS_ERR_SHAPE);
-        if (!gemm_f32()) return launch_dualpath16(dp16_args(p, x, out, B * T, T, F, CH * plane, F, plane), st);
+        if (!gemm_f32() && !p.whh) return launch_dualpath16(dp16_args(p, x, out, B * T, T, F, CH * plane, F, plane), st);
         return launch_dualpath(dp_args(p, x, out, T, F, CH * plane, F, plane), B * T, st);
     }
     RTFS_RETURN_IF(T < 8 || T > 250, RTFS_ERR_SHAPE);
     CHECK(launch_transpose(x, tA, B * CH, T, F, st));
-    if (!gemm_f32()) {
+    if (!gemm_f32() && !p.whh) {
         CHECK(launch_dualpath16(dp16_args(p, tA, tB, B * F, F, T, CH * plane, T, plane), st));
     } else {
         CHECK(launch_dualpath(dp_args(p, tA, tB, F, T, CH * plane, T, plane), B * F, st));
@@ -581,6 +592,17 @@ size_t rtfs_pack_floats(int kind) {
             return c.off;
         }
         case RTFS_PACK_DUALPATH: return pack_size<DpPack>();
+        case RTFS_PACK_DUALPATH_LSTM: {
+            Cursor c(nullptr);
+            DpPack p(c, 1);
+            (void)p;
+            return c.off;
+        }
+        case RTFS_PACK_BLOCK_LSTM: {
+            Cursor c(nullptr);
+            BlockPack::make(c, 1);
+            return c.off;
+        }
         case RTFS_PACK_ATTENTION: return pack_size<AttnPack>();
         case RTFS_PACK_TFAR: return pack_size<TfarPack>();
         case RTFS_PACK_CAF: return pack_size<CafPack>();
@@ -631,19 +653,31 @@ size_t rtfs_block_workspace_bytes(int B, int T, int F) {
     return ar.off + 256;
 }
 
-int rtfs_block_f32(const float* x, const float* x_res, const float* pack, float* out, int B, int T, int F, void* ws, size_t ws_bytes, void* stream) {
+int rtfs_block_f32(const float* x, const float* x_res, const float* pack, float* out, int B, int T, int F, void* ws, size_t ws_bytes, void* stream, int rnn_kind) {
     RTFS_RETURN_IF(!x || !pack || !out, RTFS_ERR_ARG);
     RTFS_RETURN_IF(!shape_ok_block(B, T, F), RTFS_ERR_SHAPE);
     Arena ar(ws, ws_bytes);
     BlockWs w(ar, B, T, F);
     RTFS_RETURN_IF(!ws || !ar.ok(), RTFS_ERR_WORKSPACE);
+    RTFS_RETURN_IF(rnn_kind != 0 && rnn_kind != 1, RTFS_ERR_ARG);
     Cursor c(pack);
-    BlockPack p = BlockPack::make(c);
+    BlockPack p = BlockPack::make(c, rnn_kind);
     return block_forward(p, x, x_res, out, B, T, F, w, S(stream));
 }
 
 // ------------------------------------------------------------ dual path
 size_t rtfs_dualpath_workspace_bytes(int B, int T, int F) { return 2 * ((size_t)B * CH * T * F * sizeof(float) + 256); }
+
+int rtfs_dualpath_lstm_f32(const float* x, const float* pack, float* out, int B, int T, int F, int dim, void* ws, size_t ws_bytes, void* stream) {
+    RTFS_RETURN_IF(!x || !pack || !out || B < 1 || (dim != 3 && dim != 4), RTFS_ERR_ARG);
+    Arena ar(ws, ws_bytes);
+    float* tA = ar.take<float>((size_t)B * CH * T * F);
+    float* tB = ar.take<float>((size_t)B * CH * T * F);
+    RTFS_RETURN_IF(dim == 3 && (!ws || !ar.ok()), RTFS_ERR_WORKSPACE);
+    Cursor c(pack);
+    DpPack p(c, 1);
+    return dualpath(p, x, out, B, T, F, dim, tA, tB, S(stream));
+}
 
 int rtfs_dualpath_sru_f32(const float* x, const float* pack, float* out, int B, int T, int F, int dim, void* ws, size_t ws_bytes, void* stream) {
     RTFS_RETURN_IF(!x || !pack || !out || B < 1 || (dim != 3 && dim != 4), RTFS_ERR_ARG);
@@ -822,7 +856,7 @@ size_t rtfs_separator_workspace_bytes(int B, int L, int Tv) {
 
 int rtfs_separator_forward_f32(const float* wav, const float* video_vp, const float* pack_enc, const float* pack_bn, const float* pack_block,
                                const float* pack_caf, const float* pack_s3, const float* pack_dec, float* out, int B, int L, int Tv,
-                               int repeats, void* ws, size_t ws_bytes, void* stream, void* video_ready) {
+                               int repeats, void* ws, size_t ws_bytes, void* stream, void* video_ready, int rnn_kind) {
     RTFS_RETURN_IF(!wav || !video_vp || !pack_enc || !pack_bn || !pack_block || !pack_caf || !pack_s3 || !pack_dec || !out, RTFS_ERR_ARG);
     RTFS_RETURN_IF(B < 1 || L <= 128 || Tv < 1 || repeats < 1, RTFS_ERR_ARG);
     const int T = rtfs_num_frames(L);
@@ -834,7 +868,8 @@ int rtfs_separator_forward_f32(const float* wav, const float* video_vp, const fl
     Cursor ce(pack_enc), cb(pack_bn), ck(pack_block), cc(pack_caf), cs(pack_s3), cd(pack_dec);
     EncPack pe(ce);
     BnPack pb(cb);
-    BlockPack pk = BlockPack::make(ck);
+    RTFS_RETURN_IF(rnn_kind != 0 && rnn_kind != 1, RTFS_ERR_ARG);
+    BlockPack pk = BlockPack::make(ck, rnn_kind);
     CafPack pc(cc);
     S3Pack ps(cs);
     DecPack pd(cd);

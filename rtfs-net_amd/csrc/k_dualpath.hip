@@ -21,7 +21,10 @@
 
 // STANDALONE = the bare sru.SRU operator: x (L,N,512) -> h (L,N,64); no LayerNorm / unfold / ConvTranspose
 // (a.Ls carries L+7 so the buffer arithmetic is shared, a.R carries N).
-template <bool STANDALONE>
+// LSTM = the reference's other cell, nn.LSTM(512, 32, 4 layers, bidirectional) (rnn_layers.py:116-122): same GEMM skeleton
+// (U = x.W_ih^T, columns dir*128 + gate*32 + j, gates i,f,g,o), the scan adds the recurrent term W_hh.h_{t-1} per step
+// (the lane's 4 x 32 recurrent weights live in registers, h_{t-1} is broadcast through LDS).
+template <bool STANDALONE, bool LSTM = false>
 __global__ __launch_bounds__(256) void dualpath_sru_kernel(DpArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int Ls = a.Ls, L = Ls - DP_K + 1;
@@ -29,6 +32,7 @@ __global__ __launch_bounds__(256) void dualpath_sru_kernel(DpArgs a) {
     float* bufA = lds;
     float* bufB = lds + szA;
     float* U = bufB + szB;
+    float* hprev = U + 32 * 256;  // LSTM: h_{t-1} of both directions (64 floats)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = blockIdx.x;
@@ -62,8 +66,20 @@ __global__ __launch_bounds__(256) void dualpath_sru_kernel(DpArgs a) {
         const float* hin = (layer & 1) ? bufB : bufA;  // layer 0: the normalised row in bufA
         float* hout = (layer & 1) ? bufA : bufB;
         float cstate = 0.f;  // wave 0: c_{t-1} of (dir = lane>>5, j = lane&31)
-        const float vf = a.wc[layer * 128 + lane], vr = a.wc[layer * 128 + 64 + lane];
-        const float bf = a.bias[layer * 128 + lane], br = a.bias[layer * 128 + 64 + lane];
+        const float vf = LSTM ? 0.f : a.wc[layer * 128 + lane], vr = LSTM ? 0.f : a.wc[layer * 128 + 64 + lane];
+        const float bf = LSTM ? 0.f : a.bias[layer * 128 + lane], br = LSTM ? 0.f : a.bias[layer * 128 + 64 + lane];
+        float whh[LSTM ? 128 : 1], lb[4] = {0.f, 0.f, 0.f, 0.f};
+        if (LSTM && wave == 0) {
+            const int sd_ = lane >> 5, sj = lane & 31;
+            const float* wp = a.whh + (size_t)((layer * 2 + sd_) * 32) * 128 + sj;
+#pragma unroll
+            for (int k = 0; k < 32; ++k)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) whh[k * 4 + g] = wp[k * 128 + g * 32];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) lb[g] = a.bias[layer * 256 + sd_ * 128 + g * 32 + sj];
+            hprev[lane] = 0.f;
+        }
         for (int tile = 0; tile < nT; ++tile) {
             // -- GEMM: U[tau_local][col] for this wave's direction and 64 columns
             int tau = tile * 32 + (lane & 31);
@@ -105,7 +121,26 @@ __global__ __launch_bounds__(256) void dualpath_sru_kernel(DpArgs a) {
             if (wave == 0) {
                 const int sdir = lane >> 5;
                 const int steps = min(32, L - tile * 32);
-                for (int i = 0; i < steps; ++i) {
+                for (int i = 0; LSTM && i < steps; ++i) {
+                    const int t = tile * 32 + i;
+                    const int p = sdir ? (L - 1 - t) : t;
+                    float z[4];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) z[g] = U[i * 256 + sdir * 128 + g * 32 + (lane & 31)] + lb[g];
+#pragma unroll
+                    for (int k = 0; k < 32; ++k) {
+                        const float hk = hprev[sdir * 32 + k];
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) z[g] = fmaf(whh[k * 4 + g], hk, z[g]);
+                    }
+                    const float ig = 1.0f / (1.0f + expf(-z[0])), fg = 1.0f / (1.0f + expf(-z[1]));
+                    const float gg = tanhf(z[2]), og = 1.0f / (1.0f + expf(-z[3]));
+                    cstate = fmaf(fg, cstate, ig * gg);
+                    const float hv = og * tanhf(cstate);
+                    hprev[lane] = hv;  // same wave: program order + the compiler's lgkmcnt waits order this write before the next reads
+                    hout[p * DP_HS + lane] = hv;
+                }
+                for (int i = 0; !LSTM && i < steps; ++i) {
                     const int t = tile * 32 + i;
                     const int p = sdir ? (L - 1 - t) : t;
                     const f32x4 u = *reinterpret_cast<const f32x4*>(&U[i * 256 + lane * 4]);
@@ -214,7 +249,7 @@ void dualpath_timing_end(void* slot, hipStream_t st) {
 size_t dualpath_lds_bytes(int Ls) {
     const int L = Ls - DP_K + 1;
     const size_t szA = (DP_C * Ls + 3) & ~3, szB = (L * DP_HS + 3) & ~3;
-    return (szA + szB + 32 * 256) * sizeof(float);
+    return (szA + szB + 32 * 256 + 64) * sizeof(float);
 }
 
 int launch_dualpath(const DpArgs& a, int nseq, hipStream_t st) {
@@ -222,12 +257,22 @@ int launch_dualpath(const DpArgs& a, int nseq, hipStream_t st) {
     const size_t lds = dualpath_lds_bytes(a.Ls);
     static size_t configured = 0;
     if (lds > configured) {
-        if (hipFuncSetAttribute((const void*)dualpath_sru_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)dualpath_sru_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return RTFS_ERR_LAUNCH;
         configured = lds;
     }
     TimingSlot* slot = timing_begin(a.Ls, nseq, st);
-    hipLaunchKernelGGL(dualpath_sru_kernel<false>, dim3(nseq), dim3(256), lds, st, a);
+    if (a.whh) {
+        static size_t configured_l = 0;
+        if (lds > configured_l) {
+            if (hipFuncSetAttribute((const void*)dualpath_sru_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                return RTFS_ERR_LAUNCH;
+            configured_l = lds;
+        }
+        hipLaunchKernelGGL((dualpath_sru_kernel<false, true>), dim3(nseq), dim3(256), lds, st, a);
+    } else {
+        hipLaunchKernelGGL((dualpath_sru_kernel<false, false>), dim3(nseq), dim3(256), lds, st, a);
+    }
     if (slot) (void)hipEventRecord(slot->end, st);
     return rtfs_launch_status();
 }

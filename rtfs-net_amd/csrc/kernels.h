@@ -131,6 +131,8 @@ struct DpArgs {
     const float* bias = nullptr;      // 4 x (128)   [b_f | b_r]
     const float* Wt = nullptr;        // (512 = kk*64+ci, 64 co)  ConvTranspose1d weight, re-ordered
     const float* bt = nullptr;        // (64)
+    const float* whh = nullptr;       // LSTM cell: 4 x 2 x (32 k, 128 = gate*32 + j) recurrent weights; then W0/Wl columns are
+                                      // dir*128 + gate*32 + j (gates i,f,g,o) and bias is 4 x (256) = b_ih + b_hh
 };
 size_t dualpath_lds_bytes(int Ls);
 int launch_dualpath(const DpArgs& a, int nseq, hipStream_t st);

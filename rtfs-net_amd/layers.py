@@ -262,10 +262,10 @@ class DualPathRNN(PackedModule):
     def __init__(self, in_chan, hid_chan, dim, kernel_size=8, stride=1, rnn_type="LSTM", num_layers=1,
                  norm_type="LayerNormalization4D", act_type="Tanh", bidirectional=True, apply_ffn=False, *args, **kwargs):
         super().__init__()
-        if not (rnn_type == "SRU" and in_chan == 64 and hid_chan == 32 and kernel_size == 8 and stride == 1 and num_layers == 4
+        if not (rnn_type in ("SRU", "LSTM") and in_chan == 64 and hid_chan == 32 and kernel_size == 8 and stride == 1 and num_layers == 4
                 and bidirectional and norm_type == "LayerNormalization4D" and not apply_ffn and dim in (3, 4)):
             raise ValueError("MI355X DualPathRNN supports the RTFS-Net yaml configuration only "
-                             "(SRU, in 64, hid 32, kernel 8, stride 1, 4 layers, bidirectional, LN4D)")
+                             "(SRU or LSTM, in 64, hid 32, kernel 8, stride 1, 4 layers, bidirectional, LN4D)")
         self.in_chan, self.hid_chan, self.dim, self.kernel_size, self.stride = in_chan, hid_chan, dim, kernel_size, stride
         self.rnn_type, self.num_layers, self.norm_type, self.act_type = rnn_type, num_layers, norm_type, act_type
         self.bidirectional, self.apply_ffn = bidirectional, apply_ffn
@@ -273,7 +273,10 @@ class DualPathRNN(PackedModule):
         self.unfolded_chan = in_chan * kernel_size
         self.rnn_out_chan = hid_chan * 2
         self.norm = LayerNormalization4D((in_chan, 1))
-        self.rnn = SRU(self.unfolded_chan, hid_chan, num_layers=num_layers, bidirectional=True)
+        if rnn_type == "SRU":
+            self.rnn = SRU(self.unfolded_chan, hid_chan, num_layers=num_layers, bidirectional=True)
+        else:  # parameter holder with nn.LSTM's names (weight_ih_l0, weight_hh_l0_reverse, ...); the arithmetic is the HIP kernel's
+            self.rnn = nn.LSTM(input_size=self.unfolded_chan, hidden_size=hid_chan, num_layers=num_layers, bidirectional=True)
         self.linear = nn.ConvTranspose1d(self.rnn_out_chan, in_chan, kernel_size, stride=stride)
 
     def forward(self, x):
@@ -285,8 +288,9 @@ class DualPathRNN(PackedModule):
             raise ValueError(f"sweep axis shorter than kernel_size {self.kernel_size}")  # nn.Unfold raises in the reference
         out = torch.empty_like(x)
         ws = _lib.workspace(lib.rtfs_dualpath_workspace_bytes(B, T, Fq), x.device)
-        _lib.check(lib.rtfs_dualpath_sru_f32(_lib.ptr(x), _lib.ptr(self.pack()), _lib.ptr(out), B, T, Fq, self.dim, _lib.ptr(ws),
-                                             ws.numel(), _lib.stream_of(x)), "rtfs_dualpath_sru_f32")
+        fn = lib.rtfs_dualpath_sru_f32 if self.rnn_type == "SRU" else lib.rtfs_dualpath_lstm_f32
+        _lib.check(fn(_lib.ptr(x), _lib.ptr(self.pack()), _lib.ptr(out), B, T, Fq, self.dim, _lib.ptr(ws), ws.numel(), _lib.stream_of(x)),
+                   "rtfs_dualpath_%s_f32" % self.rnn_type.lower())
         return out
 
 

@@ -146,9 +146,12 @@ class TDANetBlock(PackedModule):
         if self._hip:
             kinds = [type(m).__name__ for m in self.globalatt]
             dims = [getattr(m, "dim", None) for m in self.globalatt]
+            cells = [getattr(m, "rnn_type", None) for m in self.globalatt][:2]
             if not (in_chan == 256 and hid_chan == 64 and kernel_size == 4 and stride == 2 and norm_type == "gLN" and act_type == "PReLU"
-                    and upsampling_depth == 2 and kinds == ["DualPathRNN", "DualPathRNN", "MultiHeadSelfAttention2D"] and dims == [4, 3, 3]):
-                raise ValueError("MI355X RTFS block supports the RTFS-Net yaml audio_params only")
+                    and upsampling_depth == 2 and kinds == ["DualPathRNN", "DualPathRNN", "MultiHeadSelfAttention2D"] and dims == [4, 3, 3]
+                    and cells in (["SRU", "SRU"], ["LSTM", "LSTM"])):
+                raise ValueError("MI355X RTFS block supports the RTFS-Net yaml audio_params only (both sweeps SRU, or both LSTM)")
+            self.rnn_kind = 1 if cells[0] == "LSTM" else 0
 
     def _vp_supported(self):
         kinds = [type(m).__name__ for m in self.globalatt]
@@ -192,7 +195,7 @@ class TDANetBlock(PackedModule):
         out = torch.empty_like(x)
         ws = _lib.workspace(lib.rtfs_block_workspace_bytes(B, T, Fq), x.device)
         _lib.check(lib.rtfs_block_f32(_lib.ptr(x), _lib.ptr(x_res), _lib.ptr(self.pack()), _lib.ptr(out), B, T, Fq, _lib.ptr(ws), ws.numel(),
-                                      _lib.stream_of(x)), "rtfs_block_f32")
+                                      _lib.stream_of(x), self.rnn_kind), "rtfs_block_f32")
         return out
 
     def _forward_1d(self, x):
@@ -448,7 +451,7 @@ class AVNet(BaseAVModel):
                  rm.crossmodal_fusion.get_fusion_block(0).audio_lstm.pack(), self.mask_generator.pack(), self.decoder.pack()]
         _lib.check(lib.rtfs_separator_forward_f32(_lib.ptr(wav), _lib.ptr(vp), *[_lib.ptr(p) for p in packs], _lib.ptr(out), B, L, Tv,
                                                   int(self.audio_params["repeats"]), _lib.ptr(ws), ws.numel(), _lib.stream_of(wav),
-                                                  ctypes.c_void_p(ready.cuda_event)),
+                                                  ctypes.c_void_p(ready.cuda_event), rm.audio_net.get_block(0).rnn_kind),
                    "rtfs_separator_forward_f32")
         return out
 

@@ -83,8 +83,25 @@ def _dualpath_parts(sd):
     return parts
 
 
+def _dualpath_lstm_parts(sd):
+    """DualPathRNN with rnn_type LSTM (nn.LSTM(512, 32, 4 layers, bidirectional)).  Columns of the input projections:
+    dir*128 + gate*32 + j (gates i,f,g,o); bias = b_ih + b_hh; recurrent weights as [layer][dir][k][gate*32 + j]."""
+    def wih(layer):  # (K, 256)
+        return torch.cat([sd[f"rnn.weight_ih_l{layer}{suf}"].t() for suf in ("", "_reverse")], 1)
+    parts = [sd["norm.gamma"].reshape(64), sd["norm.beta"].reshape(64), wih(0), torch.stack([wih(i) for i in (1, 2, 3)])]
+    parts.append(torch.stack([torch.cat([sd[f"rnn.bias_ih_l{i}{suf}"] + sd[f"rnn.bias_hh_l{i}{suf}"] for suf in ("", "_reverse")]) for i in range(4)]))
+    parts.append(torch.stack([torch.stack([sd[f"rnn.weight_hh_l{i}{suf}"].t() for suf in ("", "_reverse")]) for i in range(4)]))  # (4,2,32,128)
+    parts.append(sd["linear.weight"].permute(2, 0, 1).reshape(512, 64))
+    parts.append(sd["linear.bias"])
+    return parts
+
+
+def _is_lstm(sd):
+    return "rnn.weight_ih_l0" in sd
+
+
 def pack_dualpath(sd):
-    return _cat(_dualpath_parts(sd))
+    return _cat(_dualpath_lstm_parts(sd) if _is_lstm(sd) else _dualpath_parts(sd))
 
 
 def _attention_parts(sd):
@@ -133,8 +150,9 @@ def pack_block(sd):
     for i in (0, 1):
         p = f"downsample_layers.{i}.full_layer."
         parts += [sd[p + "2.weight"].reshape(64, 16), sd[p + "2.bias"], sd[p + "3.norm.weight"], sd[p + "3.norm.bias"]]
-    parts += _dualpath_parts(_sub(sd, "globalatt.0"))
-    parts += _dualpath_parts(_sub(sd, "globalatt.1"))
+    for g in ("globalatt.0", "globalatt.1"):
+        sub = _sub(sd, g)
+        parts += _dualpath_lstm_parts(sub) if _is_lstm(sub) else _dualpath_parts(sub)
     parts += _attention_parts(_sub(sd, "globalatt.2"))
     parts += _tfar_parts(_sub(sd, "fusion_layers.0"))
     parts += _tfar_parts(_sub(sd, "fusion_layers.1"))

@@ -245,6 +245,70 @@ def test_end_to_end_vs_golden(name, R, B, L, Tv, seed, fused):
     close(f"{name} fused={fused}", out, g["out"], tol)
 
 
+def test_end_to_end_4s_vs_oracle():
+    """BASELINE config 5 shape (4 s @16 kHz: T = 501, T' = 250, Tv = 100): exercises the unpaired 4 s sweep kernel,
+    250-key attention and the 100-frame VP block inside the fused separator.  No reference vector at this size
+    (the oracle is the checker), R = 2 keeps the CPU side short."""
+    m = model(4)
+    import copy, rtfs_net_amd as R
+    from tests.test_host import RTFS4_AUDIONET
+    c = copy.deepcopy(RTFS4_AUDIONET); c["audio_params"]["repeats"] = 2
+    m2 = R.AVNet(print_macs=False, **c)
+    m2.load_state_dict(m.state_dict())
+    m2 = m2.cuda().eval()
+    wav, emb = make_inputs(1, 64000, 100, 21)
+    out = host(m2(dev(wav), dev(emb)))
+    ref = O.avnet_forward(wav, emb, SD, repeats=2)
+    close("e2e 4 s R=2", out, ref)
+
+
+# ---------------- rnn_type LSTM: every number in these vectors is the reference's own arithmetic (stock nn.LSTM)
+_LSTM = {}
+
+
+def lstm_model():
+    import copy, json, os
+    import rtfs_net_amd as R
+    from tests.test_host import RTFS4_AUDIONET
+    from tests.util import GOLDEN
+    if "m" not in _LSTM:
+        c = copy.deepcopy(RTFS4_AUDIONET)
+        for k in ("layer_1", "layer_2"):
+            c["audio_params"]["layers"][k]["rnn_type"] = "LSTM"
+        sd = make_state_dict(json.load(open(os.path.join(GOLDEN, "state_spec_R4_lstm.json"))), 0)
+        m = R.AVNet(print_macs=False, **c)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        _LSTM["m"], _LSTM["sd"] = m.cuda().eval(), sd
+    return _LSTM["m"], _LSTM["sd"]
+
+
+@pytest.mark.parametrize("name,idx,dim", [("mod_dualpath_f_lstm", 0, 4), ("mod_dualpath_t_lstm", 1, 3)])
+def test_dualpath_lstm(name, idx, dim):
+    m, sd = lstm_model()
+    x = rand((2, 64, 12, 64), 103)
+    y = host(m.refinement_module.audio_net.blocks.globalatt[idx](dev(x)))
+    close(name, y, O.dualpath_rnn(x, O._sub(O._sub(sd, "refinement_module.audio_net.blocks"), f"globalatt.{idx}"), dim))
+    check_probe(load_golden(name), "out", y, TOL)
+
+
+def test_dualpath_lstm_full_rows():
+    m, sd = lstm_model()
+    for dim, shape in [(4, (1, 64, 125, 64)), (3, (1, 64, 125, 64))]:
+        x = rand(shape, 40 + dim)
+        idx = 0 if dim == 4 else 1
+        y = host(m.refinement_module.audio_net.blocks.globalatt[idx](dev(x)))
+        close(f"dualpath lstm dim{dim}", y, O.dualpath_rnn(x, O._sub(O._sub(sd, "refinement_module.audio_net.blocks"), f"globalatt.{idx}"), dim))
+
+
+@pytest.mark.parametrize("name,B,L,Tv,seed", [("e2e_lstm_R4_L4096_B2", 2, 4096, 7, 1), ("e2e_lstm_R4_L32000_B1", 1, 32000, 50, 2)])
+def test_end_to_end_lstm_vs_reference(name, B, L, Tv, seed):
+    m, _ = lstm_model()
+    g = load_golden(name)
+    wav, emb = make_inputs(B, L, Tv, seed)
+    out = host(m(dev(wav), dev(emb)))
+    close(name, out, g["out"])
+
+
 def test_input_rank_variants_match():
     m = model()
     wav, emb = make_inputs(1, 4096, 7, 9)

@@ -166,9 +166,25 @@ def test_unsupported_configs_fail_loudly():
     import copy
     import rtfs_net_amd as R
     c = copy.deepcopy(RTFS4_AUDIONET)
-    c["audio_params"]["layers"]["layer_1"]["rnn_type"] = "LSTM"
+    c["audio_params"]["layers"]["layer_1"]["rnn_type"] = "GRU"
     with pytest.raises(ValueError):
         R.AVNet(print_macs=False, **c)
+    c["audio_params"]["layers"]["layer_1"]["rnn_type"] = "LSTM"  # mixed cells are not on any yaml
+    with pytest.raises(ValueError):
+        R.AVNet(print_macs=False, **c)
+
+
+def test_lstm_variant_state_dict_matches_reference():
+    import copy
+    import rtfs_net_amd as R
+    from tests.util import GOLDEN
+    c = copy.deepcopy(RTFS4_AUDIONET)
+    for k in ("layer_1", "layer_2"):
+        c["audio_params"]["layers"][k]["rnn_type"] = "LSTM"
+    m = R.AVNet(print_macs=False, **c)
+    spec = json.load(open(os.path.join(GOLDEN, "state_spec_R4_lstm.json")))
+    assert [k for k, _, _ in spec] == list(m.state_dict().keys())
+    assert sum(p.numel() for p in m.parameters()) == 832112  # RTFS-Net-4 with rnn_type LSTM
 
 
 def test_no_cpu_fallback_and_no_training_mode():

@@ -104,3 +104,26 @@ def test_end_to_end_full_size_2s():
     out = O.avnet_forward(wav, emb, SD, repeats=4)
     e = rel_err(out, g["out"])
     assert e <= 1e-4, f"2 s end-to-end rel err {e:.3e}"
+
+
+# ---------------- rnn_type LSTM: the one configuration whose vectors are 100 % reference arithmetic (stock nn.LSTM)
+def _lstm_sd():
+    import json, os
+    from tests.util import GOLDEN
+    return make_state_dict(json.load(open(os.path.join(GOLDEN, "state_spec_R4_lstm.json"))), 0)
+
+
+@pytest.mark.parametrize("name,idx,dim", [("mod_dualpath_f_lstm", 0, 4), ("mod_dualpath_t_lstm", 1, 3)])
+def test_dualpath_lstm(name, idx, dim):
+    blk = O._sub(_lstm_sd(), "refinement_module.audio_net.blocks")
+    y = O.dualpath_rnn(rand((2, 64, 12, 64), 103), O._sub(blk, f"globalatt.{idx}"), dim)
+    check_probe(load_golden(name), "out", y, TOL)
+
+
+def test_end_to_end_lstm():
+    g = load_golden("e2e_lstm_R4_L4096_B2")
+    wav, emb = make_inputs(2, 4096, 7, 1)
+    out, ints = O.avnet_forward(wav, emb, _lstm_sd(), repeats=4, return_internals=True)
+    for k in ["a0", "a1", "refined", "sep"]:
+        check_probe(g, k, ints[k], 5 * TOL, "lstm.")
+    assert rel_err(out, g["out"]) <= 5 * TOL
