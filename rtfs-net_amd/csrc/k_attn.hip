@@ -9,129 +9,227 @@
 
 #define AF 64  // n_freqs: LayerNormalization4D gamma/beta are (1,C,1,64), so F' is tied to 64
 
-// X row (64 ch x 64 f) -> NOUT channels; wave w owns NOUT/4 consecutive output channels, lane = f.
+// X row (64 ch x 64 f) -> NOUT channels: D[o][f] = sum_c W[o][c] X[c][f] on the f16 matrix cores with the 3-term hi/lo
+// split (x = xh + xl, 256 w = wh + wl; same scheme and error as k_pw16.hip).  Wave w owns f-tile (w & 1) and output
+// tiles {w >> 1, (w >> 1) + 2}.  A workgroup sweeps RCAN_ROWS consecutive frames with the weight fragments and the
+// LayerNorm affine of its rows held in registers; the X fragments come straight from HBM (lane = f -> coalesced 128 B
+// segments) and the next row's X / residual loads are issued before the current row's GEMM + LayerNorm, so the
+// kernel (few waves per CU: register-heavy) never waits on a cold load.
+#define RCAN_ROWS 8
+#define RCAN_LD 72  // Ys row stride: D-layout writes (rows +4 on the upper half-wave) land in the other 32 banks
 template <int NOUT>
 __global__ __launch_bounds__(256) void row_can_kernel(RowCanArgs a) {
-    constexpr int PER = NOUT / 4;
-    __shared__ float Xs[64][AF];
-    __shared__ float Ys[NOUT][AF];
-    const int t = blockIdx.x, b = blockIdx.y, T = a.T;
-    const int tid = threadIdx.x, f = tid & 63;
+    constexpr int MT = NOUT / 32, MTW = (MT + 1) / 2;
+    constexpr int NR = NOUT / 4;  // LayerNorm rows per wave: 96 -> Q_w (4) + K_w (4) + V_w (16); 64 -> 16 of the one group
+    constexpr float WSC = 256.f, WINV = 1.f / 256.f;
+    __shared__ float Ys[NOUT][RCAN_LD];
+    __shared__ float bias_s[NOUT], slope_s[NOUT];
+    __shared__ float red[8];
+    const int T = a.T, b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    for (int idx = tid; idx < 64 * AF; idx += 256) {
-        const int c = idx >> 6, ff = idx & 63;
-        Xs[c][ff] = a.x[(((size_t)b * 64 + c) * T + t) * AF + ff];
+    const int nt = wave & 1, mp = wave >> 1;
+    for (int o = tid; o < NOUT; o += 256) {
+        bias_s[o] = a.bias[o] * WSC;
+        slope_s[o] = a.slope[NOUT == 96 ? a.group_of[o] : 0];
     }
+    half8 wh[MTW][4], wl[MTW][4];
+#pragma unroll
+    for (int m = 0; m < MTW; ++m) {
+        const int mt = min(mp + 2 * m, MT - 1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float w = a.wt[(ks * 16 + 8 * h + j) * NOUT + mt * 32 + r] * WSC;
+                const _Float16 hi = (_Float16)w;
+                wh[m][ks][j] = hi;
+                wl[m][ks][j] = (_Float16)(w - (float)hi);
+            }
+    }
+    // LayerNorm rows of this wave (lane = f) and their affine
+    auto ln_row = [&](int i) -> int {
+        if (NOUT == 64) return wave * 16 + i;
+        return i < 4 ? 4 * wave + i : i < 8 ? 16 + 4 * wave + (i - 4) : 32 + 16 * wave + (i - 8);
+    };
+    float gam[NR], bet[NR];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        gam[i] = a.gamma[ln_row(i) * AF + lane];
+        bet[i] = a.beta[ln_row(i) * AF + lane];
+    }
+    const int t0 = blockIdx.x * RCAN_ROWS;
+    const int nrows = min(RCAN_ROWS, T - t0);
+    const float* __restrict__ X = a.x + (size_t)b * 64 * T * AF + nt * 32 + r;
+    const float* __restrict__ RES = NOUT == 64 ? a.res + ((size_t)b * 64 + wave * 16) * T * AF + lane : nullptr;
+    float v[4][8];
+    float rs[NOUT == 64 ? 16 : 1];
+    auto load_x = [&](int t) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[ks][j] = X[((size_t)(ks * 16 + 8 * h + j) * T + t) * AF];
+    };
+    load_x(t0);
     __syncthreads();
-    float acc[PER];
+    for (int rr = 0; rr < nrows; ++rr) {
+        const int t = t0 + rr;
+        half8 bh[4], bl[4];
 #pragma unroll
-    for (int i = 0; i < PER; ++i) acc[i] = a.bias[wave * PER + i];
-    for (int c = 0; c < 64; ++c) {
-        const float xv = Xs[c][f];
-        const float* w = a.wt + c * NOUT + wave * PER;  // transposed weight (64, NOUT): wave-uniform -> scalar loads
+        for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-        for (int i = 0; i < PER; ++i) acc[i] = fmaf(w[i], xv, acc[i]);
-    }
+            for (int j = 0; j < 8; ++j) {
+                const _Float16 hi = (_Float16)v[ks][j];
+                bh[ks][j] = hi;
+                bl[ks][j] = (_Float16)(v[ks][j] - (float)hi);
+            }
+        if (NOUT == 64) {
 #pragma unroll
-    for (int i = 0; i < PER; ++i) {
-        const int o = wave * PER + i;
-        Ys[o][f] = preluf_(acc[i], a.slope[a.group_of[o]]);
-    }
-    __syncthreads();
-    // LayerNorm per group over (channels of the group, F)
-    for (int g = wave; g < a.ngroups; g += 4) {
-        const int o0 = a.group_start[g], gs = a.group_start[g + 1] - o0;
-        float s = 0.f;
-        for (int i = 0; i < gs; ++i) s += Ys[o0 + i][f];
-        const float mean = wave_sum(s) / (float)(gs * AF);
-        float v = 0.f;
-        for (int i = 0; i < gs; ++i) {
-            const float d = Ys[o0 + i][f] - mean;
-            v = fmaf(d, d, v);
+            for (int i = 0; i < 16; ++i) rs[i] = RES[((size_t)i * T + t) * AF];
         }
-        const float rstd = 1.0f / sqrtf(wave_sum(v) / (float)(gs * AF) + RTFS_EPS);
-        for (int i = 0; i < gs; ++i) {
-            const int o = o0 + i;
-            const float y = fmaf((Ys[o][f] - mean) * rstd, a.gamma[o * AF + f], a.beta[o * AF + f]);
-            if (NOUT == 96) {
-                // groups 0-3 Q_h, 4-7 K_h, 8-11 V_h
-                const int kind = g >> 2, h = g & 3;
-                if (kind < 2) {
-                    float* dst = kind == 0 ? a.q : a.k;
-                    dst[(((size_t)b * 4 + h) * T + t) * (4 * AF) + i * AF + f] = y;
-                } else {
-                    a.v[(((size_t)b * 4 + h) * T + t) * (16 * AF) + i * AF + f] = y;
+        load_x(min(t + 1, T - 1));  // prefetch; consumed next iteration
+#pragma unroll
+        for (int m = 0; m < MTW; ++m) {
+            const int mt = mp + 2 * m;
+            if (mt < MT) {  // wave-uniform
+                f32x16 acc;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[q] = bias_s[mt * 32 + (q & 3) + 8 * (q >> 2) + 4 * h];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[m][ks], bh[ks], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[m][ks], bl[ks], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[m][ks], bh[ks], acc, 0, 0, 0);
                 }
-            } else {
-                const size_t off = (((size_t)b * 64 + o) * T + t) * AF + f;
-                a.out[off] = y + a.res[off];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int o = mt * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+                    Ys[o][nt * 32 + r] = preluf_(acc[q] * WINV, slope_s[o]);
+                }
             }
         }
+        __syncthreads();
+        float y[NR];
+#pragma unroll
+        for (int i = 0; i < NR; ++i) y[i] = Ys[ln_row(i)][lane];
+        if (NOUT == 96) {
+            // LayerNorm over (channels of the group, F) for Q_w (rows 0-3), K_w (4-7), V_w (8-23); outputs head-major
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                const int i0 = g == 0 ? 0 : g == 1 ? 4 : 8, gs = g == 2 ? 16 : 4;
+                float s = 0.f;
+#pragma unroll
+                for (int i = 0; i < gs; ++i) s += y[i0 + i];
+                const float mean = wave_sum(s) / (float)(gs * AF);
+                float vv = 0.f;
+#pragma unroll
+                for (int i = 0; i < gs; ++i) {
+                    y[i0 + i] -= mean;
+                    vv = fmaf(y[i0 + i], y[i0 + i], vv);
+                }
+                const float rstd = 1.0f / sqrtf(wave_sum(vv) / (float)(gs * AF) + RTFS_EPS);
+                float* __restrict__ dst = (g == 0 ? a.q : g == 1 ? a.k : a.v) + (((size_t)b * 4 + wave) * T + t) * (gs * AF) + lane;
+#pragma unroll
+                for (int i = 0; i < gs; ++i) dst[i * AF] = fmaf(y[i0 + i] * rstd, gam[i0 + i], bet[i0 + i]);
+            }
+        } else {
+            // one LayerNorm group over all (64, F): 16 channels per wave, partial sums exchanged through LDS
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s += y[i];
+            s = wave_sum(s);
+            if (lane == 0) red[wave] = s;
+            __syncthreads();
+            const float mean = (red[0] + red[1] + red[2] + red[3]) / (float)(64 * AF);
+            float vv = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                y[i] -= mean;
+                vv = fmaf(y[i], y[i], vv);
+            }
+            vv = wave_sum(vv);
+            if (lane == 0) red[4 + wave] = vv;
+            __syncthreads();
+            const float rstd = 1.0f / sqrtf((red[4] + red[5] + red[6] + red[7]) / (float)(64 * AF) + RTFS_EPS);
+            float* __restrict__ O = a.out + ((size_t)b * 64 + wave * 16) * T * AF + lane;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) O[((size_t)i * T + t) * AF] = fmaf(y[i] * rstd, gam[i], bet[i]) + rs[i];
+        }
+        __syncthreads();  // Ys / red are rewritten by the next row
     }
 }
 
-// One workgroup per (query tile of 32, head, b).  E = 256 (Q/K row), D = 1024 (V row).
+// One workgroup per (query tile of 32, head, b).  E = 256 (Q/K row), D = 1024 (V row).  Both products run on the f16
+// matrix cores with the 3-term hi/lo split.  Q, K and V fragments are read straight from HBM/L2 in fragment order (Q/K
+// rows are k-contiguous: two 16 B loads per fragment; V columns are lane-contiguous), only the 32 x T score tile lives
+// in LDS (softmax rows, then the A operand of P V).
+#define ATT_PSC 4096.f  // P in [0,1] is scaled so its low half stays above the f16 flush threshold
+__device__ __forceinline__ void split8(const float (&v)[8], float sc, half8& hi, half8& lo) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float x = v[j] * sc;
+        const _Float16 t = (_Float16)x;
+        hi[j] = t;
+        lo[j] = (_Float16)(x - (float)t);
+    }
+}
 __global__ __launch_bounds__(256) void attn_core_kernel(AttnArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
+    extern __shared__ __attribute__((aligned(16))) float S[];  // [32][ldp]
     const int T = a.T;
-    const int NKT = (T + 31) >> 5;      // key tiles
+    const int NKT = (T + 31) >> 5;  // key tiles
     const int NK = NKT * 32;
-    const int ldp = NK + 1;
-    float* Qs = lds;                    // [32][65]
-    float* Ks = Qs + 32 * 65;           // [NK][65]
-    float* S = Ks + (size_t)NK * 65;    // [32][NK+1]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int q0 = blockIdx.x * 32, h = blockIdx.y, b = blockIdx.z;
-    const float* Q = a.q + ((size_t)b * 4 + h) * T * 256;
-    const float* K = a.k + ((size_t)b * 4 + h) * T * 256;
-    const float* V = a.v + ((size_t)b * 4 + h) * T * 1024;
+    const int ldp = NK + 4;         // 16 B aligned rows, ds_read_b128 conflict-free
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q0 = blockIdx.x * 32, hd = blockIdx.y, b = blockIdx.z;
+    const float* __restrict__ Q = a.q + ((size_t)b * 4 + hd) * T * 256;
+    const float* __restrict__ K = a.k + ((size_t)b * 4 + hd) * T * 256;
+    const float* __restrict__ V = a.v + ((size_t)b * 4 + hd) * T * 1024;
 
-    // ---- scores S = Q K^T / 16
-    f32x16 acc[2];
+    // ---- scores S = Q K^T / 16: wave w owns key tiles w and w + 4
+    {
+        f32x16 acc[2];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-    for (int kc = 0; kc < 256; kc += 64) {
-        __syncthreads();
-        for (int idx = tid; idx < 32 * 64; idx += 256) {
-            const int i = idx >> 6, k = idx & 63;
-            const int q = min(q0 + i, T - 1);
-            Qs[i * 65 + k] = Q[(size_t)q * 256 + kc + k];
-        }
-        for (int idx = tid; idx < NK * 64; idx += 256) {
-            const int j = idx >> 6, k = idx & 63;
-            const float kv = K[(size_t)min(j, T - 1) * 256 + kc + k];
-            Ks[j * 65 + k] = j < T ? kv : 0.f;
-        }
-        __syncthreads();
+            for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
+        const float* __restrict__ qp = Q + (size_t)min(q0 + r, T - 1) * 256 + 8 * h;
+        const float* __restrict__ kp0 = K + (size_t)min(wave * 32 + r, T - 1) * 256 + 8 * h;
+        const float* __restrict__ kp1 = K + (size_t)min((wave + 4) * 32 + r, T - 1) * 256 + 8 * h;
+        const bool two = wave + 4 < NKT;
 #pragma unroll 4
-        for (int k0 = 0; k0 < 64; k0 += 2) {
-            const int k = k0 + (lane >> 5);
-            const float av = Qs[(lane & 31) * 65 + k];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int kt = wave + 4 * j;
-                if (kt < NKT) {
-                    const float bv = Ks[(kt * 32 + (lane & 31)) * 65 + k];
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[j], 0, 0, 0);
-                }
+        for (int ks = 0; ks < 16; ++ks) {
+            float qv[8], k0[8], k1[8];
+            *reinterpret_cast<f32x4*>(qv) = *reinterpret_cast<const f32x4*>(qp + ks * 16);
+            *reinterpret_cast<f32x4*>(qv + 4) = *reinterpret_cast<const f32x4*>(qp + ks * 16 + 4);
+            *reinterpret_cast<f32x4*>(k0) = *reinterpret_cast<const f32x4*>(kp0 + ks * 16);
+            *reinterpret_cast<f32x4*>(k0 + 4) = *reinterpret_cast<const f32x4*>(kp0 + ks * 16 + 4);
+            *reinterpret_cast<f32x4*>(k1) = *reinterpret_cast<const f32x4*>(kp1 + ks * 16);
+            *reinterpret_cast<f32x4*>(k1 + 4) = *reinterpret_cast<const f32x4*>(kp1 + ks * 16 + 4);
+            half8 ah, al, bh, bl;
+            split8(qv, 1.f, ah, al);
+            split8(k0, 1.f, bh, bl);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[0], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[0], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[0], 0, 0, 0);
+            if (two) {  // wave-uniform
+                split8(k1, 1.f, bh, bl);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[1], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[1], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[1], 0, 0, 0);
             }
         }
-    }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int kt = wave + 4 * j;
-        if (kt < NKT) {
+        for (int j = 0; j < 2; ++j) {
+            const int kt = wave + 4 * j;
+            if (kt < NKT) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                S[row * ldp + kt * 32 + (lane & 31)] = acc[j][r] * a.scale;
+                for (int q = 0; q < 16; ++q) S[((q & 3) + 8 * (q >> 2) + 4 * h) * ldp + kt * 32 + r] = acc[j][q] * a.scale;
             }
         }
     }
     __syncthreads();
-    // ---- softmax over keys, 8 rows per wave
+    // ---- softmax over keys, 8 rows per wave; keys >= T get probability 0
     for (int rr = 0; rr < 8; ++rr) {
         float* row = S + (wave * 8 + rr) * ldp;
         float m = -3.0e38f;
@@ -153,25 +251,39 @@ __global__ __launch_bounds__(256) void attn_core_kernel(AttnArgs a) {
 #pragma unroll
         for (int n = 0; n < 4; ++n)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[n][r] = 0.f;
+            for (int q = 0; q < 16; ++q) o[n][q] = 0.f;
         const int nt0 = wave * 8 + grp * 4;
-        const int KP = (T + 1) & ~1;
-#pragma unroll 2
-        for (int k0 = 0; k0 < KP; k0 += 2) {
-            const int k = k0 + (lane >> 5);
-            const float av = S[(lane & 31) * ldp + k];  // 0 for k >= T
-            const float* vrow = V + (size_t)min(k, T - 1) * 1024 + nt0 * 32 + (lane & 31);
+        const float* __restrict__ vp = V + nt0 * 32 + r;
+        for (int ks = 0; ks < NK / 16; ++ks) {
+            float vv[4][8];
 #pragma unroll
-            for (int n = 0; n < 4; ++n) o[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, vrow[n * 32], o[n], 0, 0, 0);
+            for (int j = 0; j < 8; ++j) {
+                const size_t ro = (size_t)min(ks * 16 + 8 * h + j, T - 1) * 1024;  // P is 0 on the padded keys
+#pragma unroll
+                for (int n = 0; n < 4; ++n) vv[n][j] = vp[ro + n * 32];
+            }
+            float pv[8];
+            *reinterpret_cast<f32x4*>(pv) = *reinterpret_cast<const f32x4*>(S + r * ldp + ks * 16 + 8 * h);
+            *reinterpret_cast<f32x4*>(pv + 4) = *reinterpret_cast<const f32x4*>(S + r * ldp + ks * 16 + 8 * h + 4);
+            half8 ph, pl;
+            split8(pv, ATT_PSC, ph, pl);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                half8 vh, vl;
+                split8(vv[n], 1.f, vh, vl);
+                o[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vh, o[n], 0, 0, 0);
+                o[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vl, o[n], 0, 0, 0);
+                o[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pl, vh, o[n], 0, 0, 0);
+            }
         }
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
-            const int col = (nt0 + n) * 32 + (lane & 31);
+            const int col = (nt0 + n) * 32 + r;
             const int c = col >> 6, f = col & 63;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int q = q0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (q < T) a.out[(((size_t)b * 64 + h * 16 + c) * T + q) * AF + f] = o[n][r];
+            for (int q = 0; q < 16; ++q) {
+                const int qq = q0 + (q & 3) + 8 * (q >> 2) + 4 * h;
+                if (qq < T) a.out[(((size_t)b * 64 + hd * 16 + c) * T + qq) * AF + f] = o[n][q] * (1.f / ATT_PSC);
             }
         }
     }
@@ -179,15 +291,17 @@ __global__ __launch_bounds__(256) void attn_core_kernel(AttnArgs a) {
 
 size_t attn_core_lds_bytes(int T) {
     const int NK = ((T + 31) >> 5) * 32;
-    return ((size_t)32 * 65 + (size_t)NK * 65 + (size_t)32 * (NK + 1)) * sizeof(float);
+    return (size_t)32 * (NK + 4) * sizeof(float);
 }
 
 int launch_row_can_qkv(const RowCanArgs& a, int B, hipStream_t st) {
-    hipLaunchKernelGGL(row_can_kernel<96>, dim3(a.T, B), dim3(256), 0, st, a);
+    if (a.ngroups != 12 || a.group_start[8] != 32 || a.group_start[12] != 96) return RTFS_ERR_SHAPE;  // Q_h x4, K_h x4 (4 ch), V_h x4 (16 ch)
+    hipLaunchKernelGGL(row_can_kernel<96>, dim3(cdiv(a.T, RCAN_ROWS), B), dim3(256), 0, st, a);
     return rtfs_launch_status();
 }
 int launch_row_can_proj(const RowCanArgs& a, int B, hipStream_t st) {
-    hipLaunchKernelGGL(row_can_kernel<64>, dim3(a.T, B), dim3(256), 0, st, a);
+    if (a.ngroups != 1) return RTFS_ERR_SHAPE;
+    hipLaunchKernelGGL(row_can_kernel<64>, dim3(cdiv(a.T, RCAN_ROWS), B), dim3(256), 0, st, a);
     return rtfs_launch_status();
 }
 int launch_attn_core(const AttnArgs& a, int B, hipStream_t st) {

@@ -130,9 +130,11 @@ __global__ __launch_bounds__(256) void dw_s1_kernel(DwArgs a) {
 // the first / last row band; the input gLN fold is applied to the result: conv(pad0(s*x+b)) = s*conv(pad0(x)) + b*sum(valid w).
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-template <bool IN_AFFINE, int MODE>
+template <int NCONV, bool IN_AFFINE, int MODE>
 __device__ __forceinline__ void dw1p_body(const DwArgs& a, const float* __restrict__ X, const float* __restrict__ GATE,
-                                          const float* __restrict__ EMB, const float* __restrict__ ADD, float* __restrict__ OUT) {
+                                          const float* __restrict__ EMB, const float* __restrict__ ADD, float* __restrict__ OUT,
+                                          float* __restrict__ OUT1, float* __restrict__ OUT2, float* __restrict__ OUT3) {
+    static_assert(NCONV == 1 || (MODE == 0 && !IN_AFFINE), "multi-conv: plain write + stats only");
     __shared__ double red[8];
     const int H = a.H, W = a.W, C = a.C;
     const int half = (W + 1) >> 1;
@@ -147,7 +149,7 @@ __device__ __forceinline__ void dw1p_body(const DwArgs& a, const float* __restri
     float isc = 1.f, ish = 0.f;
     if (IN_AFFINE) gln_fold(a.in_stats + 2 * b, a.in_inv_count, a.in_gamma[c], a.in_beta[c], isc, ish);
     // per-lane weights with the column padding folded in; clamped column offsets
-    f32x2 wgt[16];
+    f32x2 wgt[NCONV][16];
     int ca[4], cb[4];
     f32x2 rowsum[4];
 #pragma unroll
@@ -159,13 +161,17 @@ __device__ __forceinline__ void dw1p_body(const DwArgs& a, const float* __restri
         ca[j] = xa < 0 ? 0 : (xa < W ? xa : W - 1);
         cb[j] = xb < 0 ? 0 : (xb < W ? xb : W - 1);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float w = a.w[0][c * 16 + i * 4 + j];
-            wgt[i * 4 + j] = f32x2{oka ? w : 0.f, okb ? w : 0.f};
-            rowsum[i] += wgt[i * 4 + j];
-        }
+        for (int n = 0; n < NCONV; ++n)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float w = a.w[n][c * 16 + i * 4 + j];
+                wgt[n][i * 4 + j] = f32x2{oka ? w : 0.f, okb ? w : 0.f};
+                if (n == 0) rowsum[i] += wgt[0][i * 4 + j];
+            }
     }
-    const float bias = a.bias[0] ? a.bias[0][c] : 0.f;
+    float bias[NCONV];
+#pragma unroll
+    for (int n = 0; n < NCONV; ++n) bias[n] = a.bias[n] ? a.bias[n][c] : 0.f;
     float lsc = 1.f, lsh = 0.f, gsc = 1.f, gsh = 0.f, esc = 1.f, esh = 0.f, asc = 1.f, ash = 0.f;
     size_t gplane = 0;
     int fga = 0, fgb = 0;
@@ -193,17 +199,43 @@ __device__ __forceinline__ void dw1p_body(const DwArgs& a, const float* __restri
     load_row(r0 - 1, win[0]);
     load_row(r0, win[1]);
     load_row(r0 + 1, win[2]);
-    f32x2 s2 = {0.f, 0.f}, ss2 = {0.f, 0.f};
+    f32x2 s2[NCONV], ss2[NCONV];
+#pragma unroll
+    for (int n = 0; n < NCONV; ++n) s2[n] = ss2[n] = f32x2{0.f, 0.f};
     const f32x2 wv_full = rowsum[0] + rowsum[1] + rowsum[2] + rowsum[3];
     const int fbc = fb < W ? fb : W - 1;
 #pragma unroll 2
     for (int t = r0; t < r1; ++t) {
         load_row(t + 2, win[3]);
+        const size_t oa = plane + (size_t)t * W + fa, ob = plane + (size_t)t * W + fbc;
+        if (NCONV > 1) {  // several convolutions of the same input (G-level TFAR embeddings / gates): write + stats
+            const f32x2 m = {live ? 1.f : 0.f, liveb ? 1.f : 0.f};
+#pragma unroll
+            for (int n = 0; n < NCONV; ++n) {
+                f32x2 acc = {0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc = win[i][j] * wgt[n][i * 4 + j] + acc;
+                acc += bias[n];
+                float* __restrict__ o_ = n == 0 ? OUT : n == 1 ? OUT1 : n == 2 ? OUT2 : OUT3;
+                if (live) o_[oa] = acc.x;
+                if (liveb) o_[ob] = acc.y;
+                const f32x2 am = acc * m;
+                s2[n] += am;
+                ss2[n] = am * am + ss2[n];
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) win[i][j] = win[i + 1][j];
+            continue;
+        }
         f32x2 acc = {0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc = win[i][j] * wgt[i * 4 + j] + acc;
+            for (int j = 0; j < 4; ++j) acc = win[i][j] * wgt[0][i * 4 + j] + acc;
         if (IN_AFFINE) {
             f32x2 wv = wv_full;
             if (border) {
@@ -213,8 +245,7 @@ __device__ __forceinline__ void dw1p_body(const DwArgs& a, const float* __restri
             }
             acc = acc * isc + wv * ish;
         }
-        acc += bias;
-        const size_t oa = plane + (size_t)t * W + fa, ob = plane + (size_t)t * W + fbc;
+        acc += bias[0];
         if (MODE == 0) {
             if (live) OUT[oa] = acc.x;
             if (liveb) OUT[ob] = acc.y;
@@ -222,8 +253,8 @@ __device__ __forceinline__ void dw1p_body(const DwArgs& a, const float* __restri
         if (MODE != 2) {
             const f32x2 m = {live ? 1.f : 0.f, liveb ? 1.f : 0.f};
             const f32x2 am = acc * m;
-            s2 += am;
-            ss2 = am * am + ss2;
+            s2[0] += am;
+            ss2[0] = am * am + ss2[0];
         } else {
             const int tg = nearest_src(t, a.Hg, H);
             const size_t ga = gplane + (size_t)tg * a.Wg + fga, gb = gplane + (size_t)tg * a.Wg + fgb;
@@ -239,12 +270,18 @@ __device__ __forceinline__ void dw1p_body(const DwArgs& a, const float* __restri
 #pragma unroll
             for (int j = 0; j < 4; ++j) win[i][j] = win[i + 1][j];
     }
-    if (MODE != 2) block_stats_atomic(s2.x + s2.y, ss2.x + ss2.y, red, a.stats_out[0] + 2 * b);
+    if (MODE != 2) {
+#pragma unroll
+        for (int n = 0; n < NCONV; ++n) {
+            block_stats_atomic(s2[n].x + s2[n].y, ss2[n].x + ss2[n].y, red, a.stats_out[n] + 2 * b);
+            __syncthreads();
+        }
+    }
 }
 
-template <bool IN_AFFINE, int MODE>
+template <int NCONV, bool IN_AFFINE, int MODE>
 __global__ __launch_bounds__(256) void dw1p_kernel(DwArgs a) {
-    dw1p_body<IN_AFFINE, MODE>(a, a.x, a.gate, a.emb, a.addend, a.out[0]);
+    dw1p_body<NCONV, IN_AFFINE, MODE>(a, a.x, a.gate, a.emb, a.addend, a.out[0], a.out[1], a.out[2], a.out[3]);
 }
 
 // ---------------------------------------------------------------- stride-2 pad-1 4x4 + adaptive average pool
@@ -387,18 +424,23 @@ static int launch_dw_s1_t(const DwArgs& a, int B, hipStream_t st) {
     return rtfs_launch_status();
 }
 
-template <bool IN_AFFINE, int MODE>
+template <int NCONV, bool IN_AFFINE, int MODE>
 static int launch_dw1p_t(const DwArgs& a, int B, hipStream_t st) {
     const int half = (a.W + 1) / 2;
-    hipLaunchKernelGGL((dw1p_kernel<IN_AFFINE, MODE>), dim3(cdiv(a.C * half, 256), cdiv(a.H, a.TH), B), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((dw1p_kernel<NCONV, IN_AFFINE, MODE>), dim3(cdiv(a.C * half, 256), cdiv(a.H, a.TH), B), dim3(256), 0, st, a);
     return rtfs_launch_status();
 }
 
 int launch_dw_s1(const DwArgs& a, int nconv, bool in_affine, int mode, int B, hipStream_t st) {
-    if (nconv == 1 && a.W >= 96) {  // full-resolution passes: packed two-column variant
-        if (mode == 0) return in_affine ? launch_dw1p_t<true, 0>(a, B, st) : launch_dw1p_t<false, 0>(a, B, st);
-        if (mode == 1) return in_affine ? launch_dw1p_t<true, 1>(a, B, st) : launch_dw1p_t<false, 1>(a, B, st);
-        if (mode == 2) return in_affine ? launch_dw1p_t<true, 2>(a, B, st) : launch_dw1p_t<false, 2>(a, B, st);
+    if (a.W >= 16) {  // packed two-column variant (v_pk_fma_f32); the scalar kernel below only serves very narrow inputs
+        if (nconv == 1) {
+            if (mode == 0) return in_affine ? launch_dw1p_t<1, true, 0>(a, B, st) : launch_dw1p_t<1, false, 0>(a, B, st);
+            if (mode == 1) return in_affine ? launch_dw1p_t<1, true, 1>(a, B, st) : launch_dw1p_t<1, false, 1>(a, B, st);
+            if (mode == 2) return in_affine ? launch_dw1p_t<1, true, 2>(a, B, st) : launch_dw1p_t<1, false, 2>(a, B, st);
+        } else if (mode == 0 && !in_affine) {
+            if (nconv == 2) return launch_dw1p_t<2, false, 0>(a, B, st);
+            if (nconv == 4) return launch_dw1p_t<4, false, 0>(a, B, st);
+        }
     }
     if (mode == 0 && nconv == 1 && !in_affine) return launch_dw_s1_t<1, false, 0>(a, B, st);
     if (mode == 0 && nconv == 1 && in_affine) return launch_dw_s1_t<1, true, 0>(a, B, st);
