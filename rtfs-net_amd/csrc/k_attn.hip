@@ -181,7 +181,13 @@ __global__ __launch_bounds__(256) void attn_core_kernel(AttnArgs a) {
     const int ldp = NK + 4;         // 16 B aligned rows, ds_read_b128 conflict-free
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int q0 = blockIdx.x * 32, hd = blockIdx.y, b = blockIdx.z;
+    // XCD-aware block order: workgroup L runs on XCD L % 8, so the query tiles that share one (b, head)'s K and V are
+    // given the same residue and hit the same L2 instead of pulling V across the fabric once per tile.
+    const int nqt = (T + 31) >> 5;
+    const int slot = blockIdx.x >> 3;
+    const int pair = (slot / nqt) * 8 + (blockIdx.x & 7);
+    if (pair >= a.npairs) return;  // uniform; before any barrier
+    const int q0 = (slot % nqt) * 32, hd = pair & 3, b = pair >> 2;
     const float* __restrict__ Q = a.q + ((size_t)b * 4 + hd) * T * 256;
     const float* __restrict__ K = a.k + ((size_t)b * 4 + hd) * T * 256;
     const float* __restrict__ V = a.v + ((size_t)b * 4 + hd) * T * 1024;
@@ -254,14 +260,16 @@ __global__ __launch_bounds__(256) void attn_core_kernel(AttnArgs a) {
             for (int q = 0; q < 16; ++q) o[n][q] = 0.f;
         const int nt0 = wave * 8 + grp * 4;
         const float* __restrict__ vp = V + nt0 * 32 + r;
-        for (int ks = 0; ks < NK / 16; ++ks) {
-            float vv[4][8];
+        float vv[2][4][8];
+        auto load_v = [&](int ks, float (&dst)[4][8]) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const size_t ro = (size_t)min(ks * 16 + 8 * h + j, T - 1) * 1024;  // P is 0 on the padded keys
 #pragma unroll
-                for (int n = 0; n < 4; ++n) vv[n][j] = vp[ro + n * 32];
+                for (int n = 0; n < 4; ++n) dst[n][j] = vp[ro + n * 32];
             }
+        };
+        auto step = [&](int ks, const float (&src)[4][8]) {
             float pv[8];
             *reinterpret_cast<f32x4*>(pv) = *reinterpret_cast<const f32x4*>(S + r * ldp + ks * 16 + 8 * h);
             *reinterpret_cast<f32x4*>(pv + 4) = *reinterpret_cast<const f32x4*>(S + r * ldp + ks * 16 + 8 * h + 4);
@@ -270,11 +278,19 @@ __global__ __launch_bounds__(256) void attn_core_kernel(AttnArgs a) {
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
                 half8 vh, vl;
-                split8(vv[n], 1.f, vh, vl);
+                split8(src[n], 1.f, vh, vl);
                 o[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vh, o[n], 0, 0, 0);
                 o[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vl, o[n], 0, 0, 0);
                 o[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pl, vh, o[n], 0, 0, 0);
             }
+        };
+        const int nks = NK / 16;  // even
+        load_v(0, vv[0]);
+        for (int ks = 0; ks < nks; ks += 2) {  // two key steps per trip, the next one's V loads always in flight
+            load_v(ks + 1, vv[1]);
+            step(ks, vv[0]);
+            load_v(min(ks + 2, nks - 1), vv[0]);
+            step(ks + 1, vv[1]);
         }
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
@@ -313,6 +329,8 @@ int launch_attn_core(const AttnArgs& a, int B, hipStream_t st) {
             return RTFS_ERR_LAUNCH;
         configured = lds;
     }
-    hipLaunchKernelGGL(attn_core_kernel, dim3(cdiv(a.T, 32), 4, B), dim3(256), lds, st, a);
+    AttnArgs a2 = a;
+    a2.npairs = B * 4;
+    hipLaunchKernelGGL(attn_core_kernel, dim3(cdiv(a2.npairs, 8) * 8 * cdiv(a.T, 32)), dim3(256), lds, st, a2);
     return rtfs_launch_status();
 }

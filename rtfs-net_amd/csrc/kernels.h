@@ -160,6 +160,7 @@ struct AttnArgs {
     float* out = nullptr;  // (B,64,T,64), channel = head*16 + c
     int T = 0;
     float scale = 0.f;
+    int npairs = 0;  // B * heads, set by the launcher
 };
 int launch_row_can_qkv(const RowCanArgs& a, int B, hipStream_t st);
 int launch_row_can_proj(const RowCanArgs& a, int B, hipStream_t st);
