@@ -69,7 +69,11 @@ __global__ __launch_bounds__(512) void dp16_kernel(Dp16Args a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    const int grp = wave / (2 * NHALF), dir = (wave / NHALF) & 1, part = wave % NHALF;  // grp = sequence or pair
+    // time part MAJOR: the waves that run one part of the serialised recurrence together (8 / NHALF of them) have
+    // consecutive ids and therefore sit on different SIMDs -- the recurrence is VALU-issue bound (4 transcendentals
+    // per step), two scanning waves on one SIMD with the neighbouring SIMD idle would double its time
+    constexpr int WPP = 8 / NHALF;
+    const int part = wave / WPP, grp = (wave % WPP) >> 1, dir = wave & 1;  // grp = sequence or pair
     const int seq = PAIRED ? grp * 2 + h : grp;  // the sequence this LANE's accumulator rows / A-operand rows belong to
     // conv-transpose roles (always one sequence per wave): sequence, co tile, 64-position part
     constexpr int CPART = 4 / NSEQ;
@@ -262,21 +266,25 @@ __global__ __launch_bounds__(512) void dp16_kernel(Dp16Args a) {
                     for (int q = 0; q < 16; ++q) acc[t][m][q] *= WINV;
             __builtin_amdgcn_sched_barrier(0);
         }
+        float cin = 0.f;
         for (int hp = 0; hp < NHALF; ++hp) {
             if (part == hp) {
                 float c = 0.f;
                 if (NHALF > 1 && hp > 0) c = chand[(seq * 2 + dir) * 32 + r];
                 if (PAIRED) {
-                    // register q of tile t = time step 16t + q of this lane's own sequence
+                    // register q of tile t = time step 16t + q of this lane's own sequence.  Only the cell-state chain
+                    // c_t = u0 + (c_{t-1} - u0) f(c_{t-1}) is serial; it overwrites u0 in place.  The reset gate and the
+                    // hidden output depend on c_{t-1}, c_t but nothing depends on them: they are evaluated after the
+                    // hand-off below, concurrently with the next time part's chain.
+                    cin = c;
 #pragma unroll
                     for (int t = 0; t < 2; ++t)
 #pragma unroll
                         for (int q = 0; q < 16; ++q) {
-                            const float u0 = acc[t][0][q], xp = acc[t][3][q];
+                            const float u0 = acc[t][0][q];
                             const float f = sig2(fmaf(vf, c, acc[t][1][q]));
-                            const float g = sig2(fmaf(vr, c, acc[t][2][q]));
                             c = fmaf(c - u0, f, u0);
-                            acc[t][0][q] = fmaf(c - xp, g, xp);
+                            acc[t][0][q] = c;
                         }
                     if (NHALF > 1) chand[(seq * 2 + dir) * 32 + r] = c;
                 } else {
@@ -319,8 +327,13 @@ __global__ __launch_bounds__(512) void dp16_kernel(Dp16Args a) {
 #pragma unroll
                         for (int q = 0; q < 16; ++q) {
                             const int idx = PAIRED ? 16 * t + q : 32 * t + (q & 3) + 8 * (q >> 2) + 4 * h;
+                            float hv = acc[t][0][q];
+                            if (PAIRED) {  // deferred reset gate + highway: h = x' + (c_t - x') r(c_{t-1})
+                                const float g = sig2(fmaf(vr, cin, acc[t][2][q])), xp = acc[t][3][q];
+                                cin = hv;
+                                hv = fmaf(hv - xp, g, xp);
+                            }
                             if (idx < nvalid) {
-                                const float hv = acc[t][0][q];
                                 const _Float16 hh = (_Float16)hv;
                                 const int o = o0 + idx * ostep;
                                 Hh[o] = hh;
