@@ -355,6 +355,16 @@ __global__ __launch_bounds__(512) void dp16_kernel(Dp16Args a) {
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
+        // the residual rows of the epilogue are requested now and arrive under the GEMM (clamped addresses: dead
+        // sequences / positions read a valid element that is never stored)
+        float res[2][16];
+        const size_t rbase = seq_base(cseq);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int p = min(64 * cpart + 32 * t + r, Ls - 1);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) res[t][q] = a.x[rbase + (size_t)(ccot * 32 + (q & 3) + 8 * (q >> 2) + 4 * h) * a.cstride + p];
+        }
         // chunk 0 is already staged; the barrier that ended the layer-3 scan ordered the hidden outputs.
         // 8 chunks of 64 k' (one tap kk each): staged image [hi|lo][64 co][64 + 8 pad]
         for (int q = 0; q < 8; ++q) {
@@ -390,13 +400,10 @@ __global__ __launch_bounds__(512) void dp16_kernel(Dp16Args a) {
             for (int t = 0; t < 2; ++t) {
                 const int p = 64 * cpart + 32 * t + r;
                 if (p < Ls) {
-                    float res[16];
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) res[q] = a.x[base + (size_t)(cot * 32 + (q & 3) + 8 * (q >> 2) + 4 * h) * a.cstride + p];
 #pragma unroll
                     for (int q = 0; q < 16; ++q) {
                         const int co = cot * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
-                        a.out[base + (size_t)co * a.cstride + p] = fmaf(acc[t][q], WINV, a.bt[co]) + res[q];
+                        a.out[base + (size_t)co * a.cstride + p] = fmaf(acc[t][q], WINV, a.bt[co]) + res[t][q];
                     }
                 }
             }
