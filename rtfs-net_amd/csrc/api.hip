@@ -526,7 +526,7 @@ int audio_bn(const BnPack& p, const float* x, const double* stats, float* out, i
     a.beta = p.beta;
     a.P = P;
     a.w16 = p.w16;
-    return gemm_f32() ? launch_pw_audio_bn(a, B, st) : launch_pw16_audio_bn(a, B, st);
+    return gemm_f32() ? launch_pw_audio_bn(a, B, st) : launch_pwr_audio_bn(a, B, st);
 }
 
 CafArgs caf_args(const CafPack& p, const float* audio, const float* video, float* out, float* r, float* att, int T, int F, int Tv) {
@@ -549,7 +549,7 @@ int s3_mask(const S3Pack& p, const float* refined, const float* a0, float* out, 
     a.slope = p.slope;
     a.P = P;
     a.w16 = p.w16;
-    return gemm_f32() ? launch_pw_s3(a, B, st) : launch_pw16_s3(a, B, st);
+    return gemm_f32() ? launch_pw_s3(a, B, st) : launch_pwr_s3(a, B, st);
 }
 
 int decoder(const DecPack& p, const float* x, float* wav, float* z, int B, int T, int L, hipStream_t st) {

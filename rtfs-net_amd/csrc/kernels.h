@@ -44,6 +44,9 @@ int launch_pw16_gateway_proj(const PwArgs& a, int B, hipStream_t st);
 int launch_pw16_residual(const PwArgs& a, int B, hipStream_t st);
 int launch_pw16_s3(const PwArgs& a, int B, hipStream_t st);
 int launch_pw16_dec_taps(const PwArgs& a, int B, hipStream_t st);
+// 256 -> 256 with register-resident pixels (k_pwr.hip)
+int launch_pwr_audio_bn(const PwArgs& a, int B, hipStream_t st);
+int launch_pwr_s3(const PwArgs& a, int B, hipStream_t st);
 // block boundary: residual_conv(i) + gateway/projection(i+1) back to back (k_pws.hip)
 struct B2bArgs {
     const float* x = nullptr;     // expanded_i (B,64,P)
