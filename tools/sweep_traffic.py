@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Turns two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs, counter_collection.csv each) into
+profiles/sweep_traffic.json: measured HBM bytes per launch of the fused dual-path sweep kernel.
+
+    rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_f -o f -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline
+    rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_w -o w -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline
+    python tools/sweep_traffic.py gpurun_out/pmc_f/f_counter_collection.csv gpurun_out/pmc_w/w_counter_collection.csv
+
+Correction (guides/MI355X_MICROARCH.md, HBM / rocprofv3 section): both counters are in KiB; on gfx950 FETCH_SIZE reports
+half of a coalesced read stream, so bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024.  The factor is re-checked on a kernel
+whose traffic is known exactly (caf_apply / pws_b2b: reads and writes whole tensors once) and printed beside the result.
+"""
+import csv
+import json
+import os
+import sys
+from collections import defaultdict
+
+
+def per_kernel(path, counter):
+    acc = defaultdict(list)
+    for row in csv.DictReader(open(path)):
+        if row["Counter_Name"] == counter:
+            acc[(row["Kernel_Name"], int(row["Grid_Size"]))].append(float(row["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in acc.items()}
+
+
+def main():
+    fpath, wpath = sys.argv[1], sys.argv[2]
+    B, repeats, seconds = (int(sys.argv[3]) if len(sys.argv) > 3 else 32), 4, 2.0
+    fetch, write = per_kernel(fpath, "FETCH_SIZE"), per_kernel(wpath, "WRITE_SIZE")
+    sweeps = sorted(k for k in fetch if k[0].startswith("void dp16_kernel") or k[0].startswith("dp16_kernel"))
+    out = {"what": "HBM bytes per launch of the fused dual-path sweep kernel (dp16_kernel), RTFS-Net-4, batch %d, 2 s: "
+                   "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, corrected as MI355X_MICROARCH.md "
+                   "prescribes: bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024" % B,
+           "batch": B, "repeats": repeats, "seconds": seconds, "paths": []}
+    tot = 0.0
+    for k in sweeps:
+        hbm = (2.0 * fetch[k] + write.get(k, 0.0)) * 1024.0
+        out["paths"].append({"kernel": k[0], "grid_threads": k[1], "fetch_kb": round(fetch[k], 1),
+                             "write_kb": round(write.get(k, 0.0), 1), "hbm_bytes": round(hbm)})
+        tot += hbm
+    out["hbm_bytes_per_launch"] = round(tot / max(len(sweeps), 1))
+    # calibration rows: kernels that read / write whole tensors exactly once
+    cal = []
+    for k in fetch:
+        if "pws_b2b_kernel<false>" in k[0] or "caf_apply" in k[0]:
+            row = {"kernel": k[0], "fetch_kb": round(fetch[k], 1), "write_kb": round(write.get(k, 0.0), 1)}
+            if "pws_b2b_kernel<false>" in k[0]:  # reads expanded (64 ch) + residual (256) + a1 (256), writes residual (256) + x_enc (64)
+                px = B * 251 * 129 * 4 / 1024.0
+                row.update(expected_read_kb=round(576 * px, 1), expected_write_kb=round(320 * px, 1),
+                           read_over_fetch=round(576 * px / fetch[k], 3))
+            cal.append(row)
+    out["calibration"] = cal
+    out["calibration_note"] = ("dword-per-lane streams (this code base) are outside the guide's calibrated 16 B/lane case: on the "
+                               "block-boundary kernel, whose traffic is known exactly, true read bytes / FETCH_SIZE = read_over_fetch "
+                               "(between 1 and the guide's 2), so hbm_bytes above is an upper bound")
+    dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "sweep_traffic.json")
+    json.dump(out, open(dst, "w"), indent=1)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
