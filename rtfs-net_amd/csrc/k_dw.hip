@@ -365,6 +365,128 @@ __device__ __forceinline__ void dw_s2_pool_body(const DwArgs& a, const float* __
 
 __global__ __launch_bounds__(256) void dw_s2_pool_kernel(DwArgs a) { dw_s2_pool_body(a, a.x, a.out[0], a.out[1]); }
 
+// Packed variant of the kernel above (used when Wo >= 16): a thread owns the two output columns (j, j + ceil(Wo/2)) of one
+// channel, so the 16-tap window lives in f32x2 registers and every multiply-add is a v_pk_fma_f32.  The convolution runs on
+// the RAW input (column padding folded into per-lane weight pairs, out-of-range rows zeroed by a uniform branch) and the
+// input fold is applied once per output: conv(isc x + ish) = isc conv(x) + ish * (sum of in-bounds weights) + bias; the
+// pool likewise as isc * mean(x) + ish with the column-masked row sums carried in the rolling window.  The pool window's
+// row range is kept as an incremental quotient / remainder (no per-row integer division on the scalar unit).
+__device__ __forceinline__ void dw_s2p_body(const DwArgs& a, const float* __restrict__ X, float* __restrict__ O0, float* __restrict__ O1) {
+    __shared__ double red[8];
+    const int H = a.H, W = a.W, C = a.C, Ho = a.Hg, Wo = a.Wg;
+    const int half = (Wo + 1) >> 1;
+    const int b = blockIdx.z;
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    const bool live = g < C * half;
+    const int c = live ? g / half : 0, ja = live ? g - c * half : 0;
+    const int jb = ja + half;
+    const bool liveb = live && jb < Wo;
+    const int jbc = liveb ? jb : ja;
+    const int i0 = blockIdx.y * a.TH, i1 = min(i0 + a.TH, Ho);
+    const float* __restrict__ xp = X + ((size_t)b * C + c) * H * W;
+    float isc, ish;
+    gln_fold(a.in_stats + 2 * b, a.in_inv_count, a.in_gamma[c], a.in_beta[c], isc, ish);
+    const float bia = a.bias[0][c];
+    const int fsa = (int)(((long long)ja * W) / Wo), fea = (int)(((long long)(ja + 1) * W + Wo - 1) / Wo);
+    const int fsb = (int)(((long long)jbc * W) / Wo), feb = (int)(((long long)(jbc + 1) * W + Wo - 1) / Wo);
+    int ca[4], cb[4];
+    f32x2 wgt[16], pm[4], wrow[4];
+#pragma unroll
+    for (int di = 0; di < 4; ++di) wrow[di] = f32x2{0.f, 0.f};
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const int fa = 2 * ja - 1 + d, fb = 2 * jbc - 1 + d;
+        const bool oka = fa >= 0 && fa < W, okb = fb >= 0 && fb < W;
+        ca[d] = fa < 0 ? 0 : (fa < W ? fa : W - 1);
+        cb[d] = fb < 0 ? 0 : (fb < W ? fb : W - 1);
+        pm[d] = f32x2{fa >= fsa && fa < fea ? 1.f : 0.f, fb >= fsb && fb < feb ? 1.f : 0.f};
+#pragma unroll
+        for (int di = 0; di < 4; ++di) {
+            const float w = a.w[0][c * 16 + di * 4 + d];
+            wgt[di * 4 + d] = f32x2{oka ? w : 0.f, okb ? w : 0.f};
+            wrow[di] += wgt[di * 4 + d];
+        }
+    }
+    const f32x2 wall = wrow[0] + wrow[1] + wrow[2] + wrow[3];
+    const f32x2 nf = {(float)(fea - fsa), (float)(feb - fsb)};
+    auto load_row = [&](int t, f32x2 (&row)[4], f32x2& rs) {
+        const float* __restrict__ rp = xp + (size_t)(t < 0 ? 0 : (t < H ? t : H - 1)) * W;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) row[d] = f32x2{rp[ca[d]], rp[cb[d]]};
+        if (t < 0 || t >= H) {  // uniform: only the first / last band row of the image
+#pragma unroll
+            for (int d = 0; d < 4; ++d) row[d] = f32x2{0.f, 0.f};
+        }
+        rs = row[0] * pm[0];
+#pragma unroll
+        for (int d = 1; d < 4; ++d) rs = row[d] * pm[d] + rs;
+    };
+    f32x2 win[4][4], rsw[4];
+    load_row(2 * i0 - 1, win[0], rsw[0]);
+    load_row(2 * i0, win[1], rsw[1]);
+    // pool rows of output i: [floor(i H / Ho), ceil((i+1) H / Ho)); (q, rem) = divmod(i H, Ho) kept incrementally
+    int q = (int)(((long long)i0 * H) / Ho), rem = (int)(((long long)i0 * H) % Ho);
+    f32x2 s2 = {0.f, 0.f}, ss2 = {0.f, 0.f};
+    const f32x2 m = {live ? 1.f : 0.f, liveb ? 1.f : 0.f};
+    const size_t oplane = ((size_t)b * C + c) * Ho * Wo;
+#pragma unroll 2
+    for (int i = i0; i < i1; ++i) {
+        load_row(2 * i + 1, win[2], rsw[2]);
+        load_row(2 * i + 2, win[3], rsw[3]);
+        const int ts = q;
+        rem += H;
+        while (rem >= Ho) {
+            rem -= Ho;
+            ++q;
+        }
+        const int te = q + (rem > 0 ? 1 : 0);
+        f32x2 acc = {0.f, 0.f};
+#pragma unroll
+        for (int di = 0; di < 4; ++di)
+#pragma unroll
+            for (int dj = 0; dj < 4; ++dj) acc = win[di][dj] * wgt[di * 4 + dj] + acc;
+        f32x2 bsum = wall;
+        if (2 * i - 1 < 0 || 2 * i + 2 >= H) {  // uniform: band touches the top / bottom padding
+            bsum = f32x2{0.f, 0.f};
+#pragma unroll
+            for (int di = 0; di < 4; ++di) {
+                const int t = 2 * i - 1 + di;
+                if (t >= 0 && t < H) bsum += wrow[di];
+            }
+        }
+        acc = acc * isc + (bsum * ish + bia);
+        f32x2 ps = {0.f, 0.f};
+#pragma unroll
+        for (int di = 0; di < 4; ++di) {
+            const int t = 2 * i - 1 + di;
+            if (t >= ts && t < te) ps += rsw[di];  // uniform
+        }
+        const f32x2 cnt = nf * (float)(te - ts);
+        const f32x2 pool = f32x2{ps.x / cnt.x, ps.y / cnt.y} * isc + ish;
+        const size_t oa = oplane + (size_t)i * Wo + ja, ob = oplane + (size_t)i * Wo + jbc;
+        if (live) {
+            O0[oa] = acc.x;
+            O1[oa] = pool.x;
+        }
+        if (liveb) {
+            O0[ob] = acc.y;
+            O1[ob] = pool.y;
+        }
+        const f32x2 am = acc * m;
+        s2 += am;
+        ss2 = am * am + ss2;
+#pragma unroll
+        for (int dj = 0; dj < 4; ++dj) {
+            win[0][dj] = win[2][dj];
+            win[1][dj] = win[3][dj];
+        }
+        rsw[0] = rsw[2];
+        rsw[1] = rsw[3];
+    }
+    block_stats_atomic(s2.x + s2.y, ss2.x + ss2.y, red, a.stats_out[0] + 2 * b);
+}
+__global__ __launch_bounds__(256) void dw_s2p_kernel(DwArgs a) { dw_s2p_body(a, a.x, a.out[0], a.out[1]); }
+
 // ---------------------------------------------------------------- G-level elementwise glue
 // g = p0 + gLN(c1)           (global pooling sum, tdanet.py:116)
 __global__ __launch_bounds__(256) void g_form_kernel(const float* __restrict__ p0, const float* __restrict__ c1,
@@ -439,7 +561,14 @@ int launch_dw_s1(const DwArgs& a, int nconv, bool in_affine, int mode, int B, hi
             if (mode == 2) return in_affine ? launch_dw1p_t<1, true, 2>(a, B, st) : launch_dw1p_t<1, false, 2>(a, B, st);
         } else if (mode == 0 && !in_affine) {
             if (nconv == 2) return launch_dw1p_t<2, false, 0>(a, B, st);
-            if (nconv == 4) return launch_dw1p_t<4, false, 0>(a, B, st);
+            if (nconv == 4) {  // two 2-conv launches: the 4-conv kernel needs 256 VGPRs and runs slower than both together
+                DwArgs b = a;
+                for (int i = 0; i < 2; ++i) {
+                    b.w[i] = a.w[2 + i]; b.bias[i] = a.bias[2 + i]; b.out[i] = a.out[2 + i]; b.stats_out[i] = a.stats_out[2 + i];
+                }
+                const int rc = launch_dw1p_t<2, false, 0>(a, B, st);
+                return rc ? rc : launch_dw1p_t<2, false, 0>(b, B, st);
+            }
         }
     }
     if (mode == 0 && nconv == 1 && !in_affine) return launch_dw_s1_t<1, false, 0>(a, B, st);
@@ -455,6 +584,10 @@ int launch_dw_s1(const DwArgs& a, int nconv, bool in_affine, int mode, int B, hi
 }
 
 int launch_dw_s2_pool(const DwArgs& a, int B, hipStream_t st) {
+    if (a.Wg >= 16) {
+        hipLaunchKernelGGL(dw_s2p_kernel, dim3(cdiv(a.C * ((a.Wg + 1) / 2), 256), cdiv(a.Hg, a.TH), B), dim3(256), 0, st, a);
+        return rtfs_launch_status();
+    }
     hipLaunchKernelGGL(dw_s2_pool_kernel, dim3(cdiv(a.C * a.Wg, 256), cdiv(a.Hg, a.TH), B), dim3(256), 0, st, a);
     return rtfs_launch_status();
 }
