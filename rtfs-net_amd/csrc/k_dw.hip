@@ -204,6 +204,13 @@ __device__ __forceinline__ void dw1p_body(const DwArgs& a, const float* __restri
     for (int n = 0; n < NCONV; ++n) s2[n] = ss2[n] = f32x2{0.f, 0.f};
     const f32x2 wv_full = rowsum[0] + rowsum[1] + rowsum[2] + rowsum[3];
     const int fbc = fb < W ? fb : W - 1;
+    // MODE 2: low-resolution source row floor(t Hg / H) as an incremental quotient / remainder (a 64-bit division per row
+    // on the scalar unit costs more than the row's vector work)
+    int tgq = 0, tgr = 0;
+    if (MODE == 2) {
+        tgq = (int)(((long long)r0 * a.Hg) / H);
+        tgr = (int)(((long long)r0 * a.Hg) % H);
+    }
 #pragma unroll 2
     for (int t = r0; t < r1; ++t) {
         load_row(t + 2, win[3]);
@@ -256,7 +263,12 @@ __device__ __forceinline__ void dw1p_body(const DwArgs& a, const float* __restri
             s2[0] += am;
             ss2[0] = am * am + ss2[0];
         } else {
-            const int tg = nearest_src(t, a.Hg, H);
+            const int tg = tgq < a.Hg - 1 ? tgq : a.Hg - 1;
+            tgr += a.Hg;
+            while (tgr >= H) {  // one step when Hg <= H
+                tgr -= H;
+                ++tgq;
+            }
             const size_t ga = gplane + (size_t)tg * a.Wg + fga, gb = gplane + (size_t)tg * a.Wg + fgb;
             const f32x2 gate = {sigmoidf_(fmaf(GATE[ga], gsc, gsh)), sigmoidf_(fmaf(GATE[gb], gsc, gsh))};
             const f32x2 emb = {fmaf(EMB[ga], esc, esh), fmaf(EMB[gb], esc, esh)};
