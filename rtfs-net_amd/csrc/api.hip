@@ -362,7 +362,7 @@ int block_body(const BlockPack& p, int B, int T, int F, BlockWs& w, hipStream_t 
         a.bias[0] = p.ds0_b;
         a.out[0] = w.c0;
         a.stats_out[0] = w.st(W::S_C0, B);
-        a.C = CH; a.H = T; a.W = F; a.TH = 32;
+        a.C = CH; a.H = T; a.W = F; a.TH = 64;
         CHECK(launch_dw_s1(a, 1, false, 0, B, st));
     }
     {  // 3. downsample[1] on d0 = gLN(c0): dw 4x4 s2 -> c1 + stats; p0 = adaptive_avg_pool2d(d0)   tdanet.py:111-116
@@ -374,7 +374,7 @@ int block_body(const BlockPack& p, int B, int T, int F, BlockWs& w, hipStream_t 
         a.out[0] = w.c1;
         a.out[1] = w.p0;
         a.stats_out[0] = w.st(W::S_C1, B);
-        a.C = CH; a.H = T; a.W = F; a.Hg = Tp; a.Wg = Fp; a.TH = 32;
+        a.C = CH; a.H = T; a.W = F; a.Hg = Tp; a.Wg = Fp; a.TH = 64;
         CHECK(launch_dw_s2_pool(a, B, st));
     }
     // 4. g = pool(d0) + d1
@@ -391,7 +391,7 @@ int block_body(const BlockPack& p, int B, int T, int F, BlockWs& w, hipStream_t 
         a.out[0] = w.E0; a.out[1] = w.G0; a.out[2] = w.E1; a.out[3] = w.G1;
         a.stats_out[0] = w.st(W::S_E0, B); a.stats_out[1] = w.st(W::S_G0, B);
         a.stats_out[2] = w.st(W::S_E1, B); a.stats_out[3] = w.st(W::S_G1, B);
-        a.C = CH; a.H = Tp; a.W = Fp; a.TH = 32;
+        a.C = CH; a.H = Tp; a.W = Fp; a.TH = 64;
         CHECK(launch_dw_s1(a, 4, false, 0, B, st));
     }
     {  // 11. fusion 1 local_embedding on d1 = gLN(c1)
@@ -401,7 +401,7 @@ int block_body(const BlockPack& p, int B, int T, int F, BlockWs& w, hipStream_t 
         a.w[0] = p.fus1.loc_w;
         a.out[0] = w.L1;
         a.stats_out[0] = w.st(W::S_L1, B);
-        a.C = CH; a.H = Tp; a.W = Fp; a.TH = 32;
+        a.C = CH; a.H = Tp; a.W = Fp; a.TH = 64;
         CHECK(launch_dw_s1(a, 1, true, 0, B, st));
     }
     {  // 12. xf1 = gLN(L1) * sigmoid(gLN(G1)) + gLN(E1)                                      fusion.py:62-67
@@ -422,13 +422,13 @@ int block_body(const BlockPack& p, int B, int T, int F, BlockWs& w, hipStream_t 
         a.w[0] = p.cat0.emb_w; a.w[1] = p.cat0.gate_w;
         a.out[0] = w.E2; a.out[1] = w.G2;
         a.stats_out[0] = w.st(W::S_E2, B); a.stats_out[1] = w.st(W::S_G2, B);
-        a.C = CH; a.H = Tp; a.W = Fp; a.TH = 32;
+        a.C = CH; a.H = Tp; a.W = Fp; a.TH = 64;
         CHECK(launch_dw_s1(a, 2, false, 0, B, st));
     }
     DwArgs d0in;  // common: read d0 = gLN(c0) at full resolution
     d0in.x = w.c0;
     d0in.in_stats = w.st(W::S_C0, B); d0in.in_inv_count = icF; d0in.in_gamma = p.ds0_g; d0in.in_beta = p.ds0_be;
-    d0in.C = CH; d0in.H = T; d0in.W = F; d0in.TH = 32; d0in.Hg = Tp; d0in.Wg = Fp;
+    d0in.C = CH; d0in.H = T; d0in.W = F; d0in.TH = 64; d0in.Hg = Tp; d0in.Wg = Fp;
     {  // 14. fusion 0 local_embedding conv on d0: statistics only
         DwArgs a = d0in;
         a.w[0] = p.fus0.loc_w;
@@ -447,7 +447,7 @@ int block_body(const BlockPack& p, int B, int T, int F, BlockWs& w, hipStream_t 
     }
     DwArgs xin;  // common: read xf0
     xin.x = w.xf0;
-    xin.C = CH; xin.H = T; xin.W = F; xin.TH = 32; xin.Hg = Tp; xin.Wg = Fp;
+    xin.C = CH; xin.H = T; xin.W = F; xin.TH = 64; xin.Hg = Tp; xin.Wg = Fp;
     {  // 16. concat layer local_embedding conv on xf0: statistics only
         DwArgs a = xin;
         a.w[0] = p.cat0.loc_w;
@@ -735,14 +735,14 @@ int rtfs_tfar_f32(const float* local, const float* global, const float* pack, fl
         a.w[0] = p.emb_w; a.w[1] = p.gate_w;
         a.out[0] = E; a.out[1] = G;
         a.stats_out[0] = stE; a.stats_out[1] = stG;
-        a.C = CH; a.H = Hg; a.W = Wg; a.TH = 32;
+        a.C = CH; a.H = Hg; a.W = Wg; a.TH = 64;
         CHECK(launch_dw_s1(a, 2, false, 0, B, s));
     }
     if (up) {
         DwArgs a;
         a.x = local;
         a.w[0] = p.loc_w;
-        a.C = CH; a.H = H; a.W = W; a.TH = 32; a.Hg = Hg; a.Wg = Wg;
+        a.C = CH; a.H = H; a.W = W; a.TH = 64; a.Hg = Hg; a.Wg = Wg;
         a.stats_out[0] = stL;
         CHECK(launch_dw_s1(a, 1, false, 1, B, s));
         a.stats_out[0] = nullptr;
@@ -759,7 +759,7 @@ int rtfs_tfar_f32(const float* local, const float* global, const float* pack, fl
         a.w[0] = p.loc_w;
         a.out[0] = Lc;
         a.stats_out[0] = stL;
-        a.C = CH; a.H = H; a.W = W; a.TH = 32;
+        a.C = CH; a.H = H; a.W = W; a.TH = 64;
         CHECK(launch_dw_s1(a, 1, false, 0, B, s));
     }
     GCombineArgs a;

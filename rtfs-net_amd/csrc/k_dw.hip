@@ -10,6 +10,9 @@
 // *normalised* input, i.e. out-of-image taps contribute 0, not `shift`.
 #include "common.h"
 #include "kernels.h"
+#ifndef DW_DBG
+#define DW_DBG 0
+#endif
 
 // ---------------------------------------------------------------- stride-1 'same' 4x4 (pad lo 1, hi 2)
 // One thread per (channel, column) walks a band of TH rows with a 4x4 register window (no LDS: the four
@@ -122,13 +125,40 @@ __global__ __launch_bounds__(256) void dw_s1_kernel(DwArgs a) {
     dw_s1_body<NCONV, IN_AFFINE, MODE>(a, a.x, a.gate, a.emb, a.addend, a.out[0], a.out[1], a.out[2], a.out[3]);
 }
 
-// ---------------------------------------------------------------- packed variant for the full-resolution single-conv passes
-// The depthwise passes are VALU-bound (16 FMAs per output), so this variant halves the FMA instruction count with
-// v_pk_fma_f32: a thread owns TWO columns half a row apart (f and f + ceil(W/2)); their 4x4 windows are disjoint, so each
-// load fills one half of an operand pair and both columns' accumulators advance with one packed FMA per tap.
-// Zero padding: out-of-image COLUMNS are folded into per-lane weights (weight 0), out-of-image ROWS are selected to 0 only in
-// the first / last row band; the input gLN fold is applied to the result: conv(pad0(s*x+b)) = s*conv(pad0(x)) + b*sum(valid w).
+// ---------------------------------------------------------------- packed variant: adjacent column pairs + lane exchange
+// Measured (PMC, profiles/): these passes are bound by the texture addresser, not by HBM or the VALU -- a dword load is
+// issued at 4 lanes per clock (16 cycles per wave instruction whatever the element size), and a 4x4 window re-loads every
+// input element four times (once per horizontal tap).  So here a thread owns the ADJACENT column pair (2p, 2p+1) of one
+// channel, loads each input element exactly once, and takes the three neighbouring taps (2p-1, 2p+2, 2p+3) from the
+// adjacent lanes' registers with v_mov_b32_dpp wave_shr:1 / wave_shl:1.  A wave covers 62 pairs plus one HALO lane on each
+// side (lanes 0 and 63 only load; their outputs belong to the neighbouring waves): 3 % redundant loads instead of
+// exec-masked edge loads, which measured 15 % (a masked dword load still occupies the addresser).  Channel boundaries need
+// no care: a lane whose neighbour belongs to another channel wants a zero-padding column there, and its weight for that
+// tap is 0.
+// Both outputs of the pair advance with one v_pk_fma_f32 per tap.  Zero padding: out-of-image COLUMNS are folded into the
+// per-lane weight pairs, out-of-image ROWS are zeroed only in the first / last row band; the input gLN fold is applied to
+// the result: conv(pad0(s*x+b)) = s*conv(pad0(x)) + b*sum(valid w).
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+#define DW1P_PAIRS 62  // column pairs a wave produces (64 lanes - 2 halo lanes)
+
+// element at (wave-uniform base) + (32-bit lane BYTE offset): the form global_load/store take as saddr + voffset
+// (the empty asm keeps the zero-extension of the offset next to the access: hoisted out of the row loop it becomes a
+// 64-bit register pair and every access pays a v_lshl_add_u64 instead)
+__device__ __forceinline__ float ldo(const float* __restrict__ base, unsigned boff) {
+    asm volatile("" : "+v"(boff));
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + boff);
+}
+__device__ __forceinline__ void sto(float* __restrict__ base, unsigned boff, float v) {
+    asm volatile("" : "+v"(boff));
+    *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + boff) = v;
+}
+// lane i <- lane i-1 (lane 0: 0) / lane i <- lane i+1 (lane 63: 0), whole wave
+__device__ __forceinline__ float from_prev_lane(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, false));  // wave_shr:1
+}
+__device__ __forceinline__ float from_next_lane(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, false));  // wave_shl:1
+}
 
 template <int NCONV, bool IN_AFFINE, int MODE>
 __device__ __forceinline__ void dw1p_body(const DwArgs& a, const float* __restrict__ X, const float* __restrict__ GATE,
@@ -137,34 +167,125 @@ __device__ __forceinline__ void dw1p_body(const DwArgs& a, const float* __restri
     static_assert(NCONV == 1 || (MODE == 0 && !IN_AFFINE), "multi-conv: plain write + stats only");
     __shared__ double red[8];
     const int H = a.H, W = a.W, C = a.C;
-    const int half = (W + 1) >> 1;
+    const int NP = (W + 1) >> 1;  // column pairs per row
     const int b = blockIdx.z;
-    const int g = blockIdx.x * 256 + threadIdx.x;
-    const bool live = g < C * half;
-    const int c = live ? g / half : 0, fa = live ? g - c * half : 0, fb = fa + half;
-    const bool liveb = live && fb < W;
+    const int lane = threadIdx.x & 63;
+    // flattened (channel, pair) index: wave-slot ws covers [62 ws - 1, 62 ws + 62]; lanes 0 and 63 are halo lanes
+    const int ws = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int gi = ws * DW1P_PAIRS - 1 + lane;
+    const bool live = lane >= 1 && lane <= DW1P_PAIRS && gi < C * NP;  // gi >= 0 follows from lane >= 1
+    const int gc = gi < 0 ? 0 : (gi < C * NP ? gi : C * NP - 1);      // halo / dead lanes still load real, finite data
+    const int c = gc / NP, p = gc - c * NP;
+    const int x0 = 2 * p, x1 = 2 * p + 1;
+    const bool liveb = live && x1 < W;
     const int r0 = blockIdx.y * a.TH, r1 = min(r0 + a.TH, H);
-    const size_t plane = ((size_t)b * C + c) * H * W;
-    const float* __restrict__ xp = X + plane;
+    // addressing: wave-uniform 64-bit bases (sample, row) + 32-bit lane BYTE offsets (channel plane + column), so a load
+    // costs no vector address arithmetic (global_load saddr + voffset); the launcher checks that C*H*W*4 fits 31 bits
+    const size_t sample = (size_t)b * C * H * W;
+    const float* __restrict__ Xs_ = X + sample;
+    const unsigned pa = (unsigned)c * (unsigned)(H * W) * 4u;
+    auto col = [&](int x) { return pa + 4u * (unsigned)(x < 0 ? 0 : (x < W ? x : W - 1)); };
+    const unsigned o0 = col(x0), o1 = col(x1);
+    unsigned fga = 0, fgb = 0;
+    const size_t gsample = MODE == 2 ? (size_t)b * C * a.Hg * a.Wg : 0;
+    if (MODE == 2) {  // legacy 'nearest' source column floor(x Wg / W) (32-bit: x Wg < 2^31 is checked by the launcher)
+        const unsigned gpa = (unsigned)c * (unsigned)(a.Hg * a.Wg) * 4u;
+        const unsigned xb_ = (unsigned)(x1 < W ? x1 : W - 1);
+        fga = gpa + 4u * min((unsigned)x0 * (unsigned)a.Wg / (unsigned)W, (unsigned)a.Wg - 1u);
+        fgb = gpa + 4u * min(xb_ * (unsigned)a.Wg / (unsigned)W, (unsigned)a.Wg - 1u);
+    }
+    const bool border = r0 == 0 || r1 + 3 > H;  // block-uniform: only these bands ever see an out-of-image row
+    // MODE 2: low-resolution source row floor(t Hg / H) as an incremental quotient / remainder, advanced in LOAD order
+    // (a 64-bit division per row on the scalar unit costs more than the row's vector work)
+    int tgq = 0, tgr = 0;
+    if (MODE == 2) {
+        tgq = (int)(((long long)r0 * a.Hg) / H);
+        tgr = (int)(((long long)r0 * a.Hg) % H);
+    }
+    // A row in flight: own pair + the edge lanes' extra columns (raw) and, for MODE 2, everything else output row t-2 will
+    // need (gate / embedding gathers, addend) -- these passes are bound by bytes in flight (a wave with two rows
+    // outstanding sustains 2.6 TB/s chip-wide), so every load of a row is issued RQ rows before its use.
+    struct Raw { float v0, v1, g0, g1, m0, m1, a0, a1; };
+    auto load_raw = [&](int t) {  // window row t, and the epilogue operands of OUTPUT row t - 2
+        const int tc = t < 0 ? 0 : (t < H ? t : H - 1);
+        const float* __restrict__ rp = Xs_ + (size_t)tc * W;  // uniform
+        Raw r;
+        r.v0 = ldo(rp, o0);
+        r.v1 = ldo(rp, o1);
+        r.g0 = r.g1 = r.m0 = r.m1 = r.a0 = r.a1 = 0.f;
+        if (MODE == 2) {
+            const int to = min(max(t - 2, r0), H - 1);  // output row served (clamped: the extra rows of the last trip are dropped)
+            const int tg = tgq < a.Hg - 1 ? tgq : a.Hg - 1;
+            if (t - 2 >= r0) {  // uniform: advance once per output row
+                tgr += a.Hg;
+                while (tgr >= H) {  // one step when Hg <= H
+                    tgr -= H;
+                    ++tgq;
+                }
+            }
+            const size_t grow = gsample + (size_t)tg * a.Wg;  // uniform
+            const float* __restrict__ gp = GATE + grow;
+            const float* __restrict__ ep = EMB + grow;
+            r.g0 = ldo(gp, fga);
+            r.g1 = ldo(gp, fgb);
+            r.m0 = ldo(ep, fga);
+            r.m1 = ldo(ep, fgb);
+            if (ADD) {
+                const float* __restrict__ ap = ADD + sample + (size_t)to * W;
+                r.a0 = ldo(ap, o0);
+                r.a1 = ldo(ap, o1);
+            }
+        }
+        return r;
+    };
+    auto complete = [&](int t, const Raw& r, float (&v)[5]) {
+        v[1] = r.v0;
+        v[2] = r.v1;
+        v[0] = from_prev_lane(r.v1);
+        v[3] = from_next_lane(r.v0);
+        v[4] = from_next_lane(r.v1);
+        if (border && (t < 0 || t >= H)) {
+#pragma unroll
+            for (int j = 0; j < 5; ++j) v[j] = 0.f;
+        }
+    };
+    // ---- start-up: every load the first trip needs (window rows r0-1 .. r0+1+RQ, the weights) is requested before the
+    // first wait and before the f64 gLN folds below, so a workgroup pays one memory latency, not three
+    constexpr int RQ = 4;  // rows per trip = prefetch distance
+    Raw st0 = load_raw(r0 - 1), st1 = load_raw(r0), st2 = load_raw(r0 + 1);
+    Raw q[RQ];
+#pragma unroll
+    for (int k = 0; k < RQ; ++k) q[k] = load_raw(r0 + 2 + k);
+    f32x4 wraw[NCONV][4];
+#pragma unroll
+    for (int n = 0; n < NCONV; ++n)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wraw[n][i] = *reinterpret_cast<const f32x4*>(a.w[n] + c * 16 + i * 4);
     float isc = 1.f, ish = 0.f;
+#if !(DW_DBG & 4)
     if (IN_AFFINE) gln_fold(a.in_stats + 2 * b, a.in_inv_count, a.in_gamma[c], a.in_beta[c], isc, ish);
-    // per-lane weights with the column padding folded in; clamped column offsets
+#endif
+    float lsc = 1.f, lsh = 0.f, gsc = 1.f, gsh = 0.f, esc = 1.f, esh = 0.f, asc = 1.f, ash = 0.f;
+    if (MODE == 2) {
+        gln_fold(a.loc_stats + 2 * b, a.loc_inv_count, a.loc_gamma[c], a.loc_beta[c], lsc, lsh);
+        gln_fold(a.gate_stats + 2 * b, a.g_inv_count, a.gate_gamma[c], a.gate_beta[c], gsc, gsh);
+        gln_fold(a.emb_stats + 2 * b, a.g_inv_count, a.emb_gamma[c], a.emb_beta[c], esc, esh);
+        if (ADD) gln_fold(a.add_stats + 2 * b, a.add_inv_count, a.add_gamma[c], a.add_beta[c], asc, ash);
+    }
+    // per-lane weight pairs {output 2p, output 2p+1} with the column padding folded in: tap j reads column x0-1+j / x1-1+j
     f32x2 wgt[NCONV][16];
-    int ca[4], cb[4];
     f32x2 rowsum[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) rowsum[i] = f32x2{0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int xa = fa - 1 + j, xb = fb - 1 + j;
+        const int xa = x0 - 1 + j, xb = x1 - 1 + j;
         const bool oka = live && xa >= 0 && xa < W, okb = liveb && xb >= 0 && xb < W;
-        ca[j] = xa < 0 ? 0 : (xa < W ? xa : W - 1);
-        cb[j] = xb < 0 ? 0 : (xb < W ? xb : W - 1);
 #pragma unroll
         for (int n = 0; n < NCONV; ++n)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const float w = a.w[n][c * 16 + i * 4 + j];
+                const float w = wraw[n][i][j];
                 wgt[n][i * 4 + j] = f32x2{oka ? w : 0.f, okb ? w : 0.f};
                 if (n == 0) rowsum[i] += wgt[0][i * 4 + j];
             }
@@ -172,121 +293,90 @@ __device__ __forceinline__ void dw1p_body(const DwArgs& a, const float* __restri
     float bias[NCONV];
 #pragma unroll
     for (int n = 0; n < NCONV; ++n) bias[n] = a.bias[n] ? a.bias[n][c] : 0.f;
-    float lsc = 1.f, lsh = 0.f, gsc = 1.f, gsh = 0.f, esc = 1.f, esh = 0.f, asc = 1.f, ash = 0.f;
-    size_t gplane = 0;
-    int fga = 0, fgb = 0;
-    if (MODE == 2) {
-        gln_fold(a.loc_stats + 2 * b, a.loc_inv_count, a.loc_gamma[c], a.loc_beta[c], lsc, lsh);
-        gln_fold(a.gate_stats + 2 * b, a.g_inv_count, a.gate_gamma[c], a.gate_beta[c], gsc, gsh);
-        gln_fold(a.emb_stats + 2 * b, a.g_inv_count, a.emb_gamma[c], a.emb_beta[c], esc, esh);
-        if (ADD) gln_fold(a.add_stats + 2 * b, a.add_inv_count, a.add_gamma[c], a.add_beta[c], asc, ash);
-        gplane = ((size_t)b * C + c) * a.Hg * a.Wg;
-        fga = nearest_src(fa, a.Wg, W);
-        fgb = nearest_src(fb < W ? fb : W - 1, a.Wg, W);
-    }
-    const bool border = r0 == 0 || r1 + 2 > H;  // block-uniform: only these bands ever see an out-of-image row
-    auto load_row = [&](int t, f32x2 (&row)[4]) {
-        const int tc = t < 0 ? 0 : (t < H ? t : H - 1);
-        const float* __restrict__ rp = xp + (size_t)tc * W;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) row[j] = f32x2{rp[ca[j]], rp[cb[j]]};
-        if (border && (t < 0 || t >= H)) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) row[j] = f32x2{0.f, 0.f};
-        }
-    };
-    f32x2 win[4][4];
-    load_row(r0 - 1, win[0]);
-    load_row(r0, win[1]);
-    load_row(r0 + 1, win[2]);
+    float win[3][5];
+    complete(r0 - 1, st0, win[0]);
+    complete(r0, st1, win[1]);
+    complete(r0 + 1, st2, win[2]);
     f32x2 s2[NCONV], ss2[NCONV];
 #pragma unroll
     for (int n = 0; n < NCONV; ++n) s2[n] = ss2[n] = f32x2{0.f, 0.f};
     const f32x2 wv_full = rowsum[0] + rowsum[1] + rowsum[2] + rowsum[3];
-    const int fbc = fb < W ? fb : W - 1;
-    // MODE 2: low-resolution source row floor(t Hg / H) as an incremental quotient / remainder (a 64-bit division per row
-    // on the scalar unit costs more than the row's vector work)
-    int tgq = 0, tgr = 0;
-    if (MODE == 2) {
-        tgq = (int)(((long long)r0 * a.Hg) / H);
-        tgr = (int)(((long long)r0 * a.Hg) % H);
-    }
-#pragma unroll 2
-    for (int t = r0; t < r1; ++t) {
-        load_row(t + 2, win[3]);
-        const size_t oa = plane + (size_t)t * W + fa, ob = plane + (size_t)t * W + fbc;
-        if (NCONV > 1) {  // several convolutions of the same input (G-level TFAR embeddings / gates): write + stats
-            const f32x2 m = {live ? 1.f : 0.f, liveb ? 1.f : 0.f};
+    const f32x2 m = {live ? 1.f : 0.f, liveb ? 1.f : 0.f};
+    // one output row t (both columns of the pair) from window rows t-1 .. t+2; e = the raw record that came with row t+2
+    auto do_row = [&](int t, const float (&w0)[5], const float (&w1)[5], const float (&w2)[5], const float (&w3)[5], const Raw& e) {
+        const size_t orow = sample + (size_t)t * W;  // uniform
 #pragma unroll
-            for (int n = 0; n < NCONV; ++n) {
-                f32x2 acc = {0.f, 0.f};
+        for (int n = 0; n < NCONV; ++n) {
+            f32x2 acc = {0.f, 0.f};
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j) acc = f32x2{w0[j], w0[j + 1]} * wgt[n][j] + acc;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc = win[i][j] * wgt[n][i * 4 + j] + acc;
-                acc += bias[n];
-                float* __restrict__ o_ = n == 0 ? OUT : n == 1 ? OUT1 : n == 2 ? OUT2 : OUT3;
-                if (live) o_[oa] = acc.x;
-                if (liveb) o_[ob] = acc.y;
+            for (int j = 0; j < 4; ++j) acc = f32x2{w1[j], w1[j + 1]} * wgt[n][4 + j] + acc;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc = f32x2{w2[j], w2[j + 1]} * wgt[n][8 + j] + acc;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc = f32x2{w3[j], w3[j + 1]} * wgt[n][12 + j] + acc;
+            if (IN_AFFINE) {
+                f32x2 wv = wv_full;
+                if (border) {
+                    if (t - 1 < 0) wv -= rowsum[0];
+                    if (t + 1 >= H) wv -= rowsum[2];
+                    if (t + 2 >= H) wv -= rowsum[3];
+                }
+                acc = acc * isc + wv * ish;
+            }
+            acc += bias[n];
+            if (MODE == 0) {
+                float* __restrict__ o_ = (n == 0 ? OUT : n == 1 ? OUT1 : n == 2 ? OUT2 : OUT3) + orow;
+                if (live) sto(o_, o0, acc.x);
+                if (liveb) sto(o_, o1, acc.y);
+            }
+            if (MODE != 2) {
                 const f32x2 am = acc * m;
                 s2[n] += am;
                 ss2[n] = am * am + ss2[n];
+            } else {
+                const f32x2 gate = {sigmoidf_(fmaf(e.g0, gsc, gsh)), sigmoidf_(fmaf(e.g1, gsc, gsh))};
+                const f32x2 emb = {fmaf(e.m0, esc, esh), fmaf(e.m1, esc, esh)};
+                f32x2 y = (acc * lsc + lsh) * gate + emb;
+                if (ADD) y += f32x2{fmaf(e.a0, asc, ash), fmaf(e.a1, asc, ash)};
+                float* __restrict__ o_ = OUT + orow;
+                if (live) sto(o_, o0, y.x);
+                if (liveb) sto(o_, o1, y.y);
             }
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) win[i][j] = win[i + 1][j];
-            continue;
         }
-        f32x2 acc = {0.f, 0.f};
+    };
+    // RQ output rows per trip; the loads of the next trip's RQ window rows are issued before this trip's arithmetic
+    for (int t = r0; t < r1; t += RQ) {
+        float n[RQ][5];
+        Raw e[RQ];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc = win[i][j] * wgt[0][i * 4 + j] + acc;
-        if (IN_AFFINE) {
-            f32x2 wv = wv_full;
-            if (border) {
-                if (t - 1 < 0) wv -= rowsum[0];
-                if (t + 1 >= H) wv -= rowsum[2];
-                if (t + 2 >= H) wv -= rowsum[3];
-            }
-            acc = acc * isc + wv * ish;
-        }
-        acc += bias[0];
-        if (MODE == 0) {
-            if (live) OUT[oa] = acc.x;
-            if (liveb) OUT[ob] = acc.y;
-        }
-        if (MODE != 2) {
-            const f32x2 m = {live ? 1.f : 0.f, liveb ? 1.f : 0.f};
-            const f32x2 am = acc * m;
-            s2[0] += am;
-            ss2[0] = am * am + ss2[0];
-        } else {
-            const int tg = tgq < a.Hg - 1 ? tgq : a.Hg - 1;
-            tgr += a.Hg;
-            while (tgr >= H) {  // one step when Hg <= H
-                tgr -= H;
-                ++tgq;
-            }
-            const size_t ga = gplane + (size_t)tg * a.Wg + fga, gb = gplane + (size_t)tg * a.Wg + fgb;
-            const f32x2 gate = {sigmoidf_(fmaf(GATE[ga], gsc, gsh)), sigmoidf_(fmaf(GATE[gb], gsc, gsh))};
-            const f32x2 emb = {fmaf(EMB[ga], esc, esh), fmaf(EMB[gb], esc, esh)};
-            f32x2 y = (acc * lsc + lsh) * gate + emb;
-            if (ADD) y += f32x2{fmaf(ADD[oa], asc, ash), fmaf(ADD[ob], asc, ash)};
-            if (live) OUT[oa] = y.x;
-            if (liveb) OUT[ob] = y.y;
+        for (int k = 0; k < RQ; ++k) {
+            complete(t + 2 + k, q[k], n[k]);
+            e[k] = q[k];
         }
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
+        for (int k = 0; k < RQ; ++k) q[k] = load_raw(t + 2 + RQ + k);
+        do_row(t, win[0], win[1], win[2], n[0], e[0]);
+        if (t + 1 < r1) do_row(t + 1, win[1], win[2], n[0], n[1], e[1]);  // uniform
+        if (t + 2 < r1) do_row(t + 2, win[2], n[0], n[1], n[2], e[2]);
+        if (t + 3 < r1) do_row(t + 3, n[0], n[1], n[2], n[3], e[3]);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) win[i][j] = win[i + 1][j];
+        for (int j = 0; j < 5; ++j) {
+            win[0][j] = n[1][j];
+            win[1][j] = n[2][j];
+            win[2][j] = n[3][j];
+        }
     }
     if (MODE != 2) {
 #pragma unroll
         for (int n = 0; n < NCONV; ++n) {
+#if !(DW_DBG & 2)
             block_stats_atomic(s2[n].x + s2[n].y, ss2[n].x + ss2[n].y, red, a.stats_out[n] + 2 * b);
             __syncthreads();
+#else
+            if (s2[n].x == 123.f) a.stats_out[n][0] = ss2[n].x;
+#endif
         }
     }
 }
@@ -561,11 +651,12 @@ static int launch_dw_s1_t(const DwArgs& a, int B, hipStream_t st) {
 template <int NCONV, bool IN_AFFINE, int MODE>
 static int launch_dw1p_t(const DwArgs& a, int B, hipStream_t st) {
     const int half = (a.W + 1) / 2;
-    hipLaunchKernelGGL((dw1p_kernel<NCONV, IN_AFFINE, MODE>), dim3(cdiv(a.C * half, 256), cdiv(a.H, a.TH), B), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((dw1p_kernel<NCONV, IN_AFFINE, MODE>), dim3(cdiv(cdiv(a.C * half, DW1P_PAIRS), 4), cdiv(a.H, a.TH), B), dim3(256), 0, st, a);
     return rtfs_launch_status();
 }
 
 int launch_dw_s1(const DwArgs& a, int nconv, bool in_affine, int mode, int B, hipStream_t st) {
+    if ((size_t)a.C * a.H * a.W * 4 >= ((size_t)1 << 31)) return RTFS_ERR_SHAPE;  // 32-bit lane offsets
     if (a.W >= 16) {  // packed two-column variant (v_pk_fma_f32); the scalar kernel below only serves very narrow inputs
         if (nconv == 1) {
             if (mode == 0) return in_affine ? launch_dw1p_t<1, true, 0>(a, B, st) : launch_dw1p_t<1, false, 0>(a, B, st);

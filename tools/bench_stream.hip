@@ -1,0 +1,99 @@
+// Diagnostic micro-benchmark (not part of the product): streaming-read rates of a (B,64,251,129) fp32 tensor under
+// the access patterns of the depthwise kernels.   hipcc --offload-arch=gfx950 -O3 -o /tmp/bs tools/bench_stream.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("err %s line %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+
+__global__ __launch_bounds__(256) void v0_flat(const float* __restrict__ x, float* __restrict__ out, size_t n) {
+    float s = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) s += x[i];
+    if (s == 123.456f) out[0] = s;
+}
+__global__ __launch_bounds__(256) void v1_flat4(const float4* __restrict__ x, float* __restrict__ out, size_t n4) {
+    float s = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) { float4 v = x[i]; s += v.x + v.y + v.z + v.w; }
+    if (s == 123.456f) out[0] = s;
+}
+// thread = (channel, column pair), walks TH rows; U rows of loads issued per trip
+template <int U, bool WORK, int EDGE = 0>
+__global__ __launch_bounds__(256) void v2_rows(const float* __restrict__ x, float* __restrict__ out, int C, int H, int W, int TH) {
+    const int NP = (W + 1) / 2;
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    const bool live = g < C * NP;
+    const int c = live ? g / NP : 0, p = live ? g - c * NP : 0;
+    const int b = blockIdx.z;
+    const int r0 = blockIdx.y * TH, r1 = min(r0 + TH, H);
+    const float* xs = x + (size_t)b * C * H * W;
+    const unsigned o0 = (unsigned)c * H * W + 2 * p, o1 = (unsigned)c * H * W + min(2 * p + 1, W - 1);
+    f32x2 acc = {0.f, 0.f};
+    f32x2 w[16];
+    for (int i = 0; i < 16; ++i) w[i] = f32x2{0.01f * i, 0.02f * i + threadIdx.x * 1e-6f};
+    const int lane = threadIdx.x & 63;
+    const unsigned e0 = (unsigned)c * H * W + (lane == 0 ? max(2 * p - 1, 0) : min(2 * p + 2, W - 1)), e1 = (unsigned)c * H * W + min(2 * p + 3, W - 1);
+    float q[U][4];
+    auto ld = [&](int t, float (&d)[4]) {
+        const float* rp = xs + (size_t)min(t, H - 1) * W;
+        d[0] = rp[o0]; d[1] = rp[o1]; d[2] = 0.f; d[3] = 0.f;
+        if (EDGE == 1) { if (lane == 0 || lane == 63) d[2] = rp[e0]; if (lane == 63) d[3] = rp[e1]; }
+        if (EDGE == 2) { d[2] = rp[lane == 0 || lane == 63 ? e0 : o0]; d[3] = rp[lane == 63 ? e1 : o1]; }  // unmasked: redundant addresses
+    };
+    for (int k = 0; k < U; ++k) ld(r0 + k, q[k]);
+    for (int t = r0; t < r1; t += U) {
+        float v[U][4];
+        for (int k = 0; k < U; ++k) for (int j = 0; j < 4; ++j) v[k][j] = q[k][j];
+        for (int k = 0; k < U; ++k) ld(t + U + k, q[k]);
+        for (int k = 0; k < U; ++k) {
+            if (WORK) {
+                const float l = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[k][1]), 0x138, 0xf, 0xf, false));
+                const float r_ = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[k][0]), 0x130, 0xf, 0xf, false));
+                const float r2 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[k][1]), 0x130, 0xf, 0xf, false));
+                float vv[5] = {l, v[k][0], v[k][1], r_, r2};
+                if (EDGE) { if (lane == 0) vv[0] = v[k][2]; if (lane == 63) { vv[3] = v[k][2]; vv[4] = v[k][3]; } }
+                for (int i = 0; i < 4; ++i)
+                    for (int j = 0; j < 4; ++j) acc = f32x2{vv[j], vv[j + 1]} * w[i * 4 + j] + acc;
+            } else {
+                acc += f32x2{v[k][0], v[k][1]};
+            }
+        }
+    }
+    if (acc.x + acc.y == 123.456f) out[0] = acc.x;
+}
+
+int main() {
+    const int B = 32, C = 64, H = 251, W = 129;
+    const size_t n = (size_t)B * C * H * W;
+    float *x, *out;
+    CK(hipMalloc(&x, n * 4 + 64));
+    CK(hipMalloc(&out, 64));
+    CK(hipMemset(x, 0, n * 4 + 64));
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    auto timeit = [&](const char* name, auto launch) {
+        for (int i = 0; i < 3; ++i) launch();
+        hipEventRecord(e0);
+        const int R = 20;
+        for (int i = 0; i < R; ++i) launch();
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        printf("%-40s %8.1f us  %6.2f TB/s\n", name, ms / R * 1e3, n * 4.0 / (ms / R * 1e-3) / 1e12);
+    };
+    timeit("flat dword, 2048 WGs", [&] { hipLaunchKernelGGL(v0_flat, dim3(2048), dim3(256), 0, 0, x, out, n); });
+    timeit("flat dword, 8192 WGs", [&] { hipLaunchKernelGGL(v0_flat, dim3(8192), dim3(256), 0, 0, x, out, n); });
+    timeit("flat dwordx4, 2048 WGs", [&] { hipLaunchKernelGGL(v1_flat4, dim3(2048), dim3(256), 0, 0, (const float4*)x, out, n / 4); });
+    const int NP = (W + 1) / 2, gx = (C * NP + 255) / 256;
+    for (int TH : {32, 64}) {
+        char nm[64];
+        const dim3 grid(gx, (H + TH - 1) / TH, B);
+        snprintf(nm, 64, "rows U=2 sum TH=%d", TH);  timeit(nm, [&] { hipLaunchKernelGGL((v2_rows<2, false>), grid, dim3(256), 0, 0, x, out, C, H, W, TH); });
+        snprintf(nm, 64, "rows U=4 sum TH=%d", TH);  timeit(nm, [&] { hipLaunchKernelGGL((v2_rows<4, false>), grid, dim3(256), 0, 0, x, out, C, H, W, TH); });
+        snprintf(nm, 64, "rows U=8 sum TH=%d", TH);  timeit(nm, [&] { hipLaunchKernelGGL((v2_rows<8, false>), grid, dim3(256), 0, 0, x, out, C, H, W, TH); });
+        snprintf(nm, 64, "rows U=4 conv TH=%d", TH); timeit(nm, [&] { hipLaunchKernelGGL((v2_rows<4, true>), grid, dim3(256), 0, 0, x, out, C, H, W, TH); });
+        snprintf(nm, 64, "rows U=8 conv TH=%d", TH); timeit(nm, [&] { hipLaunchKernelGGL((v2_rows<8, true>), grid, dim3(256), 0, 0, x, out, C, H, W, TH); });
+        snprintf(nm, 64, "rows U=4 conv edge-masked TH=%d", TH); timeit(nm, [&] { hipLaunchKernelGGL((v2_rows<4, true, 1>), grid, dim3(256), 0, 0, x, out, C, H, W, TH); });
+        snprintf(nm, 64, "rows U=4 conv edge-unmasked TH=%d", TH); timeit(nm, [&] { hipLaunchKernelGGL((v2_rows<4, true, 2>), grid, dim3(256), 0, 0, x, out, C, H, W, TH); });
+    }
+    return 0;
+}
