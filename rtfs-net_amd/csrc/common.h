@@ -69,12 +69,14 @@ __device__ __forceinline__ void block_stats_atomic(float s, float ss, double* re
 // GroupNorm(1,C) affine folded to y = x*scale + shift from accumulated (sum, sumsq).
 __device__ __forceinline__ void gln_fold(const double* st, double inv_count, float gamma, float beta, float& scale,
                                          float& shift) {
+    // the cancellation-prone part (E[x^2] - mean^2, and mean * scale in the shift) stays in f64; the reciprocal square
+    // root runs in f32 (an f64 rsqrt + division costs ~80 instructions in every consumer's prologue)
     const double mean = st[0] * inv_count;
     double var = st[1] * inv_count - mean * mean;
     var = var < 0 ? 0 : var;
-    const double rstd = 1.0 / sqrt(var + (double)RTFS_EPS);
-    scale = (float)(gamma * rstd);
-    shift = (float)(beta - mean * rstd * gamma);
+    const float rstd = 1.0f / sqrtf((float)(var + (double)RTFS_EPS));
+    scale = gamma * rstd;
+    shift = (float)((double)beta - mean * (double)scale);
 }
 
 // v_exp_f32 + v_rcp_f32 (1 ulp each); saturates correctly: exp2(+inf) -> rcp(inf) = 0

@@ -244,6 +244,11 @@ __device__ __forceinline__ void dw1p_body(const DwArgs& a, const float* __restri
         v[0] = from_prev_lane(r.v1);
         v[3] = from_next_lane(r.v0);
         v[4] = from_next_lane(r.v1);
+        // zero padding of the COLUMNS (and whatever a lane of another channel / a halo lane delivered for them)
+        if (x0 == 0) v[0] = 0.f;
+        if (x0 + 1 >= W) v[2] = 0.f;
+        if (x0 + 2 >= W) v[3] = 0.f;
+        if (x0 + 3 >= W) v[4] = 0.f;
         if (border && (t < 0 || t >= H)) {
 #pragma unroll
             for (int j = 0; j < 5; ++j) v[j] = 0.f;
@@ -251,7 +256,7 @@ __device__ __forceinline__ void dw1p_body(const DwArgs& a, const float* __restri
     };
     // ---- start-up: every load the first trip needs (window rows r0-1 .. r0+1+RQ, the weights) is requested before the
     // first wait and before the f64 gLN folds below, so a workgroup pays one memory latency, not three
-    constexpr int RQ = 4;  // rows per trip = prefetch distance
+    constexpr int RQ = MODE == 2 ? 2 : 4;  // rows per trip = prefetch distance (MODE 2 carries 6 more values per row)
     Raw st0 = load_raw(r0 - 1), st1 = load_raw(r0), st2 = load_raw(r0 + 1);
     Raw q[RQ];
 #pragma unroll
@@ -272,23 +277,24 @@ __device__ __forceinline__ void dw1p_body(const DwArgs& a, const float* __restri
         gln_fold(a.emb_stats + 2 * b, a.g_inv_count, a.emb_gamma[c], a.emb_beta[c], esc, esh);
         if (ADD) gln_fold(a.add_stats + 2 * b, a.add_inv_count, a.add_gamma[c], a.add_beta[c], asc, ash);
     }
-    // per-lane weight pairs {output 2p, output 2p+1} with the column padding folded in: tap j reads column x0-1+j / x1-1+j
-    f32x2 wgt[NCONV][16];
+    // weights are per-channel scalars (the column padding lives in the window values, see complete()); rowsum = per-row sum
+    // of the weights whose tap column is inside the image, for the input-fold correction of each output of the pair
+    float wgt[NCONV][16];
     f32x2 rowsum[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) rowsum[i] = f32x2{0.f, 0.f};
 #pragma unroll
+    for (int n = 0; n < NCONV; ++n)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wgt[n][i * 4 + j] = wraw[n][i][j];
+#pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int xa = x0 - 1 + j, xb = x1 - 1 + j;
-        const bool oka = live && xa >= 0 && xa < W, okb = liveb && xb >= 0 && xb < W;
+        const bool oka = xa >= 0 && xa < W, okb = xb >= 0 && xb < W;
 #pragma unroll
-        for (int n = 0; n < NCONV; ++n)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float w = wraw[n][i][j];
-                wgt[n][i * 4 + j] = f32x2{oka ? w : 0.f, okb ? w : 0.f};
-                if (n == 0) rowsum[i] += wgt[0][i * 4 + j];
-            }
+        for (int i = 0; i < 4; ++i) rowsum[i] += f32x2{oka ? wgt[0][i * 4 + j] : 0.f, okb ? wgt[0][i * 4 + j] : 0.f};
     }
     float bias[NCONV];
 #pragma unroll
@@ -359,13 +365,22 @@ __device__ __forceinline__ void dw1p_body(const DwArgs& a, const float* __restri
         for (int k = 0; k < RQ; ++k) q[k] = load_raw(t + 2 + RQ + k);
         do_row(t, win[0], win[1], win[2], n[0], e[0]);
         if (t + 1 < r1) do_row(t + 1, win[1], win[2], n[0], n[1], e[1]);  // uniform
-        if (t + 2 < r1) do_row(t + 2, win[2], n[0], n[1], n[2], e[2]);
-        if (t + 3 < r1) do_row(t + 3, n[0], n[1], n[2], n[3], e[3]);
+        if (RQ == 4) {
+            if (t + 2 < r1) do_row(t + 2, win[2], n[0], n[1], n[RQ - 2], e[RQ - 2]);
+            if (t + 3 < r1) do_row(t + 3, n[0], n[1], n[RQ - 2], n[RQ - 1], e[RQ - 1]);
 #pragma unroll
-        for (int j = 0; j < 5; ++j) {
-            win[0][j] = n[1][j];
-            win[1][j] = n[2][j];
-            win[2][j] = n[3][j];
+            for (int j = 0; j < 5; ++j) {
+                win[0][j] = n[1][j];
+                win[1][j] = n[RQ - 2][j];
+                win[2][j] = n[RQ - 1][j];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                win[0][j] = win[2][j];
+                win[1][j] = n[0][j];
+                win[2][j] = n[1][j];
+            }
         }
     }
     if (MODE != 2) {
@@ -381,8 +396,9 @@ __device__ __forceinline__ void dw1p_body(const DwArgs& a, const float* __restri
     }
 }
 
+// single-conv variants are held to 128 VGPRs (4 waves per SIMD): these passes live on bytes in flight
 template <int NCONV, bool IN_AFFINE, int MODE>
-__global__ __launch_bounds__(256) void dw1p_kernel(DwArgs a) {
+__global__ __launch_bounds__(256, NCONV == 1 && !(IN_AFFINE && MODE == 2) ? 4 : 2) void dw1p_kernel(DwArgs a) {
     dw1p_body<NCONV, IN_AFFINE, MODE>(a, a.x, a.gate, a.emb, a.addend, a.out[0], a.out[1], a.out[2], a.out[3]);
 }
 
