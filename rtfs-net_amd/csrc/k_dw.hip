@@ -152,6 +152,18 @@ __device__ __forceinline__ void sto(float* __restrict__ base, unsigned boff, flo
     asm volatile("" : "+v"(boff));
     *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + boff) = v;
 }
+// two adjacent elements with one 8-byte access.  The address is only 4-byte aligned (odd row pitch): global loads / stores
+// take that, and a dwordx2 stream runs at 7 TB/s where the dword stream tops out at 4.9 (tools/bench_stream.hip)
+typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
+__device__ __forceinline__ f32x2 ldo2(const float* __restrict__ base, unsigned boff) {
+    asm volatile("" : "+v"(boff));
+    const f32x2u v = *reinterpret_cast<const f32x2u*>(reinterpret_cast<const char*>(base) + boff);
+    return f32x2{v.x, v.y};
+}
+__device__ __forceinline__ void sto2(float* __restrict__ base, unsigned boff, f32x2 v) {
+    asm volatile("" : "+v"(boff));
+    *reinterpret_cast<f32x2u*>(reinterpret_cast<char*>(base) + boff) = f32x2u{v.x, v.y};
+}
 // lane i <- lane i-1 (lane 0: 0) / lane i <- lane i+1 (lane 63: 0), whole wave
 __device__ __forceinline__ float from_prev_lane(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, false));  // wave_shr:1
@@ -186,6 +198,9 @@ __device__ __forceinline__ void dw1p_body(const DwArgs& a, const float* __restri
     const unsigned pa = (unsigned)c * (unsigned)(H * W) * 4u;
     auto col = [&](int x) { return pa + 4u * (unsigned)(x < 0 ? 0 : (x < W ? x : W - 1)); };
     const unsigned o0 = col(x0), o1 = col(x1);
+    // the pair as ONE 8-byte access at column x0; the odd-width row's last pair (x1 == W) reads (x0-1, x0) instead
+    const bool whole = x1 < W;
+    const unsigned o2 = whole ? o0 : o0 - 4u;
     unsigned fga = 0, fgb = 0;
     const size_t gsample = MODE == 2 ? (size_t)b * C * a.Hg * a.Wg : 0;
     if (MODE == 2) {  // legacy 'nearest' source column floor(x Wg / W) (32-bit: x Wg < 2^31 is checked by the launcher)
@@ -210,8 +225,9 @@ __device__ __forceinline__ void dw1p_body(const DwArgs& a, const float* __restri
         const int tc = t < 0 ? 0 : (t < H ? t : H - 1);
         const float* __restrict__ rp = Xs_ + (size_t)tc * W;  // uniform
         Raw r;
-        r.v0 = ldo(rp, o0);
-        r.v1 = ldo(rp, o1);
+        const f32x2 pr = ldo2(rp, o2);
+        r.v0 = whole ? pr.x : pr.y;
+        r.v1 = pr.y;  // x1 == W: zeroed in complete()
         r.g0 = r.g1 = r.m0 = r.m1 = r.a0 = r.a1 = 0.f;
         if (MODE == 2) {
             const int to = min(max(t - 2, r0), H - 1);  // output row served (clamped: the extra rows of the last trip are dropped)
@@ -232,8 +248,9 @@ __device__ __forceinline__ void dw1p_body(const DwArgs& a, const float* __restri
             r.m1 = ldo(ep, fgb);
             if (ADD) {
                 const float* __restrict__ ap = ADD + sample + (size_t)to * W;
-                r.a0 = ldo(ap, o0);
-                r.a1 = ldo(ap, o1);
+                const f32x2 ar = ldo2(ap, o2);
+                r.a0 = whole ? ar.x : ar.y;
+                r.a1 = ar.y;
             }
         }
         return r;
@@ -334,8 +351,8 @@ __device__ __forceinline__ void dw1p_body(const DwArgs& a, const float* __restri
             acc += bias[n];
             if (MODE == 0) {
                 float* __restrict__ o_ = (n == 0 ? OUT : n == 1 ? OUT1 : n == 2 ? OUT2 : OUT3) + orow;
-                if (live) sto(o_, o0, acc.x);
-                if (liveb) sto(o_, o1, acc.y);
+                if (liveb) sto2(o_, o0, acc);
+                else if (live) sto(o_, o0, acc.x);
             }
             if (MODE != 2) {
                 const f32x2 am = acc * m;
@@ -347,8 +364,8 @@ __device__ __forceinline__ void dw1p_body(const DwArgs& a, const float* __restri
                 f32x2 y = (acc * lsc + lsh) * gate + emb;
                 if (ADD) y += f32x2{fmaf(e.a0, asc, ash), fmaf(e.a1, asc, ash)};
                 float* __restrict__ o_ = OUT + orow;
-                if (live) sto(o_, o0, y.x);
-                if (liveb) sto(o_, o1, y.y);
+                if (liveb) sto2(o_, o0, y);
+                else if (live) sto(o_, o0, y.x);
             }
         }
     };

@@ -61,6 +61,32 @@ __global__ __launch_bounds__(256) void v2_rows(const float* __restrict__ x, floa
     if (acc.x + acc.y == 123.456f) out[0] = acc.x;
 }
 
+// 16-byte loads from a base that is only 4-byte aligned (row pitch odd): does the hardware take them, at what rate?
+__global__ __launch_bounds__(256) void v3_flat4_unaligned(const float* __restrict__ x, float* __restrict__ out, size_t n4) {
+    typedef float f4 __attribute__((ext_vector_type(4), aligned(4)));
+    float s = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const f4 v = *reinterpret_cast<const f4*>(x + 1 + 4 * i);
+        s += v.x + v.y + v.z + v.w;
+    }
+    if (s == 123.456f) out[0] = s;
+}
+__global__ __launch_bounds__(256) void v4_flat2_unaligned(const float* __restrict__ x, float* __restrict__ out, size_t n2) {
+    typedef float f2 __attribute__((ext_vector_type(2), aligned(4)));
+    float s = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += (size_t)gridDim.x * 256) {
+        const f2 v = *reinterpret_cast<const f2*>(x + 1 + 2 * i);
+        s += v.x + v.y;
+    }
+    if (s == 123.456f) out[0] = s;
+}
+// correctness of the unaligned vector load
+__global__ void v3_check(const float* __restrict__ x, float* __restrict__ out) {
+    typedef float f4 __attribute__((ext_vector_type(4), aligned(4)));
+    const f4 v = *reinterpret_cast<const f4*>(x + 1 + 4 * threadIdx.x);
+    out[threadIdx.x] = v.x + 10.f * v.y + 100.f * v.z + 1000.f * v.w;
+}
+
 int main() {
     const int B = 32, C = 64, H = 251, W = 129;
     const size_t n = (size_t)B * C * H * W;
@@ -83,8 +109,21 @@ int main() {
     timeit("flat dword, 2048 WGs", [&] { hipLaunchKernelGGL(v0_flat, dim3(2048), dim3(256), 0, 0, x, out, n); });
     timeit("flat dword, 8192 WGs", [&] { hipLaunchKernelGGL(v0_flat, dim3(8192), dim3(256), 0, 0, x, out, n); });
     timeit("flat dwordx4, 2048 WGs", [&] { hipLaunchKernelGGL(v1_flat4, dim3(2048), dim3(256), 0, 0, (const float4*)x, out, n / 4); });
+    timeit("flat dwordx4 +4B misaligned, 2048 WGs", [&] { hipLaunchKernelGGL(v3_flat4_unaligned, dim3(2048), dim3(256), 0, 0, x, out, n / 4 - 1); });
+    timeit("flat dwordx2 +4B misaligned, 2048 WGs", [&] { hipLaunchKernelGGL(v4_flat2_unaligned, dim3(2048), dim3(256), 0, 0, x, out, n / 2 - 1); });
+    {
+        std::vector<float> hx(1024);
+        for (int i = 0; i < 1024; ++i) hx[i] = (float)(i % 7);
+        hipMemcpy(x, hx.data(), 4096, hipMemcpyHostToDevice);
+        float* o2; hipMalloc(&o2, 256);
+        hipLaunchKernelGGL(v3_check, dim3(1), dim3(64), 0, 0, x, o2);
+        float ho[64]; hipMemcpy(ho, o2, 256, hipMemcpyDeviceToHost);
+        int bad = 0;
+        for (int t = 0; t < 64; ++t) { const float e = hx[1 + 4 * t] + 10.f * hx[2 + 4 * t] + 100.f * hx[3 + 4 * t] + 1000.f * hx[4 + 4 * t]; bad += ho[t] != e; }
+        printf("unaligned dwordx4 load check: %s\n", bad ? "WRONG" : "ok");
+    }
     const int NP = (W + 1) / 2, gx = (C * NP + 255) / 256;
-    for (int TH : {32, 64}) {
+    for (int TH : {64}) {
         char nm[64];
         const dim3 grid(gx, (H + TH - 1) / TH, B);
         snprintf(nm, 64, "rows U=2 sum TH=%d", TH);  timeit(nm, [&] { hipLaunchKernelGGL((v2_rows<2, false>), grid, dim3(256), 0, 0, x, out, C, H, W, TH); });
