@@ -14,14 +14,14 @@
 enum { PRO_NONE = 0, PRO_GATEWAY = 2 };
 enum { EPI_BIAS = 0, EPI_BIAS_RES = 1 };
 
-template <int CIN, int COUT, int PRO, int EPI, bool HAS_X2, bool CAF>
+template <int CIN, int COUT, int PRO, int EPI, bool HAS_X2, bool CAF, int S>
 __device__ __forceinline__ void pws_body(const PwArgs& a, int ntiles, int tiles_per_sample, const float* __restrict__ X,
                                          const float* __restrict__ X2, float* __restrict__ RES, const float* __restrict__ AUX,
                                          float* __restrict__ OUT) {
     constexpr int LDW = CIN + 8;       // padded weight row (halfs): 16-byte rows shifted by 4 banks -> conflict-free b128
     constexpr int MTW = COUT / 32 > 4 ? 4 : COUT / 32;  // co tiles per wave (<= 64 accumulator registers)
     constexpr int CSPLIT = COUT / 32 / MTW;             // waves sharing one 32-pixel tile (each re-reads its x)
-    constexpr int PTB = 32 * (4 / CSPLIT);              // pixels per workgroup tile
+    constexpr int PTB = 32 * S * (4 / CSPLIT);          // pixels per workgroup tile (S adjacent pixels per lane)
     constexpr float WINV = 1.0f / 256.0f;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     _Float16* Wh = reinterpret_cast<_Float16*>(smem);
@@ -62,74 +62,125 @@ __device__ __forceinline__ void pws_body(const PwArgs& a, int ntiles, int tiles_
     const int P = a.P;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int b = tile / tiles_per_sample;
-        const int p = (tile - b * tiles_per_sample) * PTB + (wave / CSPLIT) * 32 + r;
+        // lane r owns the S adjacent pixels p0 .. p0+S-1 (slot s = column r of MFMA tile s); S == 2: one unaligned 8-byte
+        // access per channel row instead of two dword accesses (a dword stream tops out at 4.9 TB/s, dwordx2 at 7)
+        const int p0 = (tile - b * tiles_per_sample) * PTB + (wave / CSPLIT) * 32 * S + S * r;
         const int m0 = (wave % CSPLIT) * MTW;
-        const bool live = p < P;
-        const size_t xb = (size_t)b * CIN * P + (live ? p : P - 1);
-        size_t cafb = 0;
+        bool live[S];
+#pragma unroll
+        for (int sl = 0; sl < S; ++sl) live[sl] = p0 + sl < P;
+        // S == 2 load position: (p0, p0+1) normally; the sample's last pixel and dead lanes read (P-2, P-1)
+        const int pl = S == 2 ? min(p0, P - 2) : (live[0] ? p0 : P - 1);
+        const bool tail = S == 2 && p0 == P - 1;  // lane holds pixel P-1 in .y
+        const size_t xb = (size_t)b * CIN * P + pl;
+        size_t cafb[S];
         if (CAF) {  // nearest up-sampling of the video-side terms: tv = floor(t * Tv / T)
-            const int t = (live ? p : P - 1) / a.caf_F;
-            cafb = (size_t)b * CIN * a.caf_Tv + nearest_src(t, a.caf_Tv, a.caf_T);
+#pragma unroll
+            for (int sl = 0; sl < S; ++sl) {
+                const int t = min(p0 + sl, P - 1) / a.caf_F;
+                cafb[sl] = (size_t)b * CIN * a.caf_Tv + nearest_src(t, a.caf_Tv, a.caf_T);
+            }
         }
-        f32x16 acc[MTW];
+        auto load = [&](const float* __restrict__ src, size_t off, float (&d)[S]) {
+            if (S == 2) {
+                typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+                const f2u t2 = *reinterpret_cast<const f2u*>(src + off);
+                d[0] = tail ? t2.y : t2.x;
+                d[S - 1] = t2.y;
+            } else {
+                d[0] = src[off];
+            }
+        };
+        auto store = [&](float* __restrict__ dst, size_t off, const float (&d)[S]) {  // off = position of pixel p0
+            if (S == 2) {
+                typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+                if (live[S - 1]) *reinterpret_cast<f2u*>(dst + off) = f2u{d[0], d[S - 1]};
+                else if (live[0]) dst[off] = d[0];
+            } else {
+                if (live[0]) dst[off] = d[0];
+            }
+        };
+        const size_t ob_in = (size_t)b * CIN * P + p0;  // store position (pixel p0) in a CIN-channel tensor
+        f32x16 acc[MTW][S];
 #pragma unroll
         for (int m = 0; m < MTW; ++m)
 #pragma unroll
-            for (int q = 0; q < 16; ++q) acc[m][q] = 0.f;
+            for (int sl = 0; sl < S; ++sl)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[m][sl][q] = 0.f;
 #pragma unroll 2
         for (int ks = 0; ks < CIN; ks += 16) {
-            float v[8];
+            float v[8][S];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const size_t off = xb + (size_t)(ks + 8 * h + j) * P;
-                v[j] = X[off];  // dead lanes read a valid (clamped) pixel; nothing of theirs is stored
+                load(X, off, v[j]);  // dead lanes read valid (clamped) pixels; nothing of theirs is stored
                 if (CAF) {
                     const int ci = ks + 8 * h + j;
-                    const size_t co_ = cafb + (size_t)ci * a.caf_Tv;
-                    v[j] = fmaf(fmaxf(fmaf(v[j], cks[ci], ckb[ci]), 0.f), a.caf_r[co_], a.caf_att[co_] * fmaf(v[j], cvs[ci], cvb[ci]));
+#pragma unroll
+                    for (int sl = 0; sl < S; ++sl) {
+                        const size_t co_ = cafb[sl] + (size_t)ci * a.caf_Tv;
+                        v[j][sl] = fmaf(fmaxf(fmaf(v[j][sl], cks[ci], ckb[ci]), 0.f), a.caf_r[co_], a.caf_att[co_] * fmaf(v[j][sl], cvs[ci], cvb[ci]));
+                    }
                 }
-                if (PRO == PRO_GATEWAY && HAS_X2) v[j] += X2[off];
+                if (PRO == PRO_GATEWAY && HAS_X2) {
+                    float x2v[S];
+                    load(X2, off, x2v);
+#pragma unroll
+                    for (int sl = 0; sl < S; ++sl) v[j][sl] += x2v[sl];
+                }
             }
             if (PRO == PRO_GATEWAY) {
                 const f32x4 s0 = *reinterpret_cast<const f32x4*>(gsc + ks + 8 * h), s1 = *reinterpret_cast<const f32x4*>(gsc + ks + 8 * h + 4);
                 const f32x4 t0 = *reinterpret_cast<const f32x4*>(gsh + ks + 8 * h), t1 = *reinterpret_cast<const f32x4*>(gsh + ks + 8 * h + 4);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    v[j] = preluf_(fmaf(v[j], j < 4 ? s0[j & 3] : s1[j & 3], j < 4 ? t0[j & 3] : t1[j & 3]), slope);
-                    if (live) RES[xb + (size_t)(ks + 8 * h + j) * P] = v[j];
+#pragma unroll
+                    for (int sl = 0; sl < S; ++sl)
+                        v[j][sl] = preluf_(fmaf(v[j][sl], j < 4 ? s0[j & 3] : s1[j & 3], j < 4 ? t0[j & 3] : t1[j & 3]), slope);
+                    store(RES, ob_in + (size_t)(ks + 8 * h + j) * P, v[j]);
                 }
             }
-            half8 bh, bl;
+            half8 bh[S], bl[S];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const _Float16 hi = (_Float16)v[j];
-                bh[j] = hi;
-                bl[j] = (_Float16)(v[j] - (float)hi);
-            }
+            for (int sl = 0; sl < S; ++sl)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const _Float16 hi = (_Float16)v[j][sl];
+                    bh[sl][j] = hi;
+                    bl[sl][j] = (_Float16)(v[j][sl] - (float)hi);
+                }
 #pragma unroll
             for (int m = 0; m < MTW; ++m) {
                 const half8 ah = *reinterpret_cast<const half8*>(Wh + ((m0 + m) * 32 + r) * LDW + ks + 8 * h);
                 const half8 al = *reinterpret_cast<const half8*>(Wl + ((m0 + m) * 32 + r) * LDW + ks + 8 * h);
-                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[m], 0, 0, 0);
-                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[m], 0, 0, 0);
-                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[m], 0, 0, 0);
+#pragma unroll
+                for (int sl = 0; sl < S; ++sl) {
+                    acc[m][sl] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[sl], acc[m][sl], 0, 0, 0);
+                    acc[m][sl] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[sl], acc[m][sl], 0, 0, 0);
+                    acc[m][sl] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[sl], acc[m][sl], 0, 0, 0);
+                }
             }
         }
-        if (live) {
-            const size_t ob = (size_t)b * COUT * P + p;
+        if (live[0]) {
+            const size_t ob = (size_t)b * COUT * P + p0, lb = (size_t)b * COUT * P + pl;
 #pragma unroll
             for (int m = 0; m < MTW; ++m) {
-                float res[16];
+                float res[16][S];
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {
                     const int co = (m0 + m) * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
-                    res[q] = 0.f;
-                    if (EPI == EPI_BIAS_RES) res[q] = AUX[ob + (size_t)co * P];
+#pragma unroll
+                    for (int sl = 0; sl < S; ++sl) res[q][sl] = 0.f;
+                    if (EPI == EPI_BIAS_RES) load(AUX, lb + (size_t)co * P, res[q]);
                 }
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {
                     const int co = (m0 + m) * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
-                    OUT[ob + (size_t)co * P] = fmaf(acc[m][q], WINV, a.bias[co]) + res[q];
+                    float o_[S];
+#pragma unroll
+                    for (int sl = 0; sl < S; ++sl) o_[sl] = fmaf(acc[m][sl][q], WINV, a.bias[co]) + res[q][sl];
+                    store(OUT, ob + (size_t)co * P, o_);
                 }
                 __builtin_amdgcn_sched_barrier(0);  // keep the 16-load / 16-store groups apart (register pressure)
             }
@@ -137,24 +188,26 @@ __device__ __forceinline__ void pws_body(const PwArgs& a, int ntiles, int tiles_
     }
 }
 
-template <int CIN, int COUT, int PRO, int EPI, bool HAS_X2, bool CAF>
+template <int CIN, int COUT, int PRO, int EPI, bool HAS_X2, bool CAF, int S>
 __global__ __launch_bounds__(256, 2) void pws_kernel(PwArgs a, int ntiles, int tiles_per_sample) {
-    pws_body<CIN, COUT, PRO, EPI, HAS_X2, CAF>(a, ntiles, tiles_per_sample, a.x, a.x2, a.res_out, a.aux, a.out);
+    pws_body<CIN, COUT, PRO, EPI, HAS_X2, CAF, S>(a, ntiles, tiles_per_sample, a.x, a.x2, a.res_out, a.aux, a.out);
 }
 
 template <int CIN, int COUT, int PRO, int EPI, bool HAS_X2, bool CAF = false>
 static int launch_pws_t(const PwArgs& a, int B, hipStream_t st) {
+    constexpr int S = COUT <= 64 ? 2 : 1;  // two pixels per lane where the accumulators allow it (COUT 64: 64 registers)
+    if (a.P < 2) return RTFS_ERR_SHAPE;
     const size_t lds = (size_t)2 * COUT * (CIN + 8) * 2 + (size_t)(CAF ? 6 : 2) * CIN * 4;
     static bool configured = false;
     if (!configured) {
-        if (hipFuncSetAttribute((const void*)pws_kernel<CIN, COUT, PRO, EPI, HAS_X2, CAF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)pws_kernel<CIN, COUT, PRO, EPI, HAS_X2, CAF, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return RTFS_ERR_LAUNCH;
         configured = true;
     }
-    constexpr int PTB = 32 * (4 / (COUT / 32 > 4 ? COUT / 32 / 4 : 1));
+    constexpr int PTB = 32 * S * (4 / (COUT / 32 > 4 ? COUT / 32 / 4 : 1));
     const int tps = cdiv(a.P, PTB), ntiles = tps * B;
     const int grid = ntiles < 512 ? ntiles : 512;  // 2 resident workgroups per CU
-    hipLaunchKernelGGL((pws_kernel<CIN, COUT, PRO, EPI, HAS_X2, CAF>), dim3(grid), dim3(256), lds, st, a, ntiles, tps);
+    hipLaunchKernelGGL((pws_kernel<CIN, COUT, PRO, EPI, HAS_X2, CAF, S>), dim3(grid), dim3(256), lds, st, a, ntiles, tps);
     return rtfs_launch_status();
 }
 

@@ -87,13 +87,48 @@ __global__ void v3_check(const float* __restrict__ x, float* __restrict__ out) {
     out[threadIdx.x] = v.x + 10.f * v.y + 100.f * v.z + 1000.f * v.w;
 }
 
+__global__ __launch_bounds__(256) void c0_copy(const float* __restrict__ x, float* __restrict__ y, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) y[i] = x[i] * 1.5f;
+}
+__global__ __launch_bounds__(256) void c1_copy4(const float4* __restrict__ x, float4* __restrict__ y, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) { float4 v = x[i]; v.x *= 1.5f; y[i] = v; }
+}
+__global__ __launch_bounds__(256) void c2_copy2u(const float* __restrict__ x, float* __restrict__ y, size_t n2) {
+    typedef float f2 __attribute__((ext_vector_type(2), aligned(4)));
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += (size_t)gridDim.x * 256) {
+        f2 v = *reinterpret_cast<const f2*>(x + 1 + 2 * i); v.x *= 1.5f; *reinterpret_cast<f2*>(y + 1 + 2 * i) = v;
+    }
+}
+// the pointwise kernels' pattern: a wave owns 32*S consecutive pixels and walks the channel rows (pitch P, odd) of one sample
+template <int S>
+__global__ __launch_bounds__(256) void c3_rows(const float* __restrict__ x, float* __restrict__ y, int C, int P, int ntiles, int tps) {
+    typedef float fv __attribute__((ext_vector_type(S), aligned(4)));
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5, wave = threadIdx.x >> 6;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int b = tile / tps;
+        const int p0 = min((tile - b * tps) * 128 * S + wave * 32 * S + S * r, P - S);
+        const float* xs = x + (size_t)b * C * P + p0;
+        float* ys = y + (size_t)b * C * P + p0;
+#pragma unroll 2
+        for (int ks = 0; ks < C; ks += 16) {
+            fv v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const fv*>(xs + (size_t)(ks + 8 * h + j) * P);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { v[j] *= 1.5f; *reinterpret_cast<fv*>(ys + (size_t)(ks + 8 * h + j) * P) = v[j]; }
+        }
+    }
+}
+
 int main() {
+    const int SCALE = 4;
     const int B = 32, C = 64, H = 251, W = 129;
     const size_t n = (size_t)B * C * H * W;
+    const size_t nbig = n * SCALE;
     float *x, *out;
-    CK(hipMalloc(&x, n * 4 + 64));
+    CK(hipMalloc(&x, nbig * 4 + 64));
     CK(hipMalloc(&out, 64));
-    CK(hipMemset(x, 0, n * 4 + 64));
+    CK(hipMemset(x, 0, nbig * 4 + 64));
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     auto timeit = [&](const char* name, auto launch) {
@@ -121,6 +156,34 @@ int main() {
         int bad = 0;
         for (int t = 0; t < 64; ++t) { const float e = hx[1 + 4 * t] + 10.f * hx[2 + 4 * t] + 100.f * hx[3 + 4 * t] + 1000.f * hx[4 + 4 * t]; bad += ho[t] != e; }
         printf("unaligned dwordx4 load check: %s\n", bad ? "WRONG" : "ok");
+    }
+    float* y;
+    CK(hipMalloc(&y, nbig * 4 + 64));
+    size_t nn = n;
+    auto timeit2 = [&](const char* name, auto launch) {
+        for (int i = 0; i < 3; ++i) launch();
+        hipEventRecord(e0);
+        const int R = 20;
+        for (int i = 0; i < R; ++i) launch();
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        printf("%-40s %8.1f us  %6.2f TB/s (read + write)\n", name, ms / R * 1e3, 2 * nn * 4.0 / (ms / R * 1e-3) / 1e12);
+    };
+    timeit2("copy dword", [&] { hipLaunchKernelGGL(c0_copy, dim3(4096), dim3(256), 0, 0, x, y, n); });
+    timeit2("copy dwordx4 aligned", [&] { hipLaunchKernelGGL(c1_copy4, dim3(4096), dim3(256), 0, 0, (const float4*)x, (float4*)y, n / 4); });
+    timeit2("copy dwordx2 +4B misaligned", [&] { hipLaunchKernelGGL(c2_copy2u, dim3(4096), dim3(256), 0, 0, x, y, n / 2 - 1); });
+    nn = nbig;
+    timeit2("copy dword 1 GB", [&] { hipLaunchKernelGGL(c0_copy, dim3(4096), dim3(256), 0, 0, x, y, nbig); });
+    timeit2("copy dwordx4 aligned 1 GB", [&] { hipLaunchKernelGGL(c1_copy4, dim3(4096), dim3(256), 0, 0, (const float4*)x, (float4*)y, nbig / 4); });
+    {
+        const int Cc = 64 * 4, P = 251 * 129, Bc = 8 * SCALE;  // (8, 256, P): same bytes as (32, 64, P); SCALE 4 = the real tensors
+        int tps = (P + 127) / 128, nt = tps * Bc;
+        timeit2("rows copy S=1 (256 ch rows, pitch odd)", [&] { hipLaunchKernelGGL((c3_rows<1>), dim3(512), dim3(256), 0, 0, x, y, Cc, P, nt, tps); });
+        tps = (P + 255) / 256; nt = tps * Bc;
+        timeit2("rows copy S=2", [&] { hipLaunchKernelGGL((c3_rows<2>), dim3(512), dim3(256), 0, 0, x, y, Cc, P, nt, tps); });
+        tps = (P + 511) / 512; nt = tps * Bc;
+        timeit2("rows copy S=4", [&] { hipLaunchKernelGGL((c3_rows<4>), dim3(512), dim3(256), 0, 0, x, y, Cc, P, nt, tps); });
     }
     const int NP = (W + 1) / 2, gx = (C * NP + 255) / 256;
     for (int TH : {64}) {
