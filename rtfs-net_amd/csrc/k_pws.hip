@@ -215,7 +215,109 @@ int launch_pws_gateway_proj(const PwArgs& a, int B, hipStream_t st) {
     if (a.caf_r) return a.x2 ? launch_pws_t<256, 64, PRO_GATEWAY, EPI_BIAS, true, true>(a, B, st) : RTFS_ERR_ARG;
     return a.x2 ? launch_pws_t<256, 64, PRO_GATEWAY, EPI_BIAS, true>(a, B, st) : launch_pws_t<256, 64, PRO_GATEWAY, EPI_BIAS, false>(a, B, st);
 }
-int launch_pws_residual(const PwArgs& a, int B, hipStream_t st) { return launch_pws_t<64, 256, PRO_NONE, EPI_BIAS_RES, false>(a, B, st); }
+
+
+// ---------------------------------------------------------------- block tail: residual_conv (64 -> 256) + bias + residual
+// (separators/tdanet.py:129) with TWO adjacent pixels per lane: every access of the 256-channel residual / output rows is
+// one unaligned 8-byte load / store (the row-walk pattern runs at 4.4 TB/s with 8-byte accesses against 3.1 with dwords,
+// tools/bench_stream.hip).  Same dataflow as GEMM 1 of the block-boundary kernel below: a wave keeps the 64 input channels
+// of its 64 pixels as B fragments and produces one 32-channel output tile at a time (16 + 16 accumulator registers).
+typedef float f32x2u_ __attribute__((ext_vector_type(2), aligned(4)));
+__device__ __forceinline__ void pws_res2_body(const PwArgs& a, int ntiles, int tiles_per_sample, const float* __restrict__ X,
+                                              const float* __restrict__ AUX, float* __restrict__ OUT) {
+    constexpr int L1 = 64 + 8;
+    constexpr float WINV = 1.0f / 256.0f;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    _Float16* W1h = reinterpret_cast<_Float16*>(smem);  // [256][L1]
+    _Float16* W1l = W1h + 256 * L1;
+    float* b1 = reinterpret_cast<float*>(W1l + 256 * L1);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    {
+        const half8* s1 = reinterpret_cast<const half8*>(a.w16);  // [2 chunks][hi|lo][256][32]
+        for (int i = tid; i < 2 * 2 * 256 * 4; i += 256) {
+            const int pc = i & 3, co = (i >> 2) & 255, part = (i >> 10) & 1, chunk = i >> 11;
+            *reinterpret_cast<half8*>((part ? W1l : W1h) + co * L1 + chunk * 32 + pc * 8) = s1[i];
+        }
+        b1[tid] = a.bias[tid];
+    }
+    __syncthreads();
+    const int P = a.P;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int b = tile / tiles_per_sample;
+        const int p0 = (tile - b * tiles_per_sample) * 256 + wave * 64 + 2 * r;  // this lane's pixels p0, p0 + 1
+        const bool live0 = p0 < P, live1 = p0 + 1 < P;
+        const int pl = min(p0, P - 2);     // load position: the sample's last pixel and dead lanes read (P-2, P-1)
+        const bool tail = p0 == P - 1;     // ... and take pixel P-1 from .y
+        const float* __restrict__ xs = X + (size_t)b * 64 * P;
+        const float* __restrict__ rs = AUX + (size_t)b * 256 * P;
+        float* __restrict__ os = OUT + (size_t)b * 256 * P;
+        half8 xh[4][2], xl[4][2];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            f32x2u_ v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const f32x2u_*>(xs + (unsigned)((ks * 16 + 8 * h + j) * P + pl));
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float v0 = tail ? v[j].y : v[j].x, v1 = v[j].y;
+                const _Float16 h0 = (_Float16)v0, h1 = (_Float16)v1;
+                xh[ks][0][j] = h0;
+                xl[ks][0][j] = (_Float16)(v0 - (float)h0);
+                xh[ks][1][j] = h1;
+                xl[ks][1][j] = (_Float16)(v1 - (float)h1);
+            }
+        }
+#pragma unroll 1
+        for (int m = 0; m < 8; ++m) {
+            const int cob = m * 32 + 4 * h;  // channel of accumulator register q: cob + (q&3) + 8*(q>>2)
+            f32x2u_ res[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) res[q] = *reinterpret_cast<const f32x2u_*>(rs + (unsigned)((cob + (q & 3) + 8 * (q >> 2)) * P + pl));
+            f32x16 acc[2];
+#pragma unroll
+            for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[sl][q] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const half8 ah = *reinterpret_cast<const half8*>(W1h + (m * 32 + r) * L1 + ks * 16 + 8 * h);
+                const half8 al = *reinterpret_cast<const half8*>(W1l + (m * 32 + r) * L1 + ks * 16 + 8 * h);
+#pragma unroll
+                for (int sl = 0; sl < 2; ++sl) {
+                    acc[sl] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xh[ks][sl], acc[sl], 0, 0, 0);
+                    acc[sl] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xl[ks][sl], acc[sl], 0, 0, 0);
+                    acc[sl] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, xh[ks][sl], acc[sl], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int co = cob + (q & 3) + 8 * (q >> 2);
+                const float bq = b1[co];
+                const float y0 = fmaf(acc[0][q], WINV, bq) + (tail ? res[q].y : res[q].x);
+                const float y1 = fmaf(acc[1][q], WINV, bq) + res[q].y;
+                if (live1) *reinterpret_cast<f32x2u_*>(os + (unsigned)(co * P + p0)) = f32x2u_{y0, y1};
+                else if (live0) os[(unsigned)(co * P + p0)] = y0;
+            }
+        }
+    }
+}
+__global__ __launch_bounds__(256, 2) void pws_res2_kernel(PwArgs a, int ntiles, int tiles_per_sample) {
+    pws_res2_body(a, ntiles, tiles_per_sample, a.x, a.aux, a.out);
+}
+static int launch_pws_res2(const PwArgs& a, int B, hipStream_t st) {
+    if (a.P < 2) return RTFS_ERR_SHAPE;
+    const size_t lds = (size_t)2 * 256 * 72 * 2 + 256 * 4;
+    static bool configured = false;
+    if (!configured) {
+        if (hipFuncSetAttribute((const void*)pws_res2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return RTFS_ERR_LAUNCH;
+        configured = true;
+    }
+    const int tps = cdiv(a.P, 256), ntiles = tps * B;
+    const int grid = ntiles < 512 ? ntiles : 512;  // 2 resident workgroups per CU
+    hipLaunchKernelGGL(pws_res2_kernel, dim3(grid), dim3(256), lds, st, a, ntiles, tps);
+    return rtfs_launch_status();
+}
 
 // ---------------------------------------------------------------- back-to-back block boundary
 // residual_conv of block i (64 -> 256, + residual_i) fused with the gateway + projection of block i+1
@@ -393,3 +495,5 @@ static int launch_b2b_t(const B2bArgs& a, int B, hipStream_t st) {
 }
 
 int launch_pws_b2b(const B2bArgs& a, int B, hipStream_t st) { return a.caf_r ? launch_b2b_t<true>(a, B, st) : launch_b2b_t<false>(a, B, st); }
+
+int launch_pws_residual(const PwArgs& a, int B, hipStream_t st) { return launch_pws_res2(a, B, st); }
