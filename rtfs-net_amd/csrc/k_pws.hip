@@ -327,6 +327,7 @@ static int launch_pws_res2(const PwArgs& a, int B, hipStream_t st) {
 // operand of GEMM 2 *as they stand* -- registers 8s..8s+7 of co-tile m hold channels 32m+16s + (j&3) + 8(j>>2) + 4h,
 // so the projection weight image is stored with its K axis permuted to that order (packing.proj_perm).
 // Both weight matrices (141 KB of f16 hi/lo) stay resident in LDS; 8 waves per workgroup, no barriers in the loop.
+#define B2B_NT 512  // threads per workgroup (8 waves, 256 registers each; 4 waves with 512 registers measured slower)
 template <bool CAF>
 __device__ __forceinline__ void pws_b2b_body(const B2bArgs& a, int ntiles, int tiles_per_sample, const float* __restrict__ X,
                                              float* __restrict__ RES, const float* __restrict__ A1, float* __restrict__ XENC) {
@@ -348,16 +349,16 @@ __device__ __forceinline__ void pws_b2b_body(const B2bArgs& a, int ntiles, int t
     const int r = lane & 31, h = lane >> 5;
     {
         const half8* s1 = reinterpret_cast<const half8*>(a.w1_16);  // [2 chunks][hi|lo][256][32]
-        for (int i = tid; i < 2 * 2 * 256 * 4; i += 512) {
+        for (int i = tid; i < 2 * 2 * 256 * 4; i += B2B_NT) {
             const int pc = i & 3, co = (i >> 2) & 255, part = (i >> 10) & 1, chunk = i >> 11;
             *reinterpret_cast<half8*>((part ? W1l : W1h) + co * L1 + chunk * 32 + pc * 8) = s1[i];
         }
         const half8* s2 = reinterpret_cast<const half8*>(a.w2_16);  // [8 chunks][hi|lo][64][32]
-        for (int i = tid; i < 8 * 2 * 64 * 4; i += 512) {
+        for (int i = tid; i < 8 * 2 * 64 * 4; i += B2B_NT) {
             const int pc = i & 3, co = (i >> 2) & 63, part = (i >> 8) & 1, chunk = i >> 9;
             *reinterpret_cast<half8*>((part ? W2l : W2h) + co * L2 + chunk * 32 + pc * 8) = s2[i];
         }
-        for (int c = tid; c < 256; c += 512) {
+        for (int c = tid; c < 256; c += B2B_NT) {
             b1[c] = a.b1[c];
             gsc[c] = a.gw[c];
             gsh[c] = a.gb[c];
@@ -376,107 +377,137 @@ __device__ __forceinline__ void pws_b2b_body(const B2bArgs& a, int ntiles, int t
     const int P = a.P;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int b = tile / tiles_per_sample;
-        const int p = (tile - b * tiles_per_sample) * 256 + wave * 32 + r;
-        const bool live = p < P;
-        const int pc_ = live ? p : P - 1;
-        unsigned cafb = 0;
-        if (CAF) cafb = (unsigned)(b * 256 * a.caf_Tv + nearest_src(pc_ / a.caf_F, a.caf_Tv, a.caf_T));
-        // ---- B fragments of GEMM 1 (expanded_i, 64 channels of this lane's pixel): loaded once per tile
-        half8 xh[4], xl[4];
+        // two adjacent pixels per lane (slots 0 / 1 = column r of two MFMA tiles): every row access is one unaligned
+        // 8-byte load / store (row walks run at 4.4 TB/s with 8-byte accesses against 3.1 with dwords)
+        const int p0 = (tile - b * tiles_per_sample) * (B2B_NT / 64 * 64) + wave * 64 + 2 * r;
+        const bool live0 = p0 < P, live1 = p0 + 1 < P;
+        const int pl = min(p0, P - 2);  // load position: the sample's last pixel and dead lanes read (P-2, P-1)
+        const bool tail = p0 == P - 1;  // ... and take pixel P-1 from .y
+        unsigned cafb[2] = {0, 0};
+        if (CAF) {
+#pragma unroll
+            for (int sl = 0; sl < 2; ++sl)
+                cafb[sl] = (unsigned)(b * 256 * a.caf_Tv + nearest_src(min(p0 + sl, P - 1) / a.caf_F, a.caf_Tv, a.caf_T));
+        }
+        // ---- B fragments of GEMM 1 (expanded_i, 64 channels of this lane's pixels): loaded once per tile
+        half8 xh[4][2], xl[4][2];
         {
-            // wave-uniform per-sample base + 32-bit lane offsets: one VGPR per address (saddr + voffset form)
             const float* __restrict__ xs = X + (size_t)b * 64 * P;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                float v[8];
+                f32x2u_ v[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = xs[(unsigned)((ks * 16 + 8 * h + j) * P + pc_)];
+                for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const f32x2u_*>(xs + (unsigned)((ks * 16 + 8 * h + j) * P + pl));
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const _Float16 hi = (_Float16)v[j];
-                    xh[ks][j] = hi;
-                    xl[ks][j] = (_Float16)(v[j] - (float)hi);
+                    const float v0 = tail ? v[j].y : v[j].x, v1 = v[j].y;
+                    const _Float16 h0 = (_Float16)v0, h1 = (_Float16)v1;
+                    xh[ks][0][j] = h0;
+                    xl[ks][0][j] = (_Float16)(v0 - (float)h0);
+                    xh[ks][1][j] = h1;
+                    xl[ks][1][j] = (_Float16)(v1 - (float)h1);
                 }
             }
         }
-        f32x16 acc2[2];
+        f32x16 acc2[2][2];  // [projection tile][slot]
 #pragma unroll
         for (int m2 = 0; m2 < 2; ++m2)
 #pragma unroll
-            for (int q = 0; q < 16; ++q) acc2[m2][q] = 0.f;
+            for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc2[m2][sl][q] = 0.f;
         float* __restrict__ ress = RES + (size_t)b * 256 * P;
         const float* __restrict__ a1s = A1 + (size_t)b * 256 * P;
-        // ---- one output-channel tile of the residual conv at a time (a real loop: keeps one 16-register accumulator
-        //      and one 32-load group live): GEMM 1 tile -> epilogue 1 (-> residual_{i+1}) -> its two K steps of GEMM 2
+        // ---- one output-channel tile of the residual conv at a time: GEMM 1 tile (both slots) -> epilogue 1 in two halves
+        //      of 8 accumulator registers (-> residual_{i+1}) -> each half is one K step of GEMM 2
 #pragma unroll 1
         for (int m = 0; m < 8; ++m) {
             const int cob = m * 32 + 4 * h;  // channel of accumulator register q: cob + (q&3) + 8*(q>>2)
-            float res[16], a1v[16];
+            f32x16 acc1[2];
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const unsigned o = (unsigned)((cob + (q & 3) + 8 * (q >> 2)) * P + pc_);
-                res[q] = ress[o];
-                a1v[q] = a1s[o];
-            }
-            f32x16 acc1;
+            for (int sl = 0; sl < 2; ++sl)
 #pragma unroll
-            for (int q = 0; q < 16; ++q) acc1[q] = 0.f;
+                for (int q = 0; q < 16; ++q) acc1[sl][q] = 0.f;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const half8 ah = *reinterpret_cast<const half8*>(W1h + (m * 32 + r) * L1 + ks * 16 + 8 * h);
                 const half8 al = *reinterpret_cast<const half8*>(W1l + (m * 32 + r) * L1 + ks * 16 + 8 * h);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xh[ks], acc1, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xl[ks], acc1, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, xh[ks], acc1, 0, 0, 0);
-            }
-            float rv[16];
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int co = cob + (q & 3) + 8 * (q >> 2);
-                float y = fmaf(acc1[q], WINV, b1[co]) + res[q];  // out_i
-                if (CAF) {
-                    const unsigned ci = cafb + (unsigned)(co * a.caf_Tv);
-                    y = fmaf(fmaxf(fmaf(y, cks[co], ckb[co]), 0.f), a.caf_r[ci], a.caf_att[ci] * fmaf(y, cvs[co], cvb[co]));
+                for (int sl = 0; sl < 2; ++sl) {
+                    acc1[sl] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xh[ks][sl], acc1[sl], 0, 0, 0);
+                    acc1[sl] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xl[ks][sl], acc1[sl], 0, 0, 0);
+                    acc1[sl] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, xh[ks][sl], acc1[sl], 0, 0, 0);
                 }
-                y += a1v[q];
-                rv[q] = preluf_(fmaf(y, gsc[co], gsh[co]), slope);
-                if (live) ress[(unsigned)(co * P + pc_)] = rv[q];
             }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                half8 bh, bl;
+            for (int s = 0; s < 2; ++s) {  // accumulator registers 8s .. 8s+7 = K step 2m+s of GEMM 2
+                half8 bh[2], bl[2];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const _Float16 hi = (_Float16)rv[8 * s + j];
-                    bh[j] = hi;
-                    bl[j] = (_Float16)(rv[8 * s + j] - (float)hi);
+                for (int u = 0; u < 2; ++u) {  // quarter tiles: 4 channels x 2 pixels of residual and a1 in flight at a time
+                    f32x2u_ res[4], a1v[4];
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        const int q = 8 * s + 4 * u + jj;
+                        const unsigned o = (unsigned)((cob + (q & 3) + 8 * (q >> 2)) * P + pl);
+                        res[jj] = *reinterpret_cast<const f32x2u_*>(ress + o);
+                        a1v[jj] = *reinterpret_cast<const f32x2u_*>(a1s + o);
+                    }
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        const int j = 4 * u + jj, q = 8 * s + j;
+                        const int co = cob + (q & 3) + 8 * (q >> 2);
+                        float y[2];
+#pragma unroll
+                        for (int sl = 0; sl < 2; ++sl) {
+                            float t = fmaf(acc1[sl][q], WINV, b1[co]) + (sl == 0 ? (tail ? res[jj].y : res[jj].x) : res[jj].y);  // out_i
+                            if (CAF) {
+                                const unsigned ci = cafb[sl] + (unsigned)(co * a.caf_Tv);
+                                t = fmaf(fmaxf(fmaf(t, cks[co], ckb[co]), 0.f), a.caf_r[ci], a.caf_att[ci] * fmaf(t, cvs[co], cvb[co]));
+                            }
+                            t += sl == 0 ? (tail ? a1v[jj].y : a1v[jj].x) : a1v[jj].y;
+                            t = preluf_(fmaf(t, gsc[co], gsh[co]), slope);
+                            y[sl] = t;
+                            const _Float16 hi = (_Float16)t;
+                            bh[sl][j] = hi;
+                            bl[sl][j] = (_Float16)(t - (float)hi);
+                        }
+                        if (live1) *reinterpret_cast<f32x2u_*>(ress + (unsigned)(co * P + p0)) = f32x2u_{y[0], y[1]};
+                        else if (live0) ress[(unsigned)(co * P + p0)] = y[0];
+                    }
                 }
                 const int kk = (2 * m + s) * 16 + 8 * h;
 #pragma unroll
                 for (int m2 = 0; m2 < 2; ++m2) {
                     const half8 ah = *reinterpret_cast<const half8*>(W2h + (m2 * 32 + r) * L2 + kk);
                     const half8 al = *reinterpret_cast<const half8*>(W2l + (m2 * 32 + r) * L2 + kk);
-                    acc2[m2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc2[m2], 0, 0, 0);
-                    acc2[m2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc2[m2], 0, 0, 0);
-                    acc2[m2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc2[m2], 0, 0, 0);
+#pragma unroll
+                    for (int sl = 0; sl < 2; ++sl) {
+                        acc2[m2][sl] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[sl], acc2[m2][sl], 0, 0, 0);
+                        acc2[m2][sl] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[sl], acc2[m2][sl], 0, 0, 0);
+                        acc2[m2][sl] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[sl], acc2[m2][sl], 0, 0, 0);
+                    }
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if (live) {
+        if (live0) {
             float* __restrict__ xes = XENC + (size_t)b * 64 * P;
 #pragma unroll
             for (int m2 = 0; m2 < 2; ++m2)
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {
                     const int co = m2 * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
-                    xes[(unsigned)(co * P + p)] = fmaf(acc2[m2][q], WINV, a.bp[co]);
+                    const float y0 = fmaf(acc2[m2][0][q], WINV, a.bp[co]), y1 = fmaf(acc2[m2][1][q], WINV, a.bp[co]);
+                    if (live1) *reinterpret_cast<f32x2u_*>(xes + (unsigned)(co * P + p0)) = f32x2u_{y0, y1};
+                    else xes[(unsigned)(co * P + p0)] = y0;
                 }
         }
     }
 }
 
 template <bool CAF>
-__global__ __launch_bounds__(512) void pws_b2b_kernel(B2bArgs a, int ntiles, int tiles_per_sample) {
+__global__ __launch_bounds__(B2B_NT) void pws_b2b_kernel(B2bArgs a, int ntiles, int tiles_per_sample) {
     pws_b2b_body<CAF>(a, ntiles, tiles_per_sample, a.x, a.res, a.a1, a.xenc);
 }
 
@@ -488,9 +519,10 @@ static int launch_b2b_t(const B2bArgs& a, int B, hipStream_t st) {
         if (hipFuncSetAttribute((const void*)pws_b2b_kernel<CAF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return RTFS_ERR_LAUNCH;
         configured = true;
     }
-    const int tps = cdiv(a.P, 256), ntiles = tps * B;
+    if (a.P < 2) return RTFS_ERR_SHAPE;
+    const int tps = cdiv(a.P, B2B_NT / 64 * 64), ntiles = tps * B;
     const int grid = ntiles < 256 ? ntiles : 256;  // one resident 8-wave workgroup per CU
-    hipLaunchKernelGGL((pws_b2b_kernel<CAF>), dim3(grid), dim3(512), lds, st, a, ntiles, tps);
+    hipLaunchKernelGGL((pws_b2b_kernel<CAF>), dim3(grid), dim3(B2B_NT), lds, st, a, ntiles, tps);
     return rtfs_launch_status();
 }
 
