@@ -201,13 +201,23 @@ __device__ __forceinline__ void dw1p_body(const DwArgs& a, const float* __restri
     // the pair as ONE 8-byte access at column x0; the odd-width row's last pair (x1 == W) reads (x0-1, x0) instead
     const bool whole = x1 < W;
     const unsigned o2 = whole ? o0 : o0 - 4u;
+    // MODE 2: the gate / embedding tensors live at low resolution (Hg x Wg); output (t, x) reads ('nearest', legacy)
+    // row floor(t Hg / H), column floor(x Wg / W).  When 2 Wg <= W the pair's two source columns are s0 and s0 or s0 + 1, and
+    // s0 + 1 is then exactly the NEXT lane's s0: one load per lane and row instead of two, the neighbour's by DPP.  The
+    // source row changes only every H / Hg output rows (a wave-uniform event): the loads and the sigmoid are redone only
+    // then.  Together 4 gathers + 2 sigmoids per output row become ~1 + ~1.
     unsigned fga = 0, fgb = 0;
+    bool gnext = false;
+    const bool gshare = MODE == 2 && 2 * a.Wg <= W;  // uniform
     const size_t gsample = MODE == 2 ? (size_t)b * C * a.Hg * a.Wg : 0;
-    if (MODE == 2) {  // legacy 'nearest' source column floor(x Wg / W) (32-bit: x Wg < 2^31 is checked by the launcher)
+    if (MODE == 2) {
         const unsigned gpa = (unsigned)c * (unsigned)(a.Hg * a.Wg) * 4u;
         const unsigned xb_ = (unsigned)(x1 < W ? x1 : W - 1);
-        fga = gpa + 4u * min((unsigned)x0 * (unsigned)a.Wg / (unsigned)W, (unsigned)a.Wg - 1u);
-        fgb = gpa + 4u * min(xb_ * (unsigned)a.Wg / (unsigned)W, (unsigned)a.Wg - 1u);
+        const unsigned s0 = min((unsigned)x0 * (unsigned)a.Wg / (unsigned)W, (unsigned)a.Wg - 1u);
+        const unsigned s1 = min(xb_ * (unsigned)a.Wg / (unsigned)W, (unsigned)a.Wg - 1u);
+        fga = gpa + 4u * s0;
+        fgb = gpa + 4u * s1;
+        gnext = s1 != s0;
     }
     const bool border = r0 == 0 || r1 + 3 > H;  // block-uniform: only these bands ever see an out-of-image row
     // MODE 2: low-resolution source row floor(t Hg / H) as an incremental quotient / remainder, advanced in LOAD order
@@ -220,7 +230,8 @@ __device__ __forceinline__ void dw1p_body(const DwArgs& a, const float* __restri
     // A row in flight: own pair + the edge lanes' extra columns (raw) and, for MODE 2, everything else output row t-2 will
     // need (gate / embedding gathers, addend) -- these passes are bound by bytes in flight (a wave with two rows
     // outstanding sustains 2.6 TB/s chip-wide), so every load of a row is issued RQ rows before its use.
-    struct Raw { float v0, v1, g0, g1, m0, m1, a0, a1; };
+    struct Raw { float v0, v1, g0, g1, m0, m1, a0, a1; int fresh; };
+    int tg_loaded = -1;
     auto load_raw = [&](int t) {  // window row t, and the epilogue operands of OUTPUT row t - 2
         const int tc = t < 0 ? 0 : (t < H ? t : H - 1);
         const float* __restrict__ rp = Xs_ + (size_t)tc * W;  // uniform
@@ -229,6 +240,7 @@ __device__ __forceinline__ void dw1p_body(const DwArgs& a, const float* __restri
         r.v0 = whole ? pr.x : pr.y;
         r.v1 = pr.y;  // x1 == W: zeroed in complete()
         r.g0 = r.g1 = r.m0 = r.m1 = r.a0 = r.a1 = 0.f;
+        r.fresh = 0;
         if (MODE == 2) {
             const int to = min(max(t - 2, r0), H - 1);  // output row served (clamped: the extra rows of the last trip are dropped)
             const int tg = tgq < a.Hg - 1 ? tgq : a.Hg - 1;
@@ -239,13 +251,20 @@ __device__ __forceinline__ void dw1p_body(const DwArgs& a, const float* __restri
                     ++tgq;
                 }
             }
-            const size_t grow = gsample + (size_t)tg * a.Wg;  // uniform
-            const float* __restrict__ gp = GATE + grow;
-            const float* __restrict__ ep = EMB + grow;
-            r.g0 = ldo(gp, fga);
-            r.g1 = ldo(gp, fgb);
-            r.m0 = ldo(ep, fga);
-            r.m1 = ldo(ep, fgb);
+            r.fresh = 0;
+            if (t - 2 >= r0 && tg != tg_loaded) {  // uniform
+                tg_loaded = tg;
+                r.fresh = 1;
+                const size_t grow = gsample + (size_t)tg * a.Wg;  // uniform
+                const float* __restrict__ gp = GATE + grow;
+                const float* __restrict__ ep = EMB + grow;
+                r.g0 = ldo(gp, fga);
+                r.m0 = ldo(ep, fga);
+                if (!gshare) {
+                    r.g1 = ldo(gp, fgb);
+                    r.m1 = ldo(ep, fgb);
+                }
+            }
             if (ADD) {
                 const float* __restrict__ ap = ADD + sample + (size_t)to * W;
                 const f32x2 ar = ldo2(ap, o2);
@@ -273,7 +292,7 @@ __device__ __forceinline__ void dw1p_body(const DwArgs& a, const float* __restri
     };
     // ---- start-up: every load the first trip needs (window rows r0-1 .. r0+1+RQ, the weights) is requested before the
     // first wait and before the f64 gLN folds below, so a workgroup pays one memory latency, not three
-    constexpr int RQ = MODE == 2 ? 2 : 4;  // rows per trip = prefetch distance (MODE 2 carries 6 more values per row)
+    constexpr int RQ = 2;  // rows per trip = prefetch distance
     Raw st0 = load_raw(r0 - 1), st1 = load_raw(r0), st2 = load_raw(r0 + 1);
     Raw q[RQ];
 #pragma unroll
@@ -325,6 +344,7 @@ __device__ __forceinline__ void dw1p_body(const DwArgs& a, const float* __restri
     for (int n = 0; n < NCONV; ++n) s2[n] = ss2[n] = f32x2{0.f, 0.f};
     const f32x2 wv_full = rowsum[0] + rowsum[1] + rowsum[2] + rowsum[3];
     const f32x2 m = {live ? 1.f : 0.f, liveb ? 1.f : 0.f};
+    f32x2 cur_gate = {0.f, 0.f}, cur_emb = {0.f, 0.f};
     // one output row t (both columns of the pair) from window rows t-1 .. t+2; e = the raw record that came with row t+2
     auto do_row = [&](int t, const float (&w0)[5], const float (&w1)[5], const float (&w2)[5], const float (&w3)[5], const Raw& e) {
         const size_t orow = sample + (size_t)t * W;  // uniform
@@ -359,9 +379,17 @@ __device__ __forceinline__ void dw1p_body(const DwArgs& a, const float* __restri
                 s2[n] += am;
                 ss2[n] = am * am + ss2[n];
             } else {
-                const f32x2 gate = {sigmoidf_(fmaf(e.g0, gsc, gsh)), sigmoidf_(fmaf(e.g1, gsc, gsh))};
-                const f32x2 emb = {fmaf(e.m0, esc, esh), fmaf(e.m1, esc, esh)};
-                f32x2 y = (acc * lsc + lsh) * gate + emb;
+                if (e.fresh) {  // uniform: new low-resolution source row
+                    float g1 = e.g1, m1 = e.m1;
+                    if (gshare) {
+                        const float gn = from_next_lane(e.g0), mn = from_next_lane(e.m0);
+                        g1 = gnext ? gn : e.g0;
+                        m1 = gnext ? mn : e.m0;
+                    }
+                    cur_gate = f32x2{sigmoidf_(fmaf(e.g0, gsc, gsh)), sigmoidf_(fmaf(g1, gsc, gsh))};
+                    cur_emb = f32x2{fmaf(e.m0, esc, esh), fmaf(m1, esc, esh)};
+                }
+                f32x2 y = (acc * lsc + lsh) * cur_gate + cur_emb;
                 if (ADD) y += f32x2{fmaf(e.a0, asc, ash), fmaf(e.a1, asc, ash)};
                 float* __restrict__ o_ = OUT + orow;
                 if (liveb) sto2(o_, o0, y);
