@@ -10,9 +10,6 @@
 // *normalised* input, i.e. out-of-image taps contribute 0, not `shift`.
 #include "common.h"
 #include "kernels.h"
-#ifndef DW_DBG
-#define DW_DBG 0
-#endif
 
 // ---------------------------------------------------------------- stride-1 'same' 4x4 (pad lo 1, hi 2)
 // One thread per (channel, column) walks a band of TH rows with a 4x4 register window (no LDS: the four
@@ -303,9 +300,7 @@ __device__ __forceinline__ void dw1p_body(const DwArgs& a, const float* __restri
 #pragma unroll
         for (int i = 0; i < 4; ++i) wraw[n][i] = *reinterpret_cast<const f32x4*>(a.w[n] + c * 16 + i * 4);
     float isc = 1.f, ish = 0.f;
-#if !(DW_DBG & 4)
     if (IN_AFFINE) gln_fold(a.in_stats + 2 * b, a.in_inv_count, a.in_gamma[c], a.in_beta[c], isc, ish);
-#endif
     float lsc = 1.f, lsh = 0.f, gsc = 1.f, gsh = 0.f, esc = 1.f, esh = 0.f, asc = 1.f, ash = 0.f;
     if (MODE == 2) {
         gln_fold(a.loc_stats + 2 * b, a.loc_inv_count, a.loc_gamma[c], a.loc_beta[c], lsc, lsh);
@@ -431,12 +426,8 @@ __device__ __forceinline__ void dw1p_body(const DwArgs& a, const float* __restri
     if (MODE != 2) {
 #pragma unroll
         for (int n = 0; n < NCONV; ++n) {
-#if !(DW_DBG & 2)
             block_stats_atomic(s2[n].x + s2[n].y, ss2[n].x + ss2[n].y, red, a.stats_out[n] + 2 * b);
             __syncthreads();
-#else
-            if (s2[n].x == 123.f) a.stats_out[n][0] = ss2[n].x;
-#endif
         }
     }
 }

@@ -46,19 +46,23 @@ __global__ __launch_bounds__(256) void stft_kernel(const float* __restrict__ wav
 }
 
 // Conv2d(2 -> C, 3x3, 'same', no bias) over spec (B,2,T,F) -> a0 (B,C,T,F) with channel stride cs.
-// One thread per pixel keeps its 18 taps in registers and walks the C output channels; the
-// weights are wave-uniform (scalar loads).  Also accumulates (sum, sumsq) of a0 per sample.
+// One thread per PAIR of adjacent pixels keeps its 2 x 18 taps in registers and walks the C output channels, one
+// unaligned 8-byte store per channel (the kernel is a 1 GB write stream); the weights are wave-uniform (scalar loads).
+// Also accumulates (sum, sumsq) of a0 per sample.
 __global__ __launch_bounds__(256) void enc_conv_kernel(const float* __restrict__ spec, const float* __restrict__ w,
                                                        float* __restrict__ a0, double* __restrict__ stats, int C, int T,
                                                        int F, size_t cs, size_t bs) {
+    typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
     __shared__ double red[8];
     const int P = T * F;
     const int b = blockIdx.y;
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    float tap[18];
-    const bool live = p < P;
-    {
-        const int t = live ? p / F : 0, f = live ? p % F : 0;
+    const int p0 = 2 * (blockIdx.x * 256 + threadIdx.x);
+    float tap[2][18];
+    const bool live0 = p0 < P, live1 = p0 + 1 < P;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const bool live = p0 + k < P;
+        const int t = live ? (p0 + k) / F : 0, f = live ? (p0 + k) % F : 0;
 #pragma unroll
         for (int ci = 0; ci < 2; ++ci)
 #pragma unroll
@@ -69,20 +73,27 @@ __global__ __launch_bounds__(256) void enc_conv_kernel(const float* __restrict__
                     const bool ok = live && tt >= 0 && tt < T && ff >= 0 && ff < F;
                     const int tc = tt < 0 ? 0 : (tt < T ? tt : T - 1), fc = ff < 0 ? 0 : (ff < F ? ff : F - 1);
                     const float v = spec[((size_t)b * 2 + ci) * P + (size_t)tc * F + fc];  // unconditional, clamped
-                    tap[ci * 9 + dt * 3 + df] = ok ? v : 0.f;
+                    tap[k][ci * 9 + dt * 3 + df] = ok ? v : 0.f;
                 }
     }
     float s = 0.f, ss = 0.f;
-    float* out = a0 + (size_t)b * bs + p;
+    float* out = a0 + (size_t)b * bs + p0;
     for (int c = 0; c < C; ++c) {
         const float* wc = w + c * 18;
-        float acc = 0.f;
+        float acc0 = 0.f, acc1 = 0.f;
 #pragma unroll
-        for (int j = 0; j < 18; ++j) acc = fmaf(tap[j], wc[j], acc);
-        if (live) {
-            out[(size_t)c * cs] = acc;
-            s += acc;
-            ss = fmaf(acc, acc, ss);
+        for (int j = 0; j < 18; ++j) {
+            acc0 = fmaf(tap[0][j], wc[j], acc0);
+            acc1 = fmaf(tap[1][j], wc[j], acc1);
+        }
+        if (live1) {
+            *reinterpret_cast<f2u*>(out + (size_t)c * cs) = f2u{acc0, acc1};
+            s += acc0 + acc1;
+            ss = fmaf(acc0, acc0, fmaf(acc1, acc1, ss));
+        } else if (live0) {
+            out[(size_t)c * cs] = acc0;
+            s += acc0;
+            ss = fmaf(acc0, acc0, ss);
         }
     }
     if (stats) block_stats_atomic(s, ss, red, stats + 2 * b);
@@ -155,7 +166,7 @@ int launch_stft(const float* wav, float* spec, int B, int L, int T, hipStream_t 
 
 int launch_enc_conv(const float* spec, const float* w, float* a0, double* stats, int B, int C, int T, int F, size_t cs,
                     size_t bs, hipStream_t st) {
-    hipLaunchKernelGGL(enc_conv_kernel, dim3(cdiv(T * F, 256), B), dim3(256), 0, st, spec, w, a0, stats, C, T, F, cs, bs);
+    hipLaunchKernelGGL(enc_conv_kernel, dim3(cdiv(cdiv(T * F, 2), 256), B), dim3(256), 0, st, spec, w, a0, stats, C, T, F, cs, bs);
     return rtfs_launch_status();
 }
 
