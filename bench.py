@@ -9,7 +9,8 @@ region.  One "step" = one forward over one batch.  Weak scaling: every rank runs
 data-path collective (utterances are independent in the forward).  Rank 0 prints ONE JSON line that also carries
   roofline      the fused dual-path sweep kernel: algorithmic bytes (20*L*N*64 per SRU layer, 4 layers per
                 launch) / its launch duration measured live with HIP events on the launch stream, vs 8 TB/s HBM
-  cpu_baseline  the CPU oracle (oracle/rtfs_oracle.py, numpy) timed on this box's host cores on a bounded sample.
+  cpu_baseline  the CPU oracle (oracle/rtfs_oracle.py, numpy) timed on this box's host cores on a bounded sample
+                (16 single-threaded worker processes, one mixture each, started before the GPU is touched).
 """
 import argparse
 import ctypes
@@ -40,23 +41,30 @@ def sweep_bytes(seq_len, n_seq):
     return 20.0 * (seq_len - 7) * n_seq * 64 * 4
 
 
-def cpu_baseline(repeats, seconds_budget=25.0):
-    from threadpoolctl import threadpool_info
-    from oracle import rtfs_oracle as O
-    from oracle.params import load_spec, make_inputs, make_state_dict
-    sd = make_state_dict(load_spec("state_spec_R4.json"), 0)
-    n, t0 = 0, time.perf_counter()
-    while True:
-        wav, emb = make_inputs(1, 32000, 50, n)
-        O.avnet_forward(wav, emb, sd, repeats=repeats)
-        n += 1
-        dt = time.perf_counter() - t0
-        if dt + dt / n > seconds_budget or n >= 8:
-            break
-    threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
-    return {"value": round(n / dt, 4), "unit": "mixtures/s", "cores": int(threads), "kind": "port",
-            "sample": f"{n} x (1 mixture, 2 s @16 kHz, RTFS-Net-{repeats}) through the numpy CPU oracle, {dt:.1f} s, "
-                      f"BLAS threads {threads} of {os.cpu_count()} host cpus"}
+def cpu_baseline(repeats, workers=None):
+    """The CPU oracle (oracle/rtfs_oracle.py, numpy) on this box's host cores: one single-threaded worker process per core
+    of the CPU share (16 per GPU), four 2 s mixtures each -> aggregate mixtures/s.  Must run BEFORE this process touches the
+    GPU (the workers are child processes)."""
+    import subprocess
+    workers = workers or min(16, os.cpu_count() or 1)
+    t0 = time.perf_counter()
+    per_worker = 4  # about 10 s of wall time on the GPU box
+    procs = [subprocess.Popen([sys.executable, "-m", "oracle.cpu_worker", str(repeats), str(per_worker), str(i)], cwd=ROOT,
+                              stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for i in range(workers)]
+    done, per = 0, []
+    for pr in procs:
+        out, _ = pr.communicate(timeout=900)
+        if pr.returncode == 0:
+            rec = json.loads(out.strip().splitlines()[-1])
+            done += rec["n"]
+            per.append(rec["seconds"])
+    dt = time.perf_counter() - t0
+    if done == 0:
+        return {"value": None, "unit": "mixtures/s", "cores": workers, "kind": "port", "sample": "CPU oracle workers failed"}
+    return {"value": round(done / dt, 4), "unit": "mixtures/s", "cores": int(workers), "kind": "port",
+            "sample": f"{done} x (1 mixture, 2 s @16 kHz, RTFS-Net-{repeats}) through the numpy CPU oracle, one single-threaded "
+                      f"process per core on {workers} of {os.cpu_count()} host cpus, wall {dt:.1f} s incl. start-up "
+                      f"(forwards alone {min(per) / per_worker:.1f}-{max(per) / per_worker:.1f} s per mixture)"}
 
 
 def rank_inputs(rank, B, L, Tv):
@@ -104,6 +112,9 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    cpu_res = None
+    if world == 1 and not args.no_cpu_baseline:
+        cpu_res = cpu_baseline(args.repeats)  # child processes: started before this process initialises the GPU
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
@@ -186,8 +197,8 @@ def main():
                 "algorithmic_bytes_per_launch": None if n_ev <= 0 else round(total_bytes / n_ev),
             },
         }
-        if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(args.repeats)
+        if cpu_res is not None:
+            res["cpu_baseline"] = cpu_res
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()

@@ -127,3 +127,16 @@ def test_end_to_end_lstm():
     for k in ["a0", "a1", "refined", "sep"]:
         check_probe(g, k, ints[k], 5 * TOL, "lstm.")
     assert rel_err(out, g["out"]) <= 5 * TOL
+
+
+def test_torch_ops_composition_matches_numpy_oracle():
+    """oracle/torch_cpu.py (stock torch CPU ops under the oracle's call graph, SURVEY 8d's second CPU baseline) agrees with
+    the numpy restatement."""
+    from oracle import rtfs_oracle as O, torch_cpu as TC
+    from oracle.params import load_spec, make_inputs, make_state_dict
+    sd = make_state_dict(load_spec("state_spec_R4.json"), 0)
+    wav, emb = make_inputs(2, 4096, 7, 3)
+    a = O.avnet_forward(wav, emb, sd, repeats=2)
+    b = TC.avnet_forward(wav, emb, sd, repeats=2)
+    assert np.abs(a - b).max() / np.abs(a).max() < 2e-5
+    assert O.pointwise.__module__ == "oracle.rtfs_oracle"  # primitives restored
