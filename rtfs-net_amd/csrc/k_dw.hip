@@ -519,127 +519,156 @@ __device__ __forceinline__ void dw_s2_pool_body(const DwArgs& a, const float* __
 
 __global__ __launch_bounds__(256) void dw_s2_pool_kernel(DwArgs a) { dw_s2_pool_body(a, a.x, a.out[0], a.out[1]); }
 
-// Packed variant of the kernel above (used when Wo >= 16): a thread owns the two output columns (j, j + ceil(Wo/2)) of one
-// channel, so the 16-tap window lives in f32x2 registers and every multiply-add is a v_pk_fma_f32.  The convolution runs on
-// the RAW input (column padding folded into per-lane weight pairs, out-of-range rows zeroed by a uniform branch) and the
-// input fold is applied once per output: conv(isc x + ish) = isc conv(x) + ish * (sum of in-bounds weights) + bias; the
-// pool likewise as isc * mean(x) + ish with the column-masked row sums carried in the rolling window.  The pool window's
-// row range is kept as an incremental quotient / remainder (no per-row integer division on the scalar unit).
-__device__ __forceinline__ void dw_s2p_body(const DwArgs& a, const float* __restrict__ X, float* __restrict__ O0, float* __restrict__ O1) {
+// Lane-exchange variant of the stride-2 kernel (used when Wo >= 16; same idea as dw1p_kernel): a thread owns the INPUT column
+// pair (2j, 2j+1) of one channel and produces output column j.  One 8-byte load per input row; the two outer taps (2j-1,
+// 2j+2) come from the adjacent lanes by DPP; 62 pairs + 2 halo lanes per wave.  The convolution runs on the RAW input
+// (column padding = zeroed window values, out-of-range rows zeroed by a uniform branch) and the input fold is applied once
+// per output: conv(isc x + ish) = isc conv(x) + ish * (sum of in-bounds weights) + bias; the pool likewise as
+// isc * mean(x) + ish with the column-masked row sums carried in the rolling window.  The pool window's row range is an
+// incremental quotient / remainder (no per-row integer division on the scalar unit).
+__device__ __forceinline__ void dw_s2x_body(const DwArgs& a, const float* __restrict__ X, float* __restrict__ O0, float* __restrict__ O1) {
     __shared__ double red[8];
     const int H = a.H, W = a.W, C = a.C, Ho = a.Hg, Wo = a.Wg;
-    const int half = (Wo + 1) >> 1;
+    const int NP = (W + 1) >> 1;  // input column pairs per row (slot j >= Wo only loads)
     const int b = blockIdx.z;
-    const int g = blockIdx.x * 256 + threadIdx.x;
-    const bool live = g < C * half;
-    const int c = live ? g / half : 0, ja = live ? g - c * half : 0;
-    const int jb = ja + half;
-    const bool liveb = live && jb < Wo;
-    const int jbc = liveb ? jb : ja;
+    const int lane = threadIdx.x & 63;
+    const int ws = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int gi = ws * DW1P_PAIRS - 1 + lane;
+    const int gc = gi < 0 ? 0 : (gi < C * NP ? gi : C * NP - 1);
+    const int c = gc / NP, j = gc - c * NP;
+    const bool live = lane >= 1 && lane <= DW1P_PAIRS && gi < C * NP && j < Wo;
+    const int x0 = 2 * j, x1 = 2 * j + 1;
     const int i0 = blockIdx.y * a.TH, i1 = min(i0 + a.TH, Ho);
-    const float* __restrict__ xp = X + ((size_t)b * C + c) * H * W;
+    const size_t sample = (size_t)b * C * H * W;
+    const float* __restrict__ Xs_ = X + sample;
+    const unsigned pa = (unsigned)c * (unsigned)(H * W) * 4u;
+    const bool whole = x1 < W;
+    const unsigned o2 = pa + 4u * (unsigned)(whole ? x0 : x0 - 1);  // the odd-width row's last pair reads (x0-1, x0)
+    auto load_raw = [&](int t) {
+        const float* __restrict__ rp = Xs_ + (size_t)(t < 0 ? 0 : (t < H ? t : H - 1)) * W;  // uniform
+        const f32x2 pr = ldo2(rp, o2);
+        return f32x2{whole ? pr.x : pr.y, pr.y};
+    };
+    // ---- start-up loads first (rows 2 i0 - 1 .. 2 i0 + 4), then the fold and the weights
+    f32x2 q[4];
+    f32x2 st0 = load_raw(2 * i0 - 1), st1 = load_raw(2 * i0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) q[k] = load_raw(2 * i0 + 1 + k);
+    f32x4 wraw[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wraw[i] = *reinterpret_cast<const f32x4*>(a.w[0] + c * 16 + i * 4);
     float isc, ish;
     gln_fold(a.in_stats + 2 * b, a.in_inv_count, a.in_gamma[c], a.in_beta[c], isc, ish);
     const float bia = a.bias[0][c];
-    const int fsa = (int)(((long long)ja * W) / Wo), fea = (int)(((long long)(ja + 1) * W + Wo - 1) / Wo);
-    const int fsb = (int)(((long long)jbc * W) / Wo), feb = (int)(((long long)(jbc + 1) * W + Wo - 1) / Wo);
-    int ca[4], cb[4];
-    f32x2 wgt[16], pm[4], wrow[4];
-#pragma unroll
-    for (int di = 0; di < 4; ++di) wrow[di] = f32x2{0.f, 0.f};
+    const int fs = (int)(((long long)j * W) / Wo), fe = (int)(((long long)(min(j, Wo - 1) + 1) * W + Wo - 1) / Wo);
+    float wgt[16], pm[4], wrow[4];
+    bool okc[4];
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
-        const int fa = 2 * ja - 1 + d, fb = 2 * jbc - 1 + d;
-        const bool oka = fa >= 0 && fa < W, okb = fb >= 0 && fb < W;
-        ca[d] = fa < 0 ? 0 : (fa < W ? fa : W - 1);
-        cb[d] = fb < 0 ? 0 : (fb < W ? fb : W - 1);
-        pm[d] = f32x2{fa >= fsa && fa < fea ? 1.f : 0.f, fb >= fsb && fb < feb ? 1.f : 0.f};
+        const int f = 2 * j - 1 + d;
+        okc[d] = f >= 0 && f < W;
+        pm[d] = f >= fs && f < fe ? 1.f : 0.f;
+    }
 #pragma unroll
-        for (int di = 0; di < 4; ++di) {
-            const float w = a.w[0][c * 16 + di * 4 + d];
-            wgt[di * 4 + d] = f32x2{oka ? w : 0.f, okb ? w : 0.f};
-            wrow[di] += wgt[di * 4 + d];
+    for (int di = 0; di < 4; ++di) {
+        wrow[di] = 0.f;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            wgt[di * 4 + d] = wraw[di][d];
+            wrow[di] += okc[d] ? wraw[di][d] : 0.f;
         }
     }
-    const f32x2 wall = wrow[0] + wrow[1] + wrow[2] + wrow[3];
-    const f32x2 nf = {(float)(fea - fsa), (float)(feb - fsb)};
-    auto load_row = [&](int t, f32x2 (&row)[4], f32x2& rs) {
-        const float* __restrict__ rp = xp + (size_t)(t < 0 ? 0 : (t < H ? t : H - 1)) * W;
-#pragma unroll
-        for (int d = 0; d < 4; ++d) row[d] = f32x2{rp[ca[d]], rp[cb[d]]};
+    const float wall = wrow[0] + wrow[1] + wrow[2] + wrow[3];
+    const float nf = (float)(fe - fs);
+    // window row: the four tap columns 2j-1 .. 2j+2 (padding zeroed) and their pool-masked sum
+    auto complete = [&](int t, f32x2 r, float (&v)[4], float& rs) {
+        v[1] = r.x;
+        v[2] = r.y;
+        v[0] = from_prev_lane(r.y);
+        v[3] = from_next_lane(r.x);
+        if (!okc[0]) v[0] = 0.f;
+        if (!okc[2]) v[2] = 0.f;
+        if (!okc[3]) v[3] = 0.f;
         if (t < 0 || t >= H) {  // uniform: only the first / last band row of the image
 #pragma unroll
-            for (int d = 0; d < 4; ++d) row[d] = f32x2{0.f, 0.f};
+            for (int d = 0; d < 4; ++d) v[d] = 0.f;
         }
-        rs = row[0] * pm[0];
+        rs = v[0] * pm[0];
 #pragma unroll
-        for (int d = 1; d < 4; ++d) rs = row[d] * pm[d] + rs;
+        for (int d = 1; d < 4; ++d) rs = fmaf(v[d], pm[d], rs);
     };
-    f32x2 win[4][4], rsw[4];
-    load_row(2 * i0 - 1, win[0], rsw[0]);
-    load_row(2 * i0, win[1], rsw[1]);
-    // pool rows of output i: [floor(i H / Ho), ceil((i+1) H / Ho)); (q, rem) = divmod(i H, Ho) kept incrementally
-    int q = (int)(((long long)i0 * H) / Ho), rem = (int)(((long long)i0 * H) % Ho);
-    f32x2 s2 = {0.f, 0.f}, ss2 = {0.f, 0.f};
-    const f32x2 m = {live ? 1.f : 0.f, liveb ? 1.f : 0.f};
-    const size_t oplane = ((size_t)b * C + c) * Ho * Wo;
-#pragma unroll 2
-    for (int i = i0; i < i1; ++i) {
-        load_row(2 * i + 1, win[2], rsw[2]);
-        load_row(2 * i + 2, win[3], rsw[3]);
-        const int ts = q;
+    float win[2][4], rsw[2];
+    complete(2 * i0 - 1, st0, win[0], rsw[0]);
+    complete(2 * i0, st1, win[1], rsw[1]);
+    // pool rows of output i: [floor(i H / Ho), ceil((i+1) H / Ho)); (qq, rem) = divmod(i H, Ho) kept incrementally
+    int qq = (int)(((long long)i0 * H) / Ho), rem = (int)(((long long)i0 * H) % Ho);
+    float s1 = 0.f, ss1 = 0.f;
+    const size_t osample = (size_t)b * C * Ho * Wo;
+    const unsigned oo = ((unsigned)c * (unsigned)(Ho * Wo) + (unsigned)min(j, Wo - 1)) * 4u;
+    auto do_row = [&](int i, const float (&w0)[4], const float (&w1)[4], const float (&w2)[4], const float (&w3)[4], float r0_, float r1_,
+                      float r2_, float r3_) {
+        const int ts = qq;
         rem += H;
         while (rem >= Ho) {
             rem -= Ho;
-            ++q;
+            ++qq;
         }
-        const int te = q + (rem > 0 ? 1 : 0);
-        f32x2 acc = {0.f, 0.f};
+        const int te = qq + (rem > 0 ? 1 : 0);
+        float acc = 0.f;
 #pragma unroll
-        for (int di = 0; di < 4; ++di)
+        for (int d = 0; d < 4; ++d) acc = fmaf(w0[d], wgt[d], acc);
 #pragma unroll
-            for (int dj = 0; dj < 4; ++dj) acc = win[di][dj] * wgt[di * 4 + dj] + acc;
-        f32x2 bsum = wall;
+        for (int d = 0; d < 4; ++d) acc = fmaf(w1[d], wgt[4 + d], acc);
+#pragma unroll
+        for (int d = 0; d < 4; ++d) acc = fmaf(w2[d], wgt[8 + d], acc);
+#pragma unroll
+        for (int d = 0; d < 4; ++d) acc = fmaf(w3[d], wgt[12 + d], acc);
+        float bsum = wall;
         if (2 * i - 1 < 0 || 2 * i + 2 >= H) {  // uniform: band touches the top / bottom padding
-            bsum = f32x2{0.f, 0.f};
+            bsum = 0.f;
 #pragma unroll
             for (int di = 0; di < 4; ++di) {
                 const int t = 2 * i - 1 + di;
                 if (t >= 0 && t < H) bsum += wrow[di];
             }
         }
-        acc = acc * isc + (bsum * ish + bia);
-        f32x2 ps = {0.f, 0.f};
+        acc = fmaf(acc, isc, fmaf(bsum, ish, bia));
+        const float rr[4] = {r0_, r1_, r2_, r3_};
+        float ps = 0.f;
 #pragma unroll
         for (int di = 0; di < 4; ++di) {
             const int t = 2 * i - 1 + di;
-            if (t >= ts && t < te) ps += rsw[di];  // uniform
+            if (t >= ts && t < te) ps += rr[di];  // uniform
         }
-        const f32x2 cnt = nf * (float)(te - ts);
-        const f32x2 pool = f32x2{ps.x / cnt.x, ps.y / cnt.y} * isc + ish;
-        const size_t oa = oplane + (size_t)i * Wo + ja, ob = oplane + (size_t)i * Wo + jbc;
+        const float pool = fmaf(ps / (nf * (float)(te - ts)), isc, ish);
+        const size_t orow = osample + (size_t)i * Wo;  // uniform
         if (live) {
-            O0[oa] = acc.x;
-            O1[oa] = pool.x;
+            sto(O0 + orow, oo, acc);
+            sto(O1 + orow, oo, pool);
+            s1 += acc;
+            ss1 = fmaf(acc, acc, ss1);
         }
-        if (liveb) {
-            O0[ob] = acc.y;
-            O1[ob] = pool.y;
-        }
-        const f32x2 am = acc * m;
-        s2 += am;
-        ss2 = am * am + ss2;
+    };
+    // two output rows (four input rows) per trip; the next trip's rows are requested before this trip's arithmetic
+    for (int i = i0; i < i1; i += 2) {
+        float n[4][4], rn[4];
 #pragma unroll
-        for (int dj = 0; dj < 4; ++dj) {
-            win[0][dj] = win[2][dj];
-            win[1][dj] = win[3][dj];
+        for (int k = 0; k < 4; ++k) complete(2 * i + 1 + k, q[k], n[k], rn[k]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) q[k] = load_raw(2 * i + 5 + k);
+        do_row(i, win[0], win[1], n[0], n[1], rsw[0], rsw[1], rn[0], rn[1]);
+        if (i + 1 < i1) do_row(i + 1, n[0], n[1], n[2], n[3], rn[0], rn[1], rn[2], rn[3]);  // uniform
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            win[0][d] = n[2][d];
+            win[1][d] = n[3][d];
         }
-        rsw[0] = rsw[2];
-        rsw[1] = rsw[3];
+        rsw[0] = rn[2];
+        rsw[1] = rn[3];
     }
-    block_stats_atomic(s2.x + s2.y, ss2.x + ss2.y, red, a.stats_out[0] + 2 * b);
+    block_stats_atomic(s1, ss1, red, a.stats_out[0] + 2 * b);
 }
-__global__ __launch_bounds__(256) void dw_s2p_kernel(DwArgs a) { dw_s2p_body(a, a.x, a.out[0], a.out[1]); }
+__global__ __launch_bounds__(256) void dw_s2x_kernel(DwArgs a) { dw_s2x_body(a, a.x, a.out[0], a.out[1]); }
 
 // ---------------------------------------------------------------- G-level elementwise glue
 // g = p0 + gLN(c1)           (global pooling sum, tdanet.py:116)
@@ -739,8 +768,8 @@ int launch_dw_s1(const DwArgs& a, int nconv, bool in_affine, int mode, int B, hi
 }
 
 int launch_dw_s2_pool(const DwArgs& a, int B, hipStream_t st) {
-    if (a.Wg >= 16) {
-        hipLaunchKernelGGL(dw_s2p_kernel, dim3(cdiv(a.C * ((a.Wg + 1) / 2), 256), cdiv(a.Hg, a.TH), B), dim3(256), 0, st, a);
+    if (a.Wg >= 16 && a.W >= 2 && (a.W + 1) / 2 >= a.Wg && (size_t)a.C * a.H * a.W * 4 < ((size_t)1 << 31)) {
+        hipLaunchKernelGGL(dw_s2x_kernel, dim3(cdiv(cdiv(a.C * ((a.W + 1) / 2), DW1P_PAIRS), 4), cdiv(a.Hg, a.TH), B), dim3(256), 0, st, a);
         return rtfs_launch_status();
     }
     hipLaunchKernelGGL(dw_s2_pool_kernel, dim3(cdiv(a.C * a.Wg, 256), cdiv(a.Hg, a.TH), B), dim3(256), 0, st, a);
