@@ -148,6 +148,15 @@ int rtfs_selftest_mfma_f16(const float* A, const float* B, float* D, void* strea
 int rtfs_sweep_timing_enable(int on);
 int rtfs_sweep_timing_collect(float* ms, int* seq_len, int* n_seq, int cap);
 
+/* Evaluation-side loss (the step after the path): PairwiseNegSDR.forward
+ * (src/losses/matrix.py:22-53; sdr_type 0 = "snr", 1 = "sisdr", 2 = "sdsdr") followed by PITLossWrapper's factorial search
+ * over source permutations (src/losses/pit_wrapper.py:84-110, pit_from = "pw_mtx", perm_reduce = None), n_src <= 4.
+ * ests, targets (B, n_src, L) -> pw_loss (B, n_src[est], n_src[target]); min_loss (B) = loss of the best permutation;
+ * perm (B, n_src) int32 with perm[b][i] = estimate assigned to target i (the reference's batch_indices, so
+ * reordered[b][i] = ests[b][perm[b][i]]).  All device pointers; the batch mean of min_loss is the wrapper's return value. */
+int rtfs_pit_pairwise_sdr_f32(const float* ests, const float* targets, int B, int n_src, int L, int sdr_type, int zero_mean,
+                              int take_log, float* pw_loss, float* min_loss, int* perm, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

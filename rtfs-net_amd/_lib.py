@@ -51,6 +51,7 @@ SIGNATURES = {
     "rtfs_selftest_mfma_f16": (_i, [_p, _p, _p, _p]),
     "rtfs_sweep_timing_enable": (_i, [_i]),
     "rtfs_sweep_timing_collect": (_i, [_p, _p, _p, _i]),
+    "rtfs_pit_pairwise_sdr_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p]),
 }
 
 _lib = None

@@ -957,4 +957,10 @@ int rtfs_sweep_timing_collect(float* ms, int* seq_len, int* n_seq, int cap) {
     return dualpath_timing_collect(ms, seq_len, n_seq, cap);
 }
 
+int rtfs_pit_pairwise_sdr_f32(const float* ests, const float* targets, int B, int n_src, int L, int sdr_type, int zero_mean,
+                              int take_log, float* pw_loss, float* min_loss, int* perm, void* stream) {
+    if (!ests || !targets || !pw_loss || !min_loss || !perm) return RTFS_ERR_ARG;
+    return launch_pit_pairwise(ests, targets, B, n_src, L, sdr_type, zero_mean, take_log, pw_loss, min_loss, perm, (hipStream_t)stream);
+}
+
 }  // extern "C"

@@ -212,3 +212,7 @@ void dualpath_timing_end(void* slot, hipStream_t st);
 // VP block (video 1-D TDANetBlock)
 size_t vp_lds_bytes(int Tv);
 int launch_vp_block(const float* video, const float* pack, float* out, int B, int Tv, hipStream_t st);
+
+// evaluation-side loss path (k_loss.hip): pairwise negative SNR / SI-SDR / SD-SDR + best permutation, n_src <= 4
+int launch_pit_pairwise(const float* est, const float* tgt, int B, int n, int L, int kind, int zero_mean, int take_log, float* pw,
+                        float* min_loss, int* perm, hipStream_t st);

@@ -1,6 +1,8 @@
 """GPU parity: the HIP path (through the C ABI via the nn.Module mirror) vs the CPU oracle on the same
 seeded inputs, and vs the golden vectors captured from the reference.  Tolerance: the north_star's
 1e-4 relative (fp32), read as max|got-ref| / max|ref| per tensor."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -335,3 +337,27 @@ def test_cpu_tensor_rejected():
     m = model()
     with pytest.raises(RuntimeError):
         m(torch.zeros(1, 4096), torch.zeros(1, 512, 7))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [0, 1, 2, 3])
+def test_pit_loss_vs_oracle_and_reference(k):
+    """rtfs_pit_pairwise_sdr_f32 through the reference-named classes: pairwise matrix vs the oracle (1e-4 dB) and vs the
+    reference's own outputs (golden), best permutation + reordered estimates bit-exact."""
+    from oracle import loss_oracle as LO
+    import rtfs_net_amd as R
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "loss_cases.npz"))
+    est, tgt = LO.make_loss_case(k)
+    e, t = torch.from_numpy(est).cuda(), torch.from_numpy(tgt).cuda()
+    for kind in ("snr", "sisdr", "sdsdr"):
+        pw = R.losses.PairwiseNegSDR(kind)(e, t).cpu().numpy()
+        ref = LO.pairwise_neg_sdr(est, tgt, kind)
+        assert np.abs(pw - ref).max() < 1e-4
+        assert np.abs(pw - g[f"c{k}_{kind}_pw"]).max() < 1e-4
+        mean, reo = R.losses.PITLossWrapper(R.losses.PairwiseNegSDR(kind), pit_from="pw_mtx")(e, t, return_ests=True)
+        assert abs(float(mean) - float(g[f"c{k}_{kind}_mean"])) < 1e-4
+        perm = g[f"c{k}_{kind}_perm"]
+        want = np.stack([est[b][perm[b]] for b in range(est.shape[0])])
+        assert np.array_equal(reo.cpu().numpy(), want)
+    with pytest.raises(TypeError):
+        R.losses.PairwiseNegSDR("snr")(e[:, :1], t)

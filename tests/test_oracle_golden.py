@@ -140,3 +140,19 @@ def test_torch_ops_composition_matches_numpy_oracle():
     b = TC.avnet_forward(wav, emb, sd, repeats=2)
     assert np.abs(a - b).max() / np.abs(a).max() < 2e-5
     assert O.pointwise.__module__ == "oracle.rtfs_oracle"  # primitives restored
+
+
+@pytest.mark.parametrize("k", [0, 1, 2, 3])
+def test_loss_oracle_matches_reference(k):
+    """oracle/loss_oracle.py vs the reference's PairwiseNegSDR + PITLossWrapper outputs (tests/golden/loss_cases.npz,
+    generated by oracle/make_golden_loss.py); tolerance 1e-4 dB (the reference computes in float32)."""
+    from oracle import loss_oracle as LO
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "loss_cases.npz"))
+    est, tgt = LO.make_loss_case(k)
+    for kind in ("snr", "sisdr", "sdsdr"):
+        pw = LO.pairwise_neg_sdr(est, tgt, kind)
+        assert np.abs(pw - g[f"c{k}_{kind}_pw"]).max() < 1e-4
+        mean, _, perm, _ = LO.pit_from_pw_mtx(pw, est)
+        assert abs(mean - g[f"c{k}_{kind}_mean"]) < 1e-4
+        assert np.array_equal(perm, g[f"c{k}_{kind}_perm"])
