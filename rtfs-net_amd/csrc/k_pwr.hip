@@ -12,8 +12,11 @@
 // tile; the next tile's rows are in registers while this one multiplies, one barrier per tile), every output tile is
 // finished -- bias / mask epilogue, coalesced stores -- as soon as its 48 MFMAs retire.
 // 256-thread workgroups, two per CU (69 KB LDS each): while one streams pixels the other multiplies.
-// (A weight-stationary variant -- weights in registers, pixels streamed through LDS -- measured no faster for the
-// bottleneck and slower for S3, whose epilogue registers do not fit beside 128 weight registers.)
+// (Measured alternatives, not kept: a weight-stationary variant -- weights in registers, pixels streamed through LDS -- no
+// faster for the bottleneck, slower for S3 whose epilogue registers do not fit beside 128 weight registers; a K-streaming
+// variant with 128 resident accumulators and two pixels per lane -- register-bound, 860 / 1100 us; 8-byte accesses through
+// an adjacent-lane channel exchange on this kernel -- 850 / 1000 us: the kernel is bound by its load-then-multiply phase
+// structure, not by the access width.)
 #include "common.h"
 #include "kernels.h"
 
