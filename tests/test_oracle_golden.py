@@ -156,3 +156,18 @@ def test_loss_oracle_matches_reference(k):
         mean, _, perm, _ = LO.pit_from_pw_mtx(pw, est)
         assert abs(mean - g[f"c{k}_{kind}_mean"]) < 1e-4
         assert np.array_equal(perm, g[f"c{k}_{kind}_perm"])
+
+
+@pytest.mark.parametrize("k,B,T", [(0, 1, 3), (1, 2, 5)])
+def test_video_oracle_matches_reference(k, B, T):
+    """oracle/video_oracle.py vs the reference's FRCNNVideoModel (ResNet-18 trunk, PReLU, eval) outputs and internal
+    tensors (tests/golden/video_cases.npz, generated by oracle/make_golden_video.py); tolerance 2e-5 relative."""
+    import os
+    from oracle import video_oracle as V
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "video_cases.npz"))
+    y, it = V.video_frontend(V.make_video_input(B, T, k), V.make_video_state_dict(0), return_internals=True)
+    assert np.abs(y - g[f"c{k}_out"]).max() / np.abs(g[f"c{k}_out"]).max() < 2e-5
+    assert np.abs(it["stem"][:, ::8, ::3, ::3] - g[f"c{k}_stem"]).max() < 2e-5
+    for li in (1, 2, 3, 4):
+        ref = g[f"c{k}_layer{li}"]
+        assert np.abs(it[f"layer{li}"][:, ::16] - ref).max() / np.abs(ref).max() < 2e-5
