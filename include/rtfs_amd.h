@@ -157,6 +157,14 @@ int rtfs_sweep_timing_collect(float* ms, int* seq_len, int* n_seq, int cap);
 int rtfs_pit_pairwise_sdr_f32(const float* ests, const float* targets, int B, int n_src, int L, int sdr_type, int zero_mean,
                               int take_log, float* pw_loss, float* min_loss, int* perm, void* stream);
 
+/* Video front-end (the step before the path): FRCNNVideoModel.forward with backbone_type "resnet",
+ * relu_type "prelu", eval mode (src/models/videomodels/frcnn_videomodel.py:61-72, resnet.py:23-118).
+ * lips (B, 1, T, 88, 88) grey-scale mouth crops -> out (B, 512, T), the lip embedding AVNet.forward takes.
+ * pack: rtfs-net_amd/packing.py:pack_video (eval BatchNorm folded into f16x3 weight images + bias, PReLU slopes). */
+size_t rtfs_video_pack_floats(void);
+size_t rtfs_video_workspace_bytes(int B, int T);
+int rtfs_video_frontend_f32(const float* lips, const float* pack, float* out, int B, int T, void* ws, size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -52,6 +52,9 @@ SIGNATURES = {
     "rtfs_sweep_timing_enable": (_i, [_i]),
     "rtfs_sweep_timing_collect": (_i, [_p, _p, _p, _i]),
     "rtfs_pit_pairwise_sdr_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p]),
+    "rtfs_video_pack_floats": (_z, []),
+    "rtfs_video_workspace_bytes": (_z, [_i, _i]),
+    "rtfs_video_frontend_f32": (_i, [_p, _p, _p, _i, _i, _p, _z, _p]),
 }
 
 _lib = None

@@ -963,4 +963,11 @@ int rtfs_pit_pairwise_sdr_f32(const float* ests, const float* targets, int B, in
     return launch_pit_pairwise(ests, targets, B, n_src, L, sdr_type, zero_mean, take_log, pw_loss, min_loss, perm, (hipStream_t)stream);
 }
 
+size_t rtfs_video_pack_floats(void) { return video_pack_floats(); }
+size_t rtfs_video_workspace_bytes(int B, int T) { return video_workspace_bytes(B, T); }
+int rtfs_video_frontend_f32(const float* lips, const float* pack, float* out, int B, int T, void* ws, size_t ws_bytes, void* stream) {
+    if (!lips || !pack || !out || !ws) return RTFS_ERR_ARG;
+    return video_frontend(lips, pack, out, B, T, ws, ws_bytes, (hipStream_t)stream);
+}
+
 }  // extern "C"

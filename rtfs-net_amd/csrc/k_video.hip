@@ -1,0 +1,306 @@
+// Video front-end ("the step before the path"): FRCNNVideoModel with the ResNet-18 trunk and PReLU,
+// eval mode (reference src/models/videomodels/frcnn_videomodel.py:16-72, resnet.py:23-118).
+//
+//   vid_pad_kernel      lips (B,1,T,88,88) -> zero-padded volume (B, T+4, 94, 94)            (Conv3d padding (2,3,3))
+//   vid_conv_kernel     implicit-GEMM convolution on the f16 matrix cores, 3-term hi/lo split (x = xh + xl,
+//                       256 w = wh + wl; same arithmetic as k_pw16.hip), eval BatchNorm folded into weights + bias:
+//                         STEM  Conv3d(1,64,(5,7,7),s(1,2,2)) + BN3d + PReLU(64)              frcnn_videomodel.py:42-52
+//                         C3    Conv2d 3x3 (stride 1|2, pad 1) + BN [+ residual] [+ PReLU]    resnet.py:51-66
+//                         C1    Conv2d 1x1 stride 2 + BN  (downsample branch)                 resnet.py:10-14
+//   vid_maxpool_kernel  MaxPool3d((1,3,3), s(1,2,2), p(0,1,1))                               frcnn_videomodel.py:53
+//   vid_avgpool_kernel  AdaptiveAvgPool2d(1) + view + transpose -> (B,512,T)                 resnet.py:116-118, frcnn:70
+//
+// Activations between convolutions are stored per frame as (n, C, H+2, W+2) with a zero border of one pixel, so the
+// 3x3 gathers need no bounds checks (kernels write interiors only; the borders are zeroed once per call).
+// GEMM view: D[co][pixel] = sum_k W[co][k] X[k][pixel], k = tap * Cin + ci (tap-major: a 32-deep K chunk lies inside one
+// tap since Cin % 32 == 0; the stem has Cin = 1 and k = tap, 245 padded to 256, gathered through an offset table).
+// Workgroup = 4 waves = 128 output pixels x 64 output channels; weights stream through a double-buffered LDS image
+// [hi|lo][64 co][32 k] per K chunk (register prefetch, one barrier per chunk); each lane gathers the 8 k-values of its
+// pixel's B fragment straight from global memory.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+enum { VM_STEM = 0, VM_C3 = 1, VM_C1 = 2 };
+constexpr int V_LDW = 40;  // staged weight row: 32 k + 8 pad halfs
+
+struct VidConvArgs {
+    const float* x;       // input activations (padded layout) or the padded volume (stem)
+    const half8* w16;     // [Cout/64][K/32][hi|lo][64][32] halfs
+    const float* bias;    // (Cout) folded BatchNorm shift
+    const float* slope;   // (Cout) PReLU slopes or null
+    const float* res;     // residual (padded layout of the OUTPUT geometry) or null
+    float* out;           // padded layout (n, Cout, Ho+2, Wo+2); stem: unpadded (n, 64, Ho, Wo)
+    int N, Cin, Cout, Hi, Wi, Ho, Wo, stride;  // Hi, Wi: input interior size (stem: 88); N frames
+    int T;                // stem: frames per clip
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256) void vid_conv_kernel(VidConvArgs a) {
+    __shared__ __attribute__((aligned(16))) _Float16 Ws[2][2 * 64 * V_LDW];
+    __shared__ int tab[MODE == VM_STEM ? 256 : 1];
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cb = blockIdx.y;                         // block of 64 output channels
+    const int npix = a.N * a.Ho * a.Wo;
+    const int pix = blockIdx.x * 128 + wave * 32 + r;  // this lane's output pixel
+    const bool live = pix < npix;
+    const int pc = live ? pix : npix - 1;
+    const int n = pc / (a.Ho * a.Wo), yx = pc - n * (a.Ho * a.Wo), y = yx / a.Wo, x = yx - y * a.Wo;
+    const int K = MODE == VM_STEM ? 256 : (MODE == VM_C3 ? 9 : 1) * a.Cin;
+    const int nchunk = K / 32;
+    const int Hp = a.Hi + 2, Wp = a.Wi + 2;  // padded input plane (2-D modes)
+    // base of this pixel's receptive field in the input
+    size_t base;
+    int cstride;  // k -> address step inside a tap (channel stride)
+    if (MODE == VM_STEM) {
+        if (tid < 256) {
+            const int k = tid, dt = k / 49, rem = k - dt * 49, dy = rem / 7, dx = rem - dy * 7;
+            tab[tid] = k < 245 ? (dt * 94 + dy) * 94 + dx : 0;  // offset inside the padded volume
+        }
+        const int b = n / a.T, t = n - b * a.T;
+        base = ((size_t)(b * (a.T + 4) + t) * 94 + 2 * y) * 94 + 2 * x;
+        cstride = 0;
+    } else {
+        const int off = MODE == VM_C3 ? 0 : 1;  // 1x1: no padding -> interior starts at (1,1)
+        base = ((size_t)n * a.Cin * Hp + (y * a.stride + off)) * Wp + (x * a.stride + off);
+        cstride = Hp * Wp;
+    }
+    const half8* wimg = a.w16 + (size_t)cb * nchunk * (2 * 64 * 4);
+    half8 pre[2];
+    auto stage_load = [&](int c) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) pre[j] = wimg[(size_t)c * 512 + tid + 256 * j];
+    };
+    auto stage_write = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int i = tid + 256 * j;  // piece: [part 2][co 64][kq 4]
+            *reinterpret_cast<half8*>(&Ws[buf][(i >> 2) * V_LDW + (i & 3) * 8]) = pre[j];
+        }
+    };
+    f32x16 acc[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[m][q] = 0.f;
+    stage_load(0);
+    stage_write(0);
+    __syncthreads();
+    for (int c = 0; c < nchunk; ++c) {
+        stage_load(c + 1 < nchunk ? c + 1 : c);
+        // gather the two k-steps of this chunk
+        float v[2][8];
+        if (MODE == VM_STEM) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[ks][j] = a.x[base + tab[c * 32 + ks * 16 + 8 * h + j]];
+        } else {
+            const int k0 = c * 32;
+            const int tap = k0 / a.Cin, ci0 = k0 - tap * a.Cin;  // uniform
+            const int dy = MODE == VM_C3 ? tap / 3 : 0, dx = MODE == VM_C3 ? tap - 3 * dy : 0;
+            const float* xp = a.x + base + (size_t)dy * Wp + dx + (size_t)ci0 * cstride;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[ks][j] = xp[(size_t)(ks * 16 + 8 * h + j) * cstride];
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            half8 bh, bl;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const _Float16 hi = (_Float16)v[ks][j];
+                bh[j] = hi;
+                bl[j] = (_Float16)(v[ks][j] - (float)hi);
+            }
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const half8 ah = *reinterpret_cast<const half8*>(&Ws[c & 1][(m * 32 + r) * V_LDW + ks * 16 + 8 * h]);
+                const half8 al = *reinterpret_cast<const half8*>(&Ws[c & 1][(64 + m * 32 + r) * V_LDW + ks * 16 + 8 * h]);
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[m], 0, 0, 0);
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[m], 0, 0, 0);
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[m], 0, 0, 0);
+            }
+        }
+        if (c + 1 < nchunk) stage_write((c + 1) & 1);
+        __syncthreads();
+    }
+    if (!live) return;
+    constexpr float WINV = 1.0f / 256.0f;
+    const int Hop = a.Ho + 2, Wop = a.Wo + 2;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int co = cb * 64 + m * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+            float val = fmaf(acc[m][q], WINV, a.bias[co]);
+            size_t o;
+            if (MODE == VM_STEM) o = ((size_t)n * a.Cout + co) * (a.Ho * a.Wo) + yx;
+            else o = (((size_t)n * a.Cout + co) * Hop + (y + 1)) * Wop + (x + 1);
+            if (a.res) val += a.res[o];
+            if (a.slope) val = preluf_(val, a.slope[co]);
+            a.out[o] = val;
+        }
+}
+
+__global__ __launch_bounds__(256) void vid_pad_kernel(const float* __restrict__ x, float* __restrict__ xp, int B, int T) {
+    // one thread per element of the padded volume (B, T+4, 94, 94)
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t total = (size_t)B * (T + 4) * 94 * 94;
+    if (i >= total) return;
+    const int xx = (int)(i % 94), yy = (int)((i / 94) % 94), tt = (int)((i / (94 * 94)) % (T + 4)), b = (int)(i / ((size_t)94 * 94 * (T + 4)));
+    const int t = tt - 2, y = yy - 3, xq = xx - 3;
+    const bool in = t >= 0 && t < T && y >= 0 && y < 88 && xq >= 0 && xq < 88;
+    xp[i] = in ? x[(((size_t)b * T + t) * 88 + y) * 88 + xq] : 0.f;
+}
+
+// (n, C, 44, 44) -> padded (n, C, 24, 24) interior 22 x 22: max over rows 2y-1..2y+1, cols 2x-1..2x+1 inside the image
+__global__ __launch_bounds__(256) void vid_maxpool_kernel(const float* __restrict__ in, float* __restrict__ out, size_t planes, int Hi, int Ho) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= planes * Ho * Ho) return;
+    const int x = (int)(i % Ho), y = (int)((i / Ho) % Ho);
+    const size_t pl = i / ((size_t)Ho * Ho);
+    const float* p = in + pl * Hi * Hi;
+    float m = -3.0e38f;
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int yy = 2 * y + dy, xx = 2 * x + dx;
+            if (yy >= 0 && yy < Hi && xx >= 0 && xx < Hi) m = fmaxf(m, p[yy * Hi + xx]);
+        }
+    out[(pl * (Ho + 2) + (y + 1)) * (Ho + 2) + (x + 1)] = m;
+}
+
+// padded (n = b*T + t, C, H+2, H+2) -> (B, C, T) mean over the H x H interior
+__global__ __launch_bounds__(256) void vid_avgpool_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int T, int C, int H) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * T * C) return;
+    const int c = i % C, n = i / C, b = n / T, t = n - b * T;
+    const float* p = in + ((size_t)n * C + c) * (H + 2) * (H + 2);
+    float s = 0.f;
+    for (int y = 1; y <= H; ++y)
+        for (int x = 1; x <= H; ++x) s += p[y * (H + 2) + x];
+    out[((size_t)b * C + c) * T + t] = s / (float)(H * H);
+}
+
+int conv_launch(int mode, const VidConvArgs& a, hipStream_t st) {
+    const dim3 grid(cdiv(a.N * a.Ho * a.Wo, 128), a.Cout / 64);
+    if (mode == VM_STEM) hipLaunchKernelGGL(vid_conv_kernel<VM_STEM>, grid, dim3(256), 0, st, a);
+    else if (mode == VM_C3) hipLaunchKernelGGL(vid_conv_kernel<VM_C3>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(vid_conv_kernel<VM_C1>, grid, dim3(256), 0, st, a);
+    return rtfs_launch_status();
+}
+
+}  // namespace
+
+// Parameter pack (rtfs-net_amd/packing.py:pack_video): for the stem and then for every convolution of the trunk in
+// forward order (conv1, [downsample], conv2 per block): image (Cout * Kpad floats), bias (Cout), slope (Cout; zeros = none)
+size_t video_pack_floats() {
+    size_t n = 0;
+    auto add = [&](size_t cout, size_t k) { n += (cout * k + 63) / 64 * 64 + 2 * ((cout + 63) / 64 * 64); };
+    add(64, 256);
+    int inpl = 64;
+    const int planes[4] = {64, 128, 256, 512};
+    for (int li = 0; li < 4; ++li)
+        for (int bi = 0; bi < 2; ++bi) {
+            const int cin = bi == 0 ? inpl : planes[li];
+            add(planes[li], 9 * cin);
+            if (bi == 0 && li > 0) add(planes[li], cin);
+            add(planes[li], 9 * planes[li]);
+            if (bi == 1) inpl = planes[li];
+        }
+    return n;
+}
+
+size_t video_workspace_bytes(int B, int T) {
+    const size_t N = (size_t)B * T;
+    size_t n = (size_t)B * (T + 4) * 94 * 94 + N * 64 * 44 * 44;
+    const int planes[4] = {64, 128, 256, 512}, hw[4] = {24, 13, 8, 5};
+    for (int li = 0; li < 4; ++li) n += 3 * N * planes[li] * hw[li] * hw[li];
+    return n * sizeof(float);
+}
+
+int video_frontend(const float* lips, const float* pack, float* out, int B, int T, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (B < 1 || T < 1) return RTFS_ERR_SHAPE;
+    if (ws_bytes < video_workspace_bytes(B, T)) return RTFS_ERR_WORKSPACE;
+    const int N = B * T;
+    float* w = reinterpret_cast<float*>(ws);
+    float* xp = w;
+    w += (size_t)B * (T + 4) * 94 * 94;
+    float* y44 = w;
+    w += (size_t)N * 64 * 44 * 44;
+    const int planes[4] = {64, 128, 256, 512}, hw[4] = {24, 13, 8, 5};
+    float* buf[4][3];
+    float* act0 = w;
+    for (int li = 0; li < 4; ++li)
+        for (int k = 0; k < 3; ++k) {
+            buf[li][k] = w;
+            w += (size_t)N * planes[li] * hw[li] * hw[li];
+        }
+    if (hipMemsetAsync(act0, 0, (size_t)(w - act0) * sizeof(float), st) != hipSuccess) return RTFS_ERR_LAUNCH;  // zero borders
+    size_t off = 0;
+    auto take = [&](size_t n) {
+        const float* r = pack + off;
+        off += (n + 63) / 64 * 64;
+        return r;
+    };
+    {
+        const size_t total = (size_t)B * (T + 4) * 94 * 94;
+        hipLaunchKernelGGL(vid_pad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, lips, xp, B, T);
+        if (rtfs_launch_status()) return RTFS_ERR_LAUNCH;
+    }
+    {  // stem conv + BN + PReLU -> (N,64,44,44); max pool -> buf[0][0] (N,64,24,24 padded)
+        VidConvArgs a{};
+        a.x = xp; a.w16 = reinterpret_cast<const half8*>(take(64 * 256)); a.bias = take(64); a.slope = take(64);
+        a.res = nullptr; a.out = y44; a.N = N; a.Cin = 1; a.Cout = 64; a.Hi = 88; a.Wi = 88; a.Ho = 44; a.Wo = 44; a.stride = 2; a.T = T;
+        if (int rc = conv_launch(VM_STEM, a, st)) return rc;
+        const size_t planes_n = (size_t)N * 64;
+        hipLaunchKernelGGL(vid_maxpool_kernel, dim3((unsigned)((planes_n * 22 * 22 + 255) / 256)), dim3(256), 0, st, y44, buf[0][0], planes_n, 44, 22);
+        if (rtfs_launch_status()) return RTFS_ERR_LAUNCH;
+    }
+    const float* x = buf[0][0];
+    int xi = 0;      // which of the 3 buffers of the current level holds x
+    int inpl = 64, Hin = 22;
+    for (int li = 0; li < 4; ++li) {
+        const int pl = planes[li], Hout = hw[li] - 2;
+        for (int bi = 0; bi < 2; ++bi) {
+            const int stride = (bi == 0 && li > 0) ? 2 : 1;
+            const int cin = bi == 0 ? inpl : pl;
+            // pick two scratch buffers of this level different from the one holding x (x may live on the previous level)
+            int s0 = 0, s1 = 1;
+            if (bi == 1 || li == 0) {
+                s0 = (xi + 1) % 3;
+                s1 = (xi + 2) % 3;
+            }
+            float* hbuf = buf[li][s0];
+            float* obuf = buf[li][s1];
+            VidConvArgs c1{};
+            c1.x = x; c1.w16 = reinterpret_cast<const half8*>(take((size_t)pl * 9 * cin)); c1.bias = take(pl); c1.slope = take(pl);
+            c1.res = nullptr; c1.out = hbuf; c1.N = N; c1.Cin = cin; c1.Cout = pl; c1.Hi = Hin; c1.Wi = Hin; c1.Ho = Hout; c1.Wo = Hout; c1.stride = stride;
+            if (int rc = conv_launch(VM_C3, c1, st)) return rc;
+            const float* resid = x;
+            if (bi == 0 && li > 0) {  // downsample branch: 1x1 stride 2 + BN -> third buffer of this level
+                float* rbuf = buf[li][2];
+                VidConvArgs d{};
+                d.x = x; d.w16 = reinterpret_cast<const half8*>(take((size_t)pl * cin)); d.bias = take(pl); (void)take(pl); d.slope = nullptr;
+                d.res = nullptr; d.out = rbuf; d.N = N; d.Cin = cin; d.Cout = pl; d.Hi = Hin; d.Wi = Hin; d.Ho = Hout; d.Wo = Hout; d.stride = 2;
+                if (int rc = conv_launch(VM_C1, d, st)) return rc;
+                resid = rbuf;
+            }
+            VidConvArgs c2{};
+            c2.x = hbuf; c2.w16 = reinterpret_cast<const half8*>(take((size_t)pl * 9 * pl)); c2.bias = take(pl); c2.slope = take(pl);
+            c2.res = resid; c2.out = obuf; c2.N = N; c2.Cin = pl; c2.Cout = pl; c2.Hi = Hout; c2.Wi = Hout; c2.Ho = Hout; c2.Wo = Hout; c2.stride = 1;
+            if (int rc = conv_launch(VM_C3, c2, st)) return rc;
+            x = obuf;
+            xi = s1;
+            Hin = Hout;
+        }
+        inpl = pl;
+    }
+    hipLaunchKernelGGL(vid_avgpool_kernel, dim3(cdiv(N * 512, 256)), dim3(256), 0, st, x, out, B, T, 512, 3);
+    return rtfs_launch_status();
+}

@@ -216,3 +216,8 @@ int launch_vp_block(const float* video, const float* pack, float* out, int B, in
 // evaluation-side loss path (k_loss.hip): pairwise negative SNR / SI-SDR / SD-SDR + best permutation, n_src <= 4
 int launch_pit_pairwise(const float* est, const float* tgt, int B, int n, int L, int kind, int zero_mean, int take_log, float* pw,
                         float* min_loss, int* perm, hipStream_t st);
+
+// video front-end (k_video.hip): FRCNNVideoModel, ResNet-18 trunk, PReLU, eval
+size_t video_pack_floats();
+size_t video_workspace_bytes(int B, int T);
+int video_frontend(const float* lips, const float* pack, float* out, int B, int T, void* ws, size_t ws_bytes, hipStream_t st);

@@ -225,3 +225,46 @@ def pack_vp(sd):
                 parts += [sd[p + "2.weight"].reshape(64, 3), sc, sh]
     parts += [sd["residual_conv.full_layer.2.weight"].reshape(512, 64).t(), sd["residual_conv.full_layer.2.bias"]]
     return _cat(parts)
+
+
+# ----------------------------------------------------------------------------- video front-end (k_video.hip)
+def _video_conv_image(w2d, bn_scale):
+    """(cout, K) f32 conv weight with the eval-BatchNorm scale folded in -> [cout/64][K/32][hi|lo][64][32] halfs (bit-cast
+    to float32), K zero-padded to a multiple of 32."""
+    cout, K = w2d.shape
+    w = (w2d.detach().to(torch.float32) * bn_scale.reshape(-1, 1)) * W16_SCALE
+    Kp = (K + 31) // 32 * 32
+    if Kp != K:
+        w = torch.cat([w, w.new_zeros(cout, Kp - K)], 1)
+    hi = w.to(torch.float16)
+    lo = (w - hi.to(torch.float32)).to(torch.float16)
+    img = torch.stack([hi.reshape(cout // 64, 64, Kp // 32, 32).permute(0, 2, 1, 3), lo.reshape(cout // 64, 64, Kp // 32, 32).permute(0, 2, 1, 3)], 2)
+    return img.contiguous().view(torch.float32).reshape(-1)  # [cb][chunk][hi|lo][64][32]
+
+
+def _video_bn_fold(sd, prefix, eps=1e-5):
+    scale = sd[prefix + ".weight"].float() / torch.sqrt(sd[prefix + ".running_var"].float() + eps)
+    return scale, sd[prefix + ".bias"].float() - sd[prefix + ".running_mean"].float() * scale
+
+
+def pack_video(sd):
+    """FRCNNVideoModel (backbone 'resnet', relu_type 'prelu') state_dict -> the pack of rtfs_video_frontend_f32: for the stem
+    and then every trunk convolution in forward order (conv1, [downsample], conv2 per block): weight image, bias, slopes."""
+    parts = []
+
+    def add(w2d, bn_prefix, slope):
+        scale, shift = _video_bn_fold(sd, bn_prefix)
+        parts.extend([_video_conv_image(w2d, scale), shift, slope if slope is not None else torch.zeros_like(shift)])
+
+    add(sd["frontend3D.0.weight"].reshape(64, 245), "frontend3D.1", sd["frontend3D.2.weight"])
+    for li in (1, 2, 3, 4):
+        for bi in (0, 1):
+            pre = f"trunk.layer{li}.{bi}"
+            w1 = sd[pre + ".conv1.weight"]  # (planes, cin, 3, 3) -> k = (dy*3+dx)*cin + ci
+            add(w1.permute(0, 2, 3, 1).reshape(w1.shape[0], -1), pre + ".bn1", sd[pre + ".relu1.weight"])
+            if pre + ".downsample.0.weight" in sd:
+                wd = sd[pre + ".downsample.0.weight"]
+                add(wd.reshape(wd.shape[0], -1), pre + ".downsample.1", None)
+            w2 = sd[pre + ".conv2.weight"]
+            add(w2.permute(0, 2, 3, 1).reshape(w2.shape[0], -1), pre + ".bn2", sd[pre + ".relu2.weight"])
+    return _cat(parts)

@@ -361,3 +361,27 @@ def test_pit_loss_vs_oracle_and_reference(k):
         assert np.array_equal(reo.cpu().numpy(), want)
     with pytest.raises(TypeError):
         R.losses.PairwiseNegSDR("snr")(e[:, :1], t)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,B,T", [(0, 1, 3), (1, 2, 5)])
+def test_video_frontend_vs_oracle_and_reference(k, B, T):
+    """rtfs_video_frontend_f32 through the reference-named FRCNNVideoModel: vs the numpy oracle and vs the reference
+    module's own output (golden); tolerance 1e-4 relative (f16x3 split arithmetic, f32 accumulate)."""
+    from oracle import video_oracle as V
+    import rtfs_net_amd as R
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "video_cases.npz"))
+    sd = V.make_video_state_dict(0)
+    m = R.FRCNNVideoModel(print_macs=False)
+    assert [(n, tuple(p.shape)) for n, p in m.state_dict().items()] == [(n, tuple(s)) for n, s in V.video_state_spec()]
+    m.load_state_dict({n: torch.from_numpy(np.asarray(v)) for n, v in sd.items()})
+    m = m.cuda().eval()
+    x = V.make_video_input(B, T, k)
+    with torch.no_grad():
+        y = m(torch.from_numpy(x).cuda()).cpu().numpy()
+    ref = V.video_frontend(x, sd)
+    assert y.shape == (B, 512, T)
+    assert rel_err(y, ref) < 1e-4
+    assert rel_err(y, g[f"c{k}_out"]) < 1e-4
+    with pytest.raises(ValueError):
+        m(torch.zeros(1, 1, 2, 64, 64, device="cuda"))
