@@ -36,13 +36,14 @@ struct VidConvArgs {
     int T;                // stem: frames per clip
 };
 
-template <int MODE>
+template <int MODE, int MT>  // MT = 32-row output tiles per wave: a workgroup covers 32 MT output channels
 __global__ __launch_bounds__(256) void vid_conv_kernel(VidConvArgs a) {
-    __shared__ __attribute__((aligned(16))) _Float16 Ws[2][2 * 64 * V_LDW];
+    constexpr int CO = 32 * MT;
+    __shared__ __attribute__((aligned(16))) _Float16 Ws[2][2 * CO * V_LDW];
     __shared__ int tab[MODE == VM_STEM ? 256 : 1];
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int cb = blockIdx.y;                         // block of 64 output channels
+    const int cb = blockIdx.y;                         // block of CO output channels
     const int npix = a.N * a.Ho * a.Wo;
     const int pix = blockIdx.x * 128 + wave * 32 + r;  // this lane's output pixel
     const bool live = pix < npix;
@@ -67,31 +68,31 @@ __global__ __launch_bounds__(256) void vid_conv_kernel(VidConvArgs a) {
         base = ((size_t)n * a.Cin * Hp + (y * a.stride + off)) * Wp + (x * a.stride + off);
         cstride = Hp * Wp;
     }
-    const half8* wimg = a.w16 + (size_t)cb * nchunk * (2 * 64 * 4);
-    half8 pre[2];
+    // image: [Cout/64][K/32][hi|lo][64][32]; a block of CO channels = CO/64 consecutive 64-blocks
+    const half8* wimg = a.w16 + (size_t)cb * (CO / 64) * nchunk * 512;
+    half8 pre[2 * (CO / 64)];
     auto stage_load = [&](int c) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) pre[j] = wimg[(size_t)c * 512 + tid + 256 * j];
+        for (int sb = 0; sb < CO / 64; ++sb)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) pre[sb * 2 + j] = wimg[((size_t)sb * nchunk + c) * 512 + tid + 256 * j];
     };
     auto stage_write = [&](int buf) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int i = tid + 256 * j;  // piece: [part 2][co 64][kq 4]
-            *reinterpret_cast<half8*>(&Ws[buf][(i >> 2) * V_LDW + (i & 3) * 8]) = pre[j];
-        }
-    };
-    f32x16 acc[2];
+        for (int sb = 0; sb < CO / 64; ++sb)
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+            for (int j = 0; j < 2; ++j) {
+                const int i = tid + 256 * j;  // piece: [part 2][co 64][kq 4] of sub-block sb
+                const int part = i >> 8, co = sb * 64 + ((i >> 2) & 63);
+                *reinterpret_cast<half8*>(&Ws[buf][(part * CO + co) * V_LDW + (i & 3) * 8]) = pre[sb * 2 + j];
+            }
+    };
+    f32x16 acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[m][q] = 0.f;
-    stage_load(0);
-    stage_write(0);
-    __syncthreads();
-    for (int c = 0; c < nchunk; ++c) {
-        stage_load(c + 1 < nchunk ? c + 1 : c);
-        // gather the two k-steps of this chunk
-        float v[2][8];
+    auto gather = [&](int c, float (&v)[2][8]) {
         if (MODE == VM_STEM) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
@@ -107,24 +108,35 @@ __global__ __launch_bounds__(256) void vid_conv_kernel(VidConvArgs a) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[ks][j] = xp[(size_t)(ks * 16 + 8 * h + j) * cstride];
         }
+    };
+    stage_load(0);
+    stage_write(0);
+    __syncthreads();  // also orders the stem's offset table
+    float v[2][8];
+    gather(0, v);
+    for (int c = 0; c < nchunk; ++c) {
+        const int cn = c + 1 < nchunk ? c + 1 : c;
+        stage_load(cn);
+        half8 bh[2], bl[2];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            half8 bh, bl;
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const _Float16 hi = (_Float16)v[ks][j];
-                bh[j] = hi;
-                bl[j] = (_Float16)(v[ks][j] - (float)hi);
+                bh[ks][j] = hi;
+                bl[ks][j] = (_Float16)(v[ks][j] - (float)hi);
             }
+        gather(cn, v);  // the next chunk's activations arrive under this chunk's MFMAs
 #pragma unroll
-            for (int m = 0; m < 2; ++m) {
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
                 const half8 ah = *reinterpret_cast<const half8*>(&Ws[c & 1][(m * 32 + r) * V_LDW + ks * 16 + 8 * h]);
-                const half8 al = *reinterpret_cast<const half8*>(&Ws[c & 1][(64 + m * 32 + r) * V_LDW + ks * 16 + 8 * h]);
-                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[m], 0, 0, 0);
-                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[m], 0, 0, 0);
-                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[m], 0, 0, 0);
+                const half8 al = *reinterpret_cast<const half8*>(&Ws[c & 1][(CO + m * 32 + r) * V_LDW + ks * 16 + 8 * h]);
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[ks], acc[m], 0, 0, 0);
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[ks], acc[m], 0, 0, 0);
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[ks], acc[m], 0, 0, 0);
             }
-        }
         if (c + 1 < nchunk) stage_write((c + 1) & 1);
         __syncthreads();
     }
@@ -132,10 +144,10 @@ __global__ __launch_bounds__(256) void vid_conv_kernel(VidConvArgs a) {
     constexpr float WINV = 1.0f / 256.0f;
     const int Hop = a.Ho + 2, Wop = a.Wo + 2;
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-            const int co = cb * 64 + m * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+            const int co = cb * CO + m * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
             float val = fmaf(acc[m][q], WINV, a.bias[co]);
             size_t o;
             if (MODE == VM_STEM) o = ((size_t)n * a.Cout + co) * (a.Ho * a.Wo) + yx;
@@ -188,10 +200,15 @@ __global__ __launch_bounds__(256) void vid_avgpool_kernel(const float* __restric
 }
 
 int conv_launch(int mode, const VidConvArgs& a, hipStream_t st) {
-    const dim3 grid(cdiv(a.N * a.Ho * a.Wo, 128), a.Cout / 64);
-    if (mode == VM_STEM) hipLaunchKernelGGL(vid_conv_kernel<VM_STEM>, grid, dim3(256), 0, st, a);
-    else if (mode == VM_C3) hipLaunchKernelGGL(vid_conv_kernel<VM_C3>, grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(vid_conv_kernel<VM_C1>, grid, dim3(256), 0, st, a);
+    const int px = cdiv(a.N * a.Ho * a.Wo, 128);
+    if (mode == VM_STEM) hipLaunchKernelGGL((vid_conv_kernel<VM_STEM, 2>), dim3(px, 1), dim3(256), 0, st, a);
+    else if (a.Cout % 128 == 0) {  // 128 output channels per workgroup: the gathered activations are reused twice as often
+        if (mode == VM_C3) hipLaunchKernelGGL((vid_conv_kernel<VM_C3, 4>), dim3(px, a.Cout / 128), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((vid_conv_kernel<VM_C1, 4>), dim3(px, a.Cout / 128), dim3(256), 0, st, a);
+    } else {
+        if (mode == VM_C3) hipLaunchKernelGGL((vid_conv_kernel<VM_C3, 2>), dim3(px, a.Cout / 64), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((vid_conv_kernel<VM_C1, 2>), dim3(px, a.Cout / 64), dim3(256), 0, st, a);
+    }
     return rtfs_launch_status();
 }
 
