@@ -10,8 +10,10 @@
 //   vid_maxpool_kernel  MaxPool3d((1,3,3), s(1,2,2), p(0,1,1))                               frcnn_videomodel.py:53
 //   vid_avgpool_kernel  AdaptiveAvgPool2d(1) + view + transpose -> (B,512,T)                 resnet.py:116-118, frcnn:70
 //
-// Activations between convolutions are stored per frame as (n, C, H+2, W+2) with a zero border of one pixel, so the
-// 3x3 gathers need no bounds checks (kernels write interiors only; the borders are zeroed once per call).
+// Activations between convolutions are stored per frame CHANNEL-LAST as (n, H+2, W+2, C) with a zero border of one pixel:
+// the 3x3 gathers need no bounds checks (kernels write interiors only; the borders are zeroed once per call), the 8
+// consecutive channels of a B fragment are two 16-byte loads (a dword gather per channel kept the texture addresser, not the
+// matrix cores, busy), and an accumulator tile's 4-channel groups are 16-byte stores.
 // GEMM view: D[co][pixel] = sum_k W[co][k] X[k][pixel], k = tap * Cin + ci (tap-major: a 32-deep K chunk lies inside one
 // tap since Cin % 32 == 0; the stem has Cin = 1 and k = tap, 245 padded to 256, gathered through an offset table).
 // Workgroup = 4 waves = 128 output pixels x 64 output channels; weights stream through a double-buffered LDS image
@@ -26,17 +28,20 @@ enum { VM_STEM = 0, VM_C3 = 1, VM_C1 = 2 };
 constexpr int V_LDW = 40;  // staged weight row: 32 k + 8 pad halfs
 
 struct VidConvArgs {
-    const float* x;       // input activations (padded layout) or the padded volume (stem)
+    const float* x;       // input activations (padded channel-last layout) or the padded volume (stem)
     const half8* w16;     // [Cout/64][K/32][hi|lo][64][32] halfs
     const float* bias;    // (Cout) folded BatchNorm shift
     const float* slope;   // (Cout) PReLU slopes or null
     const float* res;     // residual (padded layout of the OUTPUT geometry) or null
-    float* out;           // padded layout (n, Cout, Ho+2, Wo+2); stem: unpadded (n, 64, Ho, Wo)
+    float* out;           // padded layout (n, Ho+2, Wo+2, Cout); stem: unpadded (n, Ho, Wo, 64)
     int N, Cin, Cout, Hi, Wi, Ho, Wo, stride;  // Hi, Wi: input interior size (stem: 88); N frames
     int T;                // stem: frames per clip
 };
 
-template <int MODE, int MT>  // MT = 32-row output tiles per wave: a workgroup covers 32 MT output channels
+// MT = 32-row output tiles per wave (a workgroup covers 32 MT output channels); PT = 32-pixel tiles per wave (a workgroup
+// covers 128 PT pixels; PT = 2 measured no faster: the 3x3 gathers re-read the input nine times through L2, which is what
+// bounds these kernels -- an LDS-resident input tile reused across the taps is the next step)
+template <int MODE, int MT, int PT = 1>
 __global__ __launch_bounds__(256) void vid_conv_kernel(VidConvArgs a) {
     constexpr int CO = 32 * MT;
     __shared__ __attribute__((aligned(16))) _Float16 Ws[2][2 * CO * V_LDW];
@@ -45,28 +50,31 @@ __global__ __launch_bounds__(256) void vid_conv_kernel(VidConvArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cb = blockIdx.y;                         // block of CO output channels
     const int npix = a.N * a.Ho * a.Wo;
-    const int pix = blockIdx.x * 128 + wave * 32 + r;  // this lane's output pixel
-    const bool live = pix < npix;
-    const int pc = live ? pix : npix - 1;
-    const int n = pc / (a.Ho * a.Wo), yx = pc - n * (a.Ho * a.Wo), y = yx / a.Wo, x = yx - y * a.Wo;
     const int K = MODE == VM_STEM ? 256 : (MODE == VM_C3 ? 9 : 1) * a.Cin;
     const int nchunk = K / 32;
     const int Hp = a.Hi + 2, Wp = a.Wi + 2;  // padded input plane (2-D modes)
-    // base of this pixel's receptive field in the input
-    size_t base;
-    int cstride;  // k -> address step inside a tap (channel stride)
-    if (MODE == VM_STEM) {
-        if (tid < 256) {
-            const int k = tid, dt = k / 49, rem = k - dt * 49, dy = rem / 7, dx = rem - dy * 7;
-            tab[tid] = k < 245 ? (dt * 94 + dy) * 94 + dx : 0;  // offset inside the padded volume
+    if (MODE == VM_STEM && tid < 256) {
+        const int k = tid, dt = k / 49, rem = k - dt * 49, dy = rem / 7, dx = rem - dy * 7;
+        tab[tid] = k < 245 ? (dt * 94 + dy) * 94 + dx : 0;  // offset inside the padded volume
+    }
+    // this lane's output pixels (one per pixel tile) and the base of their receptive fields in the input
+    bool live[PT];
+    int pcs[PT], ns[PT], ys[PT], xs[PT];
+    size_t base[PT];
+#pragma unroll
+    for (int t = 0; t < PT; ++t) {
+        const int pix = (blockIdx.x * PT + t) * 128 + wave * 32 + r;
+        live[t] = pix < npix;
+        const int pc = live[t] ? pix : npix - 1;
+        const int n = pc / (a.Ho * a.Wo), yx = pc - n * (a.Ho * a.Wo), y = yx / a.Wo, x = yx - y * a.Wo;
+        pcs[t] = pc; ns[t] = n; ys[t] = y; xs[t] = x;
+        if (MODE == VM_STEM) {
+            const int b = n / a.T, tt = n - b * a.T;
+            base[t] = ((size_t)(b * (a.T + 4) + tt) * 94 + 2 * y) * 94 + 2 * x;
+        } else {
+            const int off = MODE == VM_C3 ? 0 : 1;  // 1x1: no padding -> interior starts at (1,1)
+            base[t] = (((size_t)n * Hp + (y * a.stride + off)) * Wp + (x * a.stride + off)) * a.Cin;
         }
-        const int b = n / a.T, t = n - b * a.T;
-        base = ((size_t)(b * (a.T + 4) + t) * 94 + 2 * y) * 94 + 2 * x;
-        cstride = 0;
-    } else {
-        const int off = MODE == VM_C3 ? 0 : 1;  // 1x1: no padding -> interior starts at (1,1)
-        base = ((size_t)n * a.Cin * Hp + (y * a.stride + off)) * Wp + (x * a.stride + off);
-        cstride = Hp * Wp;
     }
     // image: [Cout/64][K/32][hi|lo][64][32]; a block of CO channels = CO/64 consecutive 64-blocks
     const half8* wimg = a.w16 + (size_t)cb * (CO / 64) * nchunk * 512;
@@ -87,45 +95,53 @@ __global__ __launch_bounds__(256) void vid_conv_kernel(VidConvArgs a) {
                 *reinterpret_cast<half8*>(&Ws[buf][(part * CO + co) * V_LDW + (i & 3) * 8]) = pre[sb * 2 + j];
             }
     };
-    f32x16 acc[MT];
+    f32x16 acc[PT][MT];
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
+    for (int t = 0; t < PT; ++t)
 #pragma unroll
-        for (int q = 0; q < 16; ++q) acc[m][q] = 0.f;
-    auto gather = [&](int c, float (&v)[2][8]) {
-        if (MODE == VM_STEM) {
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
+            for (int q = 0; q < 16; ++q) acc[t][m][q] = 0.f;
+    auto gather = [&](int c, float (&v)[PT][2][8]) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[ks][j] = a.x[base + tab[c * 32 + ks * 16 + 8 * h + j]];
-        } else {
-            const int k0 = c * 32;
-            const int tap = k0 / a.Cin, ci0 = k0 - tap * a.Cin;  // uniform
-            const int dy = MODE == VM_C3 ? tap / 3 : 0, dx = MODE == VM_C3 ? tap - 3 * dy : 0;
-            const float* xp = a.x + base + (size_t)dy * Wp + dx + (size_t)ci0 * cstride;
+        for (int t = 0; t < PT; ++t) {
+            if (MODE == VM_STEM) {
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
+                for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[ks][j] = xp[(size_t)(ks * 16 + 8 * h + j) * cstride];
+                    for (int j = 0; j < 8; ++j) v[t][ks][j] = a.x[base[t] + tab[c * 32 + ks * 16 + 8 * h + j]];
+            } else {
+                const int k0 = c * 32;
+                const int tap = k0 / a.Cin, ci0 = k0 - tap * a.Cin;  // uniform
+                const int dy = MODE == VM_C3 ? tap / 3 : 0, dx = MODE == VM_C3 ? tap - 3 * dy : 0;
+                const float* xp = a.x + base[t] + ((size_t)dy * Wp + dx) * a.Cin + ci0 + 8 * h;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    *reinterpret_cast<f32x4*>(&v[t][ks][0]) = *reinterpret_cast<const f32x4*>(xp + ks * 16);
+                    *reinterpret_cast<f32x4*>(&v[t][ks][4]) = *reinterpret_cast<const f32x4*>(xp + ks * 16 + 4);
+                }
+            }
         }
     };
     stage_load(0);
     stage_write(0);
     __syncthreads();  // also orders the stem's offset table
-    float v[2][8];
+    float v[PT][2][8];
     gather(0, v);
     for (int c = 0; c < nchunk; ++c) {
         const int cn = c + 1 < nchunk ? c + 1 : c;
         stage_load(cn);
-        half8 bh[2], bl[2];
+        half8 bh[PT][2], bl[PT][2];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        for (int t = 0; t < PT; ++t)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const _Float16 hi = (_Float16)v[ks][j];
-                bh[ks][j] = hi;
-                bl[ks][j] = (_Float16)(v[ks][j] - (float)hi);
-            }
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const _Float16 hi = (_Float16)v[t][ks][j];
+                    bh[t][ks][j] = hi;
+                    bl[t][ks][j] = (_Float16)(v[t][ks][j] - (float)hi);
+                }
         gather(cn, v);  // the next chunk's activations arrive under this chunk's MFMAs
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
@@ -133,29 +149,38 @@ __global__ __launch_bounds__(256) void vid_conv_kernel(VidConvArgs a) {
             for (int m = 0; m < MT; ++m) {
                 const half8 ah = *reinterpret_cast<const half8*>(&Ws[c & 1][(m * 32 + r) * V_LDW + ks * 16 + 8 * h]);
                 const half8 al = *reinterpret_cast<const half8*>(&Ws[c & 1][(CO + m * 32 + r) * V_LDW + ks * 16 + 8 * h]);
-                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[ks], acc[m], 0, 0, 0);
-                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[ks], acc[m], 0, 0, 0);
-                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[ks], acc[m], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < PT; ++t) {
+                    acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[t][ks], acc[t][m], 0, 0, 0);
+                    acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[t][ks], acc[t][m], 0, 0, 0);
+                    acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[t][ks], acc[t][m], 0, 0, 0);
+                }
             }
         if (c + 1 < nchunk) stage_write((c + 1) & 1);
         __syncthreads();
     }
-    if (!live) return;
     constexpr float WINV = 1.0f / 256.0f;
     const int Hop = a.Ho + 2, Wop = a.Wo + 2;
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
+    for (int t = 0; t < PT; ++t) {
+        if (!live[t]) continue;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int co = cb * CO + m * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
-            float val = fmaf(acc[m][q], WINV, a.bias[co]);
-            size_t o;
-            if (MODE == VM_STEM) o = ((size_t)n * a.Cout + co) * (a.Ho * a.Wo) + yx;
-            else o = (((size_t)n * a.Cout + co) * Hop + (y + 1)) * Wop + (x + 1);
-            if (a.res) val += a.res[o];
-            if (a.slope) val = preluf_(val, a.slope[co]);
-            a.out[o] = val;
-        }
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {  // accumulator registers 4 q4 .. 4 q4 + 3 = 4 consecutive output channels
+                const int co = cb * CO + m * 32 + 8 * q4 + 4 * h;
+                const size_t o = (MODE == VM_STEM ? (size_t)pcs[t] : ((size_t)ns[t] * Hop + (ys[t] + 1)) * Wop + (xs[t] + 1)) * a.Cout + co;
+                f32x4 val;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) val[i] = fmaf(acc[t][m][4 * q4 + i], WINV, a.bias[co + i]);
+                if (a.res) val += *reinterpret_cast<const f32x4*>(a.res + o);
+                if (a.slope) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) val[i] = preluf_(val[i], a.slope[co + i]);
+                }
+                *reinterpret_cast<f32x4*>(a.out + o) = val;
+            }
+    }
 }
 
 __global__ __launch_bounds__(256) void vid_pad_kernel(const float* __restrict__ x, float* __restrict__ xp, int B, int T) {
@@ -169,33 +194,32 @@ __global__ __launch_bounds__(256) void vid_pad_kernel(const float* __restrict__ 
     xp[i] = in ? x[(((size_t)b * T + t) * 88 + y) * 88 + xq] : 0.f;
 }
 
-// (n, C, 44, 44) -> padded (n, C, 24, 24) interior 22 x 22: max over rows 2y-1..2y+1, cols 2x-1..2x+1 inside the image
-__global__ __launch_bounds__(256) void vid_maxpool_kernel(const float* __restrict__ in, float* __restrict__ out, size_t planes, int Hi, int Ho) {
+// channel-last (n, Hi, Hi, C) -> padded (n, Ho+2, Ho+2, C) interior: max over rows 2y-1..2y+1, cols 2x-1..2x+1 in the image
+__global__ __launch_bounds__(256) void vid_maxpool_kernel(const float* __restrict__ in, float* __restrict__ out, int N, int C, int Hi, int Ho) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= planes * Ho * Ho) return;
-    const int x = (int)(i % Ho), y = (int)((i / Ho) % Ho);
-    const size_t pl = i / ((size_t)Ho * Ho);
-    const float* p = in + pl * Hi * Hi;
+    if (i >= (size_t)N * Ho * Ho * C) return;
+    const int c = (int)(i % C), x = (int)((i / C) % Ho), y = (int)((i / ((size_t)C * Ho)) % Ho), n = (int)(i / ((size_t)C * Ho * Ho));
+    const float* p = in + (size_t)n * Hi * Hi * C + c;
     float m = -3.0e38f;
 #pragma unroll
     for (int dy = -1; dy <= 1; ++dy)
 #pragma unroll
         for (int dx = -1; dx <= 1; ++dx) {
             const int yy = 2 * y + dy, xx = 2 * x + dx;
-            if (yy >= 0 && yy < Hi && xx >= 0 && xx < Hi) m = fmaxf(m, p[yy * Hi + xx]);
+            if (yy >= 0 && yy < Hi && xx >= 0 && xx < Hi) m = fmaxf(m, p[((size_t)yy * Hi + xx) * C]);
         }
-    out[(pl * (Ho + 2) + (y + 1)) * (Ho + 2) + (x + 1)] = m;
+    out[(((size_t)n * (Ho + 2) + (y + 1)) * (Ho + 2) + (x + 1)) * C + c] = m;
 }
 
-// padded (n = b*T + t, C, H+2, H+2) -> (B, C, T) mean over the H x H interior
+// padded channel-last (n = b*T + t, H+2, H+2, C) -> (B, C, T) mean over the H x H interior
 __global__ __launch_bounds__(256) void vid_avgpool_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int T, int C, int H) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= B * T * C) return;
     const int c = i % C, n = i / C, b = n / T, t = n - b * T;
-    const float* p = in + ((size_t)n * C + c) * (H + 2) * (H + 2);
+    const float* p = in + (size_t)n * (H + 2) * (H + 2) * C + c;
     float s = 0.f;
     for (int y = 1; y <= H; ++y)
-        for (int x = 1; x <= H; ++x) s += p[y * (H + 2) + x];
+        for (int x = 1; x <= H; ++x) s += p[((size_t)y * (H + 2) + x) * C];
     out[((size_t)b * C + c) * T + t] = s / (float)(H * H);
 }
 
@@ -275,8 +299,7 @@ int video_frontend(const float* lips, const float* pack, float* out, int B, int 
         a.x = xp; a.w16 = reinterpret_cast<const half8*>(take(64 * 256)); a.bias = take(64); a.slope = take(64);
         a.res = nullptr; a.out = y44; a.N = N; a.Cin = 1; a.Cout = 64; a.Hi = 88; a.Wi = 88; a.Ho = 44; a.Wo = 44; a.stride = 2; a.T = T;
         if (int rc = conv_launch(VM_STEM, a, st)) return rc;
-        const size_t planes_n = (size_t)N * 64;
-        hipLaunchKernelGGL(vid_maxpool_kernel, dim3((unsigned)((planes_n * 22 * 22 + 255) / 256)), dim3(256), 0, st, y44, buf[0][0], planes_n, 44, 22);
+        hipLaunchKernelGGL(vid_maxpool_kernel, dim3((unsigned)(((size_t)N * 64 * 22 * 22 + 255) / 256)), dim3(256), 0, st, y44, buf[0][0], N, 64, 44, 22);
         if (rtfs_launch_status()) return RTFS_ERR_LAUNCH;
     }
     const float* x = buf[0][0];
