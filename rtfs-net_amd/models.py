@@ -378,14 +378,18 @@ class BaseAVModel(nn.Module):
 
     @staticmethod
     def from_pretrain(pretrained_model_conf_or_path, *args, **kwargs):
-        conf = torch.load(pretrained_model_conf_or_path, map_location="cpu", weights_only=True) \
-            if isinstance(pretrained_model_conf_or_path, str) else pretrained_model_conf_or_path
+        if isinstance(pretrained_model_conf_or_path, str):
+            # non-executing loader; the reference's serialize() stores torch.__version__ (a str subclass) under infos
+            with torch.serialization.safe_globals([torch.torch_version.TorchVersion]):
+                conf = torch.load(pretrained_model_conf_or_path, map_location="cpu", weights_only=True)
+        else:
+            conf = pretrained_model_conf_or_path
         model = get(conf["model_name"])(print_macs=False, *args, **kwargs)
         model.load_state_dict(conf["state_dict"])
         return model
 
     def serialize(self):
-        infos = dict(software_versions=dict(torch_version=torch.__version__, python_version=sys.version))
+        infos = dict(software_versions=dict(torch_version=str(torch.__version__), python_version=sys.version))
         return dict(model_name=self.__class__.__name__, state_dict=self.get_state_dict(), model_args=self.get_config(), infos=infos)
 
     def get_state_dict(self):

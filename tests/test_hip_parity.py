@@ -385,3 +385,33 @@ def test_video_frontend_vs_oracle_and_reference(k, B, T):
     assert rel_err(y, g[f"c{k}_out"]) < 1e-4
     with pytest.raises(ValueError):
         m(torch.zeros(1, 1, 2, 64, 64, device="cuda"))
+
+
+@pytest.mark.gpu
+def test_system_forward_and_validation_step():
+    """System.forward (core.py:78-92): raw lips -> video front-end -> separator, and validation_step -> PIT loss, all on
+    the HIP path; checked against the composition of the three oracles."""
+    import copy
+    from oracle import loss_oracle as LO, video_oracle as V
+    from tests.test_host import RTFS4_AUDIONET
+    import rtfs_net_amd as R
+    B, L, Tv = 1, 4096, 3
+    sd = make_state_dict(spec_R4(), 0)
+    vsd = V.make_video_state_dict(0)
+    audio = R.AVNet(print_macs=False, **copy.deepcopy(RTFS4_AUDIONET))
+    audio.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    video = R.FRCNNVideoModel(print_macs=False)
+    video.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in vsd.items()})
+    loss = {"val": R.losses.PITLossWrapper(R.losses.PairwiseNegSDR("snr"), pit_from="pw_mtx")}
+    s = R.System(audio_model=audio, video_model=video, loss_func=loss).cuda().eval()
+    wav, _ = make_inputs(B, L, Tv, 5)
+    lips = V.make_video_input(B, Tv, 9)
+    tgt = np.random.RandomState(3).randn(B, 1, L).astype(np.float32) * 0.05  # the test config has n_src = 1
+    with torch.no_grad():
+        est = s(torch.from_numpy(wav).cuda(), torch.from_numpy(lips).cuda())
+        out = s.validation_step((torch.from_numpy(wav).cuda(), torch.from_numpy(tgt).cuda(), torch.from_numpy(lips).cuda(), None), 0)
+    emb = V.video_frontend(lips, vsd)
+    ref = O.avnet_forward(wav, emb, sd, repeats=4)
+    assert rel_err(est.cpu().numpy(), ref) < 1e-4
+    ref_loss = LO.pit_from_pw_mtx(LO.pairwise_neg_sdr(ref, tgt, "snr"))[0]
+    assert abs(float(out["val_loss"]) - float(ref_loss)) < 1e-3

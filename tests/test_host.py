@@ -213,3 +213,33 @@ def test_vp_block_torch_ops_match_golden_on_cpu():
         for name, tv, seed in [("mod_vp50", 50, 109), ("mod_vp7", 7, 110)]:
             y = m.refinement_module.video_net.blocks(torch.from_numpy(rand((2, 512, tv), seed))).numpy()
             check_probe(load_golden(name), "out", y, 2e-5)
+
+
+def test_system_checkpoint_formats(tmp_path):
+    """Lightning .ckpt (audio_model./video_model. prefixes, core.py:178-181) and best_model.pth (train.py:156-160) round
+    trips through the non-executing loaders."""
+    import copy
+    import torch
+    import rtfs_net_amd as R
+    cfg = copy.deepcopy(RTFS4_AUDIONET)
+    torch.manual_seed(1)
+    a0, v0 = R.AVNet(print_macs=False, **copy.deepcopy(cfg)), R.FRCNNVideoModel(print_macs=False)
+    sd = {**{"audio_model." + k: v for k, v in a0.state_dict().items()}, **{"video_model." + k: v for k, v in v0.state_dict().items()}}
+    ck = tmp_path / "epoch=1.ckpt"
+    torch.save({"state_dict": sd, "training_config": {"exp": {"exp_name": "x"}}}, ck)
+    torch.manual_seed(2)
+    s = R.System(audio_model=R.AVNet(print_macs=False, **copy.deepcopy(cfg)), video_model=R.FRCNNVideoModel(print_macs=False))
+    assert s.load_lightning_checkpoint(str(ck)) == {"exp": {"exp_name": "x"}}
+    for k, v in a0.state_dict().items():
+        assert torch.equal(v, s.audio_model.state_dict()[k]), k
+    for k, v in v0.state_dict().items():
+        assert torch.equal(v, s.video_model.state_dict()[k]), k
+    best = tmp_path / "best_model.pth"
+    ser = a0.serialize()
+    ser["infos"]["software_versions"]["torch_version"] = torch.__version__  # as the reference writes it (TorchVersion)
+    torch.save(ser, best)
+    a1 = R.system.load_best_model(str(best), **copy.deepcopy(cfg))
+    for k, v in a0.state_dict().items():
+        assert torch.equal(v, a1.state_dict()[k]), k
+    with pytest.raises(ValueError):
+        R.System(audio_model=a0, optimizer=object())
