@@ -41,19 +41,22 @@ struct VidConvArgs {
 // MT = 32-row output tiles per wave (a workgroup covers 32 MT output channels); PT = 32-pixel tiles per wave (a workgroup
 // covers 128 PT pixels; PT = 2 measured no faster: the 3x3 gathers re-read the input nine times through L2, which is what
 // bounds these kernels -- an LDS-resident input tile reused across the taps is the next step)
-template <int MODE, int MT, int PT = 1>
-__global__ __launch_bounds__(256) void vid_conv_kernel(VidConvArgs a) {
-    constexpr int CO = 32 * MT;
+// CG = output-channel groups of waves (threads = 256 CG): CG = 2 gives a 128-pixel x 256-channel workgroup tile, halving the
+// L2 traffic of both operands for the wide layers (these kernels are L2-bound: each tap re-reads the input)
+template <int MODE, int MT, int PT = 1, int CG = 1>
+__global__ __launch_bounds__(256 * CG) void vid_conv_kernel(VidConvArgs a) {
+    constexpr int CO = 32 * MT * CG, NT = 256 * CG;
     __shared__ __attribute__((aligned(16))) _Float16 Ws[2][2 * CO * V_LDW];
     __shared__ int tab[MODE == VM_STEM ? 256 : 1];
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_ = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = wave_ & 3, wcg = wave_ >> 2;     // pixel tile of the wave, output-channel group of the wave
     const int cb = blockIdx.y;                         // block of CO output channels
     const int npix = a.N * a.Ho * a.Wo;
     const int K = MODE == VM_STEM ? 256 : (MODE == VM_C3 ? 9 : 1) * a.Cin;
     const int nchunk = K / 32;
     const int Hp = a.Hi + 2, Wp = a.Wi + 2;  // padded input plane (2-D modes)
-    if (MODE == VM_STEM && tid < 256) {
+    if (MODE == VM_STEM && tid < 256) {  // (CG == 1 for the stem)
         const int k = tid, dt = k / 49, rem = k - dt * 49, dy = rem / 7, dx = rem - dy * 7;
         tab[tid] = k < 245 ? (dt * 94 + dy) * 94 + dx : 0;  // offset inside the padded volume
     }
@@ -78,22 +81,23 @@ __global__ __launch_bounds__(256) void vid_conv_kernel(VidConvArgs a) {
     }
     // image: [Cout/64][K/32][hi|lo][64][32]; a block of CO channels = CO/64 consecutive 64-blocks
     const half8* wimg = a.w16 + (size_t)cb * (CO / 64) * nchunk * 512;
-    half8 pre[2 * (CO / 64)];
+    constexpr int NPRE = 2 * CO * 4 / NT;  // 16-byte pieces per thread and chunk
+    half8 pre[NPRE];
+    // pieces of a chunk: [sub-block CO/64][part 2][co 64][kq 4] -> 512 per sub-block
     auto stage_load = [&](int c) {
 #pragma unroll
-        for (int sb = 0; sb < CO / 64; ++sb)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) pre[sb * 2 + j] = wimg[((size_t)sb * nchunk + c) * 512 + tid + 256 * j];
+        for (int j = 0; j < NPRE; ++j) {
+            const int i = tid + NT * j, sb = i >> 9, w = i & 511;
+            pre[j] = wimg[((size_t)sb * nchunk + c) * 512 + w];
+        }
     };
     auto stage_write = [&](int buf) {
 #pragma unroll
-        for (int sb = 0; sb < CO / 64; ++sb)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int i = tid + 256 * j;  // piece: [part 2][co 64][kq 4] of sub-block sb
-                const int part = i >> 8, co = sb * 64 + ((i >> 2) & 63);
-                *reinterpret_cast<half8*>(&Ws[buf][(part * CO + co) * V_LDW + (i & 3) * 8]) = pre[sb * 2 + j];
-            }
+        for (int j = 0; j < NPRE; ++j) {
+            const int i = tid + NT * j, sb = i >> 9, w = i & 511;
+            const int part = w >> 8, co = sb * 64 + ((w >> 2) & 63);
+            *reinterpret_cast<half8*>(&Ws[buf][(part * CO + co) * V_LDW + (w & 3) * 8]) = pre[j];
+        }
     };
     f32x16 acc[PT][MT];
 #pragma unroll
@@ -147,8 +151,8 @@ __global__ __launch_bounds__(256) void vid_conv_kernel(VidConvArgs a) {
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
-                const half8 ah = *reinterpret_cast<const half8*>(&Ws[c & 1][(m * 32 + r) * V_LDW + ks * 16 + 8 * h]);
-                const half8 al = *reinterpret_cast<const half8*>(&Ws[c & 1][(CO + m * 32 + r) * V_LDW + ks * 16 + 8 * h]);
+                const half8 ah = *reinterpret_cast<const half8*>(&Ws[c & 1][((wcg * MT + m) * 32 + r) * V_LDW + ks * 16 + 8 * h]);
+                const half8 al = *reinterpret_cast<const half8*>(&Ws[c & 1][(CO + (wcg * MT + m) * 32 + r) * V_LDW + ks * 16 + 8 * h]);
 #pragma unroll
                 for (int t = 0; t < PT; ++t) {
                     acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[t][ks], acc[t][m], 0, 0, 0);
@@ -168,8 +172,148 @@ __global__ __launch_bounds__(256) void vid_conv_kernel(VidConvArgs a) {
         for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int q4 = 0; q4 < 4; ++q4) {  // accumulator registers 4 q4 .. 4 q4 + 3 = 4 consecutive output channels
-                const int co = cb * CO + m * 32 + 8 * q4 + 4 * h;
+                const int co = cb * CO + (wcg * MT + m) * 32 + 8 * q4 + 4 * h;
                 const size_t o = (MODE == VM_STEM ? (size_t)pcs[t] : ((size_t)ns[t] * Hop + (ys[t] + 1)) * Wop + (xs[t] + 1)) * a.Cout + co;
+                f32x4 val;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) val[i] = fmaf(acc[t][m][4 * q4 + i], WINV, a.bias[co + i]);
+                if (a.res) val += *reinterpret_cast<const f32x4*>(a.res + o);
+                if (a.slope) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) val[i] = preluf_(val[i], a.slope[co + i]);
+                }
+                *reinterpret_cast<f32x4*>(a.out + o) = val;
+            }
+    }
+}
+
+// ---------------------------------------------------------------- stride-1 3x3 convolution with an LDS-resident input tile
+// The gather kernel above re-reads the input once per tap (9x the tensor through L2, which is what bounds it).  Here a
+// workgroup owns up to 256 output pixels -- G whole frames, or a band of RH rows of one frame (layer 1: 11 of 22 rows) --
+// and loads their input footprint (G x (RH+2) x (W+2) padded pixels x 32 channels) into LDS once per 32-channel chunk;
+// the nine taps then read their B fragments from LDS (two ds_read_b128 per fragment; 144-byte pixel rows, conflict-free).
+// 4 waves x 2 pixel tiles x MT output tiles; the weight chunks stream through a double-buffered LDS image as above.
+constexpr int VL_PIXLD = 36;  // floats per staged pixel (32 channels + 4 pad)
+
+template <int MT>
+__global__ __launch_bounds__(256) void vid_conv3l_kernel(VidConvArgs a, int G, int RH, int bands) {
+    constexpr int CO = 32 * MT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char vsm[];
+    _Float16* Ws = reinterpret_cast<_Float16*>(vsm);                       // [2][2 * CO * V_LDW]
+    float* Xs = reinterpret_cast<float*>(vsm + (size_t)2 * 2 * CO * V_LDW * 2);  // [G][(RH+2)][Wp][VL_PIXLD]
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cb = blockIdx.y;
+    const int H = a.Ho, W = a.Wo, Wp = W + 2, Hp = H + 2;  // stride 1: input and output geometry coincide
+    const int grp = blockIdx.x / bands, band = blockIdx.x - grp * bands;
+    const int n0 = grp * G, y0 = band * RH;
+    const int nfr = min(G, a.N - n0), rows = min(RH, H - y0);
+    const int npx = nfr * rows * W;         // live output pixels of this workgroup (<= 256)
+    const int tile_px = nfr * (rows + 2) * Wp;  // staged input pixels
+    // this lane's two output pixels: slot -> (frame in group, row in band, column); staged-pixel index of tap (0,0)
+    bool live[2];
+    int sbase[2], on[2], oy[2], ox[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int slot = (wave * 2 + t) * 32 + r;
+        live[t] = slot < npx;
+        const int sc = live[t] ? slot : 0;
+        const int gf = sc / (rows * W), rem = sc - gf * (rows * W), y = rem / W, x = rem - y * W;
+        on[t] = n0 + gf; oy[t] = y0 + y; ox[t] = x;
+        sbase[t] = ((gf * (rows + 2) + y) * Wp + x) * VL_PIXLD + 8 * h;
+    }
+    const int nci = a.Cin / 32;
+    const half8* wimg = a.w16 + (size_t)cb * (CO / 64) * (9 * nci) * 512;
+    half8 pre[2 * (CO / 64)];
+    auto stage_load = [&](int c) {
+#pragma unroll
+        for (int sb = 0; sb < CO / 64; ++sb)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) pre[sb * 2 + j] = wimg[((size_t)sb * (9 * nci) + c) * 512 + tid + 256 * j];
+    };
+    auto stage_write = [&](int buf) {
+#pragma unroll
+        for (int sb = 0; sb < CO / 64; ++sb)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int i = tid + 256 * j;
+                const int part = i >> 8, co = sb * 64 + ((i >> 2) & 63);
+                *reinterpret_cast<half8*>(Ws + buf * (2 * CO * V_LDW) + (part * CO + co) * V_LDW + (i & 3) * 8) = pre[sb * 2 + j];
+            }
+    };
+    f32x16 acc[2][MT];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[t][m][q] = 0.f;
+    // weight chunk order: for each 32-channel chunk cic, the nine taps (image chunk index = tap * nci + cic)
+    stage_load(0);
+    int wbuf = 0;
+    for (int cic = 0; cic < nci; ++cic) {
+        __syncthreads();  // every wave has finished reading the previous input tile (and the last weight buffer)
+        // ---- input tile of this channel chunk: global (n, Hp, Wp, Cin) channel-last -> LDS [pixel][32 + pad]
+        for (int i = tid; i < tile_px * 8; i += 256) {
+            const int px = i >> 3, piece = i & 7;
+            const int gf = px / ((rows + 2) * Wp), rem = px - gf * ((rows + 2) * Wp), yy = rem / Wp, xx = rem - yy * Wp;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(a.x + (((size_t)(n0 + gf) * Hp + (y0 + yy)) * Wp + xx) * a.Cin + cic * 32 + piece * 4);
+            *reinterpret_cast<f32x4*>(Xs + px * VL_PIXLD + piece * 4) = v;
+        }
+        stage_write(wbuf);
+        __syncthreads();
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) {
+            const int cnext = tap < 8 ? (tap + 1) * nci + cic : (cic + 1 < nci ? cic + 1 : cic);  // next chunk in this order
+            stage_load(cnext);
+            const int dy = tap / 3, dx = tap - 3 * dy;
+            const int toff = (dy * Wp + dx) * VL_PIXLD;
+            const _Float16* wb = Ws + wbuf * (2 * CO * V_LDW);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                half8 bh[2], bl[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    float v[8];
+                    *reinterpret_cast<f32x4*>(v) = *reinterpret_cast<const f32x4*>(Xs + sbase[t] + toff + ks * 16);
+                    *reinterpret_cast<f32x4*>(v + 4) = *reinterpret_cast<const f32x4*>(Xs + sbase[t] + toff + ks * 16 + 4);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const _Float16 hi = (_Float16)v[j];
+                        bh[t][j] = hi;
+                        bl[t][j] = (_Float16)(v[j] - (float)hi);
+                    }
+                }
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    const half8 ah = *reinterpret_cast<const half8*>(wb + (m * 32 + r) * V_LDW + ks * 16 + 8 * h);
+                    const half8 al = *reinterpret_cast<const half8*>(wb + (CO + m * 32 + r) * V_LDW + ks * 16 + 8 * h);
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[t], acc[t][m], 0, 0, 0);
+                        acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[t], acc[t][m], 0, 0, 0);
+                        acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[t], acc[t][m], 0, 0, 0);
+                    }
+                }
+            }
+            if (tap < 8) {  // the next tap's weights go to the other buffer; the chunk after tap 8 is written after the tile swap
+                stage_write(wbuf ^ 1);
+                __syncthreads();
+                wbuf ^= 1;
+            }
+        }
+        wbuf ^= 1;  // tap 8's prefetch (first chunk of the next cic) is written at the top of the next iteration
+    }
+    constexpr float WINV = 1.0f / 256.0f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        if (!live[t]) continue;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const int co = cb * CO + m * 32 + 8 * q4 + 4 * h;
+                const size_t o = (((size_t)on[t] * Hp + (oy[t] + 1)) * Wp + (ox[t] + 1)) * a.Cout + co;
                 f32x4 val;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) val[i] = fmaf(acc[t][m][4 * q4 + i], WINV, a.bias[co + i]);
@@ -223,10 +367,37 @@ __global__ __launch_bounds__(256) void vid_avgpool_kernel(const float* __restric
     out[((size_t)b * C + c) * T + t] = s / (float)(H * H);
 }
 
+template <int MT>
+int conv3l_launch(const VidConvArgs& a, hipStream_t st) {
+    // frames per workgroup / row band so that a workgroup owns <= 256 output pixels
+    const int hw = a.Ho * a.Wo;
+    int G = 1, RH = a.Ho, bands = 1;
+    if (hw > 256) {
+        bands = cdiv(hw, 256);
+        RH = cdiv(a.Ho, bands);
+        bands = cdiv(a.Ho, RH);
+        if (RH * a.Wo > 256) return RTFS_ERR_SHAPE;
+    } else {
+        G = 256 / hw;
+    }
+    const size_t lds = (size_t)2 * 2 * (32 * MT) * V_LDW * 2 + (size_t)G * (RH + 2) * (a.Wo + 2) * VL_PIXLD * 4;
+    if (lds > 160 * 1024) return RTFS_ERR_SHAPE;
+    static size_t configured = 0;
+    if (lds > configured) {
+        if (hipFuncSetAttribute((const void*)vid_conv3l_kernel<MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return RTFS_ERR_LAUNCH;
+        configured = lds;
+    }
+    hipLaunchKernelGGL((vid_conv3l_kernel<MT>), dim3(cdiv(a.N, G) * bands, a.Cout / (32 * MT)), dim3(256), lds, st, a, G, RH, bands);
+    return rtfs_launch_status();
+}
+
 int conv_launch(int mode, const VidConvArgs& a, hipStream_t st) {
     const int px = cdiv(a.N * a.Ho * a.Wo, 128);
+    // LDS-resident input tile (nine taps per load): pays off for the large-plane 64-channel layer only -- the deeper layers'
+    // small planes give too few, too LDS-heavy workgroups (measured 376 us against 243 for the gather kernel)
+    if (mode == VM_C3 && a.stride == 1 && a.Hi == a.Ho && a.Wi == a.Wo && a.Cout == 64) return conv3l_launch<2>(a, st);
     if (mode == VM_STEM) hipLaunchKernelGGL((vid_conv_kernel<VM_STEM, 2>), dim3(px, 1), dim3(256), 0, st, a);
-    else if (a.Cout % 128 == 0) {  // 128 output channels per workgroup: the gathered activations are reused twice as often
+    else if (a.Cout % 128 == 0) {  // (CG = 2, a 256-channel tile on 8 waves, measured slower: 309 us against 243)  // 128 output channels per workgroup: the gathered activations are reused twice as often
         if (mode == VM_C3) hipLaunchKernelGGL((vid_conv_kernel<VM_C3, 4>), dim3(px, a.Cout / 128), dim3(256), 0, st, a);
         else hipLaunchKernelGGL((vid_conv_kernel<VM_C1, 4>), dim3(px, a.Cout / 128), dim3(256), 0, st, a);
     } else {
