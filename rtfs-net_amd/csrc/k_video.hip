@@ -51,7 +51,13 @@ __global__ __launch_bounds__(256 * CG) void vid_conv_kernel(VidConvArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
     const int wave_ = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wave = wave_ & 3, wcg = wave_ >> 2;     // pixel tile of the wave, output-channel group of the wave
-    const int cb = blockIdx.y;                         // block of CO output channels
+    // XCD-aware block order (workgroup L runs on XCD L % 8): the output-channel blocks of one pixel tile share its gathered
+    // input, so they get the same residue and consecutive slots -> the input is fetched into ONE L2, once
+    const int ncb = a.Cout / CO;
+    const int slot = blockIdx.x >> 3;
+    const int ptile = (slot / ncb) * 8 + (blockIdx.x & 7);
+    const int cb = slot - (slot / ncb) * ncb;          // block of CO output channels
+    if (ptile * 128 * PT >= a.N * a.Ho * a.Wo) return;  // uniform; before any barrier
     const int npix = a.N * a.Ho * a.Wo;
     const int K = MODE == VM_STEM ? 256 : (MODE == VM_C3 ? 9 : 1) * a.Cin;
     const int nchunk = K / 32;
@@ -66,7 +72,7 @@ __global__ __launch_bounds__(256 * CG) void vid_conv_kernel(VidConvArgs a) {
     size_t base[PT];
 #pragma unroll
     for (int t = 0; t < PT; ++t) {
-        const int pix = (blockIdx.x * PT + t) * 128 + wave * 32 + r;
+        const int pix = (ptile * PT + t) * 128 + wave * 32 + r;
         live[t] = pix < npix;
         const int pc = live[t] ? pix : npix - 1;
         const int n = pc / (a.Ho * a.Wo), yx = pc - n * (a.Ho * a.Wo), y = yx / a.Wo, x = yx - y * a.Wo;
@@ -396,13 +402,14 @@ int conv_launch(int mode, const VidConvArgs& a, hipStream_t st) {
     // LDS-resident input tile (nine taps per load): pays off for the large-plane 64-channel layer only -- the deeper layers'
     // small planes give too few, too LDS-heavy workgroups (measured 376 us against 243 for the gather kernel)
     if (mode == VM_C3 && a.stride == 1 && a.Hi == a.Ho && a.Wi == a.Wo && a.Cout == 64) return conv3l_launch<2>(a, st);
-    if (mode == VM_STEM) hipLaunchKernelGGL((vid_conv_kernel<VM_STEM, 2>), dim3(px, 1), dim3(256), 0, st, a);
+    auto grid1 = [&](int ncb) { return dim3((unsigned)(cdiv(px, 8) * 8 * ncb)); };
+    if (mode == VM_STEM) hipLaunchKernelGGL((vid_conv_kernel<VM_STEM, 2>), grid1(1), dim3(256), 0, st, a);
     else if (a.Cout % 128 == 0) {  // (CG = 2, a 256-channel tile on 8 waves, measured slower: 309 us against 243)  // 128 output channels per workgroup: the gathered activations are reused twice as often
-        if (mode == VM_C3) hipLaunchKernelGGL((vid_conv_kernel<VM_C3, 4>), dim3(px, a.Cout / 128), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((vid_conv_kernel<VM_C1, 4>), dim3(px, a.Cout / 128), dim3(256), 0, st, a);
+        if (mode == VM_C3) hipLaunchKernelGGL((vid_conv_kernel<VM_C3, 4>), grid1(a.Cout / 128), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((vid_conv_kernel<VM_C1, 4>), grid1(a.Cout / 128), dim3(256), 0, st, a);
     } else {
-        if (mode == VM_C3) hipLaunchKernelGGL((vid_conv_kernel<VM_C3, 2>), dim3(px, a.Cout / 64), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((vid_conv_kernel<VM_C1, 2>), dim3(px, a.Cout / 64), dim3(256), 0, st, a);
+        if (mode == VM_C3) hipLaunchKernelGGL((vid_conv_kernel<VM_C3, 2>), grid1(a.Cout / 64), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((vid_conv_kernel<VM_C1, 2>), grid1(a.Cout / 64), dim3(256), 0, st, a);
     }
     return rtfs_launch_status();
 }
