@@ -344,21 +344,27 @@ __global__ __launch_bounds__(256) void vid_pad_kernel(const float* __restrict__ 
     xp[i] = in ? x[(((size_t)b * T + t) * 88 + y) * 88 + xq] : 0.f;
 }
 
-// channel-last (n, Hi, Hi, C) -> padded (n, Ho+2, Ho+2, C) interior: max over rows 2y-1..2y+1, cols 2x-1..2x+1 in the image
+// channel-last (n, Hi, Hi, C) -> padded (n, Ho+2, Ho+2, C) interior: max over rows 2y-1..2y+1, cols 2x-1..2x+1 in the image;
+// one thread per (pixel, 4 channels): 16-byte accesses
 __global__ __launch_bounds__(256) void vid_maxpool_kernel(const float* __restrict__ in, float* __restrict__ out, int N, int C, int Hi, int Ho) {
+    const int c4 = C / 4;
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (size_t)N * Ho * Ho * C) return;
-    const int c = (int)(i % C), x = (int)((i / C) % Ho), y = (int)((i / ((size_t)C * Ho)) % Ho), n = (int)(i / ((size_t)C * Ho * Ho));
+    if (i >= (size_t)N * Ho * Ho * c4) return;
+    const int c = (int)(i % c4) * 4, x = (int)((i / c4) % Ho), y = (int)((i / ((size_t)c4 * Ho)) % Ho), n = (int)(i / ((size_t)c4 * Ho * Ho));
     const float* p = in + (size_t)n * Hi * Hi * C + c;
-    float m = -3.0e38f;
+    f32x4 m = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
 #pragma unroll
     for (int dy = -1; dy <= 1; ++dy)
 #pragma unroll
         for (int dx = -1; dx <= 1; ++dx) {
             const int yy = 2 * y + dy, xx = 2 * x + dx;
-            if (yy >= 0 && yy < Hi && xx >= 0 && xx < Hi) m = fmaxf(m, p[((size_t)yy * Hi + xx) * C]);
+            if (yy >= 0 && yy < Hi && xx >= 0 && xx < Hi) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(p + ((size_t)yy * Hi + xx) * C);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) m[k] = fmaxf(m[k], v[k]);
+            }
         }
-    out[(((size_t)n * (Ho + 2) + (y + 1)) * (Ho + 2) + (x + 1)) * C + c] = m;
+    *reinterpret_cast<f32x4*>(out + (((size_t)n * (Ho + 2) + (y + 1)) * (Ho + 2) + (x + 1)) * C + c) = m;
 }
 
 // padded channel-last (n = b*T + t, H+2, H+2, C) -> (B, C, T) mean over the H x H interior
@@ -395,6 +401,19 @@ int conv3l_launch(const VidConvArgs& a, hipStream_t st) {
     }
     hipLaunchKernelGGL((vid_conv3l_kernel<MT>), dim3(cdiv(a.N, G) * bands, a.Cout / (32 * MT)), dim3(256), lds, st, a, G, RH, bands);
     return rtfs_launch_status();
+}
+
+// zero the one-pixel border of a padded channel-last activation buffer (n, H+2, H+2, C): 4 (H+1) border pixels per frame
+__global__ __launch_bounds__(256) void vid_border_kernel(float* __restrict__ buf, int N, int H, int C) {
+    const int c4 = C / 4, nb = 4 * (H + 1);
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)N * nb * c4) return;
+    const int cc = (int)(i % c4), k = (int)((i / c4) % nb), n = (int)(i / ((size_t)c4 * nb));
+    const int Hp = H + 2, side = k / (H + 1), j = k - side * (H + 1);
+    // side 0: top row, columns 0..H; 1: right column, rows 0..H; 2: bottom row, columns 1..H+1; 3: left column, rows 1..H+1
+    const int y = side == 0 ? 0 : side == 1 ? j : side == 2 ? Hp - 1 : j + 1;
+    const int x = side == 0 ? j : side == 1 ? Hp - 1 : side == 2 ? j + 1 : 0;
+    *reinterpret_cast<f32x4*>(buf + (((size_t)n * Hp + y) * Hp + x) * C + cc * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
 }
 
 int conv_launch(int mode, const VidConvArgs& a, hipStream_t st) {
@@ -460,7 +479,13 @@ int video_frontend(const float* lips, const float* pack, float* out, int B, int 
             buf[li][k] = w;
             w += (size_t)N * planes[li] * hw[li] * hw[li];
         }
-    if (hipMemsetAsync(act0, 0, (size_t)(w - act0) * sizeof(float), st) != hipSuccess) return RTFS_ERR_LAUNCH;  // zero borders
+    (void)act0;
+    for (int li = 0; li < 4; ++li)  // zero borders (interiors are always written before they are read)
+        for (int k = 0; k < 3; ++k) {
+            const size_t cnt = (size_t)N * 4 * (hw[li] - 1) * (planes[li] / 4);
+            hipLaunchKernelGGL(vid_border_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, buf[li][k], N, hw[li] - 2, planes[li]);
+        }
+    if (rtfs_launch_status()) return RTFS_ERR_LAUNCH;
     size_t off = 0;
     auto take = [&](size_t n) {
         const float* r = pack + off;
@@ -477,7 +502,7 @@ int video_frontend(const float* lips, const float* pack, float* out, int B, int 
         a.x = xp; a.w16 = reinterpret_cast<const half8*>(take(64 * 256)); a.bias = take(64); a.slope = take(64);
         a.res = nullptr; a.out = y44; a.N = N; a.Cin = 1; a.Cout = 64; a.Hi = 88; a.Wi = 88; a.Ho = 44; a.Wo = 44; a.stride = 2; a.T = T;
         if (int rc = conv_launch(VM_STEM, a, st)) return rc;
-        hipLaunchKernelGGL(vid_maxpool_kernel, dim3((unsigned)(((size_t)N * 64 * 22 * 22 + 255) / 256)), dim3(256), 0, st, y44, buf[0][0], N, 64, 44, 22);
+        hipLaunchKernelGGL(vid_maxpool_kernel, dim3((unsigned)(((size_t)N * 16 * 22 * 22 + 255) / 256)), dim3(256), 0, st, y44, buf[0][0], N, 64, 44, 22);
         if (rtfs_launch_status()) return RTFS_ERR_LAUNCH;
     }
     const float* x = buf[0][0];

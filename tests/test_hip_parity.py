@@ -377,6 +377,9 @@ def test_video_frontend_vs_oracle_and_reference(k, B, T):
     m.load_state_dict({n: torch.from_numpy(np.asarray(v)) for n, v in sd.items()})
     m = m.cuda().eval()
     x = V.make_video_input(B, T, k)
+    from rtfs_net_amd import _lib
+    lib = _lib.load()
+    _lib.workspace(lib.rtfs_video_workspace_bytes(B, T), torch.device("cuda", 0)).fill_(0xFF)  # poison: scratch is NaN on entry
     with torch.no_grad():
         y = m(torch.from_numpy(x).cuda()).cpu().numpy()
     ref = V.video_frontend(x, sd)
