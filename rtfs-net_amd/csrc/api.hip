@@ -157,9 +157,11 @@ struct S3Pack {
 };
 struct DecPack {
     const float *wt, *w16;  // (256, 32): 18 tap maps (o*3+dt)*3+df, zero padded to 32; and its f16 split image
+    const float* w16p;      // the same maps with K in accumulator-register order (S3 + taps kernel)
     explicit DecPack(Cursor& c) {
         wt = c.take(CA * 32);
         w16 = c.take(CA * 32);
+        w16p = c.take(8192);
     }
 };
 
@@ -908,6 +910,12 @@ int rtfs_separator_forward_f32(const float* wav, const float* video_vp, const fl
             if (i + 1 < repeats) CHECK(block_boundary(pk, w.a1, B, T, NF, w.blk, st, i == 0 ? &ca : nullptr));
             else CHECK(block_tail(pk, cur, B, T, NF, w.blk, st));
         }
+    }
+    if (!gemm_f32() && !getenv("RTFS_NO_S3T")) {  // S3 + decoder taps in one kernel: the separated spectrum never goes to HBM
+        PwArgs a;
+        a.x = cur; a.bias = ps.bias; a.aux = w.a0; a.out = w.z; a.slope = ps.slope; a.P = P; a.w16 = ps.w16; a.w16b = pd.w16p; a.cout_live = 18;
+        CHECK(launch_pwr_s3_taps(a, B, st));
+        return launch_dec_istft(w.z, out, B, T, NF, L, (size_t)T * NF, (size_t)18 * T * NF, st);
     }
     CHECK(s3_mask(ps, cur, w.a0, nxt, B, P, st));
     return decoder(pd, nxt, out, w.z, B, T, L, st);

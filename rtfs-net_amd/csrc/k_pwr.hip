@@ -22,7 +22,7 @@
 
 namespace {
 
-enum { PWR_BN = 0, PWR_S3 = 1 };
+enum { PWR_BN = 0, PWR_S3 = 1, PWR_S3T = 2 };  // S3T: S3 fused with the decoder's per-tap 1x1 maps (writes z, not sep)
 
 constexpr int PWR_LDW = 264;                       // staged weight row: 256 k + 8 pad halfs (528 B, ds_read_b128 conflict-free)
 constexpr int PWR_BUF = 2 * 32 * PWR_LDW;          // halfs per buffer: [hi|lo][32 co][PWR_LDW]
@@ -43,10 +43,10 @@ __device__ __forceinline__ void pwr_body(const PwArgs& a, const float* __restric
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int P = a.P;
     bs[tid] = a.bias[tid];  // visible after the first barrier
-    const float slope = MODE == PWR_S3 ? a.slope[0] : 0.f;
+    const float slope = MODE != PWR_BN ? a.slope[0] : 0.f;
 
     // output tile order: S3 needs rows c and c + 128 (mask real / imaginary part) back to back
-    auto tile_of = [](int i) { return MODE == PWR_S3 ? (i >> 1) + 4 * (i & 1) : i; };
+    auto tile_of = [](int i) { return MODE != PWR_BN ? (i >> 1) + 4 * (i & 1) : i; };
 
     // weight rows of output tile ct: the k_pw16 image is [k chunk 8][hi|lo][256 co][32 k]; a (chunk, part, tile) piece is
     // 32 rows x 64 B = 2 KB contiguous.  2048 16-byte pieces per tile, 8 per thread.
@@ -109,12 +109,17 @@ __device__ __forceinline__ void pwr_body(const PwArgs& a, const float* __restric
         }
         // ---- 8 output tiles of 32 rows
         f32x16 keep;  // S3: the mask's real-part tile waits for its imaginary partner
+        f32x16 acc2;  // S3T: decoder taps (32 rows, 18 live) x this wave's 32 pixels
+        if (MODE == PWR_S3T) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc2[q] = 0.f;
+        }
         float er[16], ei[16];
 #pragma unroll 1
         for (int i = 0; i < 8; ++i) {
             const int ct = tile_of(i);
             stage_load(tile_of((i + 1) & 7));  // i == 7: tile 0 again, for the next pixel tile
-            if (MODE == PWR_S3 && (i & 1)) {
+            if (MODE == PWR_S3 && (i & 1)) {  // (S3T loads them in halves at the point of use: register budget)
                 // encoder output rows of this pair, requested under the second tile's MFMAs
                 const float* __restrict__ Ab = AUX + ((size_t)b * 256 + (ct - 4) * 32 + 4 * h) * P + pc;
 #pragma unroll
@@ -148,6 +153,47 @@ __device__ __forceinline__ void pwr_body(const PwArgs& a, const float* __restric
                 }
             } else if (!(i & 1)) {
                 keep = acc;
+            } else if (MODE == PWR_S3T) {
+                // separated spectrum rows c = m*32 + row (real) and c + 128 (imaginary) of this lane's pixel, eight rows (one
+                // K step of the taps GEMM) at a time; they feed the matrix cores as they stand: the taps weight image
+                // (packing.taps_perm_image) has its K axis in accumulator-register order
+                const int m = ct - 4;
+                const float* __restrict__ Ab = AUX + ((size_t)b * 256 + m * 32 + 4 * h) * P + pc;
+                const half8* __restrict__ TW = reinterpret_cast<const half8*>(a.w16b);
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    float er[8], ei[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const unsigned ro = (unsigned)((j & 3) + 8 * (2 * s2 + (j >> 2))) * (unsigned)P;
+                        er[j] = Ab[ro];
+                        ei[j] = Ab[ro + (unsigned)(128 * P)];
+                    }
+                    half8 rh, rl, ih, il;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int q = 8 * s2 + j;
+                        const int c = m * 32 + 4 * h + (q & 3) + 8 * (q >> 2);
+                        const float mr = fmaxf(fmaf(keep[q], WINV, bs[c]), 0.f);
+                        const float mi = fmaxf(fmaf(acc[q], WINV, bs[c + 128]), 0.f);
+                        const float o_r = er[j] * mr - ei[j] * mi, o_i = er[j] * mi + ei[j] * mr;
+                        const _Float16 a_ = (_Float16)o_r, b_ = (_Float16)o_i;
+                        rh[j] = a_;
+                        rl[j] = (_Float16)(o_r - (float)a_);
+                        ih[j] = b_;
+                        il[j] = (_Float16)(o_i - (float)b_);
+                    }
+                    // image: [m 4][part 2][s 2][hi|lo][32 taps][16 k] halfs -> 16-byte piece index ((idx*2 + hl)*32 + r)*2 + h
+                    const int idx_r = (m * 2 + 0) * 2 + s2, idx_i = (m * 2 + 1) * 2 + s2;
+                    const half8 trh = TW[((idx_r * 2 + 0) * 32 + r) * 2 + h], trl = TW[((idx_r * 2 + 1) * 32 + r) * 2 + h];
+                    const half8 tih = TW[((idx_i * 2 + 0) * 32 + r) * 2 + h], til = TW[((idx_i * 2 + 1) * 32 + r) * 2 + h];
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(trh, rh, acc2, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(trh, rl, acc2, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(trl, rh, acc2, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(tih, ih, acc2, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(tih, il, acc2, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(til, ih, acc2, 0, 0, 0);
+                }
             } else {
                 float* __restrict__ Ob = OUT + ((size_t)b * 256 + (ct - 4) * 32 + 4 * h) * P + pc;
                 if (live) {
@@ -165,6 +211,14 @@ __device__ __forceinline__ void pwr_body(const PwArgs& a, const float* __restric
             }
             stage_write((i + 1) & 1);
             if (i < 7) __syncthreads();  // after i == 7 the barrier at the top of the next pixel tile orders buffer 0
+        }
+        if (MODE == PWR_S3T && live) {  // z (B, 18, P): tap row (q&3) + 8(q>>2) + 4h of the accumulator tile
+            float* __restrict__ Zb = OUT + (size_t)b * a.cout_live * P + pc;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int tap = (q & 3) + 8 * (q >> 2) + 4 * h;
+                if (tap < a.cout_live) Zb[(unsigned)tap * (unsigned)P] = acc2[q] * (WINV);
+            }
         }
     }
 }
@@ -192,3 +246,4 @@ int launch_pwr_t(const PwArgs& a, int B, hipStream_t st) {
 
 int launch_pwr_audio_bn(const PwArgs& a, int B, hipStream_t st) { return launch_pwr_t<PWR_BN>(a, B, st); }
 int launch_pwr_s3(const PwArgs& a, int B, hipStream_t st) { return launch_pwr_t<PWR_S3>(a, B, st); }
+int launch_pwr_s3_taps(const PwArgs& a, int B, hipStream_t st) { return a.w16b ? launch_pwr_t<PWR_S3T>(a, B, st) : RTFS_ERR_ARG; }

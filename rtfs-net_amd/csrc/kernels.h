@@ -10,6 +10,7 @@ struct PwArgs {
     float* res_out = nullptr;     // gateway: PReLU(dw1x1(x [+x2])) written through, (B, CIN, P)
     const float* wt = nullptr;    // (CIN, COUT) transposed 1x1 weight (exact-f32 kernels)
     const void* w16 = nullptr;    // [CIN/32][hi|lo][COUT][32] f16 split image of 256*W (f16x3 kernels)
+    const void* w16b = nullptr;   // S3 + decoder taps: K-permuted taps image (packing.taps_perm_image)
     const float* bias = nullptr;  // (COUT)
     const float* aux = nullptr;   // EPI_BIAS_RES: residual (B,COUT,P); EPI_S3: encoder output a0 (B,COUT,P)
     float* out = nullptr;         // (B, COUT, P)
@@ -47,6 +48,7 @@ int launch_pw16_dec_taps(const PwArgs& a, int B, hipStream_t st);
 // 256 -> 256 with register-resident pixels (k_pwr.hip)
 int launch_pwr_audio_bn(const PwArgs& a, int B, hipStream_t st);
 int launch_pwr_s3(const PwArgs& a, int B, hipStream_t st);
+int launch_pwr_s3_taps(const PwArgs& a, int B, hipStream_t st);  // S3 + decoder taps: writes z (B,18,P), not the separated spectrum
 // block boundary: residual_conv(i) + gateway/projection(i+1) back to back (k_pws.hip)
 struct B2bArgs {
     const float* x = nullptr;     // expanded_i (B,64,P)

@@ -189,7 +189,26 @@ def pack_decoder(sd):
     """STFTDecoder: ConvTranspose2d weight (256,2,3,3) -> 18 per-tap 1x1 maps, zero padded to 32."""
     w = sd["decoder.weight"].reshape(256, 18)
     w = torch.cat([w, w.new_zeros(256, 14)], 1)  # (cin 256, 32 taps)
-    return _cat([w, split16_image(w.t())])
+    return _cat([w, split16_image(w.t()), taps_perm_image(w.t())])
+
+
+def taps_perm_image(wt):
+    """(32 taps, 256 ch) decoder tap maps -> A fragments of the S3 + taps kernel (k_pwr.hip, PWR_S3T): the separated
+    spectrum reaches the matrix cores as accumulator registers, so K runs in register order.  Layout
+    [m 4][part 2][s 2][hi|lo][tap 32][16] halfs with k = 8h + j <-> channel part*128 + m*32 + 16s + 4h + (j&3) + 8(j>>2)."""
+    ws = wt.detach().to(torch.float32) * W16_SCALE
+    idx = torch.empty(4, 2, 2, 16, dtype=torch.long)
+    for m in range(4):
+        for part in range(2):
+            for s_ in range(2):
+                for hh in range(2):
+                    for j in range(8):
+                        idx[m, part, s_, 8 * hh + j] = part * 128 + m * 32 + 16 * s_ + 4 * hh + (j & 3) + 8 * (j >> 2)
+    g = ws[:, idx.reshape(-1)].reshape(32, 4, 2, 2, 16).permute(1, 2, 3, 0, 4)  # [m][part][s][tap][16]
+    hi = g.to(torch.float16)
+    lo = (g - hi.to(torch.float32)).to(torch.float16)
+    img = torch.stack([hi, lo], 3)  # [m][part][s][hl][tap][16]
+    return img.contiguous().view(torch.float32).reshape(-1)
 
 
 def _bn_fold(sd, prefix, conv_bias=None, eps=1e-5):
