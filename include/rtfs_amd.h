@@ -131,6 +131,26 @@ int rtfs_separator_forward_f32(const float* wav, const float* video_vp, const fl
 size_t rtfs_sru_workspace_bytes(int L, int N);
 int rtfs_sru_f32(const float* x, const float* pack, float* h, int L, int N, void* ws, size_t ws_bytes, void* stream);
 
+/* Training side of the same operator (upstream sru's forward/backward pair behind
+ * rnn_layers.py:150 when the module is used from train.py).  The forward keeps U = x.W, the cell states and the
+ * inter-layer activations of all four layers in `saved` (rtfs_sru_saved_floats(L,N) floats, caller-owned) for the backward.
+ * tpack (rtfs_sru_train_pack_floats() floats, rtfs-net_amd/packing.py:pack_sru_train):
+ *   Wt0 (256,512) | Wt1..3 (192,64) | Wp0 (512,256) | Wp1..3 (64,192) | weight_c (4,128) | bias (4,128)
+ *   with Wt = Wp^T and projection columns re-ordered to m*64 + dir*32 + j.
+ * backward: dh (L,N,64) -> dx (L,N,512) and dparams (rtfs_sru_grad_floats() floats, overwritten):
+ *   dWp0 (512,256) | dWp1..3 (64,192) | d weight_c (4,128) | d bias (4,128). */
+size_t rtfs_sru_train_pack_floats(void);
+size_t rtfs_sru_grad_floats(void);
+size_t rtfs_sru_saved_floats(int L, int N);
+size_t rtfs_sru_backward_workspace_bytes(int L, int N);
+int rtfs_sru_forward_train_f32(const float* x, const float* tpack, float* h, float* saved, int L, int N, void* stream);
+int rtfs_sru_backward_f32(const float* x, const float* tpack, const float* saved, const float* dh, float* dx, float* dparams,
+                          int L, int N, void* ws, size_t ws_bytes, void* stream);
+/* The two GEMM forms of the training path (bf16x3 split on the matrix cores), exposed for tests:
+ * kind 0: C (M,N) = A (M,K) . B (N,K)^T (accumulate != 0: C += ...), N % 64 == 0, K % 16 == 0;
+ * kind 1: C (M,N) += A (K,M)^T . B (K,N), M % 64 == 0, N % 64 == 0. */
+int rtfs_debug_gemm_f32(int kind, const float* A, const float* B, float* C, int M, int N, int K, int accumulate, void* stream);
+
 /* Diagnostic build of the dual-path sweep with s_memtime stamps at phase boundaries (profiling aid only).
  * x, out: (B, 64, R, Ls) with sequences along the last axis; stamps: DEVICE u64 [ceil(B*R/seqs_per_wg)][16]. */
 int rtfs_debug_sweep_stamps(const float* x, const float* pack, float* out, int B, int R, int Ls, unsigned long long* stamps,

@@ -1,0 +1,51 @@
+"""Gradient oracle for the training side (TEST INFRASTRUCTURE ONLY - the product never imports this).
+
+Differentiable float64 restatements, in torch ops, of the functions in ``rtfs_oracle.py`` that the backward kernels
+are checked against; gradients come from torch.autograd, so nothing here restates a backward formula.  Pinning:
+forward values are compared with the numpy restatement (``tests/test_oracle_golden.py``), which in turn is pinned by the
+reference's vectors where the reference arithmetic exists; the SRU cell is third-party (``sru``, absent offline), so its
+recurrence - forward and therefore backward - stays "parity unpinned" exactly as in ``rtfs_oracle.sru_forward``.
+"""
+from __future__ import annotations
+
+import torch
+
+
+def sru_forward_torch(x, layers):
+    """rtfs_oracle.sru_forward in torch (call site reference rnn_layers.py:99-105,150).
+    x (L,N,Din); layers = [(weight (Din, 2d*k), weight_c (4d), bias (4d))]; returns h (L,N,2d)."""
+    L, N, _ = x.shape
+    h_in = x
+    for (W, wc, bias) in layers:
+        d2 = wc.shape[0] // 2
+        d = d2 // 2
+        k = W.shape[1] // d2
+        U = (h_in.reshape(L * N, -1) @ W).reshape(L, N, 2, d, k)
+        vf, vr = wc.reshape(2, 2, d)
+        bf, br = bias.reshape(2, 2, d)
+        xprime = U[..., 3] if k == 4 else h_in.reshape(L, N, 2, d)
+        outs = []
+        for di in range(2):
+            c = torch.zeros(N, d, dtype=x.dtype)
+            hs = [None] * L
+            for t in (range(L) if di == 0 else range(L - 1, -1, -1)):
+                u0 = U[t, :, di, :, 0]
+                f = torch.sigmoid(U[t, :, di, :, 1] + c * vf[di] + bf[di])
+                r = torch.sigmoid(U[t, :, di, :, 2] + c * vr[di] + br[di])
+                c = u0 + (c - u0) * f
+                xp = xprime[t, :, di, :]
+                hs[t] = xp + (c - xp) * r
+            outs.append(torch.stack(hs))
+        h_in = torch.stack(outs, 2).reshape(L, N, d2)
+    return h_in
+
+
+def sru_grads(x, layers, dh):
+    """numpy in / numpy out: (h, dx, [(dW, dwc, dbias)]) of sum(h * dh) by autograd in float64."""
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    lt = [tuple(torch.tensor(p, dtype=torch.float64, requires_grad=True) for p in lay) for lay in layers]
+    h = sru_forward_torch(xt, lt)
+    flat = [p for lay in lt for p in lay]
+    grads = torch.autograd.grad(h, [xt] + flat, torch.tensor(dh, dtype=torch.float64))
+    gl = [tuple(g.numpy() for g in grads[1 + 3 * i: 4 + 3 * i]) for i in range(len(lt))]
+    return h.detach().numpy(), grads[0].numpy(), gl

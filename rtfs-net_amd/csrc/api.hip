@@ -938,6 +938,85 @@ int rtfs_sru_f32(const float* x, const float* pack, float* h, int L, int N, void
     return launch_sru_standalone(x, h, L, N, p.W0, p.Wl, p.wc, p.bias, S(stream));
 }
 
+// ------------------------------------------------------------ SRU operator, training side (k_train.hip)
+namespace {
+constexpr size_t TP_WT0 = 0, TP_WTL = TP_WT0 + 256 * 512, TP_WP0 = TP_WTL + 3 * 192 * 64, TP_WPL = TP_WP0 + 512 * 256,
+                 TP_WC = TP_WPL + 3 * 64 * 192, TP_BIAS = TP_WC + 512, TP_END = TP_BIAS + 512;
+constexpr size_t GP_W0 = 0, GP_WL = 512 * 256, GP_WC = GP_WL + 3 * 64 * 192, GP_BIAS = GP_WC + 512, GP_END = GP_BIAS + 512;
+struct SruSaved {  // views into the saved-state buffer of one forward
+    float *U[4], *c[4], *h[3];
+    SruSaved(float* p, size_t LN) {
+        U[0] = p; p += LN * 256;
+        for (int l = 1; l < 4; ++l) { U[l] = p; p += LN * 192; }
+        for (int l = 0; l < 4; ++l) { c[l] = p; p += LN * 64; }
+        for (int l = 0; l < 3; ++l) { h[l] = p; p += LN * 64; }
+    }
+};
+}  // namespace
+
+size_t rtfs_sru_train_pack_floats(void) { return TP_END; }
+size_t rtfs_sru_grad_floats(void) { return GP_END; }
+size_t rtfs_sru_saved_floats(int L, int N) { return (size_t)L * N * (256 + 3 * 192 + 4 * 64 + 3 * 64); }
+size_t rtfs_sru_backward_workspace_bytes(int L, int N) { return (size_t)L * N * (256 + 2 * 64) * sizeof(float) + 256; }
+
+int rtfs_sru_forward_train_f32(const float* x, const float* tpack, float* h, float* saved, int L, int N, void* stream) {
+    RTFS_RETURN_IF(!x || !tpack || !h || !saved || L < 1 || N < 1, RTFS_ERR_ARG);
+    RTFS_RETURN_IF((size_t)L * N > 0x7fffffffu / 512, RTFS_ERR_SHAPE);
+    const int LN = L * N;
+    SruSaved sv(saved, (size_t)LN);
+    hipStream_t st = S(stream);
+    for (int l = 0; l < 4; ++l) {
+        const float* xin = l == 0 ? x : sv.h[l - 1];
+        const int K = l == 0 ? 512 : 64, KC = l == 0 ? 256 : 192;
+        const float* Wt = l == 0 ? tpack + TP_WT0 : tpack + TP_WTL + (size_t)(l - 1) * 192 * 64;
+        CHECK(launch_gemm_nt(xin, K, Wt, K, sv.U[l], KC, LN, KC, K, false, st));
+        SruScanArgs a;
+        a.U = sv.U[l]; a.xin = l == 0 ? nullptr : xin; a.wc = tpack + TP_WC + 128 * l; a.bias = tpack + TP_BIAS + 128 * l;
+        a.h = l == 3 ? h : sv.h[l]; a.c = sv.c[l]; a.L = L; a.N = N; a.KC = KC;
+        CHECK(launch_sru_scan_fwd(a, st));
+    }
+    return RTFS_OK;
+}
+
+int rtfs_sru_backward_f32(const float* x, const float* tpack, const float* saved, const float* dh, float* dx, float* dparams, int L,
+                          int N, void* ws, size_t ws_bytes, void* stream) {
+    RTFS_RETURN_IF(!x || !tpack || !saved || !dh || !dx || !dparams || L < 1 || N < 1, RTFS_ERR_ARG);
+    RTFS_RETURN_IF((size_t)L * N > 0x7fffffffu / 512, RTFS_ERR_SHAPE);
+    RTFS_RETURN_IF(!ws || ws_bytes < rtfs_sru_backward_workspace_bytes(L, N), RTFS_ERR_WORKSPACE);
+    const int LN = L * N;
+    SruSaved sv(const_cast<float*>(saved), (size_t)LN);
+    hipStream_t st = S(stream);
+    float* dU = (float*)ws;
+    float* gbuf[2] = {dU + (size_t)LN * 256, dU + (size_t)LN * 320};
+    if (hipMemsetAsync(dparams, 0, GP_END * sizeof(float), st) != hipSuccess) return RTFS_ERR_LAUNCH;
+    const float* g = dh;
+    for (int l = 3; l >= 0; --l) {
+        const int K = l == 0 ? 512 : 64, KC = l == 0 ? 256 : 192;
+        const float* xin = l == 0 ? x : sv.h[l - 1];
+        float* gnext = gbuf[l & 1];
+        SruScanArgs a;
+        a.U = sv.U[l]; a.xin = l == 0 ? nullptr : xin; a.wc = tpack + TP_WC + 128 * l; a.bias = tpack + TP_BIAS + 128 * l;
+        a.c = sv.c[l]; a.g = g; a.dU = dU; a.dxp = l == 0 ? nullptr : gnext; a.dwc = dparams + GP_WC + 128 * l;
+        a.dbias = dparams + GP_BIAS + 128 * l; a.L = L; a.N = N; a.KC = KC;
+        CHECK(launch_sru_scan_bwd(a, st));
+        const float* Wp = l == 0 ? tpack + TP_WP0 : tpack + TP_WPL + (size_t)(l - 1) * 64 * 192;
+        float* dWp = l == 0 ? dparams + GP_W0 : dparams + GP_WL + (size_t)(l - 1) * 64 * 192;
+        // input gradient: dU . W^T (+ the highway term the scan already wrote for layers 1-3)
+        CHECK(launch_gemm_nt(dU, KC, Wp, KC, l == 0 ? dx : gnext, K, LN, K, KC, l != 0, st));
+        CHECK(launch_gemm_tn(xin, K, dU, KC, dWp, KC, K, KC, (long)LN, st));
+        g = gnext;
+    }
+    return RTFS_OK;
+}
+
+// C = A . Bt^T (kind 0; accumulate adds to C) or C += A^T . B (kind 1): the two GEMM forms of the training path, exposed for tests
+int rtfs_debug_gemm_f32(int kind, const float* A, const float* B, float* C, int M, int N, int K, int accumulate, void* stream) {
+    RTFS_RETURN_IF(!A || !B || !C, RTFS_ERR_ARG);
+    if (kind == 0) return launch_gemm_nt(A, K, B, K, C, N, M, N, K, accumulate != 0, S(stream));
+    if (kind == 1) return launch_gemm_tn(A, M, B, N, C, N, M, N, (long)K, S(stream));
+    return RTFS_ERR_ARG;
+}
+
 // ------------------------------------------------------------ diagnostics
 // Runs the dual-path sweep (dim 4: along F, dim 3: x is already (B,64,F,T) transposed) in the phase-stamped
 // diagnostic build; stamps: DEVICE buffer of ceil(nseq/NSEQ) x 16 u64.  Not part of the product path.

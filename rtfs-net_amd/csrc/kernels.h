@@ -223,3 +223,33 @@ int launch_pit_pairwise(const float* est, const float* tgt, int B, int n, int L,
 size_t video_pack_floats();
 size_t video_workspace_bytes(int B, int T);
 int video_frontend(const float* lips, const float* pack, float* out, int B, int T, void* ws, size_t ws_bytes, hipStream_t st);
+
+// training side of the SRU operator (k_train.hip)
+struct GemmArgs {
+    const float *A = nullptr, *B = nullptr;
+    float* C = nullptr;
+    int lda = 0, ldb = 0, ldc = 0, M = 0, N = 0, K = 0;
+    int ncb = 0, nrb = 0;  // NT: column / row blocks
+    int kchunk = 0;        // TN: k range of one wave
+};
+// C (M,N) [+]= A (M,K) . Bt (N,K)^T  (both K-contiguous; N % 64 == 0, K % 16 == 0)
+int launch_gemm_nt(const float* A, int lda, const float* Bt, int ldb, float* C, int ldc, int M, int N, int K, bool accumulate,
+                   hipStream_t st);
+// C (M,N) += A (K,M)^T . B (K,N)  (split-K with f32 atomics; M, N % 64 == 0)
+int launch_gemm_tn(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, long K, hipStream_t st);
+struct SruScanArgs {
+    const float* U = nullptr;    // (L, N, KC), column m*64 + dir*32 + j
+    const float* xin = nullptr;  // (L, N, 64) highway input of layers 1-3; nullptr: U's m = 3 block (layer 0)
+    const float* wc = nullptr;   // (128) v_f | v_r
+    const float* bias = nullptr; // (128) b_f | b_r
+    float* h = nullptr;          // forward: (L, N, 64)
+    float* c = nullptr;          // forward: written; backward: read
+    const float* g = nullptr;    // backward: dL/dh (L, N, 64)
+    float* dU = nullptr;         // backward: (L, N, KC)
+    float* dxp = nullptr;        // backward, layers 1-3: highway gradient (L, N, 64)
+    float* dwc = nullptr;        // backward: (128) running sums
+    float* dbias = nullptr;      // backward: (128)
+    int L = 0, N = 0, KC = 0;
+};
+int launch_sru_scan_fwd(const SruScanArgs& a, hipStream_t st);
+int launch_sru_scan_bwd(const SruScanArgs& a, hipStream_t st);

@@ -229,6 +229,40 @@ def _sru_pack(sd):
     return packing.pack_dualpath(full)
 
 
+class _SRUTrainFn(torch.autograd.Function):
+    """sru.SRU forward/backward on the training kernels (csrc/k_train.hip).  Inputs: x, then (weight, weight_c, bias) x 4."""
+
+    @staticmethod
+    def forward(ctx, x, *params):
+        lib = _lib.load()
+        x = x.contiguous()
+        L, N, _ = x.shape
+        tpack = packing.pack_sru_train(params[0::3], params[1::3], params[2::3])
+        h = torch.empty(L, N, 64, device=x.device, dtype=torch.float32)
+        saved = torch.empty(lib.rtfs_sru_saved_floats(L, N), device=x.device, dtype=torch.float32)
+        _lib.check(lib.rtfs_sru_forward_train_f32(_lib.ptr(x), _lib.ptr(tpack), _lib.ptr(h), _lib.ptr(saved), L, N, _lib.stream_of(x)),
+                   "rtfs_sru_forward_train_f32")
+        ctx.save_for_backward(x, tpack, saved)
+        return h
+
+    @staticmethod
+    def backward(ctx, dh):
+        lib = _lib.load()
+        x, tpack, saved = ctx.saved_tensors
+        L, N, _ = x.shape
+        dh = dh.contiguous().to(torch.float32)
+        dx = torch.empty_like(x)
+        dpar = torch.empty(lib.rtfs_sru_grad_floats(), device=x.device, dtype=torch.float32)
+        ws = _lib.workspace(lib.rtfs_sru_backward_workspace_bytes(L, N), x.device)
+        _lib.check(lib.rtfs_sru_backward_f32(_lib.ptr(x), _lib.ptr(tpack), _lib.ptr(saved), _lib.ptr(dh), _lib.ptr(dx), _lib.ptr(dpar), L, N,
+                                             _lib.ptr(ws), ws.numel(), _lib.stream_of(x)), "rtfs_sru_backward_f32")
+        dws, dwcs, dbs = packing.unpack_sru_grads(dpar)
+        out = [dx]
+        for i in range(4):
+            out += [dws[i], dwcs[i], dbs[i]]
+        return tuple(out)
+
+
 class SRU(PackedModule):
     """Drop-in for ``sru.SRU(input_size=512, hidden_size=32, num_layers=4, bidirectional=True)`` as called at
     reference rnn_layers.py:99-105,150: forward(x (L,N,512)) -> (h (L,N,64), None)."""
@@ -243,8 +277,11 @@ class SRU(PackedModule):
         self.rnn_lst = nn.ModuleList([SRUCell(input_size if i == 0 else 2 * hidden_size, hidden_size, True) for i in range(num_layers)])
 
     def forward(self, x):
-        self._guard(x)
+        _lib.need_gpu(x)  # no train/eval difference in this operator (no dropout at the reference call site)
         lib = _lib.load()
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            params = [p for cell in self.rnn_lst for p in (cell.weight, cell.weight_c, cell.bias)]
+            return _SRUTrainFn.apply(x, *params), None
         x = x.contiguous()
         L, N, _ = x.shape
         h = torch.empty(L, N, 64, device=x.device, dtype=torch.float32)

@@ -83,6 +83,31 @@ def _dualpath_parts(sd):
     return parts
 
 
+def pack_sru_train(weights, weight_cs, biases):
+    """Training-side pack of sru.SRU(512, 32, 4 layers, bidirectional) (layout contract: include/rtfs_amd.h,
+    rtfs_sru_forward_train_f32): projections re-ordered to column m*64 + dir*32 + j, once K-major (Wt) and once as is (Wp)."""
+    wp = []
+    for w in weights:
+        din = w.shape[0]
+        k = w.shape[1] // 64
+        wp.append(w.detach().to(torch.float32).reshape(din, 64, k).permute(0, 2, 1).reshape(din, 64 * k))
+    parts = [wp[0].t()] + [w.t() for w in wp[1:]] + wp + [torch.stack(list(weight_cs)), torch.stack(list(biases))]
+    return _cat([t.contiguous() for t in parts])
+
+
+def unpack_sru_grads(flat):
+    """Inverse of the gradient layout of rtfs_sru_backward_f32: flat -> ([dweight], [dweight_c], [dbias]) in the module's shapes."""
+    sizes = [(512, 4), (64, 3), (64, 3), (64, 3)]
+    dws, off = [], 0
+    for din, k in sizes:
+        n = din * 64 * k
+        dws.append(flat[off:off + n].reshape(din, k, 64).permute(0, 2, 1).reshape(din, 64 * k))
+        off += n
+    dwc = flat[off:off + 512].reshape(4, 128)
+    db = flat[off + 512:off + 1024].reshape(4, 128)
+    return dws, list(dwc), list(db)
+
+
 def _dualpath_lstm_parts(sd):
     """DualPathRNN with rnn_type LSTM (nn.LSTM(512, 32, 4 layers, bidirectional)).  Columns of the input projections:
     dir*128 + gate*32 + j (gates i,f,g,o); bias = b_ih + b_hh; recurrent weights as [layer][dir][k][gate*32 + j]."""

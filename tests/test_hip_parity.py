@@ -154,6 +154,60 @@ def test_sru_operator():
     close("sru operator", host(h), O.sru_forward(x, O._sru_layers(p)))
 
 
+@pytest.mark.parametrize("kind,M,N,K,acc", [(0, 300, 192, 64, 0), (0, 1000, 512, 256, 1), (0, 37, 64, 512, 0), (1, 512, 256, 1237, 0),
+                                             (1, 64, 192, 5, 0), (1, 64, 64, 40000, 0)])
+def test_training_gemms(kind, M, N, K, acc):
+    """The two bf16x3 GEMM forms of the training path against float64 numpy (error budget ~2^-17 per product)."""
+    from rtfs_net_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(M + N + K)
+    if kind == 0:
+        A, B = rng.standard_normal((M, K)).astype(np.float32), rng.standard_normal((N, K)).astype(np.float32)
+        ref = A.astype(np.float64) @ B.astype(np.float64).T
+    else:
+        A, B = rng.standard_normal((K, M)).astype(np.float32), rng.standard_normal((K, N)).astype(np.float32)
+        A[:, 0] *= 1e-12  # a column far below f16's range: bf16 keeps the exponent
+        ref = A.astype(np.float64).T @ B.astype(np.float64)
+    C0 = rng.standard_normal((M, N)).astype(np.float32) if (acc or kind == 1) else np.zeros((M, N), np.float32)
+    if kind == 1:
+        C0[0] = 0
+    C = dev(C0)
+    a, b = dev(A), dev(B)
+    _lib.check(lib.rtfs_debug_gemm_f32(kind, _lib.ptr(a), _lib.ptr(b), _lib.ptr(C), M, N, K, acc, _lib.stream_of(a)), "gemm")
+    want = ref + (C0 if (acc or kind == 1) else 0)
+    close(f"gemm kind {kind} {M}x{N}x{K}", host(C), want, tol=2e-5)
+    if kind == 1:  # the tiny column by itself
+        close("gemm tiny column", host(C)[0], ref[0], tol=2e-5)
+
+
+@pytest.mark.parametrize("L,N,seed", [(19, 5, 21), (57, 37, 22), (250, 3, 23)])
+def test_sru_training_forward_backward(L, N, seed):
+    """sru.SRU used from a training step: forward (with saved state) and backward kernels against the autograd oracle."""
+    import rtfs_net_amd as R
+    from oracle import grad_oracle as G
+    p = O._sub(BLK, "globalatt.0")
+    layers = O._sru_layers(p)
+    sru = R.layers.SRU(512, 32, num_layers=4, bidirectional=True)
+    sru.load_state_dict({k[len("rnn."):]: torch.from_numpy(v) for k, v in p.items() if k.startswith("rnn.")})
+    sru = sru.cuda().train()
+    x = rand((L, N, 512), seed)
+    dh = rand((L, N, 64), seed + 100)
+    xt = dev(x).requires_grad_(True)
+    h, _ = sru(xt)
+    h.backward(dev(dh))
+    h_ref, dx_ref, g_ref = G.sru_grads(x, layers, dh)
+    close("sru train forward", host(h), h_ref)
+    close("sru dx", host(xt.grad), dx_ref, tol=2e-4)
+    for i, cell in enumerate(sru.rnn_lst):
+        close(f"sru layer {i} dW", host(cell.weight.grad), g_ref[i][0], tol=2e-4)
+        close(f"sru layer {i} dweight_c", host(cell.weight_c.grad), g_ref[i][1], tol=2e-4)
+        close(f"sru layer {i} dbias", host(cell.bias.grad), g_ref[i][2], tol=2e-4)
+    # inference kernel and training forward agree
+    with torch.no_grad():
+        if L <= 243:
+            close("sru eval vs train forward", host(sru(dev(x))[0]), host(h))
+
+
 @pytest.mark.parametrize("shape,seed", [((2, 64, 12, 64), 103), ((1, 64, 125, 64), 5), ((1, 64, 250, 64), 6), ((2, 64, 33, 64), 8)])
 def test_mhsa2d(shape, seed):
     m = model()
