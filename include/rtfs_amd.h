@@ -146,6 +146,22 @@ size_t rtfs_sru_backward_workspace_bytes(int L, int N);
 int rtfs_sru_forward_train_f32(const float* x, const float* tpack, float* h, float* saved, int L, int N, void* stream);
 int rtfs_sru_backward_f32(const float* x, const float* tpack, const float* saved, const float* dh, float* dx, float* dparams,
                           int L, int N, void* ws, size_t ws_bytes, void* stream);
+/* DualPathRNN.forward / backward for training (src/models/layers/rnn_layers.py:136-162 with rnn_type SRU).
+ * x, out, dout, dx (B,64,T,F); dim as in the reference (4: sweep along F, 3: along T).  `saved` (rtfs_dualpath_saved_floats)
+ * is written by the forward and read by the backward; the same workspace size serves both.
+ * tpack (rtfs_dualpath_train_pack_floats(), packing.py:pack_dualpath_train):
+ *   LN gamma (64) | LN beta (64) | SRU training pack with layer-0 rows in k*64 + c order | ConvTranspose1d weight as
+ *   (co, (7-k)*64 + ci) | as (ci, k*64 + co) | bias (64).
+ * dparams (rtfs_dualpath_grad_floats(), overwritten): dgamma | dbeta | SRU gradients (rtfs_sru_backward_f32 layout, layer-0
+ *   rows k*64 + c) | d ConvTranspose1d weight as ((7-k)*64 + ci, co) | d bias. */
+size_t rtfs_dualpath_train_pack_floats(void);
+size_t rtfs_dualpath_grad_floats(void);
+size_t rtfs_dualpath_saved_floats(int B, int T, int F, int dim);
+size_t rtfs_dualpath_train_workspace_bytes(int B, int T, int F, int dim);
+int rtfs_dualpath_forward_train_f32(const float* x, const float* tpack, float* out, float* saved, int B, int T, int F, int dim,
+                                    void* ws, size_t ws_bytes, void* stream);
+int rtfs_dualpath_backward_f32(const float* x, const float* tpack, const float* saved, const float* dout, float* dx,
+                               float* dparams, int B, int T, int F, int dim, void* ws, size_t ws_bytes, void* stream);
 /* The two GEMM forms of the training path (bf16x3 split on the matrix cores), exposed for tests:
  * kind 0: C (M,N) = A (M,K) . B (N,K)^T (accumulate != 0: C += ...), N % 64 == 0, K % 16 == 0;
  * kind 1: C (M,N) += A (K,M)^T . B (K,N), M % 64 == 0, N % 64 == 0. */

@@ -49,3 +49,39 @@ def sru_grads(x, layers, dh):
     grads = torch.autograd.grad(h, [xt] + flat, torch.tensor(dh, dtype=torch.float64))
     gl = [tuple(g.numpy() for g in grads[1 + 3 * i: 4 + 3 * i]) for i in range(len(lt))]
     return h.detach().numpy(), grads[0].numpy(), gl
+
+
+def dualpath_rnn_torch(x, p, dim, kernel_size=8):
+    """rtfs_oracle.dualpath_rnn in torch (reference rnn_layers.py:136-162, SRU cell).  x (B,C,T,F) float64 tensor;
+    p = dict of tensors with the module's state_dict names."""
+    if dim == 4:
+        x = x.permute(0, 1, 3, 2)
+    B, C, nT, nF = x.shape
+    res = x
+    mu = x.mean(1, keepdim=True)
+    var = ((x - mu) ** 2).mean(1, keepdim=True)
+    xn = (x - mu) / torch.sqrt(var + 1e-5) * p["norm.gamma"].reshape(1, C, 1, 1) + p["norm.beta"].reshape(1, C, 1, 1)
+    seq = xn.permute(0, 3, 1, 2).reshape(B * nF, C, nT)
+    Lr = nT - kernel_size + 1
+    unf = torch.stack([seq[:, :, kk:kk + Lr] for kk in range(kernel_size)], 2).reshape(B * nF, C * kernel_size, Lr).permute(2, 0, 1)
+    layers = []
+    i = 0
+    while f"rnn.rnn_lst.{i}.weight" in p:
+        layers.append((p[f"rnn.rnn_lst.{i}.weight"], p[f"rnn.rnn_lst.{i}.weight_c"], p[f"rnn.rnn_lst.{i}.bias"]))
+        i += 1
+    h = sru_forward_torch(unf, layers).permute(1, 2, 0)  # N, 2d, L
+    y = torch.nn.functional.conv_transpose1d(h, p["linear.weight"], p["linear.bias"])
+    y = y.reshape(B, nF, C, nT).permute(0, 2, 3, 1) + res
+    if dim == 4:
+        y = y.permute(0, 1, 3, 2)
+    return y
+
+
+def dualpath_grads(x, p, dim, dout):
+    """numpy in / numpy out: (out, dx, {name: dparam}) of sum(out * dout) by autograd in float64."""
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    pt = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in p.items()}
+    out = dualpath_rnn_torch(xt, pt, dim)
+    names = sorted(pt)
+    grads = torch.autograd.grad(out, [xt] + [pt[k] for k in names], torch.tensor(dout, dtype=torch.float64))
+    return out.detach().numpy(), grads[0].numpy(), {k: g.numpy() for k, g in zip(names, grads[1:])}

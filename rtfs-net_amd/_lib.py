@@ -53,6 +53,12 @@ SIGNATURES = {
     "rtfs_sru_backward_workspace_bytes": (_z, [_i, _i]),
     "rtfs_sru_forward_train_f32": (_i, [_p, _p, _p, _p, _i, _i, _p]),
     "rtfs_sru_backward_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _p, _z, _p]),
+    "rtfs_dualpath_train_pack_floats": (_z, []),
+    "rtfs_dualpath_grad_floats": (_z, []),
+    "rtfs_dualpath_saved_floats": (_z, [_i, _i, _i, _i]),
+    "rtfs_dualpath_train_workspace_bytes": (_z, [_i, _i, _i, _i]),
+    "rtfs_dualpath_forward_train_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _z, _p]),
+    "rtfs_dualpath_backward_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _z, _p]),
     "rtfs_debug_gemm_f32": (_i, [_i, _p, _p, _p, _i, _i, _i, _i, _p]),
     "rtfs_debug_sweep_stamps": (_i, [_p, _p, _p, _i, _i, _i, _p, _p]),
     "rtfs_selftest_mfma_f16": (_i, [_p, _p, _p, _p]),

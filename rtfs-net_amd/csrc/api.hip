@@ -969,10 +969,10 @@ int rtfs_sru_forward_train_f32(const float* x, const float* tpack, float* h, flo
         const float* xin = l == 0 ? x : sv.h[l - 1];
         const int K = l == 0 ? 512 : 64, KC = l == 0 ? 256 : 192;
         const float* Wt = l == 0 ? tpack + TP_WT0 : tpack + TP_WTL + (size_t)(l - 1) * 192 * 64;
-        CHECK(launch_gemm_nt(xin, K, Wt, K, sv.U[l], KC, LN, KC, K, false, st));
+        CHECK(launch_gemm_nt(xin, K, Wt, K, sv.U[l], KC, LN, KC, K, 0, st));
         SruScanArgs a;
         a.U = sv.U[l]; a.xin = l == 0 ? nullptr : xin; a.wc = tpack + TP_WC + 128 * l; a.bias = tpack + TP_BIAS + 128 * l;
-        a.h = l == 3 ? h : sv.h[l]; a.c = sv.c[l]; a.L = L; a.N = N; a.KC = KC;
+        a.h = l == 3 ? h : sv.h[l]; a.c = sv.c[l]; a.L = L; a.N = N; a.KC = KC; a.ts = N; a.ns = 1;
         CHECK(launch_sru_scan_fwd(a, st));
     }
     return RTFS_OK;
@@ -997,22 +997,165 @@ int rtfs_sru_backward_f32(const float* x, const float* tpack, const float* saved
         SruScanArgs a;
         a.U = sv.U[l]; a.xin = l == 0 ? nullptr : xin; a.wc = tpack + TP_WC + 128 * l; a.bias = tpack + TP_BIAS + 128 * l;
         a.c = sv.c[l]; a.g = g; a.dU = dU; a.dxp = l == 0 ? nullptr : gnext; a.dwc = dparams + GP_WC + 128 * l;
-        a.dbias = dparams + GP_BIAS + 128 * l; a.L = L; a.N = N; a.KC = KC;
+        a.dbias = dparams + GP_BIAS + 128 * l; a.L = L; a.N = N; a.KC = KC; a.ts = N; a.ns = 1;
         CHECK(launch_sru_scan_bwd(a, st));
         const float* Wp = l == 0 ? tpack + TP_WP0 : tpack + TP_WPL + (size_t)(l - 1) * 64 * 192;
         float* dWp = l == 0 ? dparams + GP_W0 : dparams + GP_WL + (size_t)(l - 1) * 64 * 192;
         // input gradient: dU . W^T (+ the highway term the scan already wrote for layers 1-3)
-        CHECK(launch_gemm_nt(dU, KC, Wp, KC, l == 0 ? dx : gnext, K, LN, K, KC, l != 0, st));
+        CHECK(launch_gemm_nt(dU, KC, Wp, KC, l == 0 ? dx : gnext, K, LN, K, KC, l != 0 ? 1 : 0, st));
         CHECK(launch_gemm_tn(xin, K, dU, KC, dWp, KC, K, KC, (long)LN, st));
         g = gnext;
     }
     return RTFS_OK;
 }
 
+// ------------------------------------------------------------ DualPathRNN (SRU cell), training side
+namespace {
+constexpr size_t DT_G = 0, DT_B = 64, DT_SRU = 128, DT_WCF = DT_SRU + TP_END, DT_WCB = DT_WCF + 64 * 512, DT_BT = DT_WCB + 64 * 512,
+                 DT_END = DT_BT + 64;
+constexpr size_t DG_G = 0, DG_B = 64, DG_SRU = 128, DG_WCT = DG_SRU + GP_END, DG_BT = DG_WCT + 512 * 64, DG_END = DG_BT + 64;
+struct DpSaved {  // sequence-major training layout, see k_train.hip
+    float *xn, *U[4], *c[4], *hpad[4];
+    size_t floats;
+    DpSaved(float* p, size_t rows) {
+        float* p0 = p;
+        xn = p; p += (rows + 8) * 64;
+        U[0] = p; p += rows * 256;
+        for (int l = 1; l < 4; ++l) { U[l] = p; p += rows * 192; }
+        for (int l = 0; l < 4; ++l) { c[l] = p; p += rows * 64; }
+        for (int l = 0; l < 4; ++l) { hpad[l] = p; p += (rows + 8) * 64; }
+        floats = (size_t)(p - p0);
+    }
+};
+struct DpGeom {
+    int nseq, R, Ls, L;
+    size_t rows, elems;
+    DpGeom(int B, int T, int F, int dim) {
+        R = dim == 4 ? T : F;
+        Ls = dim == 4 ? F : T;
+        L = Ls - 7;
+        nseq = B * R;
+        rows = (size_t)nseq * Ls;
+        elems = (size_t)B * CH * T * F;
+    }
+    bool ok() const { return Ls >= 8 && Ls <= 256 && rows * 512 < 0x7fffffffu; }
+};
+}  // namespace
+
+size_t rtfs_dualpath_train_pack_floats(void) { return DT_END; }
+size_t rtfs_dualpath_grad_floats(void) { return DG_END; }
+size_t rtfs_dualpath_saved_floats(int B, int T, int F, int dim) {
+    DpGeom g(B, T, F, dim);
+    return DpSaved(nullptr, g.rows).floats;
+}
+size_t rtfs_dualpath_train_workspace_bytes(int B, int T, int F, int dim) {
+    DpGeom g(B, T, F, dim);
+    // forward: xt, out_t, y; backward: xt, dout_t, dx_t, dy, dU, 2 x g, dxn  (the larger of the two, plus alignment slack)
+    const size_t fwd = 2 * g.elems + g.rows * 64, bwd = 3 * g.elems + (g.rows + 8) * 64 * 2 + g.rows * (256 + 128);
+    return (fwd > bwd ? fwd : bwd) * sizeof(float) + 16 * 256;
+}
+
+int rtfs_dualpath_forward_train_f32(const float* x, const float* tpack, float* out, float* saved, int B, int T, int F, int dim, void* ws,
+                                    size_t ws_bytes, void* stream) {
+    RTFS_RETURN_IF(!x || !tpack || !out || !saved || B < 1 || (dim != 3 && dim != 4), RTFS_ERR_ARG);
+    DpGeom g(B, T, F, dim);
+    RTFS_RETURN_IF(!g.ok(), RTFS_ERR_SHAPE);
+    RTFS_RETURN_IF(!ws || ws_bytes < rtfs_dualpath_train_workspace_bytes(B, T, F, dim), RTFS_ERR_WORKSPACE);
+    Arena ar(ws, ws_bytes);
+    float* xt = ar.take<float>(g.elems);
+    float* ot = ar.take<float>(g.elems);
+    float* y = ar.take<float>(g.rows * 64);
+    DpSaved sv(saved, g.rows);
+    hipStream_t st = S(stream);
+    const int M = (int)g.rows;
+    const float* src = x;
+    if (dim == 3) {
+        CHECK(launch_transpose(x, xt, B * CH, T, F, st));
+        src = xt;
+    }
+    // rows past the last slot are read by the last windows: keep them zero
+    if (hipMemsetAsync(sv.xn + g.rows * 64, 0, 8 * 64 * sizeof(float), st) != hipSuccess) return RTFS_ERR_LAUNCH;
+    for (int l = 0; l < 4; ++l)
+        if (hipMemsetAsync(sv.hpad[l] + g.rows * 64, 0, 8 * 64 * sizeof(float), st) != hipSuccess) return RTFS_ERR_LAUNCH;
+    CHECK(launch_dp_ln_fwd(src, tpack + DT_G, tpack + DT_B, sv.xn, g.nseq, g.R, g.Ls, st));
+    const float* sp = tpack + DT_SRU;
+    for (int l = 0; l < 4; ++l) {
+        const float* xin = l == 0 ? sv.xn : sv.hpad[l - 1] + 7 * 64;
+        const int K = l == 0 ? 512 : 64, KC = l == 0 ? 256 : 192;
+        const float* Wt = l == 0 ? sp + TP_WT0 : sp + TP_WTL + (size_t)(l - 1) * 192 * 64;
+        CHECK(launch_gemm_nt(xin, 64, Wt, K, sv.U[l], KC, M, KC, K, 0, st));
+        SruScanArgs a;
+        a.U = sv.U[l]; a.xin = l == 0 ? nullptr : xin; a.wc = sp + TP_WC + 128 * l; a.bias = sp + TP_BIAS + 128 * l;
+        a.h = sv.hpad[l] + 7 * 64; a.c = sv.c[l]; a.L = g.L; a.N = g.nseq; a.KC = KC; a.ts = 1; a.ns = g.Ls; a.pad = 1;
+        CHECK(launch_sru_scan_fwd(a, st));
+    }
+    // ConvTranspose1d as a GEMM over the 8-row windows of the zero-padded hidden sequence (rnn_layers.py:129,153)
+    CHECK(launch_gemm_nt(sv.hpad[3], 64, tpack + DT_WCF, 512, y, 64, M, 64, 512, 0, st));
+    CHECK(launch_dp_out(y, tpack + DT_BT, src, dim == 4 ? out : ot, g.nseq, g.R, g.Ls, st));
+    if (dim == 3) CHECK(launch_transpose(ot, out, B * CH, F, T, st));
+    return RTFS_OK;
+}
+
+int rtfs_dualpath_backward_f32(const float* x, const float* tpack, const float* saved, const float* dout, float* dx, float* dparams, int B,
+                               int T, int F, int dim, void* ws, size_t ws_bytes, void* stream) {
+    RTFS_RETURN_IF(!x || !tpack || !saved || !dout || !dx || !dparams || B < 1 || (dim != 3 && dim != 4), RTFS_ERR_ARG);
+    DpGeom g(B, T, F, dim);
+    RTFS_RETURN_IF(!g.ok(), RTFS_ERR_SHAPE);
+    RTFS_RETURN_IF(!ws || ws_bytes < rtfs_dualpath_train_workspace_bytes(B, T, F, dim), RTFS_ERR_WORKSPACE);
+    Arena ar(ws, ws_bytes);
+    float* xt = ar.take<float>(g.elems);
+    float* dt = ar.take<float>(g.elems);
+    float* dxt = ar.take<float>(g.elems);
+    float* dy = ar.take<float>((g.rows + 8) * 64);
+    float* dxn = ar.take<float>((g.rows + 8) * 64);
+    float* dU = ar.take<float>(g.rows * 256);
+    float* gbuf[2] = {ar.take<float>(g.rows * 64), ar.take<float>(g.rows * 64)};
+    RTFS_RETURN_IF(!ar.ok(), RTFS_ERR_WORKSPACE);
+    DpSaved sv(const_cast<float*>(saved), g.rows);
+    hipStream_t st = S(stream);
+    const int M = (int)g.rows;
+    const float *srcx = x, *srcd = dout;
+    if (dim == 3) {
+        CHECK(launch_transpose(x, xt, B * CH, T, F, st));
+        CHECK(launch_transpose(dout, dt, B * CH, T, F, st));
+        srcx = xt;
+        srcd = dt;
+    }
+    if (hipMemsetAsync(dparams, 0, DG_END * sizeof(float), st) != hipSuccess) return RTFS_ERR_LAUNCH;
+    if (hipMemsetAsync(dy + g.rows * 64, 0, 8 * 64 * sizeof(float), st) != hipSuccess) return RTFS_ERR_LAUNCH;
+    if (hipMemsetAsync(dxn, 0, (g.rows + 8) * 64 * sizeof(float), st) != hipSuccess) return RTFS_ERR_LAUNCH;
+    CHECK(launch_dp_dy(srcd, dy, dparams + DG_BT, g.nseq, g.R, g.Ls, st));
+    // ConvTranspose1d: weight gradient = (windows of h)^T . dy, input gradient = windows of dy . W
+    CHECK(launch_gemm_tn(sv.hpad[3], 64, dy, 64, dparams + DG_WCT, 64, 512, 64, (long)M, st));
+    CHECK(launch_gemm_nt(dy, 64, tpack + DT_WCB, 512, gbuf[0], 64, M, 64, 512, 0, st));
+    const float* gcur = gbuf[0];
+    const float* sp = tpack + DT_SRU;
+    float* gp = dparams + DG_SRU;
+    for (int l = 3; l >= 0; --l) {
+        const int K = l == 0 ? 512 : 64, KC = l == 0 ? 256 : 192;
+        const float* xin = l == 0 ? sv.xn : sv.hpad[l - 1] + 7 * 64;
+        float* gnext = gcur == gbuf[0] ? gbuf[1] : gbuf[0];
+        SruScanArgs a;
+        a.U = sv.U[l]; a.xin = l == 0 ? nullptr : xin; a.wc = sp + TP_WC + 128 * l; a.bias = sp + TP_BIAS + 128 * l;
+        a.c = sv.c[l]; a.g = gcur; a.dU = dU; a.dxp = l == 0 ? nullptr : gnext; a.dwc = gp + GP_WC + 128 * l;
+        a.dbias = gp + GP_BIAS + 128 * l; a.L = g.L; a.N = g.nseq; a.KC = KC; a.ts = 1; a.ns = g.Ls; a.pad = 1;
+        CHECK(launch_sru_scan_bwd(a, st));
+        const float* Wp = l == 0 ? sp + TP_WP0 : sp + TP_WPL + (size_t)(l - 1) * 64 * 192;
+        float* dWp = l == 0 ? gp + GP_W0 : gp + GP_WL + (size_t)(l - 1) * 64 * 192;
+        if (l == 0) CHECK(launch_gemm_nt(dU, KC, Wp, KC, dxn, 64, M, 512, KC, 2, st));  // fold: adjoint of the unfold windows
+        else CHECK(launch_gemm_nt(dU, KC, Wp, KC, gnext, 64, M, 64, KC, 1, st));
+        CHECK(launch_gemm_tn(xin, 64, dU, KC, dWp, KC, K, KC, (long)M, st));
+        gcur = gnext;
+    }
+    CHECK(launch_dp_ln_bwd(srcx, dxn, srcd, tpack + DT_G, dim == 4 ? dx : dxt, dparams + DG_G, dparams + DG_B, g.nseq, g.R, g.Ls, st));
+    if (dim == 3) CHECK(launch_transpose(dxt, dx, B * CH, F, T, st));
+    return RTFS_OK;
+}
+
 // C = A . Bt^T (kind 0; accumulate adds to C) or C += A^T . B (kind 1): the two GEMM forms of the training path, exposed for tests
 int rtfs_debug_gemm_f32(int kind, const float* A, const float* B, float* C, int M, int N, int K, int accumulate, void* stream) {
     RTFS_RETURN_IF(!A || !B || !C, RTFS_ERR_ARG);
-    if (kind == 0) return launch_gemm_nt(A, K, B, K, C, N, M, N, K, accumulate != 0, S(stream));
+    if (kind == 0) return launch_gemm_nt(A, K, B, K, C, N, M, N, K, accumulate != 0 ? 1 : 0, S(stream));
     if (kind == 1) return launch_gemm_tn(A, M, B, N, C, N, M, N, (long)K, S(stream));
     return RTFS_ERR_ARG;
 }

@@ -42,7 +42,9 @@ __device__ __forceinline__ void mfma3(f32x16& acc, const Frag& a, const Frag& b)
 // A (M, K) and Bt (N, K), both K-contiguous (lda, ldb multiples of 4 floats); C (M, N).  N % 64 == 0, K % 16 == 0, any M.
 // Workgroup = 4 waves stacked along M (256 rows x 64 columns), wave tile 64 x 64.  Workgroups that share the A rows
 // (the column blocks of one row block) share blockIdx % 8, i.e. one XCD's L2.
-template <bool ACC>
+// MODE 0: C = ..., 1: C += ... (read-modify-write), 2: fold form - column block j lands j rows further down in a 64-wide C
+// (C[(row + j) * ldc + col % 64] += ..., atomics: the adjoint of the unfold windows, see the dual-path backward).
+template <int MODE>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
     const int id = blockIdx.x;
     const int rowblk = (id / (8 * g.ncb)) * 8 + (id & 7), colblk = (id >> 3) % g.ncb;
@@ -107,8 +109,12 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
             if (row < g.M) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    float* p = g.C + (size_t)row * g.ldc + n0 + 32 * j + r;
-                    *p = ACC ? *p + acc[i][j][q] : acc[i][j][q];
+                    if (MODE == 2) {
+                        unsafeAtomicAdd(g.C + (size_t)(row + colblk) * g.ldc + 32 * j + r, acc[i][j][q]);
+                    } else {
+                        float* p = g.C + (size_t)row * g.ldc + n0 + 32 * j + r;
+                        *p = MODE == 1 ? *p + acc[i][j][q] : acc[i][j][q];
+                    }
                 }
             }
         }
@@ -170,7 +176,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmArgs g) {
             }
 }
 
-int launch_gemm_nt(const float* A, int lda, const float* Bt, int ldb, float* C, int ldc, int M, int N, int K, bool accumulate,
+int launch_gemm_nt(const float* A, int lda, const float* Bt, int ldb, float* C, int ldc, int M, int N, int K, int mode,
                    hipStream_t st) {
     if (M < 1 || N < 64 || (N & 63) || K < 16 || (K & 15) || (lda & 3) || (ldb & 3)) return RTFS_ERR_SHAPE;
     GemmArgs g;
@@ -179,8 +185,9 @@ int launch_gemm_nt(const float* A, int lda, const float* Bt, int ldb, float* C, 
     g.nrb = cdiv(M, 256);
     const long grid = (long)cdiv(g.nrb, 8) * 8 * g.ncb;
     if (grid > 0x7fffffffL) return RTFS_ERR_SHAPE;
-    if (accumulate) hipLaunchKernelGGL(gemm_nt_kernel<true>, dim3((unsigned)grid), dim3(256), 0, st, g);
-    else hipLaunchKernelGGL(gemm_nt_kernel<false>, dim3((unsigned)grid), dim3(256), 0, st, g);
+    if (mode == 2) hipLaunchKernelGGL(gemm_nt_kernel<2>, dim3((unsigned)grid), dim3(256), 0, st, g);
+    else if (mode == 1) hipLaunchKernelGGL(gemm_nt_kernel<1>, dim3((unsigned)grid), dim3(256), 0, st, g);
+    else hipLaunchKernelGGL(gemm_nt_kernel<0>, dim3((unsigned)grid), dim3(256), 0, st, g);
     return rtfs_launch_status();
 }
 
@@ -201,6 +208,9 @@ int launch_gemm_tn(const float* A, int lda, const float* B, int ldb, float* C, i
 }
 
 // ------------------------------------------------------------------------------------------------ SRU scans
+// Row addressing: step t of sequence n lives at row t*ts + n*ns of every (rows, width) array.  The operator alone uses the
+// upstream (L, N, .) order (ts = N, ns = 1); the dual-path layout is sequence-major with pitch Ls = L + 7 (ts = 1, ns = Ls),
+// where `pad` asks the wave to zero the 7 rows of its sequence that are not steps (see the layout notes further down).
 // forward with saved state: h and c of every step go to HBM (the backward reads c; h feeds the next layer)
 __global__ __launch_bounds__(256) void sru_scan_fwd_kernel(SruScanArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, dir = lane >> 5;
@@ -208,11 +218,12 @@ __global__ __launch_bounds__(256) void sru_scan_fwd_kernel(SruScanArgs a) {
     if (n >= a.N) return;
     const float vf = a.wc[lane], vr = a.wc[64 + lane], bf = a.bias[lane], br = a.bias[64 + lane];
     const int KC = a.KC, L = a.L;
+    const size_t ts = a.ts, nb = (size_t)n * a.ns;
     float c = 0.f;
 #pragma unroll 4
     for (int s = 0; s < L; ++s) {
         const int t = dir ? L - 1 - s : s;
-        const size_t row = (size_t)t * a.N + n;
+        const size_t row = (size_t)t * ts + nb;
         const float* u = a.U + row * KC + lane;
         const float u0 = u[0], u1 = u[64], u2 = u[128];
         const float xp = a.xin ? a.xin[row * 64 + lane] : u[192];
@@ -221,6 +232,8 @@ __global__ __launch_bounds__(256) void sru_scan_fwd_kernel(SruScanArgs a) {
         a.c[row * 64 + lane] = c;
         a.h[row * 64 + lane] = xp + (c - xp) * rg;
     }
+    if (a.pad)  // h is stored 7 rows into its sequence slot: rows -7..-1 are the zero steps the conv-transpose windows read
+        for (int i = 1; i <= 7; ++i) a.h[((long)nb - i) * 64 + lane] = 0.f;
 }
 
 // backward: walks each direction's steps in reverse; dc is the only carried quantity
@@ -230,17 +243,18 @@ __global__ __launch_bounds__(256) void sru_scan_bwd_kernel(SruScanArgs a) {
     const int n = blockIdx.x * 4 + wave;
     const float vf = a.wc[lane], vr = a.wc[64 + lane], bf = a.bias[lane], br = a.bias[64 + lane];
     const int KC = a.KC, L = a.L;
+    const size_t ts = a.ts, nb = (size_t)n * a.ns;
     float s_vf = 0.f, s_bf = 0.f, s_vr = 0.f, s_br = 0.f;
     if (n < a.N) {
         float dc = 0.f;
-        float ct = a.c[((size_t)(dir ? 0 : L - 1) * a.N + n) * 64 + lane];
+        float ct = a.c[((size_t)(dir ? 0 : L - 1) * ts + nb) * 64 + lane];
 #pragma unroll 2
         for (int s = L - 1; s >= 0; --s) {
             const int t = dir ? L - 1 - s : s;
-            const size_t row = (size_t)t * a.N + n;
+            const size_t row = (size_t)t * ts + nb;
             const int tp = dir ? t + 1 : t - 1;
             const int tpc = min(max(tp, 0), L - 1);
-            const float cpl = a.c[((size_t)tpc * a.N + n) * 64 + lane];
+            const float cpl = a.c[((size_t)tpc * ts + nb) * 64 + lane];
             const float cp = s > 0 ? cpl : 0.f;
             const float* u = a.U + row * KC + lane;
             const float u0 = u[0], u1 = u[64], u2 = u[128];
@@ -263,6 +277,12 @@ __global__ __launch_bounds__(256) void sru_scan_bwd_kernel(SruScanArgs a) {
             else d[192] = dxp;
             ct = cp;
         }
+        if (a.pad)  // rows L..L+6 of the slot are not steps: the weight-gradient GEMMs sum over every row, so they must be zero
+            for (int i = 0; i < 7; ++i) {
+                const size_t row = nb + L + i;
+                for (int m = 0; m < KC; m += 64) a.dU[row * KC + m + lane] = 0.f;
+                if (a.xin) a.dxp[row * 64 + lane] = 0.f;
+            }
     }
     red[wave][0][lane] = s_vf;
     red[wave][1][lane] = s_vr;
@@ -281,5 +301,193 @@ int launch_sru_scan_fwd(const SruScanArgs& a, hipStream_t st) {
 }
 int launch_sru_scan_bwd(const SruScanArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(sru_scan_bwd_kernel, dim3(cdiv(a.N, 4)), dim3(256), 0, st, a);
+    return rtfs_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------ dual-path layout kernels
+// Training layout of DualPathRNN (rnn_layers.py:136-162): sequence-major, channel-last.  Sequence n owns a slot of Ls = L + 7
+// rows of 64 floats; an Unfold(8) window of step l is then the 512 contiguous floats starting at row n*Ls + l (feature order
+// k*64 + c, the weights are permuted to match), so the unfolded matrix is an addressing mode of the GEMM's A operand and the
+// ConvTranspose1d and both of their adjoints are the same GEMMs over windows.  Rows l >= L of a slot are not steps: GEMM
+// outputs there are ignored, and everything the weight-gradient GEMMs sum over is kept zero there.
+// Source tensor: (B, 64, R, Ls) with the sweep axis contiguous (the T-sweep goes through launch_transpose first).
+namespace {
+__device__ __forceinline__ size_t seq_base(int n, int R, int Ls) { return ((size_t)(n / R) * 64 * R + (n % R)) * Ls; }
+}
+
+// LayerNorm over channels per position + layout change: x -> xn[n*Ls + s][c]
+__global__ __launch_bounds__(256) void dp_ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float* __restrict__ xn, int R, int Ls) {
+    extern __shared__ float tile[];  // [64][Ls + 1]
+    __shared__ float mu[256], rs[256];
+    const int n = blockIdx.x, tid = threadIdx.x, P = Ls + 1;
+    const size_t base = seq_base(n, R, Ls), cs = (size_t)R * Ls;
+    for (int idx = tid; idx < 64 * Ls; idx += 256) {
+        const int c = idx / Ls, s = idx - c * Ls;
+        tile[c * P + s] = x[base + c * cs + s];
+    }
+    __syncthreads();
+    for (int s = tid; s < Ls; s += 256) {
+        float m = 0.f;
+        for (int c = 0; c < 64; ++c) m += tile[c * P + s];
+        m *= (1.f / 64);
+        float v = 0.f;
+        for (int c = 0; c < 64; ++c) {
+            const float d = tile[c * P + s] - m;
+            v = fmaf(d, d, v);
+        }
+        mu[s & 255] = m;
+        rs[s & 255] = 1.0f / sqrtf(v * (1.f / 64) + RTFS_EPS);
+        // Ls <= 256 is guaranteed by the launcher, so one round of this loop
+    }
+    __syncthreads();
+    const int c = tid & 63;
+    const float g = gamma[c], b = beta[c];
+    for (int s = tid >> 6; s < Ls; s += 4) xn[((size_t)n * Ls + s) * 64 + c] = fmaf((tile[c * P + s] - mu[s]) * rs[s], g, b);
+}
+
+// out = y[n*Ls + s][c] + bias[c] + x  (back to the (B, 64, R, Ls) layout)
+__global__ __launch_bounds__(256) void dp_out_kernel(const float* __restrict__ y, const float* __restrict__ bias,
+                                                     const float* __restrict__ x, float* __restrict__ out, int R, int Ls) {
+    extern __shared__ float tile[];  // [Ls][65]
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const size_t base = seq_base(n, R, Ls), cs = (size_t)R * Ls;
+    for (int idx = tid; idx < 64 * Ls; idx += 256) tile[(idx >> 6) * 65 + (idx & 63)] = y[(size_t)n * Ls * 64 + idx] + bias[idx & 63];
+    __syncthreads();
+    for (int idx = tid; idx < 64 * Ls; idx += 256) {
+        const int c = idx / Ls, s = idx - c * Ls;
+        out[base + c * cs + s] = tile[s * 65 + c] + x[base + c * cs + s];
+    }
+}
+
+// dy[n*Ls + s][c] = dout; dbias[c] += sum_s dout
+__global__ __launch_bounds__(256) void dp_dy_kernel(const float* __restrict__ dout, float* __restrict__ dy, float* __restrict__ dbias,
+                                                    int R, int Ls) {
+    extern __shared__ float tile[];  // [Ls][65]
+    __shared__ float part[4][64];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const size_t base = seq_base(n, R, Ls), cs = (size_t)R * Ls;
+    for (int idx = tid; idx < 64 * Ls; idx += 256) {
+        const int c = idx / Ls, s = idx - c * Ls;
+        tile[s * 65 + c] = dout[base + c * cs + s];
+    }
+    __syncthreads();
+    const int c = tid & 63;
+    float acc = 0.f;
+    for (int s = tid >> 6; s < Ls; s += 4) {
+        const float v = tile[s * 65 + c];
+        dy[((size_t)n * Ls + s) * 64 + c] = v;
+        acc += v;
+    }
+    part[tid >> 6][c] = acc;
+    __syncthreads();
+    if (tid < 64) unsafeAtomicAdd(dbias + tid, part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid]);
+}
+
+// LayerNorm backward + residual: dx = rstd * (gamma*dxn - mean_c(gamma*dxn) - xhat * mean_c(gamma*dxn*xhat)) + dout,
+// dgamma[c] += sum dxn * xhat, dbeta[c] += sum dxn  (normalizations.py:33-37 differentiated; statistics recomputed from x)
+__global__ __launch_bounds__(256) void dp_ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dxn,
+                                                        const float* __restrict__ dout, const float* __restrict__ gamma,
+                                                        float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                        int R, int Ls) {
+    extern __shared__ float lds[];  // X [64][Ls + 1] (becomes xhat), D [64][Ls + 1] (dxn)
+    __shared__ float rs[256], ma[256], mb[256], part[2][4][64];
+    const int n = blockIdx.x, tid = threadIdx.x, P = Ls + 1;
+    float* X = lds;
+    float* D = lds + 64 * P;
+    const size_t base = seq_base(n, R, Ls), cs = (size_t)R * Ls;
+    for (int idx = tid; idx < 64 * Ls; idx += 256) {
+        const int c = idx / Ls, s = idx - c * Ls;
+        X[c * P + s] = x[base + c * cs + s];
+    }
+    for (int idx = tid; idx < 64 * Ls; idx += 256) D[(idx & 63) * P + (idx >> 6)] = dxn[(size_t)n * Ls * 64 + idx];
+    __syncthreads();
+    for (int s = tid; s < Ls; s += 256) {
+        float m = 0.f;
+        for (int c = 0; c < 64; ++c) m += X[c * P + s];
+        m *= (1.f / 64);
+        float v = 0.f;
+        for (int c = 0; c < 64; ++c) {
+            const float d = X[c * P + s] - m;
+            v = fmaf(d, d, v);
+        }
+        const float r = 1.0f / sqrtf(v * (1.f / 64) + RTFS_EPS);
+        float a = 0.f, b = 0.f;
+        for (int c = 0; c < 64; ++c) {
+            const float xh = (X[c * P + s] - m) * r;
+            X[c * P + s] = xh;
+            const float gd = gamma[c] * D[c * P + s];
+            a += gd;
+            b = fmaf(gd, xh, b);
+        }
+        rs[s] = r;
+        ma[s] = a * (1.f / 64);
+        mb[s] = b * (1.f / 64);
+    }
+    __syncthreads();
+    {   // parameter gradients: thread (c = tid & 63) sums its quarter of the positions
+        const int c = tid & 63;
+        float sg = 0.f, sb = 0.f;
+        for (int s = tid >> 6; s < Ls; s += 4) {
+            const float d = D[c * P + s];
+            sg = fmaf(d, X[c * P + s], sg);
+            sb += d;
+        }
+        part[0][tid >> 6][c] = sg;
+        part[1][tid >> 6][c] = sb;
+    }
+    for (int idx = tid; idx < 64 * Ls; idx += 256) {
+        const int c = idx / Ls, s = idx - c * Ls;
+        const float v = rs[s] * (gamma[c] * D[c * P + s] - ma[s] - X[c * P + s] * mb[s]);
+        dx[base + c * cs + s] = v + dout[base + c * cs + s];
+    }
+    __syncthreads();
+    if (tid < 128) {
+        const int w = tid >> 6, c = tid & 63;
+        unsafeAtomicAdd((w ? dbeta : dgamma) + c, part[w][0][c] + part[w][1][c] + part[w][2][c] + part[w][3][c]);
+    }
+}
+
+namespace {
+template <typename K>
+int set_lds(K kernel, size_t bytes) {
+    if (bytes > 160 * 1024) return RTFS_ERR_SHAPE;
+    if (bytes > 48 * 1024 && hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess)
+        return RTFS_ERR_LAUNCH;
+    return RTFS_OK;
+}
+}  // namespace
+
+int launch_dp_ln_fwd(const float* x, const float* gamma, const float* beta, float* xn, int nseq, int R, int Ls, hipStream_t st) {
+    if (Ls < 8 || Ls > 256) return RTFS_ERR_SHAPE;
+    const size_t lds = (size_t)64 * (Ls + 1) * sizeof(float);
+    int rc = set_lds(dp_ln_fwd_kernel, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(dp_ln_fwd_kernel, dim3(nseq), dim3(256), lds, st, x, gamma, beta, xn, R, Ls);
+    return rtfs_launch_status();
+}
+int launch_dp_out(const float* y, const float* bias, const float* x, float* out, int nseq, int R, int Ls, hipStream_t st) {
+    if (Ls < 8 || Ls > 256) return RTFS_ERR_SHAPE;
+    const size_t lds = (size_t)Ls * 65 * sizeof(float);
+    int rc = set_lds(dp_out_kernel, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(dp_out_kernel, dim3(nseq), dim3(256), lds, st, y, bias, x, out, R, Ls);
+    return rtfs_launch_status();
+}
+int launch_dp_dy(const float* dout, float* dy, float* dbias, int nseq, int R, int Ls, hipStream_t st) {
+    if (Ls < 8 || Ls > 256) return RTFS_ERR_SHAPE;
+    const size_t lds = (size_t)Ls * 65 * sizeof(float);
+    int rc = set_lds(dp_dy_kernel, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(dp_dy_kernel, dim3(nseq), dim3(256), lds, st, dout, dy, dbias, R, Ls);
+    return rtfs_launch_status();
+}
+int launch_dp_ln_bwd(const float* x, const float* dxn, const float* dout, const float* gamma, float* dx, float* dgamma, float* dbeta,
+                     int nseq, int R, int Ls, hipStream_t st) {
+    if (Ls < 8 || Ls > 256) return RTFS_ERR_SHAPE;
+    const size_t lds = (size_t)2 * 64 * (Ls + 1) * sizeof(float);
+    int rc = set_lds(dp_ln_bwd_kernel, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(dp_ln_bwd_kernel, dim3(nseq), dim3(256), lds, st, x, dxn, dout, gamma, dx, dgamma, dbeta, R, Ls);
     return rtfs_launch_status();
 }

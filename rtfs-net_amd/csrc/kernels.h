@@ -233,7 +233,8 @@ struct GemmArgs {
     int kchunk = 0;        // TN: k range of one wave
 };
 // C (M,N) [+]= A (M,K) . Bt (N,K)^T  (both K-contiguous; N % 64 == 0, K % 16 == 0)
-int launch_gemm_nt(const float* A, int lda, const float* Bt, int ldb, float* C, int ldc, int M, int N, int K, bool accumulate,
+// mode 0: C = ; 1: C += ; 2: C (rows x 64) [(row + colblk) * ldc + col % 64] += (atomics; the fold of unfold windows)
+int launch_gemm_nt(const float* A, int lda, const float* Bt, int ldb, float* C, int ldc, int M, int N, int K, int mode,
                    hipStream_t st);
 // C (M,N) += A (K,M)^T . B (K,N)  (split-K with f32 atomics; M, N % 64 == 0)
 int launch_gemm_tn(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, long K, hipStream_t st);
@@ -250,6 +251,14 @@ struct SruScanArgs {
     float* dwc = nullptr;        // backward: (128) running sums
     float* dbias = nullptr;      // backward: (128)
     int L = 0, N = 0, KC = 0;
+    long ts = 0, ns = 0;  // row of (step t, sequence n) = t*ts + n*ns
+    int pad = 0;          // sequence-major dual-path layout: zero the 7 non-step rows of each slot
 };
 int launch_sru_scan_fwd(const SruScanArgs& a, hipStream_t st);
 int launch_sru_scan_bwd(const SruScanArgs& a, hipStream_t st);
+// dual-path training layout kernels: x (B, 64, R, Ls) <-> rows [n*Ls + s][64]
+int launch_dp_ln_fwd(const float* x, const float* gamma, const float* beta, float* xn, int nseq, int R, int Ls, hipStream_t st);
+int launch_dp_out(const float* y, const float* bias, const float* x, float* out, int nseq, int R, int Ls, hipStream_t st);
+int launch_dp_dy(const float* dout, float* dy, float* dbias, int nseq, int R, int Ls, hipStream_t st);
+int launch_dp_ln_bwd(const float* x, const float* dxn, const float* dout, const float* gamma, float* dx, float* dgamma, float* dbeta,
+                     int nseq, int R, int Ls, hipStream_t st);

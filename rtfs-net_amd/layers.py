@@ -291,6 +291,45 @@ class SRU(PackedModule):
 
 
 # ----------------------------------------------------------------------------- dual-path RNN
+class _DualPathTrainFn(torch.autograd.Function):
+    """DualPathRNN (SRU cell) forward/backward on the training kernels.  Inputs: x, dim, gamma, beta, (weight, weight_c, bias) x 4,
+    ConvTranspose1d weight, bias."""
+
+    @staticmethod
+    def forward(ctx, x, dim, gamma, beta, *rest):
+        lib = _lib.load()
+        x = x.contiguous()
+        B, _, T, Fq = x.shape
+        sru, lin_w, lin_b = rest[:12], rest[12], rest[13]
+        tpack = packing.pack_dualpath_train(gamma, beta, sru[0::3], sru[1::3], sru[2::3], lin_w, lin_b)
+        out = torch.empty_like(x)
+        saved = torch.empty(lib.rtfs_dualpath_saved_floats(B, T, Fq, dim), device=x.device, dtype=torch.float32)
+        ws = _lib.workspace(lib.rtfs_dualpath_train_workspace_bytes(B, T, Fq, dim), x.device)
+        _lib.check(lib.rtfs_dualpath_forward_train_f32(_lib.ptr(x), _lib.ptr(tpack), _lib.ptr(out), _lib.ptr(saved), B, T, Fq, dim,
+                                                       _lib.ptr(ws), ws.numel(), _lib.stream_of(x)), "rtfs_dualpath_forward_train_f32")
+        ctx.save_for_backward(x, tpack, saved)
+        ctx.dim = dim
+        ctx.shapes = (gamma.shape, beta.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        x, tpack, saved = ctx.saved_tensors
+        B, _, T, Fq = x.shape
+        dout = dout.contiguous().to(torch.float32)
+        dx = torch.empty_like(x)
+        dpar = torch.empty(lib.rtfs_dualpath_grad_floats(), device=x.device, dtype=torch.float32)
+        ws = _lib.workspace(lib.rtfs_dualpath_train_workspace_bytes(B, T, Fq, ctx.dim), x.device)
+        _lib.check(lib.rtfs_dualpath_backward_f32(_lib.ptr(x), _lib.ptr(tpack), _lib.ptr(saved), _lib.ptr(dout), _lib.ptr(dx), _lib.ptr(dpar),
+                                                  B, T, Fq, ctx.dim, _lib.ptr(ws), ws.numel(), _lib.stream_of(x)), "rtfs_dualpath_backward_f32")
+        dg, db, dws, dwcs, dbs, dlw, dlb = packing.unpack_dualpath_grads(dpar)
+        out = [dx, None, dg.reshape(ctx.shapes[0]), db.reshape(ctx.shapes[1])]
+        for i in range(4):
+            out += [dws[i], dwcs[i], dbs[i]]
+        return tuple(out + [dlw, dlb])
+
+
 class DualPathRNN(PackedModule):
     """reference rnn_layers.py:62-162 with rnn_type SRU.  x (B,64,T,F) -> same shape."""
 
@@ -317,12 +356,17 @@ class DualPathRNN(PackedModule):
         self.linear = nn.ConvTranspose1d(self.rnn_out_chan, in_chan, kernel_size, stride=stride)
 
     def forward(self, x):
-        self._guard(x)
+        _lib.need_gpu(x)  # no train/eval difference in this module (dropout is off at the reference call site)
         lib = _lib.load()
         x = x.contiguous()
         B, C, T, Fq = x.shape
         if (T if self.dim == 3 else Fq) < self.kernel_size:
             raise ValueError(f"sweep axis shorter than kernel_size {self.kernel_size}")  # nn.Unfold raises in the reference
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            if self.rnn_type != "SRU":
+                raise RuntimeError("DualPathRNN: the backward pass is built for the SRU cell only")
+            sru = [p for cell in self.rnn.rnn_lst for p in (cell.weight, cell.weight_c, cell.bias)]
+            return _DualPathTrainFn.apply(x, self.dim, self.norm.gamma, self.norm.beta, *sru, self.linear.weight, self.linear.bias)
         out = torch.empty_like(x)
         ws = _lib.workspace(lib.rtfs_dualpath_workspace_bytes(B, T, Fq), x.device)
         fn = lib.rtfs_dualpath_sru_f32 if self.rnn_type == "SRU" else lib.rtfs_dualpath_lstm_f32

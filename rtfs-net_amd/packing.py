@@ -108,6 +108,28 @@ def unpack_sru_grads(flat):
     return dws, list(dwc), list(db)
 
 
+def pack_dualpath_train(gamma, beta, weights, weight_cs, biases, lin_w, lin_b):
+    """Training-side pack of DualPathRNN with the SRU cell (layout contract: include/rtfs_amd.h,
+    rtfs_dualpath_forward_train_f32).  The Unfold feature order c*8 + k becomes k*64 + c (a window of the channel-last
+    sequence), the ConvTranspose1d weight (ci, co, k) is laid out once for the forward windows and once for the adjoint."""
+    w0 = weights[0].detach().to(torch.float32).reshape(64, 8, 256).permute(1, 0, 2).reshape(512, 256)  # rows k*64 + c
+    sru = pack_sru_train([w0] + list(weights[1:]), weight_cs, biases)
+    lw = lin_w.detach().to(torch.float32)
+    wcf = lw.flip(2).permute(1, 2, 0).reshape(64, 512)  # (co, (7-k)*64 + ci)
+    wcb = lw.permute(0, 2, 1).reshape(64, 512)          # (ci, k*64 + co)
+    return _cat([gamma.reshape(64), beta.reshape(64), sru, wcf.contiguous(), wcb.contiguous(), lin_b])
+
+
+def unpack_dualpath_grads(flat):
+    """rtfs_dualpath_backward_f32's gradient buffer -> (dgamma (64), dbeta (64), [dweight], [dweight_c], [dbias], dlin_w, dlin_b)."""
+    n_sru = 512 * 256 + 3 * 64 * 192 + 1024
+    dws, dwcs, dbs = unpack_sru_grads(flat[128:128 + n_sru])
+    dws[0] = dws[0].reshape(8, 64, 256).permute(1, 0, 2).reshape(512, 256)  # rows back to c*8 + k
+    off = 128 + n_sru
+    dlw = flat[off:off + 512 * 64].reshape(8, 64, 64).flip(0).permute(1, 2, 0)  # ((7-k), ci, co) -> (ci, co, k)
+    return flat[0:64], flat[64:128], dws, dwcs, dbs, dlw, flat[off + 512 * 64:off + 512 * 64 + 64]
+
+
 def _dualpath_lstm_parts(sd):
     """DualPathRNN with rnn_type LSTM (nn.LSTM(512, 32, 4 layers, bidirectional)).  Columns of the input projections:
     dir*128 + gate*32 + j (gates i,f,g,o); bias = b_ih + b_hh; recurrent weights as [layer][dir][k][gate*32 + j]."""

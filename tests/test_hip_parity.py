@@ -208,6 +208,34 @@ def test_sru_training_forward_backward(L, N, seed):
             close("sru eval vs train forward", host(sru(dev(x))[0]), host(h))
 
 
+@pytest.mark.parametrize("idx,shape,seed", [(0, (2, 64, 11, 13), 31), (1, (2, 64, 11, 13), 32), (0, (1, 64, 5, 64), 33), (1, (1, 64, 125, 9), 34),
+                                            (1, (1, 64, 250, 3), 35)])
+def test_dualpath_training_forward_backward(idx, shape, seed):
+    """DualPathRNN (SRU cell) used from a training step: forward + backward kernels against the autograd oracle
+    (LayerNorm, Unfold windows, SRU, ConvTranspose1d, residual; both sweep directions)."""
+    import rtfs_net_amd as R
+    from oracle import grad_oracle as G
+    p = O._sub(BLK, f"globalatt.{idx}")
+    dim = 4 if idx == 0 else 3
+    mod = R.layers.DualPathRNN(64, 32, dim, kernel_size=8, stride=1, rnn_type="SRU", num_layers=4, bidirectional=True)
+    mod.load_state_dict({k: torch.from_numpy(v) for k, v in p.items()})
+    mod = mod.cuda().train()
+    x = rand(shape, seed)
+    dout = rand(shape, seed + 100)
+    xt = dev(x).requires_grad_(True)
+    out = mod(xt)
+    out.backward(dev(dout))
+    o_ref, dx_ref, g_ref = G.dualpath_grads(x, p, dim, dout)
+    close("dualpath train forward", host(out), o_ref)
+    close("dualpath dx", host(xt.grad), dx_ref, tol=2e-4)
+    got = {k: v.grad for k, v in mod.named_parameters()}
+    assert set(got) == set(g_ref)
+    for k in sorted(g_ref):
+        close(f"dualpath d {k}", host(got[k]).reshape(g_ref[k].shape), g_ref[k], tol=2e-4)
+    with torch.no_grad():
+        close("dualpath eval vs train forward", host(mod(dev(x))), host(out))
+
+
 @pytest.mark.parametrize("shape,seed", [((2, 64, 12, 64), 103), ((1, 64, 125, 64), 5), ((1, 64, 250, 64), 6), ((2, 64, 33, 64), 8)])
 def test_mhsa2d(shape, seed):
     m = model()

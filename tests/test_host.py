@@ -243,3 +243,78 @@ def test_system_checkpoint_formats(tmp_path):
         assert torch.equal(v, a1.state_dict()[k]), k
     with pytest.raises(ValueError):
         R.System(audio_model=a0, optimizer=object())
+
+
+# ---------------------------------------------------------------------------------------------- training side (host logic)
+def test_sru_and_dualpath_training_pack_layouts_roundtrip():
+    """pack_*_train re-orders the projections for the training kernels; unpack_*_grads must be the exact inverse
+    re-ordering (a gradient laid out like the packed weight comes back in the module's parameter layout)."""
+    import torch
+    from rtfs_net_amd import packing, _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(0)
+    ws = [torch.randn(512, 256, generator=g)] + [torch.randn(64, 192, generator=g) for _ in range(3)]
+    wcs = [torch.randn(128, generator=g) for _ in range(4)]
+    bs = [torch.randn(128, generator=g) for _ in range(4)]
+    tp = packing.pack_sru_train(ws, wcs, bs)
+    assert tp.numel() == lib.rtfs_sru_train_pack_floats()
+    # the Wp part of the pack (second copy of the projections) is exactly the gradient layout
+    off = 256 * 512 + 3 * 192 * 64
+    flat = torch.cat([tp[off:off + 512 * 256 + 3 * 64 * 192], torch.stack(wcs).reshape(-1), torch.stack(bs).reshape(-1)])
+    assert flat.numel() == lib.rtfs_sru_grad_floats()
+    dws, dwcs, dbs = packing.unpack_sru_grads(flat)
+    for a, b in zip(dws + dwcs + dbs, ws + wcs + bs):
+        assert torch.equal(a, b)
+    # Wt is Wp transposed
+    assert torch.equal(tp[:256 * 512].reshape(256, 512).t(), tp[off:off + 512 * 256].reshape(512, 256))
+    gamma, beta = torch.randn(1, 64, 1, 1, generator=g), torch.randn(1, 64, 1, 1, generator=g)
+    lw, lb = torch.randn(64, 64, 8, generator=g), torch.randn(64, generator=g)
+    dp = packing.pack_dualpath_train(gamma, beta, ws, wcs, bs, lw, lb)
+    assert dp.numel() == lib.rtfs_dualpath_train_pack_floats()
+    sru_off = 128 + off
+    wcf = dp[128 + lib.rtfs_sru_train_pack_floats():][:64 * 512].reshape(64, 512)
+    gflat = torch.cat([dp[:128], dp[sru_off:sru_off + 512 * 256 + 3 * 64 * 192], torch.stack(wcs).reshape(-1), torch.stack(bs).reshape(-1),
+                       wcf.t().reshape(-1), lb])
+    assert gflat.numel() == lib.rtfs_dualpath_grad_floats()
+    dg, db, dws, dwcs, dbs, dlw, dlb = packing.unpack_dualpath_grads(gflat)
+    assert torch.equal(dg, gamma.reshape(64)) and torch.equal(db, beta.reshape(64)) and torch.equal(dlb, lb)
+    for a, b in zip(dws + dwcs + dbs, ws + wcs + bs):
+        assert torch.equal(a, b)
+    assert torch.equal(dlw, lw)
+
+
+def test_gradient_oracle_matches_numpy_oracle_and_finite_differences():
+    """oracle/grad_oracle.py: forward equals the numpy restatement; its autograd gradient equals a central finite difference
+    of the numpy restatement's own forward (so the backward kernels are checked against something that restates no backward)."""
+    import numpy as np
+    from oracle import rtfs_oracle as O, grad_oracle as G
+    rng = np.random.default_rng(5)
+    L, N = 6, 2
+    x = rng.standard_normal((L, N, 512)).astype(np.float32)
+    layers = []
+    for i in range(4):
+        din, k = (512, 4) if i == 0 else (64, 3)
+        layers.append(((rng.standard_normal((din, 64 * k)) / np.sqrt(din)).astype(np.float32), rng.standard_normal(128).astype(np.float32),
+                       (0.1 * rng.standard_normal(128)).astype(np.float32)))
+    dh = rng.standard_normal((L, N, 64))
+    h, dx, gl = G.sru_grads(x, layers, dh)
+    assert np.abs(h - O.sru_forward(x, layers)).max() < 2e-6
+
+    def loss(xv, lay):
+        t = [tuple(torch.tensor(p, dtype=torch.float64) for p in l) for l in lay]
+        return float((G.sru_forward_torch(torch.tensor(xv, dtype=torch.float64), t) * torch.tensor(dh)).sum())
+    import torch
+    eps = 1e-5
+    for idx in [(0, 0, 3), (5, 1, 500), (2, 0, 77)]:
+        xp, xm = x.astype(np.float64).copy(), x.astype(np.float64).copy()
+        xp[idx] += eps
+        xm[idx] -= eps
+        fd = (loss(xp, layers) - loss(xm, layers)) / (2 * eps)
+        assert abs(fd - dx[idx]) <= 1e-6 * max(1.0, abs(fd)), (idx, fd, dx[idx])
+    for li, pi, idx in [(0, 0, (17, 200)), (2, 1, (70,)), (3, 2, (5,)), (1, 0, (63, 191))]:
+        lp = [tuple(np.array(p, dtype=np.float64) for p in l) for l in layers]
+        lm = [tuple(np.array(p, dtype=np.float64) for p in l) for l in layers]
+        lp[li][pi][idx] += eps
+        lm[li][pi][idx] -= eps
+        fd = (loss(x, lp) - loss(x, lm)) / (2 * eps)
+        assert abs(fd - gl[li][pi][idx]) <= 1e-6 * max(1.0, abs(fd)), (li, pi, idx, fd, gl[li][pi][idx])
