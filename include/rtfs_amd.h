@@ -162,6 +162,22 @@ int rtfs_dualpath_forward_train_f32(const float* x, const float* tpack, float* o
                                     void* ws, size_t ws_bytes, void* stream);
 int rtfs_dualpath_backward_f32(const float* x, const float* tpack, const float* saved, const float* dout, float* dx,
                                float* dparams, int B, int T, int F, int dim, void* ws, size_t ws_bytes, void* stream);
+/* ConvNormAct.forward / backward for training (src/models/layers/conv_layers.py:65-129: pre_norm -> pre_act -> conv -> norm -> act),
+ * 1x1 dense or depthwise k x k (k <= 4, stride 1 "same" or stride 2 symmetric), norms: none | gLN, acts: none | ReLU | PReLU | Sigmoid.
+ * cfg (HOST int[11]): Cin, Cout, k, stride, depthwise, pre_norm (0/1), pre_act (0 none, 1 ReLU, 2 PReLU, 3 Sigmoid), norm, act,
+ *   has_bias, is2d.  x (B,Cin,H,W) -> out (B,Cout,Ho,Wo) (rtfs_cna_out_shape).
+ * params (rtfs_cna_param_floats, packing.py:pack_cna_train; every slot padded to 64 floats, unused slots ignored):
+ *   pre gamma | pre beta | pre slope | W (Cout,Cin) or (C,kh*kw) | W^T (dense only) | bias | gamma | beta | slope.
+ * dparams (rtfs_cna_grad_floats, overwritten): the same slots without W^T. */
+size_t rtfs_cna_param_floats(const int* cfg);
+size_t rtfs_cna_grad_floats(const int* cfg);
+size_t rtfs_cna_saved_floats(const int* cfg, int B, int H, int W);
+size_t rtfs_cna_workspace_bytes(const int* cfg, int B, int H, int W);
+void rtfs_cna_out_shape(const int* cfg, int H, int W, int* Ho, int* Wo);
+int rtfs_cna_forward_train_f32(const float* x, const float* params, float* out, float* saved, const int* cfg, int B, int H, int W,
+                               void* ws, size_t ws_bytes, void* stream);
+int rtfs_cna_backward_f32(const float* params, const float* saved, const float* dout, float* dx, float* dparams, const int* cfg,
+                          int B, int H, int W, void* ws, size_t ws_bytes, void* stream);
 /* The two GEMM forms of the training path (bf16x3 split on the matrix cores), exposed for tests:
  * kind 0: C (M,N) = A (M,K) . B (N,K)^T (accumulate != 0: C += ...), N % 64 == 0, K % 16 == 0;
  * kind 1: C (M,N) += A (K,M)^T . B (K,N), M % 64 == 0, N % 64 == 0. */

@@ -85,3 +85,39 @@ def dualpath_grads(x, p, dim, dout):
     names = sorted(pt)
     grads = torch.autograd.grad(out, [xt] + [pt[k] for k in names], torch.tensor(dout, dtype=torch.float64))
     return out.detach().numpy(), grads[0].numpy(), {k: g.numpy() for k, g in zip(names, grads[1:])}
+
+
+def conv_norm_act_torch(x, p, cfg):
+    """ConvNormAct (reference conv_layers.py:65-129: pre_norm -> pre_act -> conv -> norm -> act) in float64 torch ops.
+    cfg = (Cin, Cout, k, stride, depthwise, pre_norm, pre_act, norm, act, has_bias, is2d); p = dict with the state_dict names
+    full_layer.{0.norm.weight/bias, 1.weight, 2.weight/bias, 3.norm.weight/bias, 4.weight}."""
+    import torch.nn.functional as F
+    cin, cout, k, stride, depthwise, pre_norm, pre_act, norm, act, has_bias, is2d = cfg
+
+    def act_fn(v, kind, slope):
+        if kind == 1:
+            return torch.relu(v)
+        if kind == 2:
+            return F.prelu(v, slope)
+        if kind == 3:
+            return torch.sigmoid(v)
+        return v
+    if pre_norm:
+        x = F.group_norm(x, 1, p["full_layer.0.norm.weight"], p["full_layer.0.norm.bias"], 1e-5)
+    x = act_fn(x, pre_act, p.get("full_layer.1.weight"))
+    conv = F.conv2d if is2d else F.conv1d
+    pad = (k - 1) // 2 if stride > 1 else "same"
+    x = conv(x, p["full_layer.2.weight"], p.get("full_layer.2.bias") if has_bias else None, stride=stride, padding=pad,
+             groups=cin if depthwise else 1)
+    if norm:
+        x = F.group_norm(x, 1, p["full_layer.3.norm.weight"], p["full_layer.3.norm.bias"], 1e-5)
+    return act_fn(x, act, p.get("full_layer.4.weight"))
+
+
+def cna_grads(x, p, cfg, dout):
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    pt = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in p.items()}
+    out = conv_norm_act_torch(xt, pt, cfg)
+    names = sorted(pt)
+    grads = torch.autograd.grad(out, [xt] + [pt[k] for k in names], torch.tensor(dout, dtype=torch.float64))
+    return out.detach().numpy(), grads[0].numpy(), {k: g.numpy() for k, g in zip(names, grads[1:])}

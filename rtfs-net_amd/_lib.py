@@ -59,6 +59,13 @@ SIGNATURES = {
     "rtfs_dualpath_train_workspace_bytes": (_z, [_i, _i, _i, _i]),
     "rtfs_dualpath_forward_train_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _z, _p]),
     "rtfs_dualpath_backward_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _z, _p]),
+    "rtfs_cna_param_floats": (_z, [_p]),
+    "rtfs_cna_grad_floats": (_z, [_p]),
+    "rtfs_cna_saved_floats": (_z, [_p, _i, _i, _i]),
+    "rtfs_cna_workspace_bytes": (_z, [_p, _i, _i, _i]),
+    "rtfs_cna_out_shape": (None, [_p, _i, _i, _p, _p]),
+    "rtfs_cna_forward_train_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p, _z, _p]),
+    "rtfs_cna_backward_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _z, _p]),
     "rtfs_debug_gemm_f32": (_i, [_i, _p, _p, _p, _i, _i, _i, _i, _p]),
     "rtfs_debug_sweep_stamps": (_i, [_p, _p, _p, _i, _i, _i, _p, _p]),
     "rtfs_selftest_mfma_f16": (_i, [_p, _p, _p, _p]),

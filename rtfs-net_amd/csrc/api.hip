@@ -1152,6 +1152,177 @@ int rtfs_dualpath_backward_f32(const float* x, const float* tpack, const float* 
     return RTFS_OK;
 }
 
+// ------------------------------------------------------------ ConvNormAct, training side (channel-last rows inside)
+namespace {
+struct CnaCfg {
+    int Cin, Cout, k, stride, depthwise, pre_norm, pre_act, norm, act, has_bias, is2d;
+    int kh, kw, pt, pl, H, W, Ho, Wo, B;
+    size_t rows_in, rows_out;
+    // parameter / gradient layout (floats)
+    size_t o_pg, o_pb, o_ps, o_w, o_wt, o_b, o_g, o_be, o_s, p_end;      // params
+    size_t g_pg, g_pb, g_ps, g_w, g_b, g_g, g_be, g_s, g_end;            // grads
+    bool ok;
+    CnaCfg(const int* c, int B_, int H_, int W_) {
+        Cin = c[0]; Cout = c[1]; k = c[2]; stride = c[3]; depthwise = c[4]; pre_norm = c[5]; pre_act = c[6]; norm = c[7]; act = c[8];
+        has_bias = c[9]; is2d = c[10];
+        B = B_; H = H_; W = W_;
+        kh = is2d ? k : 1;
+        kw = k;
+        const int p = stride > 1 ? (k - 1) / 2 : (k - 1) / 2;  // stride 1: "same" puts the smaller half first; stride > 1: symmetric
+        pt = is2d ? p : 0;
+        pl = p;
+        if (stride == 1) { Ho = H; Wo = W; }
+        else { Ho = is2d ? (H + 2 * p - k) / stride + 1 : 1; Wo = (W + 2 * p - k) / stride + 1; }
+        rows_in = (size_t)B * H * W;
+        rows_out = (size_t)B * Ho * Wo;
+        auto pad64 = [](size_t n) { return (n + 63) / 64 * 64; };
+        const size_t wn = depthwise ? (size_t)Cout * kh * kw : (size_t)Cout * Cin;
+        size_t o = 0;
+        o_pg = o; o += pad64(Cin); o_pb = o; o += pad64(Cin); o_ps = o; o += 64;
+        o_w = o; o += pad64(wn); o_wt = o; o += depthwise ? 0 : pad64(wn);
+        o_b = o; o += pad64(Cout); o_g = o; o += pad64(Cout); o_be = o; o += pad64(Cout); o_s = o; o += 64; p_end = o;
+        o = 0;
+        g_pg = o; o += pad64(Cin); g_pb = o; o += pad64(Cin); g_ps = o; o += 64; g_w = o; o += pad64(wn);
+        g_b = o; o += pad64(Cout); g_g = o; o += pad64(Cout); g_be = o; o += pad64(Cout); g_s = o; o += 64; g_end = o;
+        auto pow2 = [](int v) { return v >= 1 && v <= 256 && !(v & (v - 1)); };
+        ok = pow2(Cin) && pow2(Cout) && k >= 1 && kh * kw <= 16 && (stride == 1 || stride == 2) && Ho >= 1 && Wo >= 1 &&
+             (depthwise ? Cin == Cout : (k == 1 && stride == 1 && Cin % 16 == 0 && Cout % 64 == 0 && Cin % 64 == 0)) &&
+             pre_norm >= 0 && pre_norm <= 1 && norm >= 0 && norm <= 1 && pre_act >= 0 && pre_act <= 3 && act >= 0 && act <= 3 &&
+             rows_in * (size_t)(Cin > Cout ? Cin : Cout) < 0x7fffffffu;
+    }
+    bool pre() const { return pre_norm || pre_act; }
+    bool post() const { return norm || act; }
+};
+struct CnaSaved {
+    float *r0, *r2, *r3;
+    double *st0, *st3;
+    size_t floats;
+    CnaSaved(float* p, const CnaCfg& c) {
+        float* p0 = p;
+        r0 = p; p += c.rows_in * c.Cin;
+        r2 = p; p += c.rows_in * c.Cin;
+        r3 = p; p += c.rows_out * c.Cout;
+        st0 = (double*)p; p += 4 * c.B;
+        st3 = (double*)p; p += 4 * c.B;
+        floats = (size_t)(p - p0);
+    }
+};
+}  // namespace
+
+size_t rtfs_cna_param_floats(const int* cfg) { return CnaCfg(cfg, 1, 8, 8).p_end; }
+size_t rtfs_cna_grad_floats(const int* cfg) { return CnaCfg(cfg, 1, 8, 8).g_end; }
+size_t rtfs_cna_saved_floats(const int* cfg, int B, int H, int W) {
+    CnaCfg c(cfg, B, H, W);
+    return CnaSaved(nullptr, c).floats + 64;
+}
+size_t rtfs_cna_workspace_bytes(const int* cfg, int B, int H, int W) {
+    CnaCfg c(cfg, B, H, W);
+    return (2 * c.rows_out * c.Cout + 2 * c.rows_in * c.Cin + 4 * (size_t)B) * sizeof(float) + 8 * 256;
+}
+void rtfs_cna_out_shape(const int* cfg, int H, int W, int* Ho, int* Wo) {
+    CnaCfg c(cfg, 1, H, W);
+    *Ho = c.Ho;
+    *Wo = c.Wo;
+}
+
+int rtfs_cna_forward_train_f32(const float* x, const float* params, float* out, float* saved, const int* cfg, int B, int H, int W,
+                               void* ws, size_t ws_bytes, void* stream) {
+    RTFS_RETURN_IF(!x || !params || !out || !saved || !cfg || B < 1 || H < 1 || W < 1, RTFS_ERR_ARG);
+    CnaCfg c(cfg, B, H, W);
+    RTFS_RETURN_IF(!c.ok, RTFS_ERR_SHAPE);
+    RTFS_RETURN_IF(!ws || ws_bytes < rtfs_cna_workspace_bytes(cfg, B, H, W), RTFS_ERR_WORKSPACE);
+    CnaSaved sv((float*)align_up((size_t)saved, 16), c);
+    Arena ar(ws, ws_bytes);
+    float* r5 = ar.take<float>(c.rows_out * c.Cout);
+    hipStream_t st = S(stream);
+    const size_t n_in = (size_t)H * W * c.Cin, n_out = (size_t)c.Ho * c.Wo * c.Cout;
+    CHECK(launch_transpose(x, sv.r0, B, c.Cin, H * W, st));  // (B, C, P) -> (B, P, C)
+    const float* conv_in = sv.r0;
+    if (c.pre()) {
+        ClStageArgs a;
+        a.x = sv.r0; a.y = sv.r2; a.n = n_in; a.C = c.Cin; a.norm = c.pre_norm; a.act = c.pre_act;
+        a.gamma = params + c.o_pg; a.beta = params + c.o_pb; a.slope = params + c.o_ps; a.stats = sv.st0;
+        if (c.pre_norm) {
+            if (hipMemsetAsync(sv.st0, 0, sizeof(double) * 2 * B, st) != hipSuccess) return RTFS_ERR_LAUNCH;
+            CHECK(launch_stats(sv.r0, sv.st0, B, n_in, st));
+        }
+        CHECK(launch_cl_norm_act_fwd(a, B, st));
+        conv_in = sv.r2;
+    }
+    float* conv_out = c.post() ? sv.r3 : r5;
+    if (c.depthwise) {
+        ClDwArgs d;
+        d.x = conv_in; d.w = params + c.o_w; d.bias = c.has_bias ? params + c.o_b : nullptr; d.y = conv_out;
+        d.B = B; d.H = H; d.W = W; d.C = c.Cin; d.Ho = c.Ho; d.Wo = c.Wo; d.kh = c.kh; d.kw = c.kw; d.s = c.stride; d.pt = c.pt; d.pl = c.pl;
+        CHECK(launch_cl_dw(d, 0, st));
+    } else {
+        CHECK(launch_gemm_nt(conv_in, c.Cin, params + c.o_w, c.Cin, conv_out, c.Cout, (int)c.rows_in, c.Cout, c.Cin, 0, st,
+                             c.has_bias ? params + c.o_b : nullptr));
+    }
+    if (c.post()) {
+        ClStageArgs a;
+        a.x = sv.r3; a.y = r5; a.n = n_out; a.C = c.Cout; a.norm = c.norm; a.act = c.act;
+        a.gamma = params + c.o_g; a.beta = params + c.o_be; a.slope = params + c.o_s; a.stats = sv.st3;
+        if (c.norm) {
+            if (hipMemsetAsync(sv.st3, 0, sizeof(double) * 2 * B, st) != hipSuccess) return RTFS_ERR_LAUNCH;
+            CHECK(launch_stats(sv.r3, sv.st3, B, n_out, st));
+        }
+        CHECK(launch_cl_norm_act_fwd(a, B, st));
+    }
+    return launch_transpose(r5, out, B, c.Ho * c.Wo, c.Cout, st);  // (B, P, C) -> (B, C, P)
+}
+
+int rtfs_cna_backward_f32(const float* params, const float* saved, const float* dout, float* dx, float* dparams, const int* cfg, int B,
+                          int H, int W, void* ws, size_t ws_bytes, void* stream) {
+    RTFS_RETURN_IF(!params || !saved || !dout || !dx || !dparams || !cfg || B < 1, RTFS_ERR_ARG);
+    CnaCfg c(cfg, B, H, W);
+    RTFS_RETURN_IF(!c.ok, RTFS_ERR_SHAPE);
+    RTFS_RETURN_IF(!ws || ws_bytes < rtfs_cna_workspace_bytes(cfg, B, H, W), RTFS_ERR_WORKSPACE);
+    CnaSaved sv((float*)align_up((size_t)saved, 16), c);
+    Arena ar(ws, ws_bytes);
+    float* d5 = ar.take<float>(c.rows_out * c.Cout);
+    float* d3b = ar.take<float>(c.rows_out * c.Cout);
+    float* d2 = ar.take<float>(c.rows_in * c.Cin);
+    float* d0 = ar.take<float>(c.rows_in * c.Cin);
+    double* Sb = ar.take<double>(2 * (size_t)B);
+    RTFS_RETURN_IF(!ar.ok(), RTFS_ERR_WORKSPACE);
+    hipStream_t st = S(stream);
+    const size_t n_in = (size_t)H * W * c.Cin, n_out = (size_t)c.Ho * c.Wo * c.Cout;
+    if (hipMemsetAsync(dparams, 0, c.g_end * sizeof(float), st) != hipSuccess) return RTFS_ERR_LAUNCH;
+    CHECK(launch_transpose(dout, d5, B, c.Cout, c.Ho * c.Wo, st));
+    const float* d3 = d5;
+    if (c.post()) {
+        ClStageArgs a;
+        a.x = sv.r3; a.dy = d5; a.dx = d3b; a.n = n_out; a.C = c.Cout; a.norm = c.norm; a.act = c.act;
+        a.gamma = params + c.o_g; a.beta = params + c.o_be; a.slope = params + c.o_s; a.stats = sv.st3; a.S = Sb;
+        a.dgamma = dparams + c.g_g; a.dbeta = dparams + c.g_be; a.dslope = dparams + c.g_s;
+        CHECK(launch_cl_norm_act_bwd(a, B, st));
+        d3 = d3b;
+    }
+    const float* conv_in = c.pre() ? sv.r2 : sv.r0;
+    if (c.has_bias) CHECK(launch_cl_colsum(d3, dparams + c.g_b, c.rows_out * c.Cout, c.Cout, st));
+    if (c.depthwise) {
+        ClDwArgs d;
+        d.x = conv_in; d.w = params + c.o_w; d.dy = d3; d.dx = d2; d.dw = dparams + c.g_w;
+        d.B = B; d.H = H; d.W = W; d.C = c.Cin; d.Ho = c.Ho; d.Wo = c.Wo; d.kh = c.kh; d.kw = c.kw; d.s = c.stride; d.pt = c.pt; d.pl = c.pl;
+        CHECK(launch_cl_dw(d, 1, st));
+        CHECK(launch_cl_dw(d, 2, st));
+    } else {
+        CHECK(launch_gemm_nt(d3, c.Cout, params + c.o_wt, c.Cout, d2, c.Cin, (int)c.rows_in, c.Cin, c.Cout, 0, st));
+        CHECK(launch_gemm_tn(d3, c.Cout, conv_in, c.Cin, dparams + c.g_w, c.Cin, c.Cout, c.Cin, (long)c.rows_in, st));
+    }
+    const float* dfirst = d2;
+    if (c.pre()) {
+        ClStageArgs a;
+        a.x = sv.r0; a.dy = d2; a.dx = d0; a.n = n_in; a.C = c.Cin; a.norm = c.pre_norm; a.act = c.pre_act;
+        a.gamma = params + c.o_pg; a.beta = params + c.o_pb; a.slope = params + c.o_ps; a.stats = sv.st0; a.S = Sb;
+        a.dgamma = dparams + c.g_pg; a.dbeta = dparams + c.g_pb; a.dslope = dparams + c.g_ps;
+        CHECK(launch_cl_norm_act_bwd(a, B, st));
+        dfirst = d0;
+    }
+    return launch_transpose(dfirst, dx, B, H * W, c.Cin, st);
+}
+
 // C = A . Bt^T (kind 0; accumulate adds to C) or C += A^T . B (kind 1): the two GEMM forms of the training path, exposed for tests
 int rtfs_debug_gemm_f32(int kind, const float* A, const float* B, float* C, int M, int N, int K, int accumulate, void* stream) {
     RTFS_RETURN_IF(!A || !B || !C, RTFS_ERR_ARG);

@@ -66,6 +66,9 @@ __device__ __forceinline__ void block_stats_atomic(float s, float ss, double* re
     }
 }
 
+// same, for two float partial sums whose destination is a pair of doubles (dst[0] += s, dst[1] += ss)
+__device__ __forceinline__ void block_stats_atomic_pair(float s, float ss, double* red, double* dst) { block_stats_atomic(s, ss, red, dst); }
+
 // GroupNorm(1,C) affine folded to y = x*scale + shift from accumulated (sum, sumsq).
 __device__ __forceinline__ void gln_fold(const double* st, double inv_count, float gamma, float beta, float& scale,
                                          float& shift) {

@@ -113,7 +113,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
                         unsafeAtomicAdd(g.C + (size_t)(row + colblk) * g.ldc + 32 * j + r, acc[i][j][q]);
                     } else {
                         float* p = g.C + (size_t)row * g.ldc + n0 + 32 * j + r;
-                        *p = MODE == 1 ? *p + acc[i][j][q] : acc[i][j][q];
+                        const float v = acc[i][j][q] + (g.bias ? g.bias[n0 + 32 * j + r] : 0.f);
+                        *p = MODE == 1 ? *p + v : v;
                     }
                 }
             }
@@ -177,10 +178,10 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmArgs g) {
 }
 
 int launch_gemm_nt(const float* A, int lda, const float* Bt, int ldb, float* C, int ldc, int M, int N, int K, int mode,
-                   hipStream_t st) {
+                   hipStream_t st, const float* bias) {
     if (M < 1 || N < 64 || (N & 63) || K < 16 || (K & 15) || (lda & 3) || (ldb & 3)) return RTFS_ERR_SHAPE;
     GemmArgs g;
-    g.A = A; g.B = Bt; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
+    g.A = A; g.B = Bt; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.bias = bias;
     g.ncb = N >> 6;
     g.nrb = cdiv(M, 256);
     const long grid = (long)cdiv(g.nrb, 8) * 8 * g.ncb;
@@ -489,5 +490,257 @@ int launch_dp_ln_bwd(const float* x, const float* dxn, const float* dout, const 
     int rc = set_lds(dp_ln_bwd_kernel, lds);
     if (rc) return rc;
     hipLaunchKernelGGL(dp_ln_bwd_kernel, dim3(nseq), dim3(256), lds, st, x, dxn, dout, gamma, dx, dgamma, dbeta, R, Ls);
+    return rtfs_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------ channel-last training kernels
+// ConvNormAct (conv_layers.py:65-129) in training: activations as rows (b, h, w) x C channels, C fastest.  A stage
+// "norm + act" is y = act((x - mean_b) * rstd_b * gamma_c + beta_c) with gLN statistics per sample (normalizations.py:8-17).
+// act: 0 none, 1 ReLU, 2 PReLU (one slope), 3 Sigmoid.
+namespace {
+__device__ __forceinline__ void stats_of(const double* st, int b, double inv_n, float& mean, float& rstd) {
+    const double m = st[2 * b] * inv_n;
+    double var = st[2 * b + 1] * inv_n - m * m;
+    var = var < 0 ? 0 : var;
+    mean = (float)m;
+    rstd = (float)(1.0 / sqrt(var + (double)RTFS_EPS));
+}
+__device__ __forceinline__ float act_fwd(float z, int act, float slope) {
+    if (act == 1) return fmaxf(z, 0.f);
+    if (act == 2) return z >= 0.f ? z : slope * z;
+    if (act == 3) return 1.0f / (1.0f + __expf(-z));
+    return z;
+}
+// d act / dz times dy; for PReLU also the slope's gradient contribution
+__device__ __forceinline__ float act_bwd(float z, float dy, int act, float slope, float& dslope) {
+    if (act == 1) return z > 0.f ? dy : 0.f;
+    if (act == 2) {
+        if (z >= 0.f) return dy;
+        dslope += dy * z;
+        return dy * slope;
+    }
+    if (act == 3) {
+        const float y = 1.0f / (1.0f + __expf(-z));
+        return dy * y * (1.f - y);
+    }
+    return dy;
+}
+}  // namespace
+
+// grid (chunks, B): each workgroup a contiguous chunk of one sample's n = rows*C elements
+__global__ __launch_bounds__(256) void cl_norm_act_fwd_kernel(ClStageArgs a) {
+    const int b = blockIdx.y;
+    float mean = 0.f, rstd = 1.f;
+    if (a.norm) stats_of(a.stats, b, 1.0 / (double)a.n, mean, rstd);
+    const float slope = a.act == 2 ? a.slope[0] : 0.f;
+    const size_t base = (size_t)b * a.n;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i & (a.C - 1));
+        float z = a.x[base + i];
+        if (a.norm) z = fmaf((z - mean) * rstd, a.gamma[c], a.beta[c]);
+        a.y[base + i] = act_fwd(z, a.act, slope);
+    }
+}
+
+// reductions of the stage's backward: per sample S1 = sum da*gamma, S2 = sum da*gamma*xhat (f64 atomics into S[2b..]);
+// per channel dgamma += sum da*xhat, dbeta += sum da; dslope
+__global__ __launch_bounds__(256) void cl_norm_act_bwd_reduce_kernel(ClStageArgs a) {
+    __shared__ double red[16];
+    __shared__ float part[3][256];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    float mean = 0.f, rstd = 1.f;
+    if (a.norm) stats_of(a.stats, b, 1.0 / (double)a.n, mean, rstd);
+    const float slope = a.act == 2 ? a.slope[0] : 0.f;
+    const size_t base = (size_t)b * a.n;
+    const int c = tid & (a.C - 1);  // fixed per thread: the stride below is a multiple of C (C <= 256, power of two)
+    const float g = a.norm ? a.gamma[c] : 1.f, be = a.norm ? a.beta[c] : 0.f;
+    float s1 = 0.f, s2 = 0.f, dg = 0.f, db = 0.f, dsl = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + tid; i < a.n; i += (size_t)gridDim.x * 256) {
+        const float xv = a.x[base + i];
+        const float xh = a.norm ? (xv - mean) * rstd : xv;
+        const float z = a.norm ? fmaf(xh, g, be) : xv;
+        const float da = act_bwd(z, a.dy[base + i], a.act, slope, dsl);
+        dg = fmaf(da, xh, dg);
+        db += da;
+        s1 = fmaf(da, g, s1);
+        s2 = fmaf(da * g, xh, s2);
+    }
+    if (a.norm) {
+        block_stats_atomic_pair(s1, s2, red, a.S + 2 * b);
+        part[0][tid] = dg;
+        part[1][tid] = db;
+    }
+    part[2][tid] = dsl;
+    __syncthreads();
+    if (a.norm && tid < a.C) {
+        float sg = 0.f, sb = 0.f;
+        for (int j = tid; j < 256; j += a.C) {
+            sg += part[0][j];
+            sb += part[1][j];
+        }
+        unsafeAtomicAdd(a.dgamma + tid, sg);
+        unsafeAtomicAdd(a.dbeta + tid, sb);
+    }
+    if (a.act == 2 && tid < 64) {
+        float v = part[2][tid] + part[2][tid + 64] + part[2][tid + 128] + part[2][tid + 192];
+        v = wave_sum(v);
+        if (tid == 0) unsafeAtomicAdd(a.dslope, v);
+    }
+}
+
+__global__ __launch_bounds__(256) void cl_norm_act_bwd_apply_kernel(ClStageArgs a) {
+    const int b = blockIdx.y;
+    float mean = 0.f, rstd = 1.f, m1 = 0.f, m2 = 0.f;
+    if (a.norm) {
+        stats_of(a.stats, b, 1.0 / (double)a.n, mean, rstd);
+        m1 = (float)(a.S[2 * b] / (double)a.n);
+        m2 = (float)(a.S[2 * b + 1] / (double)a.n);
+    }
+    const float slope = a.act == 2 ? a.slope[0] : 0.f;
+    const size_t base = (size_t)b * a.n;
+    float dummy = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i & (a.C - 1));
+        const float xv = a.x[base + i];
+        const float g = a.norm ? a.gamma[c] : 1.f;
+        const float xh = a.norm ? (xv - mean) * rstd : xv;
+        const float z = a.norm ? fmaf(xh, g, a.beta[c]) : xv;
+        const float da = act_bwd(z, a.dy[base + i], a.act, slope, dummy);
+        a.dx[base + i] = a.norm ? rstd * (da * g - m1 - xh * m2) : da;
+    }
+}
+
+// out[c] += sum over rows of d[row][c]   (bias gradients)
+__global__ __launch_bounds__(256) void cl_colsum_kernel(const float* __restrict__ d, float* __restrict__ out, size_t n, int C) {
+    __shared__ float part[256];
+    const int tid = threadIdx.x;
+    float s = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + tid; i < n; i += (size_t)gridDim.x * 256) s += d[i];
+    part[tid] = s;
+    __syncthreads();
+    if (tid < C) {
+        float v = 0.f;
+        for (int j = tid; j < 256; j += C) v += part[j];
+        unsafeAtomicAdd(out + tid, v);
+    }
+}
+
+// depthwise k x k convolution, channel-last: x (B, H, W, C), w (C, kh*kw), y (B, Ho, Wo, C); cross-correlation with
+// top/left padding (pt, pl) and stride s (conv_layers.py:100-101: "same" k = 4 -> pt = pl = 1, stride 2 -> symmetric 1)
+__global__ __launch_bounds__(256) void cl_dw_fwd_kernel(ClDwArgs a) {
+    const size_t total = (size_t)a.B * a.Ho * a.Wo * a.C;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % a.C);
+        size_t r = i / a.C;
+        const int wo = (int)(r % a.Wo);
+        r /= a.Wo;
+        const int ho = (int)(r % a.Ho), b = (int)(r / a.Ho);
+        float acc = a.bias ? a.bias[c] : 0.f;
+        for (int ki = 0; ki < a.kh; ++ki) {
+            const int h = ho * a.s - a.pt + ki;
+            if (h < 0 || h >= a.H) continue;
+            for (int kj = 0; kj < a.kw; ++kj) {
+                const int w = wo * a.s - a.pl + kj;
+                if (w < 0 || w >= a.W) continue;
+                acc = fmaf(a.w[c * a.kh * a.kw + ki * a.kw + kj], a.x[(((size_t)b * a.H + h) * a.W + w) * a.C + c], acc);
+            }
+        }
+        a.y[i] = acc;
+    }
+}
+
+// input gradient: dx[b,h,w,c] = sum over taps with (h + pt - ki) = ho*s, (w + pl - kj) = wo*s of w[c,ki,kj] * dy[b,ho,wo,c]
+__global__ __launch_bounds__(256) void cl_dw_bwd_data_kernel(ClDwArgs a) {
+    const size_t total = (size_t)a.B * a.H * a.W * a.C;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % a.C);
+        size_t r = i / a.C;
+        const int w = (int)(r % a.W);
+        r /= a.W;
+        const int h = (int)(r % a.H), b = (int)(r / a.H);
+        float acc = 0.f;
+        for (int ki = 0; ki < a.kh; ++ki) {
+            const int hn = h + a.pt - ki;
+            if (hn < 0 || hn % a.s) continue;
+            const int ho = hn / a.s;
+            if (ho >= a.Ho) continue;
+            for (int kj = 0; kj < a.kw; ++kj) {
+                const int wn = w + a.pl - kj;
+                if (wn < 0 || wn % a.s) continue;
+                const int wo = wn / a.s;
+                if (wo >= a.Wo) continue;
+                acc = fmaf(a.w[c * a.kh * a.kw + ki * a.kw + kj], a.dy[(((size_t)b * a.Ho + ho) * a.Wo + wo) * a.C + c], acc);
+            }
+        }
+        a.dx[i] = acc;
+    }
+}
+
+// weight gradient: dw[c,ki,kj] += sum_{b,ho,wo} dy * x(shifted).  Thread = (channel, one of 256/C row lanes); up to 16 taps.
+__global__ __launch_bounds__(256) void cl_dw_wgrad_kernel(ClDwArgs a) {
+    __shared__ float part[256];
+    const int tid = threadIdx.x, c = tid % a.C, lanes = 256 / a.C, rl = tid / a.C;
+    const int taps = a.kh * a.kw;
+    float acc[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) acc[t] = 0.f;
+    const size_t rows = (size_t)a.B * a.Ho * a.Wo;
+    for (size_t r = (size_t)blockIdx.x * lanes + rl; r < rows; r += (size_t)gridDim.x * lanes) {
+        const int wo = (int)(r % a.Wo);
+        const size_t q = r / a.Wo;
+        const int ho = (int)(q % a.Ho), b = (int)(q / a.Ho);
+        const float d = a.dy[r * a.C + c];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            if (t < taps) {
+                const int ki = t / a.kw, kj = t - ki * a.kw;
+                const int h = ho * a.s - a.pt + ki, w = wo * a.s - a.pl + kj;
+                if (h >= 0 && h < a.H && w >= 0 && w < a.W) acc[t] = fmaf(d, a.x[(((size_t)b * a.H + h) * a.W + w) * a.C + c], acc[t]);
+            }
+        }
+    }
+    for (int t = 0; t < taps; ++t) {
+        part[tid] = acc[t];
+        __syncthreads();
+        if (tid < a.C) {
+            float v = 0.f;
+            for (int j = tid; j < 256; j += a.C) v += part[j];
+            unsafeAtomicAdd(a.dw + tid * taps + t, v);
+        }
+        __syncthreads();
+    }
+}
+
+namespace {
+inline unsigned grid_for(size_t n, unsigned cap = 8192) {
+    size_t g = (n + 255) / 256;
+    return (unsigned)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+}  // namespace
+
+int launch_cl_norm_act_fwd(const ClStageArgs& a, int B, hipStream_t st) {
+    if (a.C < 1 || a.C > 256 || (a.C & (a.C - 1))) return RTFS_ERR_SHAPE;
+    hipLaunchKernelGGL(cl_norm_act_fwd_kernel, dim3(grid_for(a.n, 2048), B), dim3(256), 0, st, a);
+    return rtfs_launch_status();
+}
+int launch_cl_norm_act_bwd(const ClStageArgs& a, int B, hipStream_t st) {
+    if (a.C < 1 || a.C > 256 || (a.C & (a.C - 1))) return RTFS_ERR_SHAPE;
+    if (a.norm || a.act == 2) {
+        if (a.norm && hipMemsetAsync(a.S, 0, sizeof(double) * 2 * B, st) != hipSuccess) return RTFS_ERR_LAUNCH;
+        hipLaunchKernelGGL(cl_norm_act_bwd_reduce_kernel, dim3(grid_for(a.n, 256), B), dim3(256), 0, st, a);
+    }
+    hipLaunchKernelGGL(cl_norm_act_bwd_apply_kernel, dim3(grid_for(a.n, 2048), B), dim3(256), 0, st, a);
+    return rtfs_launch_status();
+}
+int launch_cl_colsum(const float* d, float* out, size_t n, int C, hipStream_t st) {
+    if (C < 1 || C > 256 || (C & (C - 1))) return RTFS_ERR_SHAPE;
+    hipLaunchKernelGGL(cl_colsum_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, st, d, out, n, C);
+    return rtfs_launch_status();
+}
+int launch_cl_dw(const ClDwArgs& a, int what, hipStream_t st) {
+    if (a.kh * a.kw > 16 || a.C < 1 || a.C > 256 || (256 % a.C)) return RTFS_ERR_SHAPE;
+    if (what == 0) hipLaunchKernelGGL(cl_dw_fwd_kernel, dim3(grid_for((size_t)a.B * a.Ho * a.Wo * a.C)), dim3(256), 0, st, a);
+    else if (what == 1) hipLaunchKernelGGL(cl_dw_bwd_data_kernel, dim3(grid_for((size_t)a.B * a.H * a.W * a.C)), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(cl_dw_wgrad_kernel, dim3(grid_for((size_t)a.B * a.Ho * a.Wo * a.C / 8, 2048)), dim3(256), 0, st, a);
     return rtfs_launch_status();
 }

@@ -231,11 +231,12 @@ struct GemmArgs {
     int lda = 0, ldb = 0, ldc = 0, M = 0, N = 0, K = 0;
     int ncb = 0, nrb = 0;  // NT: column / row blocks
     int kchunk = 0;        // TN: k range of one wave
+    const float* bias = nullptr;  // NT modes 0/1: added per column
 };
 // C (M,N) [+]= A (M,K) . Bt (N,K)^T  (both K-contiguous; N % 64 == 0, K % 16 == 0)
 // mode 0: C = ; 1: C += ; 2: C (rows x 64) [(row + colblk) * ldc + col % 64] += (atomics; the fold of unfold windows)
 int launch_gemm_nt(const float* A, int lda, const float* Bt, int ldb, float* C, int ldc, int M, int N, int K, int mode,
-                   hipStream_t st);
+                   hipStream_t st, const float* bias = nullptr);
 // C (M,N) += A (K,M)^T . B (K,N)  (split-K with f32 atomics; M, N % 64 == 0)
 int launch_gemm_tn(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, long K, hipStream_t st);
 struct SruScanArgs {
@@ -262,3 +263,25 @@ int launch_dp_out(const float* y, const float* bias, const float* x, float* out,
 int launch_dp_dy(const float* dout, float* dy, float* dbias, int nseq, int R, int Ls, hipStream_t st);
 int launch_dp_ln_bwd(const float* x, const float* dxn, const float* dout, const float* gamma, float* dx, float* dgamma, float* dbeta,
                      int nseq, int R, int Ls, hipStream_t st);
+// channel-last ConvNormAct training kernels (k_train.hip)
+struct ClStageArgs {  // y = act(gLN(x)) over rows x C, per-sample statistics
+    const float* x = nullptr;
+    float* y = nullptr;
+    const double* stats = nullptr;  // (B, 2) sum, sum of squares of x per sample (norm only)
+    const float *gamma = nullptr, *beta = nullptr, *slope = nullptr;
+    const float* dy = nullptr;  // backward
+    float* dx = nullptr;
+    double* S = nullptr;        // backward scratch (B, 2)
+    float *dgamma = nullptr, *dbeta = nullptr, *dslope = nullptr;
+    size_t n = 0;               // elements per sample = rows per sample * C
+    int C = 0, norm = 0, act = 0;
+};
+struct ClDwArgs {
+    const float *x = nullptr, *w = nullptr, *bias = nullptr, *dy = nullptr;
+    float *y = nullptr, *dx = nullptr, *dw = nullptr;
+    int B = 0, H = 0, W = 0, C = 0, Ho = 0, Wo = 0, kh = 0, kw = 0, s = 1, pt = 0, pl = 0;
+};
+int launch_cl_norm_act_fwd(const ClStageArgs& a, int B, hipStream_t st);
+int launch_cl_norm_act_bwd(const ClStageArgs& a, int B, hipStream_t st);
+int launch_cl_colsum(const float* d, float* out, size_t n, int C, hipStream_t st);
+int launch_cl_dw(const ClDwArgs& a, int what /* 0 fwd, 1 bwd data, 2 wgrad */, hipStream_t st);

@@ -113,6 +113,50 @@ def _config_of(module):
     return {k: v for k, v in module.__dict__.items() if not k.startswith("_") and k != "training" and not callable(v)}
 
 
+_ACT_CODE = {nn.Identity: 0, nn.ReLU: 1, nn.PReLU: 2, nn.Sigmoid: 3}
+
+
+class _CNATrainFn(torch.autograd.Function):
+    """ConvNormAct forward/backward on the training kernels (csrc/k_train.hip, channel-last rows inside).
+    Inputs: x, cfg tuple, then pre_gamma, pre_beta, pre_slope, weight, bias, gamma, beta, slope (None where the stage is absent)."""
+
+    @staticmethod
+    def forward(ctx, x, cfg, *params):
+        import ctypes
+        lib = _lib.load()
+        x = x.contiguous()
+        B, H, W = x.shape[0], (x.shape[2] if x.dim() == 4 else 1), x.shape[-1]
+        carr = (ctypes.c_int * 11)(*cfg)
+        pk = packing.pack_cna_train(cfg, *params)
+        ho, wo = ctypes.c_int(), ctypes.c_int()
+        lib.rtfs_cna_out_shape(carr, H, W, ctypes.byref(ho), ctypes.byref(wo))
+        out = torch.empty((B, cfg[1], ho.value, wo.value) if x.dim() == 4 else (B, cfg[1], wo.value), device=x.device, dtype=torch.float32)
+        saved = torch.empty(lib.rtfs_cna_saved_floats(carr, B, H, W), device=x.device, dtype=torch.float32)
+        ws = _lib.workspace(lib.rtfs_cna_workspace_bytes(carr, B, H, W), x.device)
+        _lib.check(lib.rtfs_cna_forward_train_f32(_lib.ptr(x), _lib.ptr(pk), _lib.ptr(out), _lib.ptr(saved), carr, B, H, W, _lib.ptr(ws), ws.numel(),
+                                                  _lib.stream_of(x)), "rtfs_cna_forward_train_f32")
+        ctx.save_for_backward(pk, saved)
+        ctx.cfg, ctx.geom, ctx.xshape = cfg, (B, H, W), x.shape
+        ctx.pshapes = [None if p is None else p.shape for p in params]
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        import ctypes
+        lib = _lib.load()
+        pk, saved = ctx.saved_tensors
+        B, H, W = ctx.geom
+        carr = (ctypes.c_int * 11)(*ctx.cfg)
+        dout = dout.contiguous().to(torch.float32)
+        dx = torch.empty(ctx.xshape, device=dout.device, dtype=torch.float32)
+        dpar = torch.empty(lib.rtfs_cna_grad_floats(carr), device=dout.device, dtype=torch.float32)
+        ws = _lib.workspace(lib.rtfs_cna_workspace_bytes(carr, B, H, W), dout.device)
+        _lib.check(lib.rtfs_cna_backward_f32(_lib.ptr(pk), _lib.ptr(saved), _lib.ptr(dout), _lib.ptr(dx), _lib.ptr(dpar), carr, B, H, W,
+                                             _lib.ptr(ws), ws.numel(), _lib.stream_of(dout)), "rtfs_cna_backward_f32")
+        grads = packing.unpack_cna_grads(ctx.cfg, dpar, ctx.pshapes[3])
+        return (dx, None) + tuple(None if shp is None else g.reshape(shp) for g, shp in zip(grads, ctx.pshapes))
+
+
 class ConvNormAct(nn.Module):
     """Parameter holder with the reference's layout ``full_layer = Sequential(pre_norm, pre_act, conv, norm, act)``
     (conv_layers.py:65-129), hence keys ``full_layer.{0,2,3,4}.*``.  kernel_size <= 0 makes every stage an
@@ -142,7 +186,31 @@ class ConvNormAct(nn.Module):
         self.full_layer = nn.Sequential(*stages)
 
     def forward(self, x):
+        if x.is_cuda and torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            return self._forward_train(x)
         return self.full_layer(x)
+
+    def _forward_train(self, x):
+        """The module inside a training step: HIP forward-with-saved-state + backward (rtfs_cna_*_f32)."""
+        pre_n, pre_a, conv, nrm, act = self.full_layer
+        if not isinstance(conv, (nn.Conv1d, nn.Conv2d)):
+            return x
+        for m in (pre_n, nrm):
+            if not isinstance(m, (nn.Identity, GlobalLayerNorm)):
+                raise RuntimeError(f"ConvNormAct: the training kernels implement gLN only, not {type(m).__name__}")
+        for m in (pre_a, act):
+            if type(m) not in _ACT_CODE:
+                raise RuntimeError(f"ConvNormAct: activation {type(m).__name__} has no training kernel")
+        depthwise = conv.groups == conv.in_channels and conv.groups == conv.out_channels and conv.groups > 1
+        if not (depthwise or conv.groups == 1) or self.dilation != 1:
+            raise RuntimeError("ConvNormAct: training kernels cover dense 1x1 and depthwise convolutions only")
+        is2d = isinstance(conv, nn.Conv2d)
+        cfg = (conv.in_channels, conv.out_channels, self.kernel_size, self.stride, int(depthwise), int(isinstance(pre_n, GlobalLayerNorm)),
+               _ACT_CODE[type(pre_a)], int(isinstance(nrm, GlobalLayerNorm)), _ACT_CODE[type(act)], int(conv.bias is not None), int(is2d))
+        gn = lambda m, a: getattr(m.norm, a) if isinstance(m, GlobalLayerNorm) else None
+        sl = lambda m: m.weight if isinstance(m, nn.PReLU) else None
+        return _CNATrainFn.apply(x, cfg, gn(pre_n, "weight"), gn(pre_n, "bias"), sl(pre_a), conv.weight, conv.bias, gn(nrm, "weight"),
+                                 gn(nrm, "bias"), sl(act))
 
     def get_config(self):
         return _config_of(self)

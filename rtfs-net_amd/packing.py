@@ -130,6 +130,37 @@ def unpack_dualpath_grads(flat):
     return flat[0:64], flat[64:128], dws, dwcs, dbs, dlw, flat[off + 512 * 64:off + 512 * 64 + 64]
 
 
+def pack_cna_train(cfg, pre_g, pre_b, pre_s, w, bias, g, b, s):
+    """Training-side parameter buffer of one ConvNormAct (layout contract: include/rtfs_amd.h, rtfs_cna_forward_train_f32).
+    cfg = (Cin, Cout, k, stride, depthwise, pre_norm, pre_act, norm, act, has_bias, is2d); absent parameters are zero-filled."""
+    cin, cout, depthwise = cfg[0], cfg[1], cfg[4]
+    dev = w.device
+    z = lambda n: torch.zeros(n, device=dev)
+    w2 = w.detach().to(torch.float32).reshape(cout, -1)
+    parts = [pre_g if pre_g is not None else z(cin), pre_b if pre_b is not None else z(cin), pre_s if pre_s is not None else z(1), w2]
+    if not depthwise:
+        parts.append(w2.t().contiguous())
+    parts += [bias if bias is not None else z(cout), g if g is not None else z(cout), b if b is not None else z(cout),
+              s if s is not None else z(1)]
+    return _cat(parts)
+
+
+def unpack_cna_grads(cfg, flat, w_shape):
+    """rtfs_cna_backward_f32's gradient buffer -> (dpre_g, dpre_b, dpre_s, dw, dbias, dg, db, ds) (flat views; caller reshapes)."""
+    cin, cout = cfg[0], cfg[1]
+    pad = lambda n: (n + ALIGN - 1) // ALIGN * ALIGN
+    wn = 1
+    for d in w_shape:
+        wn *= d
+    sizes = [cin, cin, 1, wn, cout, cout, cout, 1]
+    out, off = [], 0
+    for n in sizes:
+        out.append(flat[off:off + n])
+        off += pad(n)
+    out[3] = out[3].reshape(w_shape)
+    return out
+
+
 def _dualpath_lstm_parts(sd):
     """DualPathRNN with rnn_type LSTM (nn.LSTM(512, 32, 4 layers, bidirectional)).  Columns of the input projections:
     dir*128 + gate*32 + j (gates i,f,g,o); bias = b_ih + b_hh; recurrent weights as [layer][dir][k][gate*32 + j]."""

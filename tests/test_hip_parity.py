@@ -236,6 +236,55 @@ def test_dualpath_training_forward_backward(idx, shape, seed):
         close("dualpath eval vs train forward", host(mod(dev(x))), host(out))
 
 
+CNA_CASES = {
+    # name: (ctor kwargs, input shape)  -- the ConvNormAct configurations on the path (yaml + tdanet.py / fusion.py / tdavnet.py ctors)
+    "audio_bn": (dict(in_chan=256, out_chan=256, kernel_size=1, pre_norm_type="gLN", pre_act_type="ReLU", is2d=True), (2, 256, 9, 7)),
+    "projection": (dict(in_chan=256, out_chan=64, kernel_size=1, norm_type="gLN", act_type="PReLU", is2d=True), (2, 256, 9, 7)),
+    "gateway": (dict(in_chan=256, out_chan=256, kernel_size=1, groups=256, act_type="PReLU", is2d=True), (2, 256, 6, 5)),
+    "downsample": (dict(in_chan=64, out_chan=64, kernel_size=4, stride=2, groups=64, norm_type="gLN", is2d=True), (2, 64, 11, 9)),
+    "tfar_gate": (dict(in_chan=64, out_chan=64, kernel_size=4, groups=64, norm_type="gLN", act_type="Sigmoid", bias=False, is2d=True), (2, 64, 10, 7)),
+    "tfar_plain": (dict(in_chan=64, out_chan=64, kernel_size=4, groups=64, norm_type="gLN", bias=False, is2d=True), (1, 64, 5, 12)),
+    "residual_conv": (dict(in_chan=64, out_chan=256, kernel_size=1, is2d=True), (2, 64, 9, 7)),
+    "ffn_refiner_1d": (dict(in_chan=128, out_chan=128, kernel_size=5, groups=128, act_type="ReLU", is2d=False), (2, 128, 13)),
+    "ffn_encoder_1d": (dict(in_chan=64, out_chan=128, kernel_size=1, norm_type="gLN", bias=False, is2d=False), (3, 64, 50)),
+}
+
+
+@pytest.mark.parametrize("name", sorted(CNA_CASES))
+def test_conv_norm_act_training_forward_backward(name):
+    """ConvNormAct used from a training step (every configuration the path instantiates): forward + all gradients vs the autograd oracle."""
+    import rtfs_net_amd as R
+    from oracle import grad_oracle as G
+    kw, shape = CNA_CASES[name]
+    torch.manual_seed(sum(map(ord, name)))
+    mod = R.layers.ConvNormAct(**kw)
+    with torch.no_grad():
+        for k, v in mod.named_parameters():  # away from the init values (gamma 1, beta 0, slope 0.25)
+            if "norm" in k or k.endswith("1.weight") or k.endswith("4.weight") or k.endswith("bias"):
+                v.add_(0.3 * torch.randn_like(v))
+    p = {k: v.detach().numpy().copy() for k, v in mod.state_dict().items()}
+    mod = mod.cuda().train()
+    conv = mod.full_layer[2]
+    depthwise = conv.groups > 1
+    code = R.layers._ACT_CODE
+    cfg = (conv.in_channels, conv.out_channels, kw["kernel_size"], kw.get("stride", 1), int(depthwise), int(kw.get("pre_norm_type") == "gLN"),
+           code[type(mod.full_layer[1])], int(kw.get("norm_type") == "gLN"), code[type(mod.full_layer[4])], int(conv.bias is not None),
+           int(kw["is2d"]))
+    x = rand(shape, 7)
+    xt = dev(x).requires_grad_(True)
+    out = mod(xt)
+    dout = rand(tuple(out.shape), 8)
+    out.backward(dev(dout))
+    o_ref, dx_ref, g_ref = G.cna_grads(x, p, cfg, dout)
+    close(f"{name} forward", host(out), o_ref)
+    close(f"{name} dx", host(xt.grad), dx_ref, tol=2e-4)
+    got = {k: v.grad for k, v in mod.named_parameters()}
+    assert set(got) == set(g_ref)
+    for k in sorted(g_ref):
+        assert got[k] is not None, k
+        close(f"{name} d {k}", host(got[k]), g_ref[k], tol=2e-4)
+
+
 @pytest.mark.parametrize("shape,seed", [((2, 64, 12, 64), 103), ((1, 64, 125, 64), 5), ((1, 64, 250, 64), 6), ((2, 64, 33, 64), 8)])
 def test_mhsa2d(shape, seed):
     m = model()
