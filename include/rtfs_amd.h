@@ -178,6 +178,20 @@ int rtfs_cna_forward_train_f32(const float* x, const float* params, float* out, 
                                void* ws, size_t ws_bytes, void* stream);
 int rtfs_cna_backward_f32(const float* params, const float* saved, const float* dout, float* dx, float* dparams, const int* cfg,
                           int B, int H, int W, void* ws, size_t ws_bytes, void* stream);
+/* MultiHeadSelfAttention2D.forward / backward for training (src/models/layers/attention.py:149-189; 4 heads, hid_chan 4, n_freqs 64).
+ * x, out, dout, dx (B,64,T,64).  tpack (rtfs_tf_attention_train_pack_floats(), packing.py:pack_attention_train):
+ *   W_qkv (128,64) rows [Q h0..3 (4 each) | K h0..3 | V h0..3 (16 each) | 32 zero rows] | its transpose | bias (128) | PReLU slope per
+ *   row (128) | LN gamma (128,64) | LN beta (128,64) | W_proj (64,64) | its transpose | bias (64) | slope per row (64) | gamma (64,64) | beta.
+ * dparams (rtfs_tf_attention_grad_floats(), overwritten): dW_qkv | dbias (128) | dslope per module (64 slots, 12 used: Q h0..3, K h0..3,
+ *   V h0..3) | dgamma (128,64) | dbeta | dW_proj | dbias (64) | dslope (64 slots, 1 used) | dgamma (64,64) | dbeta. */
+size_t rtfs_tf_attention_train_pack_floats(void);
+size_t rtfs_tf_attention_grad_floats(void);
+size_t rtfs_tf_attention_saved_floats(int B, int T);
+size_t rtfs_tf_attention_train_workspace_bytes(int B, int T);
+int rtfs_tf_attention_forward_train_f32(const float* x, const float* tpack, float* out, float* saved, int B, int T, void* ws,
+                                        size_t ws_bytes, void* stream);
+int rtfs_tf_attention_backward_f32(const float* tpack, const float* saved, const float* dout, float* dx, float* dparams, int B, int T,
+                                   void* ws, size_t ws_bytes, void* stream);
 /* The two GEMM forms of the training path (bf16x3 split on the matrix cores), exposed for tests:
  * kind 0: C (M,N) = A (M,K) . B (N,K)^T (accumulate != 0: C += ...), N % 64 == 0, K % 16 == 0;
  * kind 1: C (M,N) += A (K,M)^T . B (K,N), M % 64 == 0, N % 64 == 0. */

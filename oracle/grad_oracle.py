@@ -121,3 +121,40 @@ def cna_grads(x, p, cfg, dout):
     names = sorted(pt)
     grads = torch.autograd.grad(out, [xt] + [pt[k] for k in names], torch.tensor(dout, dtype=torch.float64))
     return out.detach().numpy(), grads[0].numpy(), {k: g.numpy() for k, g in zip(names, grads[1:])}
+
+
+def mhsa2d_torch(x, p, n_head=4, masks=None):
+    """rtfs_oracle.mhsa2d in torch (reference attention.py:149-189, dim 3).  x (B,C,T,F) float64; p = state_dict-named tensors.
+    masks (optional): module name -> bool tensor "pre-activation >= 0".  PReLU's derivative jumps at 0, so a pre-activation within
+    rounding error of 0 makes the gradient of the float64 oracle and of an fp32 implementation differ by O(1) on that element;
+    with the implementation's own sign pattern given, prelu(z) = where(mask, z, slope*z) is evaluated on the same linear piece
+    (the value changes by < 1e-5 * slope for the handful of elements concerned)."""
+    import math
+    import torch.nn.functional as F
+
+    def can(v, pre):  # ConvActNorm: 1x1 conv -> PReLU -> LayerNormalization4D((C, F))
+        y = F.conv2d(v, p[pre + ".conv.weight"], p[pre + ".conv.bias"])
+        y = F.prelu(y, p[pre + ".act.weight"]) if masks is None else torch.where(masks[pre], y, p[pre + ".act.weight"] * y)
+        mu = y.mean((1, 3), keepdim=True)
+        var = ((y - mu) ** 2).mean((1, 3), keepdim=True)
+        return (y - mu) / torch.sqrt(var + 1e-5) * p[pre + ".norm.gamma"] + p[pre + ".norm.beta"]
+    B, C, T, Fq = x.shape
+    outs = []
+    for h in range(n_head):
+        Q = can(x, f"Queries.{h}").permute(0, 2, 1, 3).reshape(B, T, -1)
+        K = can(x, f"Keys.{h}").permute(0, 2, 1, 3).reshape(B, T, -1)
+        V = can(x, f"Values.{h}").permute(0, 2, 1, 3)
+        vs = V.shape
+        a = torch.softmax(Q @ K.transpose(1, 2) / math.sqrt(Q.shape[-1]), 2)
+        outs.append((a @ V.reshape(B, T, -1)).reshape(vs).permute(0, 2, 1, 3))
+    return can(torch.cat(outs, 1), "attn_concat_proj") + x
+
+
+def module_grads(fn, x, p, dout):
+    """Generic: (out, dx, {name: dparam}) of sum(fn(x, p) * dout) in float64."""
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    pt = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in p.items()}
+    out = fn(xt, pt)
+    names = sorted(pt)
+    grads = torch.autograd.grad(out, [xt] + [pt[k] for k in names], torch.tensor(dout, dtype=torch.float64), allow_unused=True)
+    return out.detach().numpy(), grads[0].numpy(), {k: (None if g is None else g.numpy()) for k, g in zip(names, grads[1:])}

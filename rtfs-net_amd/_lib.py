@@ -66,6 +66,12 @@ SIGNATURES = {
     "rtfs_cna_out_shape": (None, [_p, _i, _i, _p, _p]),
     "rtfs_cna_forward_train_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p, _z, _p]),
     "rtfs_cna_backward_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _z, _p]),
+    "rtfs_tf_attention_train_pack_floats": (_z, []),
+    "rtfs_tf_attention_grad_floats": (_z, []),
+    "rtfs_tf_attention_saved_floats": (_z, [_i, _i]),
+    "rtfs_tf_attention_train_workspace_bytes": (_z, [_i, _i]),
+    "rtfs_tf_attention_forward_train_f32": (_i, [_p, _p, _p, _p, _i, _i, _p, _z, _p]),
+    "rtfs_tf_attention_backward_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _p, _z, _p]),
     "rtfs_debug_gemm_f32": (_i, [_i, _p, _p, _p, _i, _i, _i, _i, _p]),
     "rtfs_debug_sweep_stamps": (_i, [_p, _p, _p, _i, _i, _i, _p, _p]),
     "rtfs_selftest_mfma_f16": (_i, [_p, _p, _p, _p]),

@@ -1323,6 +1323,162 @@ int rtfs_cna_backward_f32(const float* params, const float* saved, const float* 
     return launch_transpose(dfirst, dx, B, H * W, c.Cin, st);
 }
 
+// ------------------------------------------------------------ MultiHeadSelfAttention2D, training side
+namespace {
+// parameter slots (floats)
+constexpr size_t AT_W = 0, AT_WT = AT_W + 128 * 64, AT_B = AT_WT + 64 * 128, AT_SL = AT_B + 128, AT_G = AT_SL + 128, AT_BE = AT_G + 128 * 64,
+                 AT_WP = AT_BE + 128 * 64, AT_WPT = AT_WP + 64 * 64, AT_BP = AT_WPT + 64 * 64, AT_SLP = AT_BP + 64, AT_GP = AT_SLP + 64,
+                 AT_BEP = AT_GP + 64 * 64, AT_END = AT_BEP + 64 * 64;
+constexpr size_t AG_W = 0, AG_B = AG_W + 128 * 64, AG_SL = AG_B + 128, AG_G = AG_SL + 64, AG_BE = AG_G + 128 * 64, AG_WP = AG_BE + 128 * 64,
+                 AG_BP = AG_WP + 64 * 64, AG_SLP = AG_BP + 64, AG_GP = AG_SLP + 64, AG_BEP = AG_GP + 64 * 64, AG_END = AG_BEP + 64 * 64;
+struct AttGeom {
+    int B, T, Tp, nb;
+    size_t R, qk, v, sc;
+    AttGeom(int B_, int T_) : B(B_), T(T_) {
+        Tp = (T + 63) / 64 * 64;
+        nb = 4 * B;
+        R = (size_t)B * T * 64;
+        qk = (size_t)nb * Tp * 256;
+        v = (size_t)nb * Tp * 1024;
+        sc = (size_t)nb * Tp * Tp;
+    }
+};
+struct AttSaved {
+    float *r0, *Z, *st, *Qp, *Kp, *Vp, *P, *ratt, *Z2, *st2;
+    size_t floats;
+    AttSaved(float* p, const AttGeom& g) {
+        float* p0 = p;
+        r0 = p; p += g.R * 64;
+        Z = p; p += g.R * 128;
+        st = p; p += (size_t)g.B * g.T * 32;
+        Qp = p; p += g.qk;
+        Kp = p; p += g.qk;
+        Vp = p; p += g.v;
+        P = p; p += g.sc;
+        ratt = p; p += g.R * 64;
+        Z2 = p; p += g.R * 64;
+        st2 = p; p += (size_t)g.B * g.T * 32;
+        floats = (size_t)(p - p0);
+    }
+};
+void att_groups(LngArgs& a, bool qkv) {
+    if (qkv) {
+        a.CZ = 128; a.ngroups = 12;
+        for (int g = 0; g < 8; ++g) a.gstart[g] = 4 * g;
+        for (int g = 8; g <= 12; ++g) a.gstart[g] = 32 + 16 * (g - 8);
+        for (int c = 0; c < 128; ++c) a.gof[c] = c < 32 ? c / 4 : (c < 96 ? 8 + (c - 32) / 16 : 255);
+    } else {
+        a.CZ = 64; a.ngroups = 1; a.gstart[0] = 0; a.gstart[1] = 64;
+        for (int c = 0; c < 64; ++c) a.gof[c] = 0;
+    }
+}
+}  // namespace
+
+size_t rtfs_tf_attention_train_pack_floats(void) { return AT_END; }
+size_t rtfs_tf_attention_grad_floats(void) { return AG_END; }
+size_t rtfs_tf_attention_saved_floats(int B, int T) { return AttSaved(nullptr, AttGeom(B, T)).floats; }
+size_t rtfs_tf_attention_train_workspace_bytes(int B, int T) {
+    AttGeom g(B, T);
+    // backward is the larger: d rows (64), dZ2/dratt (64), dY/dZ (128 x 2), dO (v), dVp (v), dP (sc), Kt (qk), dQp, dKp (qk x 2)
+    return (g.R * (64 + 64 + 64 + 128 + 128) + 2 * g.v + g.sc + 3 * g.qk) * sizeof(float) + 16 * 256;
+}
+
+int rtfs_tf_attention_forward_train_f32(const float* x, const float* tpack, float* out, float* saved, int B, int T, void* ws,
+                                        size_t ws_bytes, void* stream) {
+    RTFS_RETURN_IF(!x || !tpack || !out || !saved || B < 1 || T < 1, RTFS_ERR_ARG);
+    RTFS_RETURN_IF(T > 256 || (size_t)B * T * 64 * 128 >= 0x7fffffffu, RTFS_ERR_SHAPE);
+    RTFS_RETURN_IF(!ws || ws_bytes < rtfs_tf_attention_train_workspace_bytes(B, T), RTFS_ERR_WORKSPACE);
+    AttGeom g(B, T);
+    AttSaved sv(saved, g);
+    Arena ar(ws, ws_bytes);
+    float* Y = ar.take<float>(g.R * 128);
+    float* Vt = ar.take<float>(g.v);
+    float* Op = ar.take<float>(g.v);
+    float* rout = ar.take<float>(g.R * 64);
+    hipStream_t st = S(stream);
+    const int R = (int)g.R;
+    CHECK(launch_transpose(x, sv.r0, B, 64, T * 64, st));
+    CHECK(launch_gemm_nt(sv.r0, 64, tpack + AT_W, 64, sv.Z, 128, R, 128, 64, 0, st, tpack + AT_B));
+    LngArgs a;
+    att_groups(a, true);
+    a.Z = sv.Z; a.Y = Y; a.stats = sv.st; a.slope = tpack + AT_SL; a.gamma = tpack + AT_G; a.beta = tpack + AT_BE;
+    CHECK(launch_att_lng(a, B * T, false, st));
+    if (hipMemsetAsync(sv.Qp, 0, (2 * g.qk + g.v) * sizeof(float), st) != hipSuccess) return RTFS_ERR_LAUNCH;  // Qp, Kp, Vp are adjacent
+    CHECK(launch_att_pack_qkv(Y, sv.Qp, sv.Kp, sv.Vp, B, T, g.Tp, 0, st));
+    // scores = Q K^T / sqrt(E * F) (attention.py:169-172), softmax over keys
+    CHECK(launch_gemm_nt(sv.Qp, 256, sv.Kp, 256, sv.P, g.Tp, T, g.Tp, 256, 0, st, nullptr, g.nb, (size_t)g.Tp * 256, (size_t)g.Tp * 256,
+                         (size_t)g.Tp * g.Tp));
+    CHECK(launch_att_softmax(sv.P, nullptr, g.nb, T, g.Tp, 1.0f / 16.0f, false, st));
+    CHECK(launch_transpose(sv.Vp, Vt, g.nb, g.Tp, 1024, st));
+    CHECK(launch_gemm_nt(sv.P, g.Tp, Vt, g.Tp, Op, 1024, T, 1024, g.Tp, 0, st, nullptr, g.nb, (size_t)g.Tp * g.Tp, (size_t)1024 * g.Tp,
+                         (size_t)g.Tp * 1024));
+    CHECK(launch_att_pack_o(sv.ratt, Op, B, T, g.Tp, 0, st));
+    CHECK(launch_gemm_nt(sv.ratt, 64, tpack + AT_WP, 64, sv.Z2, 64, R, 64, 64, 0, st, tpack + AT_BP));
+    LngArgs b;
+    att_groups(b, false);
+    b.Z = sv.Z2; b.Y = rout; b.res = sv.r0; b.stats = sv.st2; b.slope = tpack + AT_SLP; b.gamma = tpack + AT_GP; b.beta = tpack + AT_BEP;
+    CHECK(launch_att_lng(b, B * T, false, st));
+    return launch_transpose(rout, out, B, T * 64, 64, st);
+}
+
+int rtfs_tf_attention_backward_f32(const float* tpack, const float* saved, const float* dout, float* dx, float* dparams, int B, int T,
+                                   void* ws, size_t ws_bytes, void* stream) {
+    RTFS_RETURN_IF(!tpack || !saved || !dout || !dx || !dparams || B < 1 || T < 1, RTFS_ERR_ARG);
+    RTFS_RETURN_IF(T > 256 || (size_t)B * T * 64 * 128 >= 0x7fffffffu, RTFS_ERR_SHAPE);
+    RTFS_RETURN_IF(!ws || ws_bytes < rtfs_tf_attention_train_workspace_bytes(B, T), RTFS_ERR_WORKSPACE);
+    AttGeom g(B, T);
+    AttSaved sv(const_cast<float*>(saved), g);
+    Arena ar(ws, ws_bytes);
+    float* drow = ar.take<float>(g.R * 64);   // d(out rows), becomes d r0
+    float* dZ2 = ar.take<float>(g.R * 64);
+    float* dratt = ar.take<float>(g.R * 64);
+    float* dY = ar.take<float>(g.R * 128);
+    float* dZ = ar.take<float>(g.R * 128);
+    float* dO = ar.take<float>(g.v);
+    float* dVp = ar.take<float>(g.v);
+    float* dP = ar.take<float>(g.sc);
+    float* Kt = ar.take<float>(g.qk);
+    float* dQp = ar.take<float>(g.qk);
+    float* dKp = ar.take<float>(g.qk);
+    RTFS_RETURN_IF(!ar.ok(), RTFS_ERR_WORKSPACE);
+    hipStream_t st = S(stream);
+    const int R = (int)g.R;
+    const size_t sQ = (size_t)g.Tp * 256, sV = (size_t)g.Tp * 1024, sS = (size_t)g.Tp * g.Tp;
+    if (hipMemsetAsync(dparams, 0, AG_END * sizeof(float), st) != hipSuccess) return RTFS_ERR_LAUNCH;
+    CHECK(launch_transpose(dout, drow, B, 64, T * 64, st));
+    // concat projection ConvActNorm: LNG, then the 1x1 convolution
+    LngArgs b;
+    att_groups(b, false);
+    b.Z = sv.Z2; b.stats = sv.st2; b.slope = tpack + AT_SLP; b.gamma = tpack + AT_GP; b.beta = tpack + AT_BEP; b.dY = drow; b.dZ = dZ2;
+    b.dgamma = dparams + AG_GP; b.dbeta = dparams + AG_BEP; b.dslope = dparams + AG_SLP;
+    CHECK(launch_att_lng(b, B * T, true, st));
+    CHECK(launch_cl_colsum(dZ2, dparams + AG_BP, g.R * 64, 64, st));
+    CHECK(launch_gemm_tn(dZ2, 64, sv.ratt, 64, dparams + AG_WP, 64, 64, 64, (long)R, st));
+    CHECK(launch_gemm_nt(dZ2, 64, tpack + AT_WPT, 64, dratt, 64, R, 64, 64, 0, st));
+    // attention core
+    // the split-K GEMMs accumulate into their outputs; padding rows (t >= T) of dO / dQp are never read
+    if (hipMemsetAsync(dVp, 0, g.v * sizeof(float), st) != hipSuccess) return RTFS_ERR_LAUNCH;
+    if (hipMemsetAsync(dKp, 0, g.qk * sizeof(float), st) != hipSuccess) return RTFS_ERR_LAUNCH;
+    CHECK(launch_att_pack_o(dratt, dO, B, T, g.Tp, 1, st));
+    CHECK(launch_gemm_nt(dO, 1024, sv.Vp, 1024, dP, g.Tp, T, g.Tp, 1024, 0, st, nullptr, g.nb, sV, sV, sS));       // dP = dO V^T
+    CHECK(launch_gemm_tn(sv.P, g.Tp, dO, 1024, dVp, 1024, g.Tp, 1024, (long)T, st, g.nb, sS, sV, sV));              // dV = P^T dO
+    CHECK(launch_att_softmax(dP, sv.P, g.nb, T, g.Tp, 1.0f / 16.0f, true, st));                                    // dP -> dS
+    CHECK(launch_transpose(sv.Kp, Kt, g.nb, g.Tp, 256, st));
+    CHECK(launch_gemm_nt(dP, g.Tp, Kt, g.Tp, dQp, 256, T, 256, g.Tp, 0, st, nullptr, g.nb, sS, sQ, sQ));            // dQ = dS K
+    CHECK(launch_gemm_tn(dP, g.Tp, sv.Qp, 256, dKp, 256, g.Tp, 256, (long)T, st, g.nb, sS, sQ, sQ));                // dK = dS^T Q
+    CHECK(launch_att_pack_qkv(dY, dQp, dKp, dVp, B, T, g.Tp, 1, st));
+    // the twelve Q/K/V ConvActNorms
+    LngArgs a;
+    att_groups(a, true);
+    a.Z = sv.Z; a.stats = sv.st; a.slope = tpack + AT_SL; a.gamma = tpack + AT_G; a.beta = tpack + AT_BE; a.dY = dY; a.dZ = dZ;
+    a.dgamma = dparams + AG_G; a.dbeta = dparams + AG_BE; a.dslope = dparams + AG_SL;
+    CHECK(launch_att_lng(a, B * T, true, st));
+    CHECK(launch_cl_colsum(dZ, dparams + AG_B, g.R * 128, 128, st));
+    CHECK(launch_gemm_tn(dZ, 128, sv.r0, 64, dparams + AG_W, 64, 128, 64, (long)R, st));
+    CHECK(launch_gemm_nt(dZ, 128, tpack + AT_WT, 128, drow, 64, R, 64, 128, 1, st));  // + the residual's gradient already in drow
+    return launch_transpose(drow, dx, B, T * 64, 64, st);
+}
+
 // C = A . Bt^T (kind 0; accumulate adds to C) or C += A^T . B (kind 1): the two GEMM forms of the training path, exposed for tests
 int rtfs_debug_gemm_f32(int kind, const float* A, const float* B, float* C, int M, int N, int K, int accumulate, void* stream) {
     RTFS_RETURN_IF(!A || !B || !C, RTFS_ERR_ARG);

@@ -46,6 +46,9 @@ __device__ __forceinline__ void mfma3(f32x16& acc, const Frag& a, const Frag& b)
 // (C[(row + j) * ldc + col % 64] += ..., atomics: the adjoint of the unfold windows, see the dual-path backward).
 template <int MODE>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
+    g.A += (size_t)blockIdx.y * g.sA;
+    g.B += (size_t)blockIdx.y * g.sB;
+    g.C += (size_t)blockIdx.y * g.sC;
     const int id = blockIdx.x;
     const int rowblk = (id / (8 * g.ncb)) * 8 + (id & 7), colblk = (id >> 3) % g.ncb;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
@@ -125,6 +128,9 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
 // A (K, M), B (K, N), both with K as the slow axis; C (M, N) must hold the running sum (zeroed by the caller).
 // M % 64 == 0, N % 64 == 0, any K.  One wave = one 64 x 64 tile of C over one K chunk; f32 atomics merge the chunks.
 __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmArgs g) {
+    g.A += (size_t)blockIdx.y * g.sA;
+    g.B += (size_t)blockIdx.y * g.sB;
+    g.C += (size_t)blockIdx.y * g.sC;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
     const int tiles_n = g.N >> 6, tiles = (g.M >> 6) * tiles_n;
     const long gw = (long)blockIdx.x * 4 + wave;
@@ -178,24 +184,27 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmArgs g) {
 }
 
 int launch_gemm_nt(const float* A, int lda, const float* Bt, int ldb, float* C, int ldc, int M, int N, int K, int mode,
-                   hipStream_t st, const float* bias) {
+                   hipStream_t st, const float* bias, int batch, size_t sA, size_t sB, size_t sC) {
     if (M < 1 || N < 64 || (N & 63) || K < 16 || (K & 15) || (lda & 3) || (ldb & 3)) return RTFS_ERR_SHAPE;
     GemmArgs g;
     g.A = A; g.B = Bt; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.bias = bias;
+    g.sA = sA; g.sB = sB; g.sC = sC;
     g.ncb = N >> 6;
     g.nrb = cdiv(M, 256);
     const long grid = (long)cdiv(g.nrb, 8) * 8 * g.ncb;
     if (grid > 0x7fffffffL) return RTFS_ERR_SHAPE;
-    if (mode == 2) hipLaunchKernelGGL(gemm_nt_kernel<2>, dim3((unsigned)grid), dim3(256), 0, st, g);
-    else if (mode == 1) hipLaunchKernelGGL(gemm_nt_kernel<1>, dim3((unsigned)grid), dim3(256), 0, st, g);
-    else hipLaunchKernelGGL(gemm_nt_kernel<0>, dim3((unsigned)grid), dim3(256), 0, st, g);
+    if (mode == 2) hipLaunchKernelGGL(gemm_nt_kernel<2>, dim3((unsigned)grid, batch), dim3(256), 0, st, g);
+    else if (mode == 1) hipLaunchKernelGGL(gemm_nt_kernel<1>, dim3((unsigned)grid, batch), dim3(256), 0, st, g);
+    else hipLaunchKernelGGL(gemm_nt_kernel<0>, dim3((unsigned)grid, batch), dim3(256), 0, st, g);
     return rtfs_launch_status();
 }
 
-int launch_gemm_tn(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, long K, hipStream_t st) {
+int launch_gemm_tn(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, long K, hipStream_t st, int batch,
+                   size_t sA, size_t sB, size_t sC) {
     if (M < 64 || (M & 63) || N < 64 || (N & 63) || K < 1 || K > 0x7fffffffL) return RTFS_ERR_SHAPE;
     GemmArgs g;
     g.A = A; g.B = B; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.M = M; g.N = N; g.K = (int)K;
+    g.sA = sA; g.sB = sB; g.sC = sC;
     const int tiles = (M >> 6) * (N >> 6);
     // enough waves to fill the chip several times over, chunks of at least 256 k
     long splits = cdiv(8192, tiles);
@@ -204,7 +213,7 @@ int launch_gemm_tn(const float* A, int lda, const float* B, int ldb, float* C, i
     splits = (K + kchunk - 1) / kchunk;
     g.kchunk = (int)kchunk;
     const long waves = splits * tiles;
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, g);
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)((waves + 3) / 4), batch), dim3(256), 0, st, g);
     return rtfs_launch_status();
 }
 
@@ -742,5 +751,216 @@ int launch_cl_dw(const ClDwArgs& a, int what, hipStream_t st) {
     if (what == 0) hipLaunchKernelGGL(cl_dw_fwd_kernel, dim3(grid_for((size_t)a.B * a.Ho * a.Wo * a.C)), dim3(256), 0, st, a);
     else if (what == 1) hipLaunchKernelGGL(cl_dw_bwd_data_kernel, dim3(grid_for((size_t)a.B * a.H * a.W * a.C)), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(cl_dw_wgrad_kernel, dim3(grid_for((size_t)a.B * a.Ho * a.Wo * a.C / 8, 2048)), dim3(256), 0, st, a);
+    return rtfs_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------ TF attention, training side
+// MultiHeadSelfAttention2D (attention.py:149-189) on channel-last rows (b, t, f) x CZ.  "LNG" = the tail of a ConvActNorm
+// (conv_layers.py:201-205): PReLU, then LayerNormalization4D((C_out, F)) = statistics over (channels of the module, F) per (b, t)
+// with a (C_out, F) affine (normalizations.py:26,33-37).  The twelve Q/K/V modules are evaluated side by side: their channels are
+// stacked (CZ = 128, 96 used) and each module is one "group".
+__global__ __launch_bounds__(256) void att_lng_fwd_kernel(LngArgs a) {
+    extern __shared__ float tile[];  // [64 f][CZ + 1]
+    __shared__ float gm[16], gr[16];
+    const int bt = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, CZ = a.CZ, P = CZ + 1;
+    const float* z = a.Z + (size_t)bt * 64 * CZ;
+    for (int idx = tid; idx < 64 * CZ; idx += 256) {
+        const int f = idx / CZ, c = idx - f * CZ;
+        const float v = z[idx];
+        tile[f * P + c] = v >= 0.f ? v : a.slope[c] * v;
+    }
+    __syncthreads();
+    for (int g = wave; g < a.ngroups; g += 4) {
+        const int c0 = a.gstart[g], gs = a.gstart[g + 1] - c0, n = 64 * gs;
+        float s = 0.f;
+        for (int i = lane; i < n; i += 64) s += tile[(i / gs) * P + c0 + i % gs];
+        const float mean = wave_sum(s) / n;
+        float v = 0.f;
+        for (int i = lane; i < n; i += 64) {
+            const float d = tile[(i / gs) * P + c0 + i % gs] - mean;
+            v = fmaf(d, d, v);
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(v) / n + RTFS_EPS);
+        if (lane == 0) {
+            gm[g] = mean;
+            gr[g] = rstd;
+            a.stats[((size_t)bt * 16 + g) * 2] = mean;
+            a.stats[((size_t)bt * 16 + g) * 2 + 1] = rstd;
+        }
+    }
+    __syncthreads();
+    float* y = a.Y + (size_t)bt * 64 * CZ;
+    for (int idx = tid; idx < 64 * CZ; idx += 256) {
+        const int f = idx / CZ, c = idx - f * CZ, g = a.gof[c];
+        float v = 0.f;
+        if (g < 16) v = fmaf((tile[f * P + c] - gm[g]) * gr[g], a.gamma[c * 64 + f], a.beta[c * 64 + f]);
+        if (a.res) v += a.res[(size_t)bt * 64 * CZ + idx];
+        y[idx] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void att_lng_bwd_kernel(LngArgs a) {
+    extern __shared__ float lds[];  // A [64][CZ+1] (activated input, later xhat), D [64][CZ+1] (gamma * dY)
+    __shared__ float g1[16], g2[16], gsl[16];
+    const int bt = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, CZ = a.CZ, P = CZ + 1;
+    float* A = lds;
+    float* D = lds + 64 * P;
+    const float* z = a.Z + (size_t)bt * 64 * CZ;
+    const float* dy = a.dY + (size_t)bt * 64 * CZ;
+    if (tid < 16) gsl[tid] = 0.f;
+    for (int idx = tid; idx < 64 * CZ; idx += 256) {
+        const int f = idx / CZ, c = idx - f * CZ, g = a.gof[c];
+        const float v = z[idx];
+        const float act = v >= 0.f ? v : a.slope[c] * v;
+        float xh = 0.f, gd = 0.f;
+        if (g < 16) {
+            xh = (act - a.stats[((size_t)bt * 16 + g) * 2]) * a.stats[((size_t)bt * 16 + g) * 2 + 1];
+            const float d = dy[idx];
+            gd = a.gamma[c * 64 + f] * d;
+            unsafeAtomicAdd(a.dgamma + c * 64 + f, d * xh);
+            unsafeAtomicAdd(a.dbeta + c * 64 + f, d);
+        }
+        A[f * P + c] = xh;
+        D[f * P + c] = gd;
+    }
+    __syncthreads();
+    for (int g = wave; g < a.ngroups; g += 4) {
+        const int c0 = a.gstart[g], gs = a.gstart[g + 1] - c0, n = 64 * gs;
+        float s1 = 0.f, s2 = 0.f;
+        for (int i = lane; i < n; i += 64) {
+            const int o = (i / gs) * P + c0 + i % gs;
+            s1 += D[o];
+            s2 = fmaf(D[o], A[o], s2);
+        }
+        s1 = wave_sum(s1) / n;
+        s2 = wave_sum(s2) / n;
+        if (lane == 0) {
+            g1[g] = s1;
+            g2[g] = s2;
+        }
+    }
+    __syncthreads();
+    float* dz = a.dZ + (size_t)bt * 64 * CZ;
+    float dsl = 0.f;  // per-thread PReLU slope gradient, per group handled below through LDS atomics
+    for (int idx = tid; idx < 64 * CZ; idx += 256) {
+        const int f = idx / CZ, c = idx - f * CZ, g = a.gof[c];
+        float out = 0.f;
+        if (g < 16) {
+            const float rstd = a.stats[((size_t)bt * 16 + g) * 2 + 1];
+            const float dA = rstd * (D[f * P + c] - g1[g] - A[f * P + c] * g2[g]);
+            const float v = z[idx];
+            if (v >= 0.f) out = dA;
+            else {
+                out = dA * a.slope[c];
+                atomicAdd(&gsl[g], dA * v);
+            }
+        }
+        dz[idx] = out;
+    }
+    (void)dsl;
+    __syncthreads();
+    if (tid < a.ngroups && gsl[tid] != 0.f) unsafeAtomicAdd(a.dslope + tid, gsl[tid]);
+}
+
+// Y rows (b,t,f) x 128 <-> Qp, Kp (4B, Tp, 256 = f*4 + e), Vp (4B, Tp, 1024 = f*16 + c); head-major batch index h*B + b
+// (attention.py:160-168).  dir 0: rows -> packed, 1: packed -> rows (channels 96..127 of the rows get zero).
+__global__ __launch_bounds__(256) void att_pack_qkv_kernel(float* __restrict__ rows, float* __restrict__ Qp, float* __restrict__ Kp,
+                                                           float* __restrict__ Vp, int B, int T, int Tp, int dir) {
+    const size_t total = (size_t)B * T * 64 * 128;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i & 127);
+        const size_t r = i >> 7;
+        const int f = (int)(r & 63);
+        const size_t bt = r >> 6;
+        const int t = (int)(bt % T), b = (int)(bt / T);
+        float* p;
+        if (c < 16) p = Qp + (((size_t)(c >> 2) * B + b) * Tp + t) * 256 + f * 4 + (c & 3);
+        else if (c < 32) p = Kp + (((size_t)((c - 16) >> 2) * B + b) * Tp + t) * 256 + f * 4 + (c & 3);
+        else if (c < 96) p = Vp + (((size_t)((c - 32) >> 4) * B + b) * Tp + t) * 1024 + f * 16 + (c & 15);
+        else p = nullptr;
+        if (dir == 0) {
+            if (p) *p = rows[i];
+        } else {
+            rows[i] = p ? *p : 0.f;
+        }
+    }
+}
+// O (4B, Tp, 1024 = f*16 + c) <-> rows (b,t,f) x 64 with channel h*16 + c (attention.py:178-181)
+__global__ __launch_bounds__(256) void att_pack_o_kernel(float* __restrict__ rows, float* __restrict__ Op, int B, int T, int Tp, int dir) {
+    const size_t total = (size_t)B * T * 64 * 64;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i & 63);
+        const size_t r = i >> 6;
+        const int f = (int)(r & 63);
+        const size_t bt = r >> 6;
+        const int t = (int)(bt % T), b = (int)(bt / T);
+        float* p = Op + (((size_t)(c >> 4) * B + b) * Tp + t) * 1024 + f * 16 + (c & 15);
+        if (dir == 0) rows[i] = *p;
+        else *p = rows[i];
+    }
+}
+
+// one wave per score row: P = softmax(scale * S[:T]) (zeros in the padding columns);  backward in place on dP:
+// dS = scale * P * (dP - sum(P * dP))
+__global__ __launch_bounds__(256) void att_softmax_kernel(float* __restrict__ S, const float* __restrict__ Pm, size_t nrows_total, int T,
+                                                          int Tp, float scale, int bwd) {
+    const int lane = threadIdx.x & 63;
+    const size_t rid = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (rid >= nrows_total) return;
+    // rows are stored (batch, Tp rows, Tp columns) but only the first T rows of a batch are scores
+    const size_t batch = rid / T, row = rid % T;
+    float* s = S + (batch * Tp + row) * Tp;
+    if (!bwd) {
+        float v[4], m = -INFINITY;
+        for (int i = 0; i < 4; ++i) {
+            const int k = lane + 64 * i;
+            v[i] = k < T ? scale * s[k] : -INFINITY;
+            m = fmaxf(m, v[i]);
+        }
+        m = wave_max(m);
+        float sum = 0.f;
+        for (int i = 0; i < 4; ++i) {
+            v[i] = (lane + 64 * i) < T ? __expf(v[i] - m) : 0.f;
+            sum += v[i];
+        }
+        const float inv = 1.0f / wave_sum(sum);
+        for (int i = 0; i < 4; ++i)
+            if (lane + 64 * i < Tp) s[lane + 64 * i] = v[i] * inv;
+    } else {
+        const float* pm = Pm + (batch * Tp + row) * Tp;
+        float pv[4], dv[4], dot = 0.f;
+        for (int i = 0; i < 4; ++i) {
+            const int k = lane + 64 * i;
+            pv[i] = k < T ? pm[k] : 0.f;
+            dv[i] = k < T ? s[k] : 0.f;
+            dot = fmaf(pv[i], dv[i], dot);
+        }
+        dot = wave_sum(dot);
+        for (int i = 0; i < 4; ++i)
+            if (lane + 64 * i < Tp) s[lane + 64 * i] = scale * pv[i] * (dv[i] - dot);
+    }
+}
+
+int launch_att_lng(const LngArgs& a, int nbt, bool bwd, hipStream_t st) {
+    if (a.CZ != 64 && a.CZ != 128) return RTFS_ERR_SHAPE;
+    const size_t lds = (size_t)(bwd ? 2 : 1) * 64 * (a.CZ + 1) * sizeof(float);
+    int rc = bwd ? set_lds(att_lng_bwd_kernel, lds) : set_lds(att_lng_fwd_kernel, lds);
+    if (rc) return rc;
+    if (bwd) hipLaunchKernelGGL(att_lng_bwd_kernel, dim3(nbt), dim3(256), lds, st, a);
+    else hipLaunchKernelGGL(att_lng_fwd_kernel, dim3(nbt), dim3(256), lds, st, a);
+    return rtfs_launch_status();
+}
+int launch_att_pack_qkv(float* rows, float* Qp, float* Kp, float* Vp, int B, int T, int Tp, int dir, hipStream_t st) {
+    hipLaunchKernelGGL(att_pack_qkv_kernel, dim3(grid_for((size_t)B * T * 64 * 128)), dim3(256), 0, st, rows, Qp, Kp, Vp, B, T, Tp, dir);
+    return rtfs_launch_status();
+}
+int launch_att_pack_o(float* rows, float* Op, int B, int T, int Tp, int dir, hipStream_t st) {
+    hipLaunchKernelGGL(att_pack_o_kernel, dim3(grid_for((size_t)B * T * 64 * 64)), dim3(256), 0, st, rows, Op, B, T, Tp, dir);
+    return rtfs_launch_status();
+}
+int launch_att_softmax(float* S, const float* P, int nbatch, int T, int Tp, float scale, bool bwd, hipStream_t st) {
+    if (T < 1 || Tp > 256) return RTFS_ERR_SHAPE;
+    const size_t rows = (size_t)nbatch * T;
+    hipLaunchKernelGGL(att_softmax_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, S, P, rows, T, Tp, scale, bwd ? 1 : 0);
     return rtfs_launch_status();
 }

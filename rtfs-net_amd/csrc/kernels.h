@@ -232,13 +232,15 @@ struct GemmArgs {
     int ncb = 0, nrb = 0;  // NT: column / row blocks
     int kchunk = 0;        // TN: k range of one wave
     const float* bias = nullptr;  // NT modes 0/1: added per column
+    size_t sA = 0, sB = 0, sC = 0;  // batch strides (blockIdx.y)
 };
 // C (M,N) [+]= A (M,K) . Bt (N,K)^T  (both K-contiguous; N % 64 == 0, K % 16 == 0)
 // mode 0: C = ; 1: C += ; 2: C (rows x 64) [(row + colblk) * ldc + col % 64] += (atomics; the fold of unfold windows)
 int launch_gemm_nt(const float* A, int lda, const float* Bt, int ldb, float* C, int ldc, int M, int N, int K, int mode,
-                   hipStream_t st, const float* bias = nullptr);
+                   hipStream_t st, const float* bias = nullptr, int batch = 1, size_t sA = 0, size_t sB = 0, size_t sC = 0);
 // C (M,N) += A (K,M)^T . B (K,N)  (split-K with f32 atomics; M, N % 64 == 0)
-int launch_gemm_tn(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, long K, hipStream_t st);
+int launch_gemm_tn(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, long K, hipStream_t st, int batch = 1,
+                   size_t sA = 0, size_t sB = 0, size_t sC = 0);
 struct SruScanArgs {
     const float* U = nullptr;    // (L, N, KC), column m*64 + dir*32 + j
     const float* xin = nullptr;  // (L, N, 64) highway input of layers 1-3; nullptr: U's m = 3 block (layer 0)
@@ -285,3 +287,21 @@ int launch_cl_norm_act_fwd(const ClStageArgs& a, int B, hipStream_t st);
 int launch_cl_norm_act_bwd(const ClStageArgs& a, int B, hipStream_t st);
 int launch_cl_colsum(const float* d, float* out, size_t n, int C, hipStream_t st);
 int launch_cl_dw(const ClDwArgs& a, int what /* 0 fwd, 1 bwd data, 2 wgrad */, hipStream_t st);
+// TF attention training kernels (k_train.hip)
+struct LngArgs {  // PReLU + LayerNormalization4D((C_group, 64)) over rows (b,t,f) x CZ
+    const float* Z = nullptr;      // pre-activation rows
+    float* Y = nullptr;            // forward output rows
+    const float* res = nullptr;    // forward: optional residual rows added to Y (same shape)
+    float* stats = nullptr;        // (B*T, 16, 2) mean, rstd per group (written forward, read backward)
+    const float *slope = nullptr, *gamma = nullptr, *beta = nullptr;  // (CZ), (CZ,64), (CZ,64)
+    const float* dY = nullptr;     // backward
+    float* dZ = nullptr;
+    float *dgamma = nullptr, *dbeta = nullptr, *dslope = nullptr;      // (CZ,64), (CZ,64), (ngroups)
+    int CZ = 0, ngroups = 0;
+    int gstart[17] = {0};
+    unsigned char gof[128] = {0};  // channel -> group, 255 = padding channel
+};
+int launch_att_lng(const LngArgs& a, int nbt, bool bwd, hipStream_t st);
+int launch_att_pack_qkv(float* rows, float* Qp, float* Kp, float* Vp, int B, int T, int Tp, int dir, hipStream_t st);
+int launch_att_pack_o(float* rows, float* Op, int B, int T, int Tp, int dir, hipStream_t st);
+int launch_att_softmax(float* S, const float* P, int nbatch, int T, int Tp, float scale, bool bwd, hipStream_t st);

@@ -444,6 +444,39 @@ class DualPathRNN(PackedModule):
 
 
 # ----------------------------------------------------------------------------- TF self-attention
+class _AttentionTrainFn(torch.autograd.Function):
+    """MultiHeadSelfAttention2D forward/backward on the training kernels.  Inputs: x, names (tuple), then the parameters in that order."""
+
+    @staticmethod
+    def forward(ctx, x, names, *params):
+        lib = _lib.load()
+        x = x.contiguous()
+        B, _, T, _ = x.shape
+        tpack = packing.pack_attention_train(dict(zip(names, params)))
+        out = torch.empty_like(x)
+        saved = torch.empty(lib.rtfs_tf_attention_saved_floats(B, T), device=x.device, dtype=torch.float32)
+        ws = _lib.workspace(lib.rtfs_tf_attention_train_workspace_bytes(B, T), x.device)
+        _lib.check(lib.rtfs_tf_attention_forward_train_f32(_lib.ptr(x), _lib.ptr(tpack), _lib.ptr(out), _lib.ptr(saved), B, T, _lib.ptr(ws),
+                                                           ws.numel(), _lib.stream_of(x)), "rtfs_tf_attention_forward_train_f32")
+        ctx.save_for_backward(tpack, saved)
+        ctx.names, ctx.geom = names, (B, T)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        tpack, saved = ctx.saved_tensors
+        B, T = ctx.geom
+        dout = dout.contiguous().to(torch.float32)
+        dx = torch.empty_like(dout)
+        dpar = torch.empty(lib.rtfs_tf_attention_grad_floats(), device=dout.device, dtype=torch.float32)
+        ws = _lib.workspace(lib.rtfs_tf_attention_train_workspace_bytes(B, T), dout.device)
+        _lib.check(lib.rtfs_tf_attention_backward_f32(_lib.ptr(tpack), _lib.ptr(saved), _lib.ptr(dout), _lib.ptr(dx), _lib.ptr(dpar), B, T,
+                                                      _lib.ptr(ws), ws.numel(), _lib.stream_of(dout)), "rtfs_tf_attention_backward_f32")
+        g = packing.unpack_attention_grads(dpar)
+        return (dx, None) + tuple(g[n] for n in ctx.names)
+
+
 class MultiHeadSelfAttention2D(PackedModule):
     """reference attention.py:76-189 (4 heads, hid_chan 4, n_freqs 64, dim 3)."""
 
@@ -463,12 +496,15 @@ class MultiHeadSelfAttention2D(PackedModule):
         self.attn_concat_proj = mk(in_chan)
 
     def forward(self, x):
-        self._guard(x)
+        _lib.need_gpu(x)
         lib = _lib.load()
         x = x.contiguous()
         B, C, T, Fq = x.shape
         if C != 64 or Fq != 64:
             raise ValueError("expected (B, 64, T, 64)")
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            names, params = zip(*self.named_parameters())
+            return _AttentionTrainFn.apply(x, names, *params)
         out = torch.empty_like(x)
         ws = _lib.workspace(lib.rtfs_tf_attention_workspace_bytes(B, T), x.device)
         _lib.check(lib.rtfs_tf_attention_f32(_lib.ptr(x), _lib.ptr(self.pack()), _lib.ptr(out), B, T, _lib.ptr(ws), ws.numel(),

@@ -161,6 +161,53 @@ def unpack_cna_grads(cfg, flat, w_shape):
     return out
 
 
+_ATT_MODULES = [f"Queries.{h}" for h in range(4)] + [f"Keys.{h}" for h in range(4)] + [f"Values.{h}" for h in range(4)]
+
+
+def pack_attention_train(sd):
+    """Training-side pack of MultiHeadSelfAttention2D (layout contract: include/rtfs_amd.h, rtfs_tf_attention_forward_train_f32).
+    sd: name -> tensor with the module's state_dict names (live parameters are fine)."""
+    f32 = lambda t: t.detach().to(torch.float32)
+    w = torch.cat([f32(sd[m + ".conv.weight"]).reshape(-1, 64) for m in _ATT_MODULES])
+    dev = w.device
+    w = torch.cat([w, torch.zeros(32, 64, device=dev)])
+    b = torch.cat([f32(sd[m + ".conv.bias"]) for m in _ATT_MODULES] + [torch.zeros(32, device=dev)])
+    sl = torch.cat([f32(sd[m + ".act.weight"]).expand(sd[m + ".conv.bias"].numel()) for m in _ATT_MODULES] + [torch.zeros(32, device=dev)])
+    ga = torch.cat([f32(sd[m + ".norm.gamma"]).reshape(-1, 64) for m in _ATT_MODULES] + [torch.zeros(32, 64, device=dev)])
+    be = torch.cat([f32(sd[m + ".norm.beta"]).reshape(-1, 64) for m in _ATT_MODULES] + [torch.zeros(32, 64, device=dev)])
+    p = "attn_concat_proj"
+    wp = f32(sd[p + ".conv.weight"]).reshape(64, 64)
+    return _cat([w, w.t().contiguous(), b, sl, ga, be, wp, wp.t().contiguous(), f32(sd[p + ".conv.bias"]), f32(sd[p + ".act.weight"]).expand(64),
+                 f32(sd[p + ".norm.gamma"]).reshape(64, 64), f32(sd[p + ".norm.beta"]).reshape(64, 64)])
+
+
+def unpack_attention_grads(flat):
+    """rtfs_tf_attention_backward_f32's gradient buffer -> dict name -> gradient in the module's parameter shapes."""
+    o = 0
+    take = lambda n: flat[o:o + n]
+    dw = flat[0:128 * 64].reshape(128, 64); o = 128 * 64
+    db = flat[o:o + 128]; o += 128
+    dsl = flat[o:o + 64]; o += 64
+    dg = flat[o:o + 128 * 64].reshape(128, 64); o += 128 * 64
+    dbe = flat[o:o + 128 * 64].reshape(128, 64); o += 128 * 64
+    out, c0 = {}, 0
+    for i, m in enumerate(_ATT_MODULES):
+        c = 4 if i < 8 else 16
+        out[m + ".conv.weight"] = dw[c0:c0 + c].reshape(c, 64, 1, 1)
+        out[m + ".conv.bias"] = db[c0:c0 + c]
+        out[m + ".act.weight"] = dsl[i:i + 1]
+        out[m + ".norm.gamma"] = dg[c0:c0 + c].reshape(1, c, 1, 64)
+        out[m + ".norm.beta"] = dbe[c0:c0 + c].reshape(1, c, 1, 64)
+        c0 += c
+    p = "attn_concat_proj"
+    out[p + ".conv.weight"] = flat[o:o + 4096].reshape(64, 64, 1, 1); o += 4096
+    out[p + ".conv.bias"] = flat[o:o + 64]; o += 64
+    out[p + ".act.weight"] = flat[o:o + 1]; o += 64
+    out[p + ".norm.gamma"] = flat[o:o + 4096].reshape(1, 64, 1, 64); o += 4096
+    out[p + ".norm.beta"] = flat[o:o + 4096].reshape(1, 64, 1, 64)
+    return out
+
+
 def _dualpath_lstm_parts(sd):
     """DualPathRNN with rnn_type LSTM (nn.LSTM(512, 32, 4 layers, bidirectional)).  Columns of the input projections:
     dir*128 + gate*32 + j (gates i,f,g,o); bias = b_ih + b_hh; recurrent weights as [layer][dir][k][gate*32 + j]."""

@@ -285,6 +285,63 @@ def test_conv_norm_act_training_forward_backward(name):
         close(f"{name} d {k}", host(got[k]), g_ref[k], tol=2e-4)
 
 
+@pytest.mark.parametrize("shape,seed", [((2, 64, 12, 64), 41), ((1, 64, 125, 64), 42), ((3, 64, 1, 64), 43), ((1, 64, 70, 64), 44)])
+def test_mhsa2d_training_forward_backward(shape, seed):
+    """MultiHeadSelfAttention2D used from a training step: forward + every gradient (12 Q/K/V ConvActNorms, softmax attention,
+    concat projection, residual) against the autograd oracle."""
+    import rtfs_net_amd as R
+    from oracle import grad_oracle as G
+    p = {k: v.copy() for k, v in O._sub(BLK, "globalatt.2").items()}
+    rng = np.random.default_rng(seed)
+    for k in p:  # away from the init values so every gradient path is exercised
+        if "norm" in k or "act" in k or "bias" in k:
+            p[k] = (p[k] + 0.3 * rng.standard_normal(p[k].shape)).astype(np.float32)
+    mod = R.layers.MultiHeadSelfAttention2D(64, 64, n_head=4, hid_chan=4)
+    mod.load_state_dict({k: torch.from_numpy(v) for k, v in p.items()})
+    mod = mod.cuda().train()
+    x = rand(shape, seed)
+    dout = rand(shape, seed + 100)
+    xt = dev(x).requires_grad_(True)
+    out = mod(xt)
+    sv = out.grad_fn.saved_tensors[1].clone()
+    out.backward(dev(dout))
+    # the implementation's PReLU sign pattern (see grad_oracle.mhsa2d_torch): pre-activations sit in the saved-state buffer as
+    # r0 (R,64) | Z (R,128: Q h0-3, K h0-3 (4 ch each), V h0-3 (16 each), 32 pad) | stats | Qp Kp Vp | P | r_att (R,64) | Z2 (R,64)
+    B, _, T, _ = shape
+    Rr, Tp = B * T * 64, (T + 63) // 64 * 64
+    Z = host(sv[Rr * 64:Rr * 192]).reshape(B, T, 64, 128).transpose(0, 3, 1, 2)  # (B, ch, T, F)
+    off2 = Rr * 192 + B * T * 32 + 4 * B * Tp * (256 + 256 + 1024) + 4 * B * Tp * Tp + Rr * 64
+    Z2 = host(sv[off2:off2 + Rr * 64]).reshape(B, T, 64, 64).transpose(0, 3, 1, 2)
+    masks, c0 = {}, 0
+    for i, m in enumerate([f"Queries.{h}" for h in range(4)] + [f"Keys.{h}" for h in range(4)] + [f"Values.{h}" for h in range(4)]):
+        c = 4 if i < 8 else 16
+        masks[m] = torch.from_numpy(Z[:, c0:c0 + c] >= 0)
+        c0 += c
+    masks["attn_concat_proj"] = torch.from_numpy(Z2 >= 0)
+    o_ref, dx_ref, g_ref = G.module_grads(lambda a, b: G.mhsa2d_torch(a, b, masks=masks), x, p, dout)
+    close("mhsa2d train forward", host(out), o_ref)
+    got = {k: v.grad for k, v in mod.named_parameters()}
+    assert set(got) == set(g_ref)
+    # a key bias common to all keys shifts every score of a query row equally: softmax cancels it, the true gradient is 0
+    gscale = max(float(np.abs(v).max()) for v in g_ref.values())
+    # the PReLU slopes' gradients are scalars (sums with cancellation): judged against the largest of them, not their own size
+    ascale = max(float(np.abs(v).max()) for k, v in g_ref.items() if k.endswith("act.weight"))
+
+    def err_of(k):
+        if ".norm.beta" in k and k.startswith("Keys"):
+            return float(np.abs(host(got[k])).max()) / gscale
+        if k.endswith("act.weight"):
+            return float(np.abs(host(got[k]) - g_ref[k]).max()) / ascale
+        return rel_err(host(got[k]), g_ref[k])
+    errs = {k: err_of(k) for k in sorted(g_ref)}
+    bad = {k: e for k, e in errs.items() if not e <= 2e-4}
+    print(f"[parity] mhsa2d {len(g_ref)} parameter gradients: worst max-rel {max(errs.values()):.3e}")
+    assert not bad, f"mhsa2d parameter gradients off: {bad}"
+    close("mhsa2d dx", host(xt.grad), dx_ref, tol=2e-4)
+    with torch.no_grad():
+        close("mhsa2d eval vs train forward", host(mod(dev(x))), host(out))
+
+
 @pytest.mark.parametrize("shape,seed", [((2, 64, 12, 64), 103), ((1, 64, 125, 64), 5), ((1, 64, 250, 64), 6), ((2, 64, 33, 64), 8)])
 def test_mhsa2d(shape, seed):
     m = model()
