@@ -192,6 +192,16 @@ int rtfs_tf_attention_forward_train_f32(const float* x, const float* tpack, floa
                                         size_t ws_bytes, void* stream);
 int rtfs_tf_attention_backward_f32(const float* tpack, const float* saved, const float* dout, float* dx, float* dparams, int B, int T,
                                    void* ws, size_t ws_bytes, void* stream);
+/* Glue of the RTFS block with its adjoints (training side).  Planes are (N = B*C, H, W) contiguous.
+ * F.adaptive_avg_pool2d as called at separators/tdanet.py:116 and its adjoint;
+ * the last line of InjectionMultiSum.forward (layers/fusion.py:54-69): out = local * up(gate) + up(glob), up = nearest
+ * interpolation (Hg, Wg) -> (H, W) (identity when equal), and its adjoint (dlocal (N,H,W); dgate, dglob (N,Hg,Wg)). */
+int rtfs_adaptive_avg_pool2d_f32(const float* x, float* y, int N, int H, int W, int Ho, int Wo, void* stream);
+int rtfs_adaptive_avg_pool2d_backward_f32(const float* dy, float* dx, int N, int H, int W, int Ho, int Wo, void* stream);
+int rtfs_tfar_combine_f32(const float* local, const float* gate, const float* glob, float* out, int N, int H, int W, int Hg, int Wg,
+                          void* stream);
+int rtfs_tfar_combine_backward_f32(const float* dout, const float* local, const float* gate, float* dlocal, float* dgate, float* dglob,
+                                   int N, int H, int W, int Hg, int Wg, void* stream);
 /* The two GEMM forms of the training path (bf16x3 split on the matrix cores), exposed for tests:
  * kind 0: C (M,N) = A (M,K) . B (N,K)^T (accumulate != 0: C += ...), N % 64 == 0, K % 16 == 0;
  * kind 1: C (M,N) += A (K,M)^T . B (K,N), M % 64 == 0, N % 64 == 0. */

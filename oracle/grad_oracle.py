@@ -158,3 +158,46 @@ def module_grads(fn, x, p, dout):
     names = sorted(pt)
     grads = torch.autograd.grad(out, [xt] + [pt[k] for k in names], torch.tensor(dout, dtype=torch.float64), allow_unused=True)
     return out.detach().numpy(), grads[0].numpy(), {k: (None if g is None else g.numpy()) for k, g in zip(names, grads[1:])}
+
+
+def _sub(p, prefix):
+    q = prefix + "."
+    return {k[len(q):]: v for k, v in p.items() if k.startswith(q)}
+
+
+def _cna(x, p, *, k=1, stride=1, depthwise=False, norm=False, act=0, is2d=True):
+    """ConvNormAct from its state_dict sub-dict (keys full_layer.N.*)."""
+    cfg = (x.shape[1], p["full_layer.2.weight"].shape[0], k, stride, int(depthwise), 0, 0, int(norm), act, int("full_layer.2.bias" in p), int(is2d))
+    return conv_norm_act_torch(x, p, cfg)
+
+
+def injection_multi_sum_torch(local, glob, p):
+    """rtfs_oracle.injection_multi_sum in torch (reference layers/fusion.py:54-69), 2-D, kernel 4, gLN."""
+    import torch.nn.functional as F
+    kw = dict(k=4, depthwise=True, norm=True)
+    le = _cna(local, _sub(p, "local_embedding"), **kw)
+    if local.shape[-2] * local.shape[-1] > glob.shape[-2] * glob.shape[-1]:
+        ge = F.interpolate(_cna(glob, _sub(p, "global_embedding"), **kw), size=local.shape[-2:], mode="nearest")
+        gate = F.interpolate(_cna(glob, _sub(p, "global_gate"), act=3, **kw), size=local.shape[-2:], mode="nearest")
+    else:
+        gi = F.interpolate(glob, size=local.shape[-2:], mode="nearest")
+        ge, gate = _cna(gi, _sub(p, "global_embedding"), **kw), _cna(gi, _sub(p, "global_gate"), act=3, **kw)
+    return le * gate + ge
+
+
+def rtfs_block_torch(x, p):
+    """rtfs_oracle.rtfs_block in torch (reference separators/tdanet.py:104-131; is2d, upsampling_depth 2, globalatt =
+    DualPathRNN(dim 4), DualPathRNN(dim 3), MultiHeadSelfAttention2D)."""
+    import torch.nn.functional as F
+    residual = _cna(x, _sub(p, "gateway"), depthwise=True, act=2)
+    x_enc = _cna(residual, _sub(p, "projection"))
+    d0 = _cna(x_enc, _sub(p, "downsample_layers.0"), k=4, depthwise=True, norm=True)
+    d1 = _cna(d0, _sub(p, "downsample_layers.1"), k=4, stride=2, depthwise=True, norm=True)
+    g = F.adaptive_avg_pool2d(d0, d1.shape[-2:]) + d1
+    g = dualpath_rnn_torch(g, _sub(p, "globalatt.0"), 4)
+    g = dualpath_rnn_torch(g, _sub(p, "globalatt.1"), 3)
+    g = mhsa2d_torch(g, _sub(p, "globalatt.2"))
+    xf0 = injection_multi_sum_torch(d0, g, _sub(p, "fusion_layers.0"))
+    xf1 = injection_multi_sum_torch(d1, g, _sub(p, "fusion_layers.1"))
+    expanded = injection_multi_sum_torch(xf0, xf1, _sub(p, "concat_layers.0")) + d0
+    return _cna(expanded, _sub(p, "residual_conv")) + residual

@@ -1479,6 +1479,26 @@ int rtfs_tf_attention_backward_f32(const float* tpack, const float* saved, const
     return launch_transpose(drow, dx, B, T * 64, 64, st);
 }
 
+// ------------------------------------------------------------ block glue with gradients: pooling, TFAR combine
+int rtfs_adaptive_avg_pool2d_f32(const float* x, float* y, int N, int H, int W, int Ho, int Wo, void* stream) {
+    RTFS_RETURN_IF(!x || !y || N < 1, RTFS_ERR_ARG);
+    return launch_pool2d(x, y, (size_t)N, H, W, Ho, Wo, false, S(stream));
+}
+int rtfs_adaptive_avg_pool2d_backward_f32(const float* dy, float* dx, int N, int H, int W, int Ho, int Wo, void* stream) {
+    RTFS_RETURN_IF(!dy || !dx || N < 1, RTFS_ERR_ARG);
+    return launch_pool2d(dy, dx, (size_t)N, H, W, Ho, Wo, true, S(stream));
+}
+int rtfs_tfar_combine_f32(const float* local, const float* gate, const float* glob, float* out, int N, int H, int W, int Hg, int Wg,
+                          void* stream) {
+    RTFS_RETURN_IF(!local || !gate || !glob || !out || N < 1, RTFS_ERR_ARG);
+    return launch_tfar_combine(local, gate, glob, out, (size_t)N, H, W, Hg, Wg, S(stream));
+}
+int rtfs_tfar_combine_backward_f32(const float* dout, const float* local, const float* gate, float* dlocal, float* dgate, float* dglob, int N,
+                                   int H, int W, int Hg, int Wg, void* stream) {
+    RTFS_RETURN_IF(!dout || !local || !gate || !dlocal || !dgate || !dglob || N < 1, RTFS_ERR_ARG);
+    return launch_tfar_combine_bwd(dout, local, gate, dlocal, dgate, dglob, (size_t)N, H, W, Hg, Wg, S(stream));
+}
+
 // C = A . Bt^T (kind 0; accumulate adds to C) or C += A^T . B (kind 1): the two GEMM forms of the training path, exposed for tests
 int rtfs_debug_gemm_f32(int kind, const float* A, const float* B, float* C, int M, int N, int K, int accumulate, void* stream) {
     RTFS_RETURN_IF(!A || !B || !C, RTFS_ERR_ARG);

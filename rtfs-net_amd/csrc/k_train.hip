@@ -964,3 +964,99 @@ int launch_att_softmax(float* S, const float* P, int nbatch, int T, int Tp, floa
     hipLaunchKernelGGL(att_softmax_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, S, P, rows, T, Tp, scale, bwd ? 1 : 0);
     return rtfs_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------------ pooling / TFAR glue (channel-first planes)
+// adaptive average pooling (tdanet.py:116, F.adaptive_avg_pool2d): window i = [floor(i*in/out), ceil((i+1)*in/out))
+namespace {
+__device__ __forceinline__ int win_lo(int i, int n_in, int n_out) { return (int)(((long)i * n_in) / n_out); }
+__device__ __forceinline__ int win_hi(int i, int n_in, int n_out) { return (int)((((long)(i + 1)) * n_in + n_out - 1) / n_out); }
+}  // namespace
+__global__ __launch_bounds__(256) void pool2d_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, size_t N, int H, int W, int Ho,
+                                                         int Wo) {
+    const size_t total = N * Ho * Wo;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int wo = (int)(i % Wo), ho = (int)((i / Wo) % Ho);
+        const size_t n = i / ((size_t)Wo * Ho);
+        const int h0 = win_lo(ho, H, Ho), h1 = win_hi(ho, H, Ho), w0 = win_lo(wo, W, Wo), w1 = win_hi(wo, W, Wo);
+        float s = 0.f;
+        for (int h = h0; h < h1; ++h)
+            for (int w = w0; w < w1; ++w) s += x[(n * H + h) * W + w];
+        y[i] = s / (float)((h1 - h0) * (w1 - w0));
+    }
+}
+__global__ __launch_bounds__(256) void pool2d_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, size_t N, int H, int W, int Ho,
+                                                         int Wo) {
+    const size_t total = N * H * W;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int w = (int)(i % W), h = (int)((i / W) % H);
+        const size_t n = i / ((size_t)W * H);
+        // candidate windows around floor(h * out / in): window starts are non-decreasing and each is at most in/out + 1 long
+        const int hc = (int)(((long)h * Ho) / H), wc = (int)(((long)w * Wo) / W);
+        float s = 0.f;
+        for (int ho = max(hc - 1, 0); ho <= min(hc + 1, Ho - 1); ++ho) {
+            const int h0 = win_lo(ho, H, Ho), h1 = win_hi(ho, H, Ho);
+            if (h < h0 || h >= h1) continue;
+            for (int wo = max(wc - 1, 0); wo <= min(wc + 1, Wo - 1); ++wo) {
+                const int w0 = win_lo(wo, W, Wo), w1 = win_hi(wo, W, Wo);
+                if (w < w0 || w >= w1) continue;
+                s += dy[(n * Ho + ho) * Wo + wo] / (float)((h1 - h0) * (w1 - w0));
+            }
+        }
+        dx[i] = s;
+    }
+}
+// InjectionMultiSum's last line (fusion.py:54-69): out = local * up(gate) + up(global), up = F.interpolate(mode="nearest")
+__global__ __launch_bounds__(256) void tfar_combine_fwd_kernel(const float* __restrict__ le, const float* __restrict__ gate,
+                                                               const float* __restrict__ ge, float* __restrict__ out, size_t N, int H, int W,
+                                                               int Hg, int Wg) {
+    const size_t total = N * H * W;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int w = (int)(i % W), h = (int)((i / W) % H);
+        const size_t n = i / ((size_t)W * H);
+        const size_t j = (n * Hg + nearest_src(h, Hg, H)) * Wg + nearest_src(w, Wg, W);
+        out[i] = fmaf(le[i], gate[j], ge[j]);
+    }
+}
+__global__ __launch_bounds__(256) void tfar_combine_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ le,
+                                                               const float* __restrict__ gate, float* __restrict__ dle,
+                                                               float* __restrict__ dgate, float* __restrict__ dge, size_t N, int H, int W, int Hg,
+                                                               int Wg) {
+    // one thread per GLOBAL pixel: it owns the local pixels that read it (a contiguous block of rows x columns)
+    const size_t total = N * Hg * Wg;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int wg = (int)(i % Wg), hg = (int)((i / Wg) % Hg);
+        const size_t n = i / ((size_t)Wg * Hg);
+        // local h reads global floor(h * Hg / H) == hg  <=>  h in [ceil(hg*H/Hg), ceil((hg+1)*H/Hg))
+        const int h0 = (int)(((long)hg * H + Hg - 1) / Hg), h1 = min(H, (int)(((long)(hg + 1) * H + Hg - 1) / Hg));
+        const int w0 = (int)(((long)wg * W + Wg - 1) / Wg), w1 = min(W, (int)(((long)(wg + 1) * W + Wg - 1) / Wg));
+        const float g = gate[i];
+        float sg = 0.f, se = 0.f;
+        for (int h = h0; h < h1; ++h)
+            for (int w = w0; w < w1; ++w) {
+                const size_t k = (n * H + h) * W + w;
+                const float d = dout[k];
+                dle[k] = d * g;
+                sg = fmaf(d, le[k], sg);
+                se += d;
+            }
+        dgate[i] = sg;
+        dge[i] = se;
+    }
+}
+int launch_pool2d(const float* x, float* y, size_t N, int H, int W, int Ho, int Wo, bool bwd, hipStream_t st) {
+    if (H < 1 || W < 1 || Ho < 1 || Wo < 1 || Ho > H || Wo > W) return RTFS_ERR_SHAPE;
+    if (bwd) hipLaunchKernelGGL(pool2d_bwd_kernel, dim3(grid_for(N * H * W)), dim3(256), 0, st, x, y, N, H, W, Ho, Wo);
+    else hipLaunchKernelGGL(pool2d_fwd_kernel, dim3(grid_for(N * Ho * Wo)), dim3(256), 0, st, x, y, N, H, W, Ho, Wo);
+    return rtfs_launch_status();
+}
+int launch_tfar_combine(const float* le, const float* gate, const float* ge, float* out, size_t N, int H, int W, int Hg, int Wg, hipStream_t st) {
+    if (Hg < 1 || Wg < 1 || Hg > H || Wg > W) return RTFS_ERR_SHAPE;
+    hipLaunchKernelGGL(tfar_combine_fwd_kernel, dim3(grid_for(N * H * W)), dim3(256), 0, st, le, gate, ge, out, N, H, W, Hg, Wg);
+    return rtfs_launch_status();
+}
+int launch_tfar_combine_bwd(const float* dout, const float* le, const float* gate, float* dle, float* dgate, float* dge, size_t N, int H, int W,
+                            int Hg, int Wg, hipStream_t st) {
+    if (Hg < 1 || Wg < 1 || Hg > H || Wg > W) return RTFS_ERR_SHAPE;
+    hipLaunchKernelGGL(tfar_combine_bwd_kernel, dim3(grid_for(N * Hg * Wg)), dim3(256), 0, st, dout, le, gate, dle, dgate, dge, N, H, W, Hg, Wg);
+    return rtfs_launch_status();
+}

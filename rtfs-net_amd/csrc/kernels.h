@@ -305,3 +305,7 @@ int launch_att_lng(const LngArgs& a, int nbt, bool bwd, hipStream_t st);
 int launch_att_pack_qkv(float* rows, float* Qp, float* Kp, float* Vp, int B, int T, int Tp, int dir, hipStream_t st);
 int launch_att_pack_o(float* rows, float* Op, int B, int T, int Tp, int dir, hipStream_t st);
 int launch_att_softmax(float* S, const float* P, int nbatch, int T, int Tp, float scale, bool bwd, hipStream_t st);
+int launch_pool2d(const float* x, float* y, size_t N, int H, int W, int Ho, int Wo, bool bwd, hipStream_t st);
+int launch_tfar_combine(const float* le, const float* gate, const float* ge, float* out, size_t N, int H, int W, int Hg, int Wg, hipStream_t st);
+int launch_tfar_combine_bwd(const float* dout, const float* le, const float* gate, float* dle, float* dgate, float* dge, size_t N, int H, int W,
+                            int Hg, int Wg, hipStream_t st);

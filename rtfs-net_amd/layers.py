@@ -513,6 +513,80 @@ class MultiHeadSelfAttention2D(PackedModule):
 
 
 # ----------------------------------------------------------------------------- TFAR
+def _planes(t):
+    """(B, C, H, W) or (B, C, W) -> (N = B*C, H, W) geometry of a contiguous tensor."""
+    return t.shape[0] * t.shape[1], (t.shape[2] if t.dim() == 4 else 1), t.shape[-1]
+
+
+class _AdaptivePoolFn(torch.autograd.Function):
+    """F.adaptive_avg_pool2d / 1d with its adjoint on the HIP kernels (reference call site separators/tdanet.py:116)."""
+
+    @staticmethod
+    def forward(ctx, x, size):
+        lib = _lib.load()
+        x = x.contiguous()
+        N, H, W = _planes(x)
+        Ho, Wo = (size[0], size[1]) if x.dim() == 4 else (1, size[-1])
+        y = torch.empty(x.shape[:2] + ((Ho, Wo) if x.dim() == 4 else (Wo,)), device=x.device, dtype=torch.float32)
+        _lib.check(lib.rtfs_adaptive_avg_pool2d_f32(_lib.ptr(x), _lib.ptr(y), N, H, W, Ho, Wo, _lib.stream_of(x)), "rtfs_adaptive_avg_pool2d_f32")
+        ctx.geom, ctx.xshape = (N, H, W, Ho, Wo), x.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        N, H, W, Ho, Wo = ctx.geom
+        dy = dy.contiguous()
+        dx = torch.empty(ctx.xshape, device=dy.device, dtype=torch.float32)
+        _lib.check(lib.rtfs_adaptive_avg_pool2d_backward_f32(_lib.ptr(dy), _lib.ptr(dx), N, H, W, Ho, Wo, _lib.stream_of(dy)),
+                   "rtfs_adaptive_avg_pool2d_backward_f32")
+        return dx, None
+
+
+class _TfarCombineFn(torch.autograd.Function):
+    """local * up(gate) + up(glob) with nearest up-sampling, and its adjoint (layers/fusion.py:54-69)."""
+
+    @staticmethod
+    def forward(ctx, local, gate, glob):
+        lib = _lib.load()
+        local, gate, glob = local.contiguous(), gate.contiguous(), glob.contiguous()
+        N, H, W = _planes(local)
+        _, Hg, Wg = _planes(gate)
+        out = torch.empty_like(local)
+        _lib.check(lib.rtfs_tfar_combine_f32(_lib.ptr(local), _lib.ptr(gate), _lib.ptr(glob), _lib.ptr(out), N, H, W, Hg, Wg, _lib.stream_of(local)),
+                   "rtfs_tfar_combine_f32")
+        ctx.save_for_backward(local, gate)
+        ctx.geom = (N, H, W, Hg, Wg)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        local, gate = ctx.saved_tensors
+        N, H, W, Hg, Wg = ctx.geom
+        dout = dout.contiguous()
+        dl, dg, de = torch.empty_like(local), torch.empty_like(gate), torch.empty_like(gate)
+        _lib.check(lib.rtfs_tfar_combine_backward_f32(_lib.ptr(dout), _lib.ptr(local), _lib.ptr(gate), _lib.ptr(dl), _lib.ptr(dg), _lib.ptr(de),
+                                                      N, H, W, Hg, Wg, _lib.stream_of(dout)), "rtfs_tfar_combine_backward_f32")
+        return dl, dg, de
+
+
+def adaptive_avg_pool(x, size):
+    return _AdaptivePoolFn.apply(x, tuple(size))
+
+
+def _recording(*tensors_and_modules):
+    if not torch.is_grad_enabled():
+        return False
+    for o in tensors_and_modules:
+        if isinstance(o, torch.Tensor):
+            if o.requires_grad:
+                return True
+        elif any(p.requires_grad for p in o.parameters()):
+            return True
+    return False
+
+
 class InjectionMultiSum(PackedModule):
     """reference layers/fusion.py:9-69.  2-D (audio) instances run on the HIP path; 1-D (video) ones on torch ops."""
 
@@ -526,7 +600,16 @@ class InjectionMultiSum(PackedModule):
         self.global_embedding = mk()
         self.global_gate = mk("Sigmoid")
 
+    def _forward_train(self, loc, glo):
+        """Inside a training step: the three ConvNormActs on their training kernels + the combine kernel.  When the global map is
+        not smaller than the local one the reference interpolates first (an identity at equal sizes, the only such case on the path)."""
+        if tuple(loc.shape[2:]) != tuple(glo.shape[2:]) and all(a <= b for a, b in zip(loc.shape[2:], glo.shape[2:])):
+            raise RuntimeError("InjectionMultiSum: a global map larger than the local one does not occur on the RTFS path")
+        return _TfarCombineFn.apply(self.local_embedding(loc), self.global_gate(glo), self.global_embedding(glo))
+
     def forward(self, local_features, global_features):
+        if local_features.is_cuda and _recording(local_features, global_features, self):
+            return self._forward_train(local_features, global_features)
         if not self.is2d:
             return self._forward_1d(local_features, global_features)
         self._guard(local_features, global_features)

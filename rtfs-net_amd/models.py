@@ -120,6 +120,11 @@ class AudioBottleneck(ConvNormAct, PackedModule):
 
 
 # ----------------------------------------------------------------------------- RTFS block
+def L_recording(*objs):
+    from .layers import _recording
+    return _recording(*[o for o in objs if o is not None])
+
+
 class TDANetBlock(PackedModule):
     """RTFS block (2-D) / VP block (1-D): reference separators/tdanet.py:8-131."""
 
@@ -181,7 +186,29 @@ class TDANetBlock(PackedModule):
         _lib.check(lib.rtfs_vp_block_f32(_lib.ptr(x), _lib.ptr(pk), _lib.ptr(out), B, Tv, _lib.stream_of(x)), "rtfs_vp_block_f32")
         return out
 
+    def _forward_train(self, x, x_res=None):
+        """The block inside a training step (reference separators/tdanet.py:104-131, line by line): every module runs its HIP
+        forward-with-saved-state and hands autograd its HIP backward; tensor additions are the only torch ops."""
+        from . import layers as L
+        if x_res is not None:
+            x = x + x_res
+        residual = self.gateway(x)
+        x_enc = self.projection(residual)
+        down = [self.downsample_layers[0](x_enc)]
+        for i in range(1, self.upsampling_depth):
+            down.append(self.downsample_layers[i](down[-1]))
+        size = down[-1].shape[2:]
+        g = down[-1] + sum(L.adaptive_avg_pool(f, size) for f in down[:-1])  # pooling the last level onto itself is the identity
+        g = self.globalatt(g)
+        fused = [self.fusion_layers[i](down[i], g) for i in range(self.upsampling_depth)]
+        expanded = self.concat_layers[-1](fused[-2], fused[-1]) + down[-2]
+        for i in range(self.upsampling_depth - 3, -1, -1):
+            expanded = self.concat_layers[i](fused[i], expanded) + down[i]
+        return self.residual_conv(expanded) + residual
+
     def forward(self, x, x_res=None):
+        if self._hip and x.is_cuda and L_recording(x, x_res, self):
+            return self._forward_train(x, x_res)
         if not self._hip:
             x = x if x_res is None else x + x_res
             if x.is_cuda and not self.training and self._vp_supported() and x.shape[-1] <= 120:

@@ -342,6 +342,75 @@ def test_mhsa2d_training_forward_backward(shape, seed):
         close("mhsa2d eval vs train forward", host(mod(dev(x))), host(out))
 
 
+def test_pool_and_tfar_combine_adjoints():
+    """adaptive_avg_pool2d and the TFAR combine with their adjoints vs torch autograd (odd sizes: overlapping pooling windows,
+    uneven nearest-neighbour fan-out)."""
+    import rtfs_net_amd as R
+    import torch.nn.functional as F
+    L = R.layers
+    for (H, W, Ho, Wo) in [(17, 129, 8, 64), (251, 9, 125, 4), (8, 64, 8, 64), (5, 7, 2, 3)]:
+        x = rand((2, 3, H, W), H + W)
+        dy = rand((2, 3, Ho, Wo), H)
+        xt = dev(x).requires_grad_(True)
+        y = L.adaptive_avg_pool(xt, (Ho, Wo))
+        y.backward(dev(dy))
+        xr = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+        yr = F.adaptive_avg_pool2d(xr, (Ho, Wo))
+        yr.backward(torch.tensor(dy, dtype=torch.float64))
+        close(f"pool {H}x{W}->{Ho}x{Wo}", host(y), yr.detach().numpy(), tol=1e-6)
+        close("pool adjoint", host(xt.grad), xr.grad.numpy(), tol=1e-6)
+        le, ga, ge = rand((2, 3, H, W), 1), rand((2, 3, Ho, Wo), 2), rand((2, 3, Ho, Wo), 3)
+        ts = [dev(a).requires_grad_(True) for a in (le, ga, ge)]
+        o = L._TfarCombineFn.apply(*ts)
+        do = rand((2, 3, H, W), 4)
+        o.backward(dev(do))
+        rs = [torch.tensor(a, dtype=torch.float64, requires_grad=True) for a in (le, ga, ge)]
+        orf = rs[0] * F.interpolate(rs[1], size=(H, W), mode="nearest") + F.interpolate(rs[2], size=(H, W), mode="nearest")
+        orf.backward(torch.tensor(do, dtype=torch.float64))
+        close("tfar combine", host(o), orf.detach().numpy(), tol=1e-6)
+        for t, r, nm in zip(ts, rs, ("dlocal", "dgate", "dglobal")):
+            close(f"tfar combine {nm}", host(t.grad), r.grad.numpy(), tol=2e-6)
+
+
+@pytest.mark.parametrize("shape,seed,with_res", [((1, 256, 17, 129), 51, False), ((2, 256, 21, 129), 52, True)])
+def test_block_training_forward_backward(shape, seed, with_res):
+    """The whole RTFS block inside a training step (gateway, projection, 2-level pyramid, pooling, both sweeps, TF attention,
+    three TFAR fusions, residual convolution; 139 parameter tensors) against the autograd oracle.  Tolerances are loose by design:
+    PReLU's derivative jumps at 0 and a handful of the ~10^5 pre-activations land within fp32 rounding of 0, which moves single
+    gradient elements by O(1) of their size (the per-module tests pin the kernels to ~1e-5 with the kinks taken out)."""
+    import rtfs_net_amd as R
+    from oracle import grad_oracle as G
+    p = {k: v.copy() for k, v in BLK.items()}
+    blk = model().refinement_module.audio_net.get_block(0)
+    import copy
+    blk = copy.deepcopy(blk).train()
+    x = rand(shape, seed)
+    res = rand(shape, seed + 1) if with_res else None
+    dout = rand(shape, seed + 100)
+    xt = dev(x).requires_grad_(True)
+    rt = dev(res).requires_grad_(True) if with_res else None
+    out = blk(xt, rt)
+    out.backward(dev(dout))
+    xin = x + res if with_res else x
+    o_ref, dx_ref, g_ref = G.module_grads(G.rtfs_block_torch, xin, p, dout)
+    close("block train forward", host(out), o_ref)
+    print(f"[parity] block dx: max-rel {rel_err(host(xt.grad), dx_ref):.3e} l2-rel {l2_rel(host(xt.grad), dx_ref):.3e}")
+    assert l2_rel(host(xt.grad), dx_ref) <= 2e-3
+    if with_res:
+        assert torch.equal(rt.grad, xt.grad)
+    got = {k: v.grad for k, v in blk.named_parameters()}
+    assert set(got) == set(g_ref)
+    gscale = {k: float(np.abs(v).max()) for k, v in g_ref.items()}
+    l2 = {k: l2_rel(host(got[k]).reshape(g_ref[k].shape), g_ref[k]) for k in g_ref if gscale[k] > 1e-9 * max(gscale.values())}
+    worst = sorted(l2.items(), key=lambda kv: -kv[1])[:3]
+    print(f"[parity] block {len(g_ref)} parameter gradients: median l2-rel {np.median(list(l2.values())):.3e}, worst {worst}")
+    assert np.median(list(l2.values())) <= 1e-4
+    assert worst[0][1] <= 5e-2, worst
+    with torch.no_grad():
+        blk.eval()
+        close("block eval vs train forward", host(blk(dev(x), dev(res) if with_res else None)), host(out))
+
+
 @pytest.mark.parametrize("shape,seed", [((2, 64, 12, 64), 103), ((1, 64, 125, 64), 5), ((1, 64, 250, 64), 6), ((2, 64, 33, 64), 8)])
 def test_mhsa2d(shape, seed):
     m = model()
