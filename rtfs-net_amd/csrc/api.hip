@@ -1217,7 +1217,7 @@ size_t rtfs_cna_saved_floats(const int* cfg, int B, int H, int W) {
 }
 size_t rtfs_cna_workspace_bytes(const int* cfg, int B, int H, int W) {
     CnaCfg c(cfg, B, H, W);
-    return (2 * c.rows_out * c.Cout + 2 * c.rows_in * c.Cin + 4 * (size_t)B) * sizeof(float) + 8 * 256;
+    return (2 * c.rows_out * c.Cout + 2 * c.rows_in * c.Cin + 4 * (size_t)B + (size_t)CL_DW_WGRAD_MAX_WG * 20 * 256) * sizeof(float) + 8 * 256;
 }
 void rtfs_cna_out_shape(const int* cfg, int H, int W, int* Ho, int* Wo) {
     CnaCfg c(cfg, 1, H, W);
@@ -1285,6 +1285,7 @@ int rtfs_cna_backward_f32(const float* params, const float* saved, const float* 
     float* d2 = ar.take<float>(c.rows_in * c.Cin);
     float* d0 = ar.take<float>(c.rows_in * c.Cin);
     double* Sb = ar.take<double>(2 * (size_t)B);
+    float* wg_scratch = ar.take<float>(c.depthwise ? (size_t)CL_DW_WGRAD_MAX_WG * c.kh * c.kw * c.Cin : 0);
     RTFS_RETURN_IF(!ar.ok(), RTFS_ERR_WORKSPACE);
     hipStream_t st = S(stream);
     const size_t n_in = (size_t)H * W * c.Cin, n_out = (size_t)c.Ho * c.Wo * c.Cout;
@@ -1303,7 +1304,7 @@ int rtfs_cna_backward_f32(const float* params, const float* saved, const float* 
     if (c.has_bias) CHECK(launch_cl_colsum(d3, dparams + c.g_b, c.rows_out * c.Cout, c.Cout, st));
     if (c.depthwise) {
         ClDwArgs d;
-        d.x = conv_in; d.w = params + c.o_w; d.dy = d3; d.dx = d2; d.dw = dparams + c.g_w;
+        d.x = conv_in; d.w = params + c.o_w; d.dy = d3; d.dx = d2; d.dw = dparams + c.g_w; d.scratch = wg_scratch;
         d.B = B; d.H = H; d.W = W; d.C = c.Cin; d.Ho = c.Ho; d.Wo = c.Wo; d.kh = c.kh; d.kw = c.kw; d.s = c.stride; d.pt = c.pt; d.pl = c.pl;
         CHECK(launch_cl_dw(d, 1, st));
         CHECK(launch_cl_dw(d, 2, st));

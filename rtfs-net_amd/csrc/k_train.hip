@@ -637,13 +637,13 @@ __global__ __launch_bounds__(256) void cl_colsum_kernel(const float* __restrict_
 // depthwise k x k convolution, channel-last: x (B, H, W, C), w (C, kh*kw), y (B, Ho, Wo, C); cross-correlation with
 // top/left padding (pt, pl) and stride s (conv_layers.py:100-101: "same" k = 4 -> pt = pl = 1, stride 2 -> symmetric 1)
 __global__ __launch_bounds__(256) void cl_dw_fwd_kernel(ClDwArgs a) {
-    const size_t total = (size_t)a.B * a.Ho * a.Wo * a.C;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int c = (int)(i % a.C);
-        size_t r = i / a.C;
-        const int wo = (int)(r % a.Wo);
-        r /= a.Wo;
-        const int ho = (int)(r % a.Ho), b = (int)(r / a.Ho);
+    const unsigned total = (unsigned)a.B * a.Ho * a.Wo * a.C;  // < 2^31 (launcher)
+    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int c = (int)(i % (unsigned)a.C);
+        unsigned r = i / (unsigned)a.C;
+        const int wo = (int)(r % (unsigned)a.Wo);
+        r /= (unsigned)a.Wo;
+        const int ho = (int)(r % (unsigned)a.Ho), b = (int)(r / (unsigned)a.Ho);
         float acc = a.bias ? a.bias[c] : 0.f;
         for (int ki = 0; ki < a.kh; ++ki) {
             const int h = ho * a.s - a.pt + ki;
@@ -660,13 +660,13 @@ __global__ __launch_bounds__(256) void cl_dw_fwd_kernel(ClDwArgs a) {
 
 // input gradient: dx[b,h,w,c] = sum over taps with (h + pt - ki) = ho*s, (w + pl - kj) = wo*s of w[c,ki,kj] * dy[b,ho,wo,c]
 __global__ __launch_bounds__(256) void cl_dw_bwd_data_kernel(ClDwArgs a) {
-    const size_t total = (size_t)a.B * a.H * a.W * a.C;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int c = (int)(i % a.C);
-        size_t r = i / a.C;
-        const int w = (int)(r % a.W);
-        r /= a.W;
-        const int h = (int)(r % a.H), b = (int)(r / a.H);
+    const unsigned total = (unsigned)a.B * a.H * a.W * a.C;  // < 2^31 (launcher)
+    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int c = (int)(i % (unsigned)a.C);
+        unsigned r = i / (unsigned)a.C;
+        const int w = (int)(r % (unsigned)a.W);
+        r /= (unsigned)a.W;
+        const int h = (int)(r % (unsigned)a.H), b = (int)(r / (unsigned)a.H);
         float acc = 0.f;
         for (int ki = 0; ki < a.kh; ++ki) {
             const int hn = h + a.pt - ki;
@@ -685,39 +685,61 @@ __global__ __launch_bounds__(256) void cl_dw_bwd_data_kernel(ClDwArgs a) {
     }
 }
 
-// weight gradient: dw[c,ki,kj] += sum_{b,ho,wo} dy * x(shifted).  Thread = (channel, one of 256/C row lanes); up to 16 taps.
+// weight gradient: dw[c,ki,kj] += sum_{b,ho,wo} dy * x(shifted).  Thread = (channel, one of 256/C row lanes); taps up to 4 x 5,
+// fully unrolled with predicates so the accumulators stay in registers and no tap index is ever divided.
 __global__ __launch_bounds__(256) void cl_dw_wgrad_kernel(ClDwArgs a) {
     __shared__ float part[256];
     const int tid = threadIdx.x, c = tid % a.C, lanes = 256 / a.C, rl = tid / a.C;
-    const int taps = a.kh * a.kw;
-    float acc[16];
+    float acc[4][5];
 #pragma unroll
-    for (int t = 0; t < 16; ++t) acc[t] = 0.f;
-    const size_t rows = (size_t)a.B * a.Ho * a.Wo;
-    for (size_t r = (size_t)blockIdx.x * lanes + rl; r < rows; r += (size_t)gridDim.x * lanes) {
-        const int wo = (int)(r % a.Wo);
-        const size_t q = r / a.Wo;
-        const int ho = (int)(q % a.Ho), b = (int)(q / a.Ho);
-        const float d = a.dy[r * a.C + c];
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            if (t < taps) {
-                const int ki = t / a.kw, kj = t - ki * a.kw;
-                const int h = ho * a.s - a.pt + ki, w = wo * a.s - a.pl + kj;
-                if (h >= 0 && h < a.H && w >= 0 && w < a.W) acc[t] = fmaf(d, a.x[(((size_t)b * a.H + h) * a.W + w) * a.C + c], acc[t]);
+        for (int j = 0; j < 5; ++j) acc[i][j] = 0.f;
+    const unsigned rows = (unsigned)a.B * a.Ho * a.Wo, HoWo = (unsigned)a.Ho * a.Wo;
+    for (unsigned r = blockIdx.x * lanes + rl; r < rows; r += gridDim.x * lanes) {
+        const unsigned b = r / HoWo, q = r - b * HoWo;
+        const int ho = (int)(q / (unsigned)a.Wo), wo = (int)(q - (unsigned)ho * a.Wo);
+        const float d = a.dy[(size_t)r * a.C + c];
+        const int hb = ho * a.s - a.pt, wb = wo * a.s - a.pl;
+        const float* xb = a.x + ((size_t)b * a.H * a.W) * a.C + c;
+#pragma unroll
+        for (int ki = 0; ki < 4; ++ki) {
+            const int h = hb + ki;
+            if (ki < a.kh && h >= 0 && h < a.H) {
+#pragma unroll
+                for (int kj = 0; kj < 5; ++kj) {
+                    const int w = wb + kj;
+                    if (kj < a.kw && w >= 0 && w < a.W) acc[ki][kj] = fmaf(d, xb[((size_t)h * a.W + w) * a.C], acc[ki][kj]);
+                }
             }
         }
     }
-    for (int t = 0; t < taps; ++t) {
-        part[tid] = acc[t];
-        __syncthreads();
-        if (tid < a.C) {
-            float v = 0.f;
-            for (int j = tid; j < 256; j += a.C) v += part[j];
-            unsafeAtomicAdd(a.dw + tid * taps + t, v);
+#pragma unroll
+    for (int ki = 0; ki < 4; ++ki)
+#pragma unroll
+        for (int kj = 0; kj < 5; ++kj) {
+            if (ki < a.kh && kj < a.kw) {  // uniform
+                part[tid] = acc[ki][kj];
+                __syncthreads();
+                if (tid < a.C) {
+                    float v = 0.f;
+                    for (int j = tid; j < 256; j += a.C) v += part[j];
+                    // per-workgroup partial; cl_dw_wgrad_reduce_kernel sums them (atomics onto kh*kw*C addresses from thousands
+                    // of workgroups serialise: measured 515 us vs 110 us of work)
+                    a.scratch[((size_t)blockIdx.x * a.kh * a.kw + ki * a.kw + kj) * a.C + tid] = v;
+                }
+                __syncthreads();
+            }
         }
-        __syncthreads();
-    }
+}
+
+__global__ __launch_bounds__(256) void cl_dw_wgrad_reduce_kernel(const float* __restrict__ scratch, float* __restrict__ dw, int nwg, int taps,
+                                                                 int C) {
+    const int i = blockIdx.x * 256 + threadIdx.x;  // (tap, c)
+    if (i >= taps * C) return;
+    float v = 0.f;
+    for (int w = blockIdx.y; w < nwg; w += gridDim.y) v += scratch[(size_t)w * taps * C + i];
+    unsafeAtomicAdd(dw + (i % C) * taps + i / C, v);
 }
 
 namespace {
@@ -747,14 +769,22 @@ int launch_cl_colsum(const float* d, float* out, size_t n, int C, hipStream_t st
     return rtfs_launch_status();
 }
 int launch_cl_dw(const ClDwArgs& a, int what, hipStream_t st) {
-    if (a.kh * a.kw > 16 || a.C < 1 || a.C > 256 || (256 % a.C)) return RTFS_ERR_SHAPE;
+    if (a.kh > 4 || a.kw > 5 || a.C < 1 || a.C > 256 || (256 % a.C) || (size_t)a.B * a.H * a.W * a.C >= 0x7fffffffu) return RTFS_ERR_SHAPE;
     if (what == 0) hipLaunchKernelGGL(cl_dw_fwd_kernel, dim3(grid_for((size_t)a.B * a.Ho * a.Wo * a.C)), dim3(256), 0, st, a);
     else if (what == 1) hipLaunchKernelGGL(cl_dw_bwd_data_kernel, dim3(grid_for((size_t)a.B * a.H * a.W * a.C)), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(cl_dw_wgrad_kernel, dim3(grid_for((size_t)a.B * a.Ho * a.Wo * a.C / 8, 2048)), dim3(256), 0, st, a);
+    else {
+        const size_t rows = (size_t)a.B * a.Ho * a.Wo, per_wg = (size_t)(256 / a.C) * 8;
+        size_t g = (rows + per_wg - 1) / per_wg;
+        g = g < 1 ? 1 : (g > CL_DW_WGRAD_MAX_WG ? CL_DW_WGRAD_MAX_WG : g);
+        if (!a.scratch) return RTFS_ERR_WORKSPACE;
+        hipLaunchKernelGGL(cl_dw_wgrad_kernel, dim3((unsigned)g), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(cl_dw_wgrad_reduce_kernel, dim3(cdiv(a.kh * a.kw * a.C, 256), g >= 64 ? 64 : (unsigned)g), dim3(256), 0, st, a.scratch, a.dw, (int)g, a.kh * a.kw, a.C);
+    }
     return rtfs_launch_status();
 }
 
 // ------------------------------------------------------------------------------------------------ TF attention, training side
+#define LNG_BT 8  // (b,t) slices per workgroup of the LNG backward
 // MultiHeadSelfAttention2D (attention.py:149-189) on channel-last rows (b, t, f) x CZ.  "LNG" = the tail of a ConvActNorm
 // (conv_layers.py:201-205): PReLU, then LayerNormalization4D((C_out, F)) = statistics over (channels of the module, F) per (b, t)
 // with a (C_out, F) affine (normalizations.py:26,33-37).  The twelve Q/K/V modules are evaluated side by side: their channels are
@@ -802,63 +832,85 @@ __global__ __launch_bounds__(256) void att_lng_fwd_kernel(LngArgs a) {
 __global__ __launch_bounds__(256) void att_lng_bwd_kernel(LngArgs a) {
     extern __shared__ float lds[];  // A [64][CZ+1] (activated input, later xhat), D [64][CZ+1] (gamma * dY)
     __shared__ float g1[16], g2[16], gsl[16];
-    const int bt = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, CZ = a.CZ, P = CZ + 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, CZ = a.CZ, P = CZ + 1;
     float* A = lds;
     float* D = lds + 64 * P;
-    const float* z = a.Z + (size_t)bt * 64 * CZ;
-    const float* dy = a.dY + (size_t)bt * 64 * CZ;
+    // a workgroup walks LNG_BT consecutive (b,t) slices; each thread owns the same (f, c) elements in every slice, so the
+    // (C, F) affine's gradients stay in registers and reach HBM as one atomic per element per workgroup
+    float acc_g[32], acc_b[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) acc_g[k] = acc_b[k] = 0.f;
     if (tid < 16) gsl[tid] = 0.f;
-    for (int idx = tid; idx < 64 * CZ; idx += 256) {
-        const int f = idx / CZ, c = idx - f * CZ, g = a.gof[c];
-        const float v = z[idx];
-        const float act = v >= 0.f ? v : a.slope[c] * v;
-        float xh = 0.f, gd = 0.f;
-        if (g < 16) {
-            xh = (act - a.stats[((size_t)bt * 16 + g) * 2]) * a.stats[((size_t)bt * 16 + g) * 2 + 1];
-            const float d = dy[idx];
-            gd = a.gamma[c * 64 + f] * d;
-            unsafeAtomicAdd(a.dgamma + c * 64 + f, d * xh);
-            unsafeAtomicAdd(a.dbeta + c * 64 + f, d);
-        }
-        A[f * P + c] = xh;
-        D[f * P + c] = gd;
-    }
-    __syncthreads();
-    for (int g = wave; g < a.ngroups; g += 4) {
-        const int c0 = a.gstart[g], gs = a.gstart[g + 1] - c0, n = 64 * gs;
-        float s1 = 0.f, s2 = 0.f;
-        for (int i = lane; i < n; i += 64) {
-            const int o = (i / gs) * P + c0 + i % gs;
-            s1 += D[o];
-            s2 = fmaf(D[o], A[o], s2);
-        }
-        s1 = wave_sum(s1) / n;
-        s2 = wave_sum(s2) / n;
-        if (lane == 0) {
-            g1[g] = s1;
-            g2[g] = s2;
-        }
-    }
-    __syncthreads();
-    float* dz = a.dZ + (size_t)bt * 64 * CZ;
-    float dsl = 0.f;  // per-thread PReLU slope gradient, per group handled below through LDS atomics
-    for (int idx = tid; idx < 64 * CZ; idx += 256) {
-        const int f = idx / CZ, c = idx - f * CZ, g = a.gof[c];
-        float out = 0.f;
-        if (g < 16) {
-            const float rstd = a.stats[((size_t)bt * 16 + g) * 2 + 1];
-            const float dA = rstd * (D[f * P + c] - g1[g] - A[f * P + c] * g2[g]);
-            const float v = z[idx];
-            if (v >= 0.f) out = dA;
-            else {
-                out = dA * a.slope[c];
-                atomicAdd(&gsl[g], dA * v);
+    const int per = 64 * CZ / 256;  // 16 (CZ 64) or 32 (CZ 128) elements per thread
+    for (int bt = blockIdx.x * LNG_BT; bt < min(a.nbt, (blockIdx.x + 1) * LNG_BT); ++bt) {
+        const float* z = a.Z + (size_t)bt * 64 * CZ;
+        const float* dy = a.dY + (size_t)bt * 64 * CZ;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            if (k < per) {
+                const int idx = tid + 256 * k;
+                const int f = idx / CZ, c = idx - f * CZ, g = a.gof[c];
+                const float v = z[idx];
+                const float act = v >= 0.f ? v : a.slope[c] * v;
+                float xh = 0.f, gd = 0.f;
+                if (g < 16) {
+                    xh = (act - a.stats[((size_t)bt * 16 + g) * 2]) * a.stats[((size_t)bt * 16 + g) * 2 + 1];
+                    const float d = dy[idx];
+                    gd = a.gamma[c * 64 + f] * d;
+                    acc_g[k] = fmaf(d, xh, acc_g[k]);
+                    acc_b[k] += d;
+                }
+                A[f * P + c] = xh;
+                D[f * P + c] = gd;
             }
         }
-        dz[idx] = out;
+        __syncthreads();
+        for (int g = wave; g < a.ngroups; g += 4) {
+            const int c0 = a.gstart[g], gs = a.gstart[g + 1] - c0, n = 64 * gs;
+            float s1 = 0.f, s2 = 0.f;
+            for (int i = lane; i < n; i += 64) {
+                const int o = (i / gs) * P + c0 + i % gs;
+                s1 += D[o];
+                s2 = fmaf(D[o], A[o], s2);
+            }
+            s1 = wave_sum(s1) / n;
+            s2 = wave_sum(s2) / n;
+            if (lane == 0) {
+                g1[g] = s1;
+                g2[g] = s2;
+            }
+        }
+        __syncthreads();
+        float* dz = a.dZ + (size_t)bt * 64 * CZ;
+        for (int idx = tid; idx < 64 * CZ; idx += 256) {
+            const int f = idx / CZ, c = idx - f * CZ, g = a.gof[c];
+            float out = 0.f;
+            if (g < 16) {
+                const float rstd = a.stats[((size_t)bt * 16 + g) * 2 + 1];
+                const float dA = rstd * (D[f * P + c] - g1[g] - A[f * P + c] * g2[g]);
+                const float v = z[idx];
+                if (v >= 0.f) out = dA;
+                else {
+                    out = dA * a.slope[c];
+                    atomicAdd(&gsl[g], dA * v);
+                }
+            }
+            dz[idx] = out;
+        }
     }
-    (void)dsl;
     __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+        if (k < per) {
+            const int idx = tid + 256 * k;
+            const int f = idx / CZ, c = idx - f * CZ;
+            if (a.gof[c] < 16) {
+                unsafeAtomicAdd(a.dgamma + c * 64 + f, acc_g[k]);
+                unsafeAtomicAdd(a.dbeta + c * 64 + f, acc_b[k]);
+            }
+        }
+    }
     if (tid < a.ngroups && gsl[tid] != 0.f) unsafeAtomicAdd(a.dslope + tid, gsl[tid]);
 }
 
@@ -946,7 +998,11 @@ int launch_att_lng(const LngArgs& a, int nbt, bool bwd, hipStream_t st) {
     const size_t lds = (size_t)(bwd ? 2 : 1) * 64 * (a.CZ + 1) * sizeof(float);
     int rc = bwd ? set_lds(att_lng_bwd_kernel, lds) : set_lds(att_lng_fwd_kernel, lds);
     if (rc) return rc;
-    if (bwd) hipLaunchKernelGGL(att_lng_bwd_kernel, dim3(nbt), dim3(256), lds, st, a);
+    if (bwd) {
+        LngArgs b = a;
+        b.nbt = nbt;
+        hipLaunchKernelGGL(att_lng_bwd_kernel, dim3(cdiv(nbt, LNG_BT)), dim3(256), lds, st, b);
+    }
     else hipLaunchKernelGGL(att_lng_fwd_kernel, dim3(nbt), dim3(256), lds, st, a);
     return rtfs_launch_status();
 }

@@ -278,9 +278,11 @@ struct ClStageArgs {  // y = act(gLN(x)) over rows x C, per-sample statistics
     size_t n = 0;               // elements per sample = rows per sample * C
     int C = 0, norm = 0, act = 0;
 };
+#define CL_DW_WGRAD_MAX_WG 2048
 struct ClDwArgs {
     const float *x = nullptr, *w = nullptr, *bias = nullptr, *dy = nullptr;
     float *y = nullptr, *dx = nullptr, *dw = nullptr;
+    float* scratch = nullptr;  // wgrad: CL_DW_WGRAD_MAX_WG x kh*kw x C per-workgroup partial sums
     int B = 0, H = 0, W = 0, C = 0, Ho = 0, Wo = 0, kh = 0, kw = 0, s = 1, pt = 0, pl = 0;
 };
 int launch_cl_norm_act_fwd(const ClStageArgs& a, int B, hipStream_t st);
@@ -297,7 +299,7 @@ struct LngArgs {  // PReLU + LayerNormalization4D((C_group, 64)) over rows (b,t,
     const float* dY = nullptr;     // backward
     float* dZ = nullptr;
     float *dgamma = nullptr, *dbeta = nullptr, *dslope = nullptr;      // (CZ,64), (CZ,64), (ngroups)
-    int CZ = 0, ngroups = 0;
+    int CZ = 0, ngroups = 0, nbt = 0;
     int gstart[17] = {0};
     unsigned char gof[128] = {0};  // channel -> group, 255 = padding channel
 };
