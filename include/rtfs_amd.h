@@ -202,6 +202,19 @@ int rtfs_tfar_combine_f32(const float* local, const float* gate, const float* gl
                           void* stream);
 int rtfs_tfar_combine_backward_f32(const float* dout, const float* local, const float* gate, float* dlocal, float* dgate, float* dglob,
                                    int N, int H, int W, int Hg, int Wg, void* stream);
+/* Training side of STFTEncoder / STFTDecoder / the S^3 multiply.
+ * Encoder (encoder.py:161-175): the waveform is data, so only the Conv2d(2->256, 3x3) weight has a gradient: dw (256,2,3,3) from
+ *   wav (B,L) and da0 (B,256,T,129).
+ * Decoder (decoder.py:110-132): dwav (B,L) -> dx (B,256,T,129) and dw (256,2,3,3) (ConvTranspose2d weight as stored): the adjoint of
+ *   torch.istft (window, overlap-add envelope, crop) followed by the adjoint of the transposed convolution.
+ * S^3 (mask_generator.py:71-82): complex multiply of [re 128 | im 128]-split maps (B,256,P); conj_first selects conj(a) (x) b, which is
+ *   the adjoint with respect to either factor. */
+size_t rtfs_stft_encoder_backward_workspace_bytes(int B, int L);
+int rtfs_stft_encoder_backward_f32(const float* wav, const float* da0, float* dw, int B, int L, void* ws, size_t ws_bytes, void* stream);
+size_t rtfs_istft_decoder_backward_workspace_bytes(int B, int T);
+int rtfs_istft_decoder_backward_f32(const float* x, const float* w, const float* dwav, float* dx, float* dw, int B, int T, int L, void* ws,
+                                    size_t ws_bytes, void* stream);
+int rtfs_s3_cmul_f32(const float* a, const float* b, float* out, int B, int P, int conj_first, void* stream);
 /* The two GEMM forms of the training path (bf16x3 split on the matrix cores), exposed for tests:
  * kind 0: C (M,N) = A (M,K) . B (N,K)^T (accumulate != 0: C += ...), N % 64 == 0, K % 16 == 0;
  * kind 1: C (M,N) += A (K,M)^T . B (K,N), M % 64 == 0, N % 64 == 0. */

@@ -201,3 +201,38 @@ def rtfs_block_torch(x, p):
     xf1 = injection_multi_sum_torch(d1, g, _sub(p, "fusion_layers.1"))
     expanded = injection_multi_sum_torch(xf0, xf1, _sub(p, "concat_layers.0")) + d0
     return _cna(expanded, _sub(p, "residual_conv")) + residual
+
+
+def stft_encoder_torch(wav, w):
+    """STFTEncoder.forward (reference TDAVNet/encoder.py:161-175): torch.stft -> (B,2,T,F) -> Conv2d 3x3 'same', no bias."""
+    import torch.nn.functional as F
+    win = torch.hann_window(256, dtype=wav.dtype)
+    spec = torch.stft(wav, n_fft=256, hop_length=128, window=win, return_complex=True)  # (B, F, T)
+    x = torch.stack([spec.real, spec.imag], 1).transpose(2, 3).contiguous()
+    return F.conv2d(x, w, padding=1)
+
+
+def stft_decoder_torch(x, w, length):
+    """STFTDecoder.forward (reference TDAVNet/decoder.py:110-132): ConvTranspose2d 256->2 3x3 pad 1 -> complex -> istft."""
+    import torch.nn.functional as F
+    y = F.conv_transpose2d(x, w, padding=1)  # (B, 2, T, F)
+    spec = torch.complex(y[:, 0], y[:, 1]).transpose(1, 2)
+    win = torch.hann_window(256, dtype=x.dtype)
+    return torch.istft(spec, n_fft=256, hop_length=128, window=win, length=length).unsqueeze(1)
+
+
+def s3_torch(refined, a0, p):
+    """MaskGenerator.forward + apply_masks (reference TDAVNet/mask_generator.py:67-99), RI_split, n_src 1."""
+    import torch.nn.functional as F
+    m = F.relu(F.conv2d(F.prelu(refined, p["mask_generator.0.weight"]), p["mask_generator.1.full_layer.2.weight"],
+                        p["mask_generator.1.full_layer.2.bias"]))
+    mr, mi, er, ei = m[:, :128], m[:, 128:], a0[:, :128], a0[:, 128:]
+    return torch.cat([er * mr - ei * mi, er * mi + ei * mr], 1).unsqueeze(1)
+
+
+def audio_chain_torch(wav, p):
+    """encoder -> audio bottleneck -> S^3 (on the bottleneck output) -> decoder: the separator without its refinement module."""
+    a0 = stft_encoder_torch(wav, p["encoder.conv.full_layer.2.weight"])
+    a1 = conv_norm_act_torch(a0, _sub(p, "audio_bottleneck"), (256, 256, 1, 1, 0, 1, 1, 0, 0, 1, 1))
+    s = s3_torch(a1, a0, _sub(p, "mask_generator"))
+    return stft_decoder_torch(s[:, 0], p["decoder.decoder.weight"], wav.shape[-1])

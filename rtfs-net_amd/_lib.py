@@ -76,6 +76,11 @@ SIGNATURES = {
     "rtfs_adaptive_avg_pool2d_backward_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
     "rtfs_tfar_combine_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "rtfs_tfar_combine_backward_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "rtfs_stft_encoder_backward_workspace_bytes": (_z, [_i, _i]),
+    "rtfs_stft_encoder_backward_f32": (_i, [_p, _p, _p, _i, _i, _p, _z, _p]),
+    "rtfs_istft_decoder_backward_workspace_bytes": (_z, [_i, _i]),
+    "rtfs_istft_decoder_backward_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p, _z, _p]),
+    "rtfs_s3_cmul_f32": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "rtfs_debug_gemm_f32": (_i, [_i, _p, _p, _p, _i, _i, _i, _i, _p]),
     "rtfs_debug_sweep_stamps": (_i, [_p, _p, _p, _i, _i, _i, _p, _p]),
     "rtfs_selftest_mfma_f16": (_i, [_p, _p, _p, _p]),

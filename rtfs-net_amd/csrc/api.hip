@@ -1500,6 +1500,69 @@ int rtfs_tfar_combine_backward_f32(const float* dout, const float* local, const 
     return launch_tfar_combine_bwd(dout, local, gate, dlocal, dgate, dglob, (size_t)N, H, W, Hg, Wg, S(stream));
 }
 
+// ------------------------------------------------------------ encoder / decoder / S^3, training side
+namespace {
+// dW (256, 18) = big (B,256,T,F)^T . patches(z (B,2,T,F)); ws needs rows_big (R x 256) + patch rows (R x 64) + dw64 (256 x 64)
+int wgrad_3x3(const float* big, const float* z, float* dw, int B, int T, float* rows_big, float* prow, float* dw64, hipStream_t st) {
+    const size_t R = (size_t)B * T * NF;
+    CHECK(launch_transpose(big, rows_big, B, CA, T * NF, st));
+    CHECK(launch_patch3x3_rows(z, prow, B, T, NF, st));
+    if (hipMemsetAsync(dw64, 0, sizeof(float) * CA * 64, st) != hipSuccess) return RTFS_ERR_LAUNCH;
+    CHECK(launch_gemm_tn(rows_big, CA, prow, 64, dw64, 64, CA, 64, (long)R, st));
+    if (hipMemcpy2DAsync(dw, 18 * sizeof(float), dw64, 64 * sizeof(float), 18 * sizeof(float), CA, hipMemcpyDeviceToDevice, st) != hipSuccess)
+        return RTFS_ERR_LAUNCH;
+    return RTFS_OK;
+}
+size_t wgrad_3x3_floats(int B, int T) { return (size_t)B * T * NF * (CA + 64) + CA * 64 + 256; }
+}  // namespace
+
+size_t rtfs_stft_encoder_backward_workspace_bytes(int B, int L) {
+    const int T = rtfs_num_frames(L);
+    return ((size_t)B * 2 * T * NF + wgrad_3x3_floats(B, T)) * sizeof(float) + 8 * 256;
+}
+int rtfs_stft_encoder_backward_f32(const float* wav, const float* da0, float* dw, int B, int L, void* ws, size_t ws_bytes, void* stream) {
+    RTFS_RETURN_IF(!wav || !da0 || !dw || B < 1 || L <= 128, RTFS_ERR_ARG);
+    RTFS_RETURN_IF(!ws || ws_bytes < rtfs_stft_encoder_backward_workspace_bytes(B, L), RTFS_ERR_WORKSPACE);
+    const int T = rtfs_num_frames(L);
+    Arena ar(ws, ws_bytes);
+    float* spec = ar.take<float>((size_t)B * 2 * T * NF);
+    float* rows = ar.take<float>((size_t)B * T * NF * CA);
+    float* prow = ar.take<float>((size_t)B * T * NF * 64);
+    float* dw64 = ar.take<float>(CA * 64);
+    RTFS_RETURN_IF(!ar.ok(), RTFS_ERR_WORKSPACE);
+    CHECK(launch_stft(wav, spec, B, L, T, S(stream)));
+    return wgrad_3x3(da0, spec, dw, B, T, rows, prow, dw64, S(stream));
+}
+
+size_t rtfs_istft_decoder_backward_workspace_bytes(int B, int T) {
+    return ((size_t)B * 2 * T * NF + wgrad_3x3_floats(B, T)) * sizeof(float) + 8 * 256;
+}
+// x (B,256,T,129) decoder input, w = ConvTranspose2d weight (256,2,3,3) as stored, dwav (B,L) -> dx (B,256,T,129), dw (256,2,3,3)
+int rtfs_istft_decoder_backward_f32(const float* x, const float* w, const float* dwav, float* dx, float* dw, int B, int T, int L, void* ws,
+                                    size_t ws_bytes, void* stream) {
+    RTFS_RETURN_IF(!x || !w || !dwav || !dx || !dw || B < 1 || T < 1 || L < 1, RTFS_ERR_ARG);
+    RTFS_RETURN_IF(L > 128 * T + 127, RTFS_ERR_SHAPE);
+    RTFS_RETURN_IF(!ws || ws_bytes < rtfs_istft_decoder_backward_workspace_bytes(B, T), RTFS_ERR_WORKSPACE);
+    Arena ar(ws, ws_bytes);
+    float* dspec = ar.take<float>((size_t)B * 2 * T * NF);
+    float* rows = ar.take<float>((size_t)B * T * NF * CA);
+    float* prow = ar.take<float>((size_t)B * T * NF * 64);
+    float* dw64 = ar.take<float>(CA * 64);
+    RTFS_RETURN_IF(!ar.ok(), RTFS_ERR_WORKSPACE);
+    hipStream_t st = S(stream);
+    CHECK(launch_istft_adjoint(dwav, dspec, B, T, L, st));
+    // the adjoint of ConvTranspose2d(256 -> 2, 3x3, pad 1) is Conv2d(2 -> 256, 3x3, pad 1) with the same weight tensor
+    CHECK(launch_enc_conv(dspec, w, dx, nullptr, B, CA, T, NF, (size_t)T * NF, (size_t)CA * T * NF, st));
+    return wgrad_3x3(x, dspec, dw, B, T, rows, prow, dw64, st);
+}
+
+// S^3: out = e (x) m on (B, [re 128 | im 128], P) maps (mask_generator.py:71-82); conj_first != 0 gives conj(a) (x) b, the adjoint
+// with respect to the other factor (dm = conj(e) (x) dout, de = conj(m) (x) dout)
+int rtfs_s3_cmul_f32(const float* a, const float* b, float* out, int B, int P, int conj_first, void* stream) {
+    RTFS_RETURN_IF(!a || !b || !out || B < 1 || P < 1, RTFS_ERR_ARG);
+    return launch_cmul(a, b, out, B, (size_t)128 * P, conj_first, S(stream));
+}
+
 // C = A . Bt^T (kind 0; accumulate adds to C) or C += A^T . B (kind 1): the two GEMM forms of the training path, exposed for tests
 int rtfs_debug_gemm_f32(int kind, const float* A, const float* B, float* C, int M, int N, int K, int accumulate, void* stream) {
     RTFS_RETURN_IF(!A || !B || !C, RTFS_ERR_ARG);

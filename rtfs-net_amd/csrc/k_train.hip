@@ -1116,3 +1116,91 @@ int launch_tfar_combine_bwd(const float* dout, const float* le, const float* gat
     hipLaunchKernelGGL(tfar_combine_bwd_kernel, dim3(grid_for(N * Hg * Wg)), dim3(256), 0, st, dout, le, gate, dle, dgate, dge, N, H, W, Hg, Wg);
     return rtfs_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------------ encoder / decoder / S^3 adjoints
+// 3x3 "same" patches of a 2-channel map as rows: rows[(b, t, f)][(c, ki, kj)] = z[b, c, t - 1 + ki, f - 1 + kj] (18 of 64 columns used).
+// Both the encoder's Conv2d(2 -> 256) (encoder.py:146-157) and the adjoint of the decoder's ConvTranspose2d(256 -> 2)
+// (decoder.py:96-106) have the weight gradient  dW (256, 18) = big_rows^T . patch_rows.
+__global__ __launch_bounds__(256) void patch3x3_rows_kernel(const float* __restrict__ z, float* __restrict__ rows, int B, int T, int F) {
+    const unsigned total = (unsigned)B * T * F * 64;
+    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int col = (int)(i & 63);
+        unsigned r = i >> 6;
+        const int f = (int)(r % (unsigned)F);
+        r /= (unsigned)F;
+        const int t = (int)(r % (unsigned)T), b = (int)(r / (unsigned)T);
+        float v = 0.f;
+        if (col < 18) {
+            const int c = col / 9, ki = (col % 9) / 3, kj = col % 3;
+            const int tt = t - 1 + ki, ff = f - 1 + kj;
+            if (tt >= 0 && tt < T && ff >= 0 && ff < F) v = z[(((size_t)b * 2 + c) * T + tt) * F + ff];
+        }
+        rows[i] = v;
+    }
+}
+
+// adjoint of torch.istft(n_fft 256, hop 128, periodic Hann, center, length L) as used at decoder.py:122-128:
+// dwav (B, L) -> dspec (B, 2 = re|im, T, 129).  Frame t, sample m sits at padded position 128 t + m, output n = that - 128.
+__global__ __launch_bounds__(256) void istft_adjoint_kernel(const float* __restrict__ dwav, float* __restrict__ dspec, int T, int L) {
+    __shared__ float g[256], ct[256], sn[256];
+    const int t = blockIdx.x, b = blockIdx.y, m = threadIdx.x;
+    {
+        float s_, c_;
+        sincospif((float)m * (1.0f / 128.0f), &s_, &c_);
+        ct[m] = c_;
+        sn[m] = s_;
+        const float w = 0.5f - 0.5f * c_;
+        const int n = 128 * t + m - 128;
+        float v = 0.f;
+        if (n >= 0 && n < L) {
+            // envelope: this frame plus the one overlapping it on this half
+            const int mo = m < 128 ? m + 128 : m - 128, to = m < 128 ? t - 1 : t + 1;
+            float env = w * w;
+            if (to >= 0 && to < T) {
+                const float wo = 0.5f - 0.5f * cospif((float)mo * (1.0f / 128.0f));
+                env = fmaf(wo, wo, env);
+            }
+            v = w * dwav[(size_t)b * L + n] / env;
+        }
+        g[m] = v;
+    }
+    __syncthreads();
+    if (m < 129) {
+        float re = 0.f, im = 0.f;
+        for (int j = 0; j < 256; ++j) {
+            const int k = (m * j) & 255;
+            re = fmaf(g[j], ct[k], re);
+            im = fmaf(g[j], sn[k], im);
+        }
+        const float c = (m == 0 || m == 128) ? 1.0f / 256.0f : 2.0f / 256.0f;
+        const size_t o = ((size_t)b * 2 * T + t) * 129 + m;
+        dspec[o] = c * re;
+        dspec[o + (size_t)T * 129] = (m == 0 || m == 128) ? 0.f : -c * im;
+    }
+}
+
+// complex multiply of (B, 2 x 128, P) maps split as [real 128 | imag 128] (mask_generator.py:71-82): out = a (x) b, or conj(a) (x) b
+__global__ __launch_bounds__(256) void cmul_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, size_t half,
+                                                   size_t total_half, int conj_a) {
+    // half = 128 * P elements per (sample, part); total_half = B * half
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total_half; i += (size_t)gridDim.x * 256) {
+        const size_t bidx = i / half, r = i - bidx * half, o = bidx * 2 * half + r;
+        const float ar = a[o], ai = conj_a ? -a[o + half] : a[o + half], br = b[o], bi = b[o + half];
+        out[o] = ar * br - ai * bi;
+        out[o + half] = ar * bi + ai * br;
+    }
+}
+
+int launch_patch3x3_rows(const float* z, float* rows, int B, int T, int F, hipStream_t st) {
+    if ((size_t)B * T * F * 64 >= 0x7fffffffu) return RTFS_ERR_SHAPE;
+    hipLaunchKernelGGL(patch3x3_rows_kernel, dim3(grid_for((size_t)B * T * F * 64)), dim3(256), 0, st, z, rows, B, T, F);
+    return rtfs_launch_status();
+}
+int launch_istft_adjoint(const float* dwav, float* dspec, int B, int T, int L, hipStream_t st) {
+    hipLaunchKernelGGL(istft_adjoint_kernel, dim3(T, B), dim3(256), 0, st, dwav, dspec, T, L);
+    return rtfs_launch_status();
+}
+int launch_cmul(const float* a, const float* b, float* out, int B, size_t half, int conj_a, hipStream_t st) {
+    hipLaunchKernelGGL(cmul_kernel, dim3(grid_for((size_t)B * half)), dim3(256), 0, st, a, b, out, half, (size_t)B * half, conj_a);
+    return rtfs_launch_status();
+}

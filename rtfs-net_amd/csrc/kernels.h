@@ -311,3 +311,6 @@ int launch_pool2d(const float* x, float* y, size_t N, int H, int W, int Ho, int 
 int launch_tfar_combine(const float* le, const float* gate, const float* ge, float* out, size_t N, int H, int W, int Hg, int Wg, hipStream_t st);
 int launch_tfar_combine_bwd(const float* dout, const float* le, const float* gate, float* dle, float* dgate, float* dge, size_t N, int H, int W,
                             int Hg, int Wg, hipStream_t st);
+int launch_patch3x3_rows(const float* z, float* rows, int B, int T, int F, hipStream_t st);
+int launch_istft_adjoint(const float* dwav, float* dspec, int B, int T, int L, hipStream_t st);
+int launch_cmul(const float* a, const float* b, float* out, int B, size_t half, int conj_a, hipStream_t st);

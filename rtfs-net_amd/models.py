@@ -20,6 +20,94 @@ from .layers import ConvNormAct, InjectionMultiSum, PackedModule, _config_of
 
 
 # ----------------------------------------------------------------------------- encoder / decoder
+def L_recording(*objs):
+    from .layers import _recording
+    return _recording(*[o for o in objs if o is not None])
+
+
+class _EncoderTrainFn(torch.autograd.Function):
+    """STFTEncoder inside a training step: the inference kernels forward, the Conv2d weight gradient backward (the waveform is data)."""
+
+    @staticmethod
+    def forward(ctx, wav, weight, pack):
+        lib = _lib.load()
+        B, L = wav.shape
+        T = lib.rtfs_num_frames(L)
+        a0 = torch.empty(B, 256, T, 129, device=wav.device, dtype=torch.float32)
+        ws = _lib.workspace(lib.rtfs_stft_encoder_workspace_bytes(B, L), wav.device)
+        _lib.check(lib.rtfs_stft_encoder_f32(_lib.ptr(wav), _lib.ptr(pack), _lib.ptr(a0), None, B, L, _lib.ptr(ws), ws.numel(),
+                                             _lib.stream_of(wav)), "rtfs_stft_encoder_f32")
+        ctx.save_for_backward(wav)
+        ctx.wshape = weight.shape
+        return a0
+
+    @staticmethod
+    def backward(ctx, da0):
+        lib = _lib.load()
+        (wav,) = ctx.saved_tensors
+        B, L = wav.shape
+        da0 = da0.contiguous()
+        dw = torch.empty(256 * 18, device=wav.device, dtype=torch.float32)
+        ws = _lib.workspace(lib.rtfs_stft_encoder_backward_workspace_bytes(B, L), wav.device)
+        _lib.check(lib.rtfs_stft_encoder_backward_f32(_lib.ptr(wav), _lib.ptr(da0), _lib.ptr(dw), B, L, _lib.ptr(ws), ws.numel(),
+                                                      _lib.stream_of(wav)), "rtfs_stft_encoder_backward_f32")
+        return None, dw.reshape(ctx.wshape), None
+
+
+class _DecoderTrainFn(torch.autograd.Function):
+    """STFTDecoder inside a training step: inference kernels forward; iSTFT adjoint + ConvTranspose2d adjoints backward."""
+
+    @staticmethod
+    def forward(ctx, x, weight, pack, length):
+        lib = _lib.load()
+        B, _, T, _ = x.shape
+        wav = torch.empty(B, 1, length, device=x.device, dtype=torch.float32)
+        ws = _lib.workspace(lib.rtfs_istft_decoder_workspace_bytes(B, T), x.device)
+        _lib.check(lib.rtfs_istft_decoder_f32(_lib.ptr(x), _lib.ptr(pack), _lib.ptr(wav), B, T, length, _lib.ptr(ws), ws.numel(),
+                                              _lib.stream_of(x)), "rtfs_istft_decoder_f32")
+        ctx.save_for_backward(x, weight)
+        ctx.length = length
+        return wav
+
+    @staticmethod
+    def backward(ctx, dwav):
+        lib = _lib.load()
+        x, weight = ctx.saved_tensors
+        B, _, T, _ = x.shape
+        dwav = dwav.contiguous().to(torch.float32)
+        dx = torch.empty_like(x)
+        dw = torch.empty(256 * 18, device=x.device, dtype=torch.float32)
+        w = weight.detach().contiguous()
+        ws = _lib.workspace(lib.rtfs_istft_decoder_backward_workspace_bytes(B, T), x.device)
+        _lib.check(lib.rtfs_istft_decoder_backward_f32(_lib.ptr(x), _lib.ptr(w), _lib.ptr(dwav), _lib.ptr(dx), _lib.ptr(dw), B, T, ctx.length,
+                                                       _lib.ptr(ws), ws.numel(), _lib.stream_of(x)), "rtfs_istft_decoder_backward_f32")
+        return dx, dw.reshape(weight.shape), None, None
+
+
+class _S3MulFn(torch.autograd.Function):
+    """masks (B,256,T,F) x encoder output (B,256,T,F), both [re 128 | im 128]: complex product and its two adjoints."""
+
+    @staticmethod
+    def _cmul(a, b, conj):
+        lib = _lib.load()
+        out = torch.empty_like(a)
+        B, P = a.shape[0], a.shape[2] * a.shape[3]
+        _lib.check(lib.rtfs_s3_cmul_f32(_lib.ptr(a), _lib.ptr(b), _lib.ptr(out), B, P, conj, _lib.stream_of(a)), "rtfs_s3_cmul_f32")
+        return out
+
+    @staticmethod
+    def forward(ctx, masks, emb):
+        masks, emb = masks.contiguous(), emb.contiguous()
+        ctx.save_for_backward(masks, emb)
+        return _S3MulFn._cmul(emb, masks, 0)
+
+    @staticmethod
+    def backward(ctx, dout):
+        masks, emb = ctx.saved_tensors
+        dout = dout.contiguous()
+        return _S3MulFn._cmul(emb, dout, 1), _S3MulFn._cmul(masks, dout, 1)
+
+
 class STFTEncoder(PackedModule):
     """reference TDAVNet/encoder.py:122-175."""
 
@@ -50,6 +138,10 @@ class STFTEncoder(PackedModule):
 
     def forward(self, x, return_stats=False):
         x = self.unsqueeze_to_2D(x)
+        if x.is_cuda and L_recording(self):
+            _lib.need_gpu(x)
+            a0 = _EncoderTrainFn.apply(x.contiguous(), self.conv.full_layer[2].weight, self.pack())
+            return (a0, None) if return_stats else a0
         self._guard(x)
         lib = _lib.load()
         x = x.contiguous()
@@ -82,13 +174,16 @@ class STFTDecoder(PackedModule):
         self.register_buffer("window", torch.hann_window(win), False)
 
     def forward(self, x, input_shape):
-        self._guard(x)
-        lib = _lib.load()
         batch, length = int(input_shape[0]), int(input_shape[-1])
         T = x.shape[-2]
-        x = x.contiguous().view(batch * self.n_src, self.in_chan, T, x.shape[-1])
         if x.shape[-1] != 129:
             raise ValueError("expected 129 frequency bins")
+        if x.is_cuda and L_recording(x, self):
+            _lib.need_gpu(x)
+            return _DecoderTrainFn.apply(x.contiguous().view(batch * self.n_src, self.in_chan, T, 129), self.decoder.weight, self.pack(), length)
+        self._guard(x)
+        lib = _lib.load()
+        x = x.contiguous().view(batch * self.n_src, self.in_chan, T, x.shape[-1])
         wav = torch.empty(batch, self.n_src, length, device=x.device, dtype=torch.float32)
         ws = _lib.workspace(lib.rtfs_istft_decoder_workspace_bytes(batch, T), x.device)
         _lib.check(lib.rtfs_istft_decoder_f32(_lib.ptr(x), _lib.ptr(self.pack()), _lib.ptr(wav), batch, T, length, _lib.ptr(ws), ws.numel(),
@@ -105,6 +200,8 @@ class AudioBottleneck(ConvNormAct, PackedModule):
     _pack_fn = staticmethod(packing.pack_audio_bn)
 
     def forward(self, x, stats=None):
+        if x.is_cuda and L_recording(x, self):
+            return self._forward_train(x)  # ConvNormAct's training kernels
         self._guard(x)
         if not (self.in_chan == 256 and self.out_chan == 256 and self.kernel_size == 1 and self.pre_norm_type == "gLN"
                 and self.pre_act_type == "ReLU" and not self.norm_type and not self.act_type and self.bias):
@@ -120,11 +217,6 @@ class AudioBottleneck(ConvNormAct, PackedModule):
 
 
 # ----------------------------------------------------------------------------- RTFS block
-def L_recording(*objs):
-    from .layers import _recording
-    return _recording(*[o for o in objs if o is not None])
-
-
 class TDANetBlock(PackedModule):
     """RTFS block (2-D) / VP block (1-D): reference separators/tdanet.py:8-131."""
 
@@ -369,6 +461,14 @@ class MaskGenerator(PackedModule):
         self.mask_generator = nn.Sequential(nn.PReLU(), ConvNormAct(bottleneck_chan, n_src * audio_emb_dim, kernel_size, act_type=mask_act, is2d=is2d))
 
     def forward(self, refined_features, audio_mixture_embedding):
+        if refined_features.is_cuda and L_recording(refined_features, audio_mixture_embedding, self):
+            from .layers import _CNATrainFn
+            prelu, cna = self.mask_generator
+            conv = cna.full_layer[2]
+            # PReLU -> 1x1 conv -> ReLU as one ConvNormAct whose pre-activation is the stand-alone nn.PReLU (mask_generator.py:52-58)
+            masks = _CNATrainFn.apply(refined_features, (256, 256, 1, 1, 0, 0, 2, 0, 1, 1, 1), None, None, prelu.weight, conv.weight, conv.bias,
+                                      None, None, None)
+            return _S3MulFn.apply(masks, audio_mixture_embedding).unsqueeze(1)
         self._guard(refined_features, audio_mixture_embedding)
         lib = _lib.load()
         r, a0 = refined_features.contiguous(), audio_mixture_embedding.contiguous()
