@@ -163,12 +163,13 @@ int rtfs_dualpath_forward_train_f32(const float* x, const float* tpack, float* o
 int rtfs_dualpath_backward_f32(const float* x, const float* tpack, const float* saved, const float* dout, float* dx,
                                float* dparams, int B, int T, int F, int dim, void* ws, size_t ws_bytes, void* stream);
 /* ConvNormAct.forward / backward for training (src/models/layers/conv_layers.py:65-129: pre_norm -> pre_act -> conv -> norm -> act),
- * 1x1 dense or depthwise k x k (k <= 4, stride 1 "same" or stride 2 symmetric), norms: none | gLN, acts: none | ReLU | PReLU | Sigmoid.
- * cfg (HOST int[11]): Cin, Cout, k, stride, depthwise, pre_norm (0/1), pre_act (0 none, 1 ReLU, 2 PReLU, 3 Sigmoid), norm, act,
- *   has_bias, is2d.  x (B,Cin,H,W) -> out (B,Cout,Ho,Wo) (rtfs_cna_out_shape).
+ * 1x1 dense (channels up to 1024) or depthwise k x k (taps up to 4 x 5, stride 1 "same" or stride 2 symmetric), norms: none | gLN |
+ * BatchNorm with frozen running statistics (post-norm only), acts: none | ReLU | PReLU | Sigmoid.
+ * cfg (HOST int[11]): Cin, Cout, k, stride, depthwise, pre_norm (0/1), pre_act (0 none, 1 ReLU, 2 PReLU, 3 Sigmoid), norm (0 none, 1 gLN,
+ *   2 frozen BatchNorm), act, has_bias, is2d.  x (B,Cin,H,W) -> out (B,Cout,Ho,Wo) (rtfs_cna_out_shape).
  * params (rtfs_cna_param_floats, packing.py:pack_cna_train; every slot padded to 64 floats, unused slots ignored):
- *   pre gamma | pre beta | pre slope | W (Cout,Cin) or (C,kh*kw) | W^T (dense only) | bias | gamma | beta | slope.
- * dparams (rtfs_cna_grad_floats, overwritten): the same slots without W^T. */
+ *   pre gamma | pre beta | pre slope | W (Cout,Cin) or (C,kh*kw) | W^T (dense only) | bias | gamma | beta | slope | running mean | running var.
+ * dparams (rtfs_cna_grad_floats, overwritten): the slots pre gamma ... slope without W^T. */
 size_t rtfs_cna_param_floats(const int* cfg);
 size_t rtfs_cna_grad_floats(const int* cfg);
 size_t rtfs_cna_saved_floats(const int* cfg, int B, int H, int W);
@@ -215,6 +216,16 @@ size_t rtfs_istft_decoder_backward_workspace_bytes(int B, int T);
 int rtfs_istft_decoder_backward_f32(const float* x, const float* w, const float* dwav, float* dx, float* dw, int B, int T, int L, void* ws,
                                     size_t ws_bytes, void* stream);
 int rtfs_s3_cmul_f32(const float* a, const float* b, float* out, int B, int P, int conj_first, void* stream);
+/* Glue of ATTNFusionCell.forward (layers/fusion.py:252-274) with its adjoints (training side).
+ * attention: att_embed (B, 4C, Tv) -> reshape (B, C, 4, Tv) -> mean over the 4 -> softmax over Tv -> att (B, C, Tv).
+ * combine: fused = key * up(resized) + up(att) * value with key/value/fused (N = B*C, T, F), resized/att (N, Tv), up = nearest
+ * interpolation over time broadcast over F; the backward returns all four gradients. */
+int rtfs_caf_attention_f32(const float* att_embed, float* att, int B, int C, int Tv, void* stream);
+int rtfs_caf_attention_backward_f32(const float* att, const float* datt, float* datt_embed, int B, int C, int Tv, void* stream);
+int rtfs_caf_combine_f32(const float* key, const float* value, const float* resized, const float* att, float* out, int N, int T, int F,
+                         int Tv, void* stream);
+int rtfs_caf_combine_backward_f32(const float* dout, const float* key, const float* value, const float* resized, const float* att,
+                                  float* dkey, float* dvalue, float* dresized, float* datt, int N, int T, int F, int Tv, void* stream);
 /* The two GEMM forms of the training path (bf16x3 split on the matrix cores), exposed for tests:
  * kind 0: C (M,N) = A (M,K) . B (N,K)^T (accumulate != 0: C += ...), N % 64 == 0, K % 16 == 0;
  * kind 1: C (M,N) += A (K,M)^T . B (K,N), M % 64 == 0, N % 64 == 0. */

@@ -236,3 +236,27 @@ def audio_chain_torch(wav, p):
     a1 = conv_norm_act_torch(a0, _sub(p, "audio_bottleneck"), (256, 256, 1, 1, 0, 1, 1, 0, 0, 1, 1))
     s = s3_torch(a1, a0, _sub(p, "mask_generator"))
     return stft_decoder_torch(s[:, 0], p["decoder.decoder.weight"], wav.shape[-1])
+
+
+def caf_torch(a, v, p):
+    """ATTNFusionCell.forward (reference layers/fusion.py:252-274), is2d, kernel_size 4, BatchNorm in eval mode (running stats).
+    a (B,256,T,F), v (B,512,Tv); p = the cell's state_dict (running statistics included, treated as constants)."""
+    import torch.nn.functional as F
+    B, C, T, _ = a.shape
+
+    def video_conv(pre):
+        w = p[pre + ".full_layer.2.weight"]
+        y = F.conv1d(v, w, p[pre + ".full_layer.2.bias"], groups=C)
+        return F.group_norm(y, 1, p[pre + ".full_layer.3.norm.weight"], p[pre + ".full_layer.3.norm.bias"], 1e-5)
+
+    def audio_conv(pre, relu):
+        y = F.conv2d(a, p[pre + ".full_layer.2.weight"], None, groups=C)
+        y = F.batch_norm(y, p[pre + ".full_layer.3.running_mean"].detach(), p[pre + ".full_layer.3.running_var"].detach(),
+                         p[pre + ".full_layer.3.weight"], p[pre + ".full_layer.3.bias"], False, 0.0, 1e-5)
+        return torch.relu(y) if relu else y
+    b_t = F.interpolate(video_conv("resize"), size=T, mode="nearest").unsqueeze(-1)
+    k1 = audio_conv("key_embed", True) * b_t
+    val = audio_conv("value_embed", False)
+    att = video_conv("attention_embed").reshape(B, C, 4, -1).mean(2)
+    att = F.interpolate(torch.softmax(att, -1), size=T, mode="nearest").unsqueeze(-1)
+    return k1 + att * val

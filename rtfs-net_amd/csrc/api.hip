@@ -1159,7 +1159,7 @@ struct CnaCfg {
     int kh, kw, pt, pl, H, W, Ho, Wo, B;
     size_t rows_in, rows_out;
     // parameter / gradient layout (floats)
-    size_t o_pg, o_pb, o_ps, o_w, o_wt, o_b, o_g, o_be, o_s, p_end;      // params
+    size_t o_pg, o_pb, o_ps, o_w, o_wt, o_b, o_g, o_be, o_s, o_rm, o_rv, p_end;  // params
     size_t g_pg, g_pb, g_ps, g_w, g_b, g_g, g_be, g_s, g_end;            // grads
     bool ok;
     CnaCfg(const int* c, int B_, int H_, int W_) {
@@ -1180,14 +1180,16 @@ struct CnaCfg {
         size_t o = 0;
         o_pg = o; o += pad64(Cin); o_pb = o; o += pad64(Cin); o_ps = o; o += 64;
         o_w = o; o += pad64(wn); o_wt = o; o += depthwise ? 0 : pad64(wn);
-        o_b = o; o += pad64(Cout); o_g = o; o += pad64(Cout); o_be = o; o += pad64(Cout); o_s = o; o += 64; p_end = o;
+        o_b = o; o += pad64(Cout); o_g = o; o += pad64(Cout); o_be = o; o += pad64(Cout); o_s = o; o += 64;
+        o_rm = o; o += pad64(Cout); o_rv = o; o += pad64(Cout); p_end = o;
         o = 0;
         g_pg = o; o += pad64(Cin); g_pb = o; o += pad64(Cin); g_ps = o; o += 64; g_w = o; o += pad64(wn);
         g_b = o; o += pad64(Cout); g_g = o; o += pad64(Cout); g_be = o; o += pad64(Cout); g_s = o; o += 64; g_end = o;
-        auto pow2 = [](int v) { return v >= 1 && v <= 256 && !(v & (v - 1)); };
-        ok = pow2(Cin) && pow2(Cout) && k >= 1 && kh * kw <= 16 && (stride == 1 || stride == 2) && Ho >= 1 && Wo >= 1 &&
+        auto pow2 = [](int v, int cap) { return v >= 1 && v <= cap && !(v & (v - 1)); };
+        ok = pow2(Cin, depthwise ? 256 : 1024) && pow2(Cout, depthwise ? 256 : 1024) && k >= 1 && kh <= 4 && kw <= 5 &&
+             (stride == 1 || stride == 2) && Ho >= 1 && Wo >= 1 &&
              (depthwise ? Cin == Cout : (k == 1 && stride == 1 && Cin % 16 == 0 && Cout % 64 == 0 && Cin % 64 == 0)) &&
-             pre_norm >= 0 && pre_norm <= 1 && norm >= 0 && norm <= 1 && pre_act >= 0 && pre_act <= 3 && act >= 0 && act <= 3 &&
+             pre_norm >= 0 && pre_norm <= 1 && norm >= 0 && norm <= 2 && pre_act >= 0 && pre_act <= 3 && act >= 0 && act <= 3 &&
              rows_in * (size_t)(Cin > Cout ? Cin : Cout) < 0x7fffffffu;
     }
     bool pre() const { return pre_norm || pre_act; }
@@ -1263,7 +1265,8 @@ int rtfs_cna_forward_train_f32(const float* x, const float* params, float* out, 
         ClStageArgs a;
         a.x = sv.r3; a.y = r5; a.n = n_out; a.C = c.Cout; a.norm = c.norm; a.act = c.act;
         a.gamma = params + c.o_g; a.beta = params + c.o_be; a.slope = params + c.o_s; a.stats = sv.st3;
-        if (c.norm) {
+        a.rmean = params + c.o_rm; a.rvar = params + c.o_rv;
+        if (c.norm == 1) {
             if (hipMemsetAsync(sv.st3, 0, sizeof(double) * 2 * B, st) != hipSuccess) return RTFS_ERR_LAUNCH;
             CHECK(launch_stats(sv.r3, sv.st3, B, n_out, st));
         }
@@ -1296,6 +1299,7 @@ int rtfs_cna_backward_f32(const float* params, const float* saved, const float* 
         ClStageArgs a;
         a.x = sv.r3; a.dy = d5; a.dx = d3b; a.n = n_out; a.C = c.Cout; a.norm = c.norm; a.act = c.act;
         a.gamma = params + c.o_g; a.beta = params + c.o_be; a.slope = params + c.o_s; a.stats = sv.st3; a.S = Sb;
+        a.rmean = params + c.o_rm; a.rvar = params + c.o_rv;
         a.dgamma = dparams + c.g_g; a.dbeta = dparams + c.g_be; a.dslope = dparams + c.g_s;
         CHECK(launch_cl_norm_act_bwd(a, B, st));
         d3 = d3b;
@@ -1561,6 +1565,26 @@ int rtfs_istft_decoder_backward_f32(const float* x, const float* w, const float*
 int rtfs_s3_cmul_f32(const float* a, const float* b, float* out, int B, int P, int conj_first, void* stream) {
     RTFS_RETURN_IF(!a || !b || !out || B < 1 || P < 1, RTFS_ERR_ARG);
     return launch_cmul(a, b, out, B, (size_t)128 * P, conj_first, S(stream));
+}
+
+// ------------------------------------------------------------ CAF glue with adjoints
+int rtfs_caf_attention_f32(const float* att_embed, float* att, int B, int C, int Tv, void* stream) {
+    RTFS_RETURN_IF(!att_embed || !att || B < 1 || C < 1, RTFS_ERR_ARG);
+    return launch_caf_att(att_embed, att, nullptr, nullptr, B * C, Tv, false, S(stream));
+}
+int rtfs_caf_attention_backward_f32(const float* att, const float* datt, float* datt_embed, int B, int C, int Tv, void* stream) {
+    RTFS_RETURN_IF(!att || !datt || !datt_embed || B < 1 || C < 1, RTFS_ERR_ARG);
+    return launch_caf_att(nullptr, const_cast<float*>(att), datt, datt_embed, B * C, Tv, true, S(stream));
+}
+int rtfs_caf_combine_f32(const float* key, const float* value, const float* resized, const float* att, float* out, int N, int T, int F, int Tv,
+                         void* stream) {
+    RTFS_RETURN_IF(!key || !value || !resized || !att || !out || N < 1, RTFS_ERR_ARG);
+    return launch_caf_combine(key, value, resized, att, out, (size_t)N, T, F, Tv, S(stream));
+}
+int rtfs_caf_combine_backward_f32(const float* dout, const float* key, const float* value, const float* resized, const float* att, float* dkey,
+                                  float* dvalue, float* dresized, float* datt, int N, int T, int F, int Tv, void* stream) {
+    RTFS_RETURN_IF(!dout || !key || !value || !resized || !att || !dkey || !dvalue || !dresized || !datt || N < 1, RTFS_ERR_ARG);
+    return launch_caf_combine_bwd(dout, key, value, resized, att, dkey, dvalue, dresized, datt, (size_t)N, T, F, Tv, S(stream));
 }
 
 // C = A . Bt^T (kind 0; accumulate adds to C) or C += A^T . B (kind 1): the two GEMM forms of the training path, exposed for tests

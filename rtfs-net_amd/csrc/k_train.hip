@@ -536,32 +536,44 @@ __device__ __forceinline__ float act_bwd(float z, float dy, int act, float slope
 }
 }  // namespace
 
-// grid (chunks, B): each workgroup a contiguous chunk of one sample's n = rows*C elements
+// grid (chunks, B): each workgroup a strided share of one sample's n = rows*C elements.
+// norm: 0 none, 1 gLN (per-sample statistics), 2 BatchNorm with frozen running statistics (per-channel mean / variance; the
+// eval-mode arithmetic of conv_layers.py's BatchNorm stages, used when a model is fine-tuned with its BN layers in eval mode).
+namespace {
+__device__ __forceinline__ void norm_of(const ClStageArgs& a, int b, int c, float& mean, float& rstd) {
+    if (a.norm == 2) {
+        mean = a.rmean[c];
+        rstd = 1.0f / sqrtf(a.rvar[c] + RTFS_EPS);
+    }
+}
+}  // namespace
 __global__ __launch_bounds__(256) void cl_norm_act_fwd_kernel(ClStageArgs a) {
     const int b = blockIdx.y;
     float mean = 0.f, rstd = 1.f;
-    if (a.norm) stats_of(a.stats, b, 1.0 / (double)a.n, mean, rstd);
+    if (a.norm == 1) stats_of(a.stats, b, 1.0 / (double)a.n, mean, rstd);
     const float slope = a.act == 2 ? a.slope[0] : 0.f;
     const size_t base = (size_t)b * a.n;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (size_t)gridDim.x * 256) {
         const int c = (int)(i & (a.C - 1));
         float z = a.x[base + i];
+        norm_of(a, b, c, mean, rstd);
         if (a.norm) z = fmaf((z - mean) * rstd, a.gamma[c], a.beta[c]);
         a.y[base + i] = act_fwd(z, a.act, slope);
     }
 }
 
-// reductions of the stage's backward: per sample S1 = sum da*gamma, S2 = sum da*gamma*xhat (f64 atomics into S[2b..]);
-// per channel dgamma += sum da*xhat, dbeta += sum da; dslope
+// reductions of the stage's backward: per sample S1 = sum da*gamma, S2 = sum da*gamma*xhat (f64 atomics into S[2b..], gLN only);
+// per channel dgamma += sum da*xhat, dbeta += sum da; dslope.  The grid stride is a multiple of C, so a thread keeps one channel.
 __global__ __launch_bounds__(256) void cl_norm_act_bwd_reduce_kernel(ClStageArgs a) {
     __shared__ double red[16];
     __shared__ float part[3][256];
     const int b = blockIdx.y, tid = threadIdx.x;
     float mean = 0.f, rstd = 1.f;
-    if (a.norm) stats_of(a.stats, b, 1.0 / (double)a.n, mean, rstd);
+    if (a.norm == 1) stats_of(a.stats, b, 1.0 / (double)a.n, mean, rstd);
     const float slope = a.act == 2 ? a.slope[0] : 0.f;
     const size_t base = (size_t)b * a.n;
-    const int c = tid & (a.C - 1);  // fixed per thread: the stride below is a multiple of C (C <= 256, power of two)
+    const int c = (int)(((size_t)blockIdx.x * 256 + tid) & (a.C - 1));
+    norm_of(a, b, c, mean, rstd);
     const float g = a.norm ? a.gamma[c] : 1.f, be = a.norm ? a.beta[c] : 0.f;
     float s1 = 0.f, s2 = 0.f, dg = 0.f, db = 0.f, dsl = 0.f;
     for (size_t i = (size_t)blockIdx.x * 256 + tid; i < a.n; i += (size_t)gridDim.x * 256) {
@@ -574,21 +586,24 @@ __global__ __launch_bounds__(256) void cl_norm_act_bwd_reduce_kernel(ClStageArgs
         s1 = fmaf(da, g, s1);
         s2 = fmaf(da * g, xh, s2);
     }
-    if (a.norm) {
-        block_stats_atomic_pair(s1, s2, red, a.S + 2 * b);
-        part[0][tid] = dg;
-        part[1][tid] = db;
-    }
+    if (a.norm == 1) block_stats_atomic_pair(s1, s2, red, a.S + 2 * b);
+    part[0][tid] = dg;
+    part[1][tid] = db;
     part[2][tid] = dsl;
     __syncthreads();
-    if (a.norm && tid < a.C) {
-        float sg = 0.f, sb = 0.f;
-        for (int j = tid; j < 256; j += a.C) {
-            sg += part[0][j];
-            sb += part[1][j];
+    if (a.norm) {
+        if (a.C >= 256) {  // every thread of the workgroup has its own channel
+            unsafeAtomicAdd(a.dgamma + c, dg);
+            unsafeAtomicAdd(a.dbeta + c, db);
+        } else if (tid < a.C) {
+            float sg = 0.f, sb = 0.f;
+            for (int j = tid; j < 256; j += a.C) {
+                sg += part[0][j];
+                sb += part[1][j];
+            }
+            unsafeAtomicAdd(a.dgamma + tid, sg);
+            unsafeAtomicAdd(a.dbeta + tid, sb);
         }
-        unsafeAtomicAdd(a.dgamma + tid, sg);
-        unsafeAtomicAdd(a.dbeta + tid, sb);
     }
     if (a.act == 2 && tid < 64) {
         float v = part[2][tid] + part[2][tid + 64] + part[2][tid + 128] + part[2][tid + 192];
@@ -600,7 +615,7 @@ __global__ __launch_bounds__(256) void cl_norm_act_bwd_reduce_kernel(ClStageArgs
 __global__ __launch_bounds__(256) void cl_norm_act_bwd_apply_kernel(ClStageArgs a) {
     const int b = blockIdx.y;
     float mean = 0.f, rstd = 1.f, m1 = 0.f, m2 = 0.f;
-    if (a.norm) {
+    if (a.norm == 1) {
         stats_of(a.stats, b, 1.0 / (double)a.n, mean, rstd);
         m1 = (float)(a.S[2 * b] / (double)a.n);
         m2 = (float)(a.S[2 * b + 1] / (double)a.n);
@@ -611,20 +626,25 @@ __global__ __launch_bounds__(256) void cl_norm_act_bwd_apply_kernel(ClStageArgs 
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (size_t)gridDim.x * 256) {
         const int c = (int)(i & (a.C - 1));
         const float xv = a.x[base + i];
+        norm_of(a, b, c, mean, rstd);
         const float g = a.norm ? a.gamma[c] : 1.f;
         const float xh = a.norm ? (xv - mean) * rstd : xv;
         const float z = a.norm ? fmaf(xh, g, a.beta[c]) : xv;
         const float da = act_bwd(z, a.dy[base + i], a.act, slope, dummy);
-        a.dx[base + i] = a.norm ? rstd * (da * g - m1 - xh * m2) : da;
+        a.dx[base + i] = a.norm == 1 ? rstd * (da * g - m1 - xh * m2) : (a.norm == 2 ? da * g * rstd : da);
     }
 }
 
-// out[c] += sum over rows of d[row][c]   (bias gradients)
+// out[c] += sum over rows of d[row][c]   (bias gradients); grid stride a multiple of C
 __global__ __launch_bounds__(256) void cl_colsum_kernel(const float* __restrict__ d, float* __restrict__ out, size_t n, int C) {
     __shared__ float part[256];
     const int tid = threadIdx.x;
     float s = 0.f;
     for (size_t i = (size_t)blockIdx.x * 256 + tid; i < n; i += (size_t)gridDim.x * 256) s += d[i];
+    if (C >= 256) {
+        unsafeAtomicAdd(out + (((size_t)blockIdx.x * 256 + tid) & (C - 1)), s);
+        return;
+    }
     part[tid] = s;
     __syncthreads();
     if (tid < C) {
@@ -749,23 +769,27 @@ inline unsigned grid_for(size_t n, unsigned cap = 8192) {
 }
 }  // namespace
 
+namespace {
+inline bool cl_c_ok(int C) { return C >= 1 && C <= 1024 && !(C & (C - 1)); }
+inline unsigned grid4(size_t n, unsigned cap) { return (grid_for(n, cap) + 3) / 4 * 4; }  // stride (grid * 256) % C == 0 for C <= 1024
+}  // namespace
 int launch_cl_norm_act_fwd(const ClStageArgs& a, int B, hipStream_t st) {
-    if (a.C < 1 || a.C > 256 || (a.C & (a.C - 1))) return RTFS_ERR_SHAPE;
+    if (!cl_c_ok(a.C)) return RTFS_ERR_SHAPE;
     hipLaunchKernelGGL(cl_norm_act_fwd_kernel, dim3(grid_for(a.n, 2048), B), dim3(256), 0, st, a);
     return rtfs_launch_status();
 }
 int launch_cl_norm_act_bwd(const ClStageArgs& a, int B, hipStream_t st) {
-    if (a.C < 1 || a.C > 256 || (a.C & (a.C - 1))) return RTFS_ERR_SHAPE;
+    if (!cl_c_ok(a.C)) return RTFS_ERR_SHAPE;
     if (a.norm || a.act == 2) {
-        if (a.norm && hipMemsetAsync(a.S, 0, sizeof(double) * 2 * B, st) != hipSuccess) return RTFS_ERR_LAUNCH;
-        hipLaunchKernelGGL(cl_norm_act_bwd_reduce_kernel, dim3(grid_for(a.n, 256), B), dim3(256), 0, st, a);
+        if (a.norm == 1 && hipMemsetAsync(a.S, 0, sizeof(double) * 2 * B, st) != hipSuccess) return RTFS_ERR_LAUNCH;
+        hipLaunchKernelGGL(cl_norm_act_bwd_reduce_kernel, dim3(grid4(a.n, 256), B), dim3(256), 0, st, a);
     }
     hipLaunchKernelGGL(cl_norm_act_bwd_apply_kernel, dim3(grid_for(a.n, 2048), B), dim3(256), 0, st, a);
     return rtfs_launch_status();
 }
 int launch_cl_colsum(const float* d, float* out, size_t n, int C, hipStream_t st) {
-    if (C < 1 || C > 256 || (C & (C - 1))) return RTFS_ERR_SHAPE;
-    hipLaunchKernelGGL(cl_colsum_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, st, d, out, n, C);
+    if (!cl_c_ok(C)) return RTFS_ERR_SHAPE;
+    hipLaunchKernelGGL(cl_colsum_kernel, dim3(grid4(n, 1024)), dim3(256), 0, st, d, out, n, C);
     return rtfs_launch_status();
 }
 int launch_cl_dw(const ClDwArgs& a, int what, hipStream_t st) {
@@ -1202,5 +1226,111 @@ int launch_istft_adjoint(const float* dwav, float* dspec, int B, int T, int L, h
 }
 int launch_cmul(const float* a, const float* b, float* out, int B, size_t half, int conj_a, hipStream_t st) {
     hipLaunchKernelGGL(cmul_kernel, dim3(grid_for((size_t)B * half)), dim3(256), 0, st, a, b, out, half, (size_t)B * half, conj_a);
+    return rtfs_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------ CAF glue (layers/fusion.py:252-274)
+// attention weights: in (B, 4C, Tv) -> mean over the 4 channels of each group (reshape (B, C, 4, Tv)) -> softmax over Tv.
+// One wave per (b, c); Tv <= 256.  bwd: given dout and out, din[c*4 + j, t] = out * (dout - sum(out * dout)) / 4.
+__global__ __launch_bounds__(256) void caf_att_kernel(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ dout,
+                                                      float* __restrict__ din, int nbc, int Tv, int bwd) {
+    const int lane = threadIdx.x & 63, bc = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (bc >= nbc) return;
+    if (!bwd) {
+        float v[4], m = -INFINITY;
+        for (int i = 0; i < 4; ++i) {
+            const int t = lane + 64 * i;
+            v[i] = -INFINITY;
+            if (t < Tv) {
+                const float* p = in + (size_t)bc * 4 * Tv + t;
+                v[i] = 0.25f * (p[0] + p[Tv] + p[2 * Tv] + p[3 * Tv]);
+            }
+            m = fmaxf(m, v[i]);
+        }
+        m = wave_max(m);
+        float sum = 0.f;
+        for (int i = 0; i < 4; ++i) {
+            v[i] = (lane + 64 * i) < Tv ? __expf(v[i] - m) : 0.f;
+            sum += v[i];
+        }
+        const float inv = 1.0f / wave_sum(sum);
+        for (int i = 0; i < 4; ++i)
+            if (lane + 64 * i < Tv) out[(size_t)bc * Tv + lane + 64 * i] = v[i] * inv;
+    } else {
+        float pv[4], dv[4], dot = 0.f;
+        for (int i = 0; i < 4; ++i) {
+            const int t = lane + 64 * i;
+            pv[i] = t < Tv ? out[(size_t)bc * Tv + t] : 0.f;
+            dv[i] = t < Tv ? dout[(size_t)bc * Tv + t] : 0.f;
+            dot = fmaf(pv[i], dv[i], dot);
+        }
+        dot = wave_sum(dot);
+        for (int i = 0; i < 4; ++i) {
+            const int t = lane + 64 * i;
+            if (t < Tv) {
+                const float d = 0.25f * pv[i] * (dv[i] - dot);
+                float* p = din + (size_t)bc * 4 * Tv + t;
+                p[0] = d; p[Tv] = d; p[2 * Tv] = d; p[3 * Tv] = d;
+            }
+        }
+    }
+}
+// fused = key * up(r) + up(att) * value; key, value, fused (B*C, T, F); r, att (B*C, Tv); up = nearest over time, broadcast over F
+__global__ __launch_bounds__(256) void caf_combine_fwd_kernel(const float* __restrict__ key, const float* __restrict__ value,
+                                                              const float* __restrict__ r, const float* __restrict__ att,
+                                                              float* __restrict__ out, size_t N, int T, int F, int Tv) {
+    const size_t total = N * T * F;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t nt = i / F;
+        const int t = (int)(nt % T);
+        const size_t j = (nt / T) * Tv + nearest_src(t, Tv, T);
+        out[i] = fmaf(key[i], r[j], att[j] * value[i]);
+    }
+}
+// one wave per (n, tv): it owns the frames t that read tv
+__global__ __launch_bounds__(256) void caf_combine_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ key,
+                                                              const float* __restrict__ value, const float* __restrict__ r,
+                                                              const float* __restrict__ att, float* __restrict__ dkey, float* __restrict__ dvalue,
+                                                              float* __restrict__ dr, float* __restrict__ datt, size_t N, int T, int F, int Tv) {
+    const int lane = threadIdx.x & 63;
+    const size_t id = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (id >= N * Tv) return;
+    const size_t n = id / Tv;
+    const int tv = (int)(id % Tv);
+    const int t0 = (int)(((long)tv * T + Tv - 1) / Tv), t1 = min(T, (int)(((long)(tv + 1) * T + Tv - 1) / Tv));
+    const float rv = r[id], av = att[id];
+    float sr = 0.f, sa = 0.f;
+    for (int t = t0; t < t1; ++t)
+        for (int f = lane; f < F; f += 64) {
+            const size_t k = (n * T + t) * F + f;
+            const float d = dout[k];
+            dkey[k] = d * rv;
+            dvalue[k] = d * av;
+            sr = fmaf(d, key[k], sr);
+            sa = fmaf(d, value[k], sa);
+        }
+    sr = wave_sum(sr);
+    sa = wave_sum(sa);
+    if (lane == 0) {
+        dr[id] = sr;
+        datt[id] = sa;
+    }
+}
+int launch_caf_att(const float* in, float* out, const float* dout, float* din, int nbc, int Tv, bool bwd, hipStream_t st) {
+    if (Tv < 1 || Tv > 256) return RTFS_ERR_SHAPE;
+    hipLaunchKernelGGL(caf_att_kernel, dim3(cdiv(nbc, 4)), dim3(256), 0, st, in, out, dout, din, nbc, Tv, bwd ? 1 : 0);
+    return rtfs_launch_status();
+}
+int launch_caf_combine(const float* key, const float* value, const float* r, const float* att, float* out, size_t N, int T, int F, int Tv,
+                       hipStream_t st) {
+    if (Tv < 1 || Tv > T) return RTFS_ERR_SHAPE;
+    hipLaunchKernelGGL(caf_combine_fwd_kernel, dim3(grid_for(N * T * F)), dim3(256), 0, st, key, value, r, att, out, N, T, F, Tv);
+    return rtfs_launch_status();
+}
+int launch_caf_combine_bwd(const float* dout, const float* key, const float* value, const float* r, const float* att, float* dkey,
+                           float* dvalue, float* dr, float* datt, size_t N, int T, int F, int Tv, hipStream_t st) {
+    if (Tv < 1 || Tv > T) return RTFS_ERR_SHAPE;
+    hipLaunchKernelGGL(caf_combine_bwd_kernel, dim3((unsigned)((N * Tv + 3) / 4)), dim3(256), 0, st, dout, key, value, r, att, dkey, dvalue, dr,
+                       datt, N, T, F, Tv);
     return rtfs_launch_status();
 }

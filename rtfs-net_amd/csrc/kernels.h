@@ -271,6 +271,7 @@ struct ClStageArgs {  // y = act(gLN(x)) over rows x C, per-sample statistics
     float* y = nullptr;
     const double* stats = nullptr;  // (B, 2) sum, sum of squares of x per sample (norm only)
     const float *gamma = nullptr, *beta = nullptr, *slope = nullptr;
+    const float *rmean = nullptr, *rvar = nullptr;  // norm 2: BatchNorm running statistics (per channel)
     const float* dy = nullptr;  // backward
     float* dx = nullptr;
     double* S = nullptr;        // backward scratch (B, 2)
@@ -314,3 +315,8 @@ int launch_tfar_combine_bwd(const float* dout, const float* le, const float* gat
 int launch_patch3x3_rows(const float* z, float* rows, int B, int T, int F, hipStream_t st);
 int launch_istft_adjoint(const float* dwav, float* dspec, int B, int T, int L, hipStream_t st);
 int launch_cmul(const float* a, const float* b, float* out, int B, size_t half, int conj_a, hipStream_t st);
+int launch_caf_att(const float* in, float* out, const float* dout, float* din, int nbc, int Tv, bool bwd, hipStream_t st);
+int launch_caf_combine(const float* key, const float* value, const float* r, const float* att, float* out, size_t N, int T, int F, int Tv,
+                       hipStream_t st);
+int launch_caf_combine_bwd(const float* dout, const float* key, const float* value, const float* r, const float* att, float* dkey,
+                           float* dvalue, float* dr, float* datt, size_t N, int T, int F, int Tv, hipStream_t st);

@@ -127,7 +127,8 @@ class _CNATrainFn(torch.autograd.Function):
         x = x.contiguous()
         B, H, W = x.shape[0], (x.shape[2] if x.dim() == 4 else 1), x.shape[-1]
         carr = (ctypes.c_int * 11)(*cfg)
-        pk = packing.pack_cna_train(cfg, *params)
+        params, running = params[:8], params[8:]  # optional: BatchNorm running mean / var (constants)
+        pk = packing.pack_cna_train(cfg, *params, *running)
         ho, wo = ctypes.c_int(), ctypes.c_int()
         lib.rtfs_cna_out_shape(carr, H, W, ctypes.byref(ho), ctypes.byref(wo))
         out = torch.empty((B, cfg[1], ho.value, wo.value) if x.dim() == 4 else (B, cfg[1], wo.value), device=x.device, dtype=torch.float32)
@@ -138,6 +139,7 @@ class _CNATrainFn(torch.autograd.Function):
         ctx.save_for_backward(pk, saved)
         ctx.cfg, ctx.geom, ctx.xshape = cfg, (B, H, W), x.shape
         ctx.pshapes = [None if p is None else p.shape for p in params]
+        ctx.nrunning = len(running)
         return out
 
     @staticmethod
@@ -154,7 +156,8 @@ class _CNATrainFn(torch.autograd.Function):
         _lib.check(lib.rtfs_cna_backward_f32(_lib.ptr(pk), _lib.ptr(saved), _lib.ptr(dout), _lib.ptr(dx), _lib.ptr(dpar), carr, B, H, W,
                                              _lib.ptr(ws), ws.numel(), _lib.stream_of(dout)), "rtfs_cna_backward_f32")
         grads = packing.unpack_cna_grads(ctx.cfg, dpar, ctx.pshapes[3])
-        return (dx, None) + tuple(None if shp is None else g.reshape(shp) for g, shp in zip(grads, ctx.pshapes))
+        out = (dx, None) + tuple(None if shp is None else g.reshape(shp) for g, shp in zip(grads, ctx.pshapes))
+        return out + (None,) * ctx.nrunning
 
 
 class ConvNormAct(nn.Module):
@@ -195,22 +198,39 @@ class ConvNormAct(nn.Module):
         pre_n, pre_a, conv, nrm, act = self.full_layer
         if not isinstance(conv, (nn.Conv1d, nn.Conv2d)):
             return x
-        for m in (pre_n, nrm):
-            if not isinstance(m, (nn.Identity, GlobalLayerNorm)):
-                raise RuntimeError(f"ConvNormAct: the training kernels implement gLN only, not {type(m).__name__}")
+        if not isinstance(pre_n, (nn.Identity, GlobalLayerNorm)):
+            raise RuntimeError(f"ConvNormAct: the training kernels implement gLN as pre-norm only, not {type(pre_n).__name__}")
+        bn = isinstance(nrm, (nn.BatchNorm1d, nn.BatchNorm2d))
+        if bn and nrm.training:
+            raise RuntimeError("ConvNormAct: BatchNorm batch statistics are not built; put the BatchNorm layers in eval mode "
+                               "(frozen running statistics) to take gradients through them")
+        if not bn and not isinstance(nrm, (nn.Identity, GlobalLayerNorm)):
+            raise RuntimeError(f"ConvNormAct: norm {type(nrm).__name__} has no training kernel")
         for m in (pre_a, act):
             if type(m) not in _ACT_CODE:
                 raise RuntimeError(f"ConvNormAct: activation {type(m).__name__} has no training kernel")
         depthwise = conv.groups == conv.in_channels and conv.groups == conv.out_channels and conv.groups > 1
-        if not (depthwise or conv.groups == 1) or self.dilation != 1:
-            raise RuntimeError("ConvNormAct: training kernels cover dense 1x1 and depthwise convolutions only")
+        if self.dilation != 1:
+            raise RuntimeError("ConvNormAct: dilated convolutions have no training kernel")
+        weight = conv.weight
+        if not depthwise and conv.groups != 1:
+            # grouped 1x1 (CAF's video-side convolutions, fusion.py:218-232): run as a dense 1x1 whose weight is the block-diagonal
+            # expansion; the scatter is differentiable, so the gradient comes back in the grouped shape
+            if self.kernel_size != 1:
+                raise RuntimeError("ConvNormAct: grouped convolutions are supported for kernel_size 1 only")
+            cout, gin = conv.out_channels, conv.in_channels // conv.groups
+            idx = (torch.arange(cout, device=weight.device) // (cout // conv.groups))[:, None] * gin + torch.arange(gin, device=weight.device)[None, :]
+            weight = torch.zeros(cout, conv.in_channels, device=weight.device, dtype=weight.dtype).scatter(1, idx, weight.reshape(cout, gin))
+            weight = weight.reshape(cout, conv.in_channels, *([1] * (conv.weight.dim() - 2)))
         is2d = isinstance(conv, nn.Conv2d)
         cfg = (conv.in_channels, conv.out_channels, self.kernel_size, self.stride, int(depthwise), int(isinstance(pre_n, GlobalLayerNorm)),
-               _ACT_CODE[type(pre_a)], int(isinstance(nrm, GlobalLayerNorm)), _ACT_CODE[type(act)], int(conv.bias is not None), int(is2d))
-        gn = lambda m, a: getattr(m.norm, a) if isinstance(m, GlobalLayerNorm) else None
+               _ACT_CODE[type(pre_a)], 2 if bn else int(isinstance(nrm, GlobalLayerNorm)), _ACT_CODE[type(act)], int(conv.bias is not None),
+               int(is2d))
+        gn = lambda m, a: getattr(m.norm, a) if isinstance(m, GlobalLayerNorm) else (getattr(m, a) if isinstance(m, (nn.BatchNorm1d, nn.BatchNorm2d)) else None)
         sl = lambda m: m.weight if isinstance(m, nn.PReLU) else None
-        return _CNATrainFn.apply(x, cfg, gn(pre_n, "weight"), gn(pre_n, "bias"), sl(pre_a), conv.weight, conv.bias, gn(nrm, "weight"),
-                                 gn(nrm, "bias"), sl(act))
+        running = (nrm.running_mean, nrm.running_var) if bn else ()
+        return _CNATrainFn.apply(x, cfg, gn(pre_n, "weight"), gn(pre_n, "bias"), sl(pre_a), weight, conv.bias, gn(nrm, "weight"),
+                                 gn(nrm, "bias"), sl(act), *running)
 
     def get_config(self):
         return _config_of(self)
@@ -638,6 +658,60 @@ class InjectionMultiSum(PackedModule):
 
 
 # ----------------------------------------------------------------------------- CAF cell
+class _CafAttentionFn(torch.autograd.Function):
+    """(B, 4C, Tv) -> mean over each group of 4 -> softmax over Tv (fusion.py:262-265), with its adjoint."""
+
+    @staticmethod
+    def forward(ctx, emb, C):
+        lib = _lib.load()
+        emb = emb.contiguous()
+        B, _, Tv = emb.shape
+        att = torch.empty(B, C, Tv, device=emb.device, dtype=torch.float32)
+        _lib.check(lib.rtfs_caf_attention_f32(_lib.ptr(emb), _lib.ptr(att), B, C, Tv, _lib.stream_of(emb)), "rtfs_caf_attention_f32")
+        ctx.save_for_backward(att)
+        return att
+
+    @staticmethod
+    def backward(ctx, datt):
+        lib = _lib.load()
+        (att,) = ctx.saved_tensors
+        B, C, Tv = att.shape
+        datt = datt.contiguous()
+        demb = torch.empty(B, 4 * C, Tv, device=att.device, dtype=torch.float32)
+        _lib.check(lib.rtfs_caf_attention_backward_f32(_lib.ptr(att), _lib.ptr(datt), _lib.ptr(demb), B, C, Tv, _lib.stream_of(att)),
+                   "rtfs_caf_attention_backward_f32")
+        return demb, None
+
+
+class _CafCombineFn(torch.autograd.Function):
+    """key * up(resized) + up(att) * value (fusion.py:255-272), with the four adjoints."""
+
+    @staticmethod
+    def forward(ctx, key, value, resized, att):
+        lib = _lib.load()
+        key, value, resized, att = key.contiguous(), value.contiguous(), resized.contiguous(), att.contiguous()
+        B, C, T, Fq = key.shape
+        Tv = resized.shape[-1]
+        out = torch.empty_like(key)
+        _lib.check(lib.rtfs_caf_combine_f32(_lib.ptr(key), _lib.ptr(value), _lib.ptr(resized), _lib.ptr(att), _lib.ptr(out), B * C, T, Fq, Tv,
+                                            _lib.stream_of(key)), "rtfs_caf_combine_f32")
+        ctx.save_for_backward(key, value, resized, att)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        key, value, resized, att = ctx.saved_tensors
+        B, C, T, Fq = key.shape
+        Tv = resized.shape[-1]
+        dout = dout.contiguous()
+        dk, dv, dr, da = torch.empty_like(key), torch.empty_like(value), torch.empty_like(resized), torch.empty_like(att)
+        _lib.check(lib.rtfs_caf_combine_backward_f32(_lib.ptr(dout), _lib.ptr(key), _lib.ptr(value), _lib.ptr(resized), _lib.ptr(att), _lib.ptr(dk),
+                                                     _lib.ptr(dv), _lib.ptr(dr), _lib.ptr(da), B * C, T, Fq, Tv, _lib.stream_of(dout)),
+                   "rtfs_caf_combine_backward_f32")
+        return dk, dv, dr, da
+
+
 class ATTNFusionCell(PackedModule):
     """reference layers/fusion.py:194-274 (the CAF block's arithmetic)."""
 
@@ -652,7 +726,19 @@ class ATTNFusionCell(PackedModule):
         self.attention_embed = ConvNormAct(in_chan_b, kernel_size * in_chan_a, 1, groups=in_chan_a, norm_type="gLN")
         self.resize = ConvNormAct(in_chan_b, in_chan_a, 1, groups=in_chan_a, norm_type="gLN")
 
+    def _forward_train(self, a, v):
+        """Inside a training step (BatchNorm layers in eval mode = frozen statistics): the four ConvNormActs on their training kernels
+        plus the attention / combine kernels; reference layers/fusion.py:252-274 line by line."""
+        if self.kernel_size != 4:
+            raise RuntimeError("CAF training kernels: kernel_size 4 (yaml fusion_params)")
+        resized = self.resize(v)
+        att = _CafAttentionFn.apply(self.attention_embed(v), self.in_chan_a)
+        return _CafCombineFn.apply(self.key_embed(a), self.value_embed(a), resized, att)
+
     def forward(self, tensor_a, tensor_b):
+        if tensor_a.is_cuda and _recording(tensor_a, tensor_b, self):
+            _lib.need_gpu(tensor_a, tensor_b)
+            return self._forward_train(tensor_a, tensor_b)
         self._guard(tensor_a, tensor_b)
         if not (self.is2d and self.in_chan_a == 256 and self.in_chan_b == 512 and self.kernel_size == 4):
             raise ValueError("MI355X CAF kernel: audio 256 ch (2-D), video 512 ch, kernel_size 4")

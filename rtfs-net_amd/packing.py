@@ -130,7 +130,7 @@ def unpack_dualpath_grads(flat):
     return flat[0:64], flat[64:128], dws, dwcs, dbs, dlw, flat[off + 512 * 64:off + 512 * 64 + 64]
 
 
-def pack_cna_train(cfg, pre_g, pre_b, pre_s, w, bias, g, b, s):
+def pack_cna_train(cfg, pre_g, pre_b, pre_s, w, bias, g, b, s, rmean=None, rvar=None):
     """Training-side parameter buffer of one ConvNormAct (layout contract: include/rtfs_amd.h, rtfs_cna_forward_train_f32).
     cfg = (Cin, Cout, k, stride, depthwise, pre_norm, pre_act, norm, act, has_bias, is2d); absent parameters are zero-filled."""
     cin, cout, depthwise = cfg[0], cfg[1], cfg[4]
@@ -141,7 +141,7 @@ def pack_cna_train(cfg, pre_g, pre_b, pre_s, w, bias, g, b, s):
     if not depthwise:
         parts.append(w2.t().contiguous())
     parts += [bias if bias is not None else z(cout), g if g is not None else z(cout), b if b is not None else z(cout),
-              s if s is not None else z(1)]
+              s if s is not None else z(1), rmean if rmean is not None else z(cout), rvar if rvar is not None else z(cout)]
     return _cat(parts)
 
 

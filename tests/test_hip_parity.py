@@ -450,6 +450,47 @@ def test_encoder_bottleneck_s3_decoder_training(B, L, seed, smooth):
         assert max(e for e, _ in errs.values()) <= 2e-4, errs
 
 
+@pytest.mark.parametrize("B,T,F,Tv,seed", [(2, 9, 5, 4, 71), (1, 33, 129, 7, 72), (2, 20, 16, 20, 73)])
+def test_caf_training_forward_backward(B, T, F, Tv, seed):
+    """CAF cell inside a training step with its BatchNorm layers frozen (eval-mode statistics): grouped video-side convolutions +
+    gLN, depthwise audio-side convolutions + BatchNorm (+ReLU), attention softmax, nearest up-sampling; all gradients (audio input,
+    video input, 14 parameter tensors) against the autograd oracle."""
+    import rtfs_net_amd as R
+    from oracle import grad_oracle as G
+    rng = np.random.default_rng(seed)
+    p = {k: v.copy() for k, v in CELL.items()}
+    for k in p:  # BatchNorm statistics and affines away from their init values
+        if k.endswith("running_mean") or k.endswith(".bias"):
+            p[k] = (p[k] + 0.3 * rng.standard_normal(p[k].shape)).astype(np.float32)
+        if k.endswith("running_var") or k.endswith("3.weight") or k.endswith("norm.weight"):
+            p[k] = (p[k] * (1 + 0.5 * rng.random(p[k].shape))).astype(np.float32)
+    cell = R.layers.ATTNFusionCell(256, 512, kernel_size=4, is2d=True)
+    cell.load_state_dict({k: torch.from_numpy(v) for k, v in p.items()})
+    cell = cell.cuda().eval()  # frozen BatchNorm; autograd still records
+    a, v = rand((B, 256, T, F), seed), rand((B, 512, Tv), seed + 1)
+    dout = rand((B, 256, T, F), seed + 2)
+    at, vt = dev(a).requires_grad_(True), dev(v).requires_grad_(True)
+    out = cell(at, vt)
+    out.backward(dev(dout))
+    pt = {k: torch.tensor(val, dtype=torch.float64, requires_grad=("running" not in k)) for k, val in p.items() if "num_batches" not in k}
+    ar, vr = torch.tensor(a, dtype=torch.float64, requires_grad=True), torch.tensor(v, dtype=torch.float64, requires_grad=True)
+    o_ref = G.caf_torch(ar, vr, pt)
+    o_ref.backward(torch.tensor(dout, dtype=torch.float64))
+    close("caf train forward", host(out), o_ref.detach().numpy())
+    close("caf d audio", host(at.grad), ar.grad.numpy(), tol=2e-4)
+    close("caf d video", host(vt.grad), vr.grad.numpy(), tol=2e-4)
+    got = {k: v.grad for k, v in cell.named_parameters()}
+    gscale = max(float(pt[k].grad.abs().max()) for k in got)
+    for k, g in got.items():
+        assert g is not None, k
+        if k == "attention_embed.full_layer.3.norm.bias":  # constant over time: the softmax cancels it, the true gradient is 0
+            assert float(np.abs(host(g)).max()) <= 1e-5 * gscale
+            continue
+        close(f"caf d {k}", host(g), pt[k].grad.numpy(), tol=2e-4)
+    with torch.no_grad():
+        close("caf inference vs training forward", host(cell(dev(a), dev(v))), host(out))
+
+
 @pytest.mark.parametrize("shape,seed", [((2, 64, 12, 64), 103), ((1, 64, 125, 64), 5), ((1, 64, 250, 64), 6), ((2, 64, 33, 64), 8)])
 def test_mhsa2d(shape, seed):
     m = model()
