@@ -226,6 +226,11 @@ int rtfs_caf_combine_f32(const float* key, const float* value, const float* resi
                          int Tv, void* stream);
 int rtfs_caf_combine_backward_f32(const float* dout, const float* key, const float* value, const float* resized, const float* att,
                                   float* dkey, float* dvalue, float* dresized, float* datt, int N, int T, int F, int Tv, void* stream);
+/* Gradient of PITLossWrapper(PairwiseNegSDR) (src/losses/pit_wrapper.py:84-110 around matrix.py:22-53) with respect to the estimates,
+ * for the permutation the forward chose: dmin_loss (B) = upstream gradient of min_loss, perm (B, n_src) as returned by
+ * rtfs_pit_pairwise_sdr_f32 -> dests (B, n_src, L).  (The targets are data.) */
+int rtfs_pit_sdr_backward_f32(const float* ests, const float* targets, const int* perm, const float* dmin_loss, float* dests, int B,
+                              int n_src, int L, int sdr_type, int zero_mean, int take_log, void* stream);
 /* The two GEMM forms of the training path (bf16x3 split on the matrix cores), exposed for tests:
  * kind 0: C (M,N) = A (M,K) . B (N,K)^T (accumulate != 0: C += ...), N % 64 == 0, K % 16 == 0;
  * kind 1: C (M,N) += A (K,M)^T . B (K,N), M % 64 == 0, N % 64 == 0. */

@@ -260,3 +260,32 @@ def caf_torch(a, v, p):
     att = video_conv("attention_embed").reshape(B, C, 4, -1).mean(2)
     att = F.interpolate(torch.softmax(att, -1), size=T, mode="nearest").unsqueeze(-1)
     return k1 + att * val
+
+
+def avnet_torch(wav, video_vp, p, repeats):
+    """AVNet.forward (reference tdavnet.py:86-97 + refinement_module.py:45-62) in float64 torch ops, with the video-side VP block's
+    output given as a constant: encoder -> bottleneck -> block -> CAF -> (repeats-1) x block(x + a1) -> S^3 -> decoder."""
+    a0 = stft_encoder_torch(wav, p["encoder.conv.full_layer.2.weight"])
+    a1 = conv_norm_act_torch(a0, _sub(p, "audio_bottleneck"), (256, 256, 1, 1, 0, 1, 1, 0, 0, 1, 1))
+    blk = _sub(p, "refinement_module.audio_net.blocks")
+    x = rtfs_block_torch(a1, blk)
+    x = caf_torch(x, video_vp, _sub(p, "refinement_module.crossmodal_fusion.fusion_module.audio_lstm"))
+    for _ in range(repeats - 1):
+        x = rtfs_block_torch(x + a1, blk)
+    s = s3_torch(x, a0, _sub(p, "mask_generator"))
+    return stft_decoder_torch(s[:, 0], p["decoder.decoder.weight"], wav.shape[-1])
+
+
+def pit_loss_torch(est, tgt, kind="snr", zero_mean=True, take_log=True, eps=1e-8):
+    """PITLossWrapper(PairwiseNegSDR(kind)) for n_src = 1 (src/losses/matrix.py:22-53): mean over the batch."""
+    if zero_mean:
+        est, tgt = est - est.mean(2, keepdim=True), tgt - tgt.mean(2, keepdim=True)
+    if kind in ("sisdr", "sdsdr"):
+        proj = (est * tgt).sum(2, keepdim=True) * tgt / ((tgt ** 2).sum(2, keepdim=True) + eps)
+    else:
+        proj = tgt
+    noise = est - tgt if kind in ("sdsdr", "snr") else est - proj
+    sdr = (proj ** 2).sum(2) / ((noise ** 2).sum(2) + eps)
+    if take_log:
+        sdr = 10 * torch.log10(sdr + eps)
+    return (-sdr).mean()

@@ -85,6 +85,7 @@ SIGNATURES = {
     "rtfs_caf_attention_backward_f32": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "rtfs_caf_combine_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "rtfs_caf_combine_backward_f32": (_i, [_p] * 9 + [_i, _i, _i, _i, _p]),
+    "rtfs_pit_sdr_backward_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "rtfs_debug_gemm_f32": (_i, [_i, _p, _p, _p, _i, _i, _i, _i, _p]),
     "rtfs_debug_sweep_stamps": (_i, [_p, _p, _p, _i, _i, _i, _p, _p]),
     "rtfs_selftest_mfma_f16": (_i, [_p, _p, _p, _p]),

@@ -1587,6 +1587,14 @@ int rtfs_caf_combine_backward_f32(const float* dout, const float* key, const flo
     return launch_caf_combine_bwd(dout, key, value, resized, att, dkey, dvalue, dresized, datt, (size_t)N, T, F, Tv, S(stream));
 }
 
+// ------------------------------------------------------------ PIT loss gradient
+int rtfs_pit_sdr_backward_f32(const float* ests, const float* targets, const int* perm, const float* dmin_loss, float* dests, int B, int n_src,
+                              int L, int sdr_type, int zero_mean, int take_log, void* stream) {
+    RTFS_RETURN_IF(!ests || !targets || !perm || !dmin_loss || !dests || B < 1, RTFS_ERR_ARG);
+    RTFS_RETURN_IF(sdr_type < 0 || sdr_type > 2, RTFS_ERR_ARG);
+    return launch_pit_sdr_bwd(ests, targets, perm, dmin_loss, dests, B, n_src, L, sdr_type, zero_mean, take_log, S(stream));
+}
+
 // C = A . Bt^T (kind 0; accumulate adds to C) or C += A^T . B (kind 1): the two GEMM forms of the training path, exposed for tests
 int rtfs_debug_gemm_f32(int kind, const float* A, const float* B, float* C, int M, int N, int K, int accumulate, void* stream) {
     RTFS_RETURN_IF(!A || !B || !C, RTFS_ERR_ARG);

@@ -133,6 +133,63 @@ __global__ __launch_bounds__(256) void pit_pairwise_kernel(const float* __restri
 
 }  // namespace
 
+// Gradient of the PIT loss with respect to the estimates.  For the assigned pair (estimate j = perm[b][i], target i) every variant of
+// matrix.py:22-53 is a function of the second moments only, so d loss / d e = ce * e + ct * t with e, t the (mean-removed) signals;
+// one workgroup per (b, i): one pass for the five moments in float64, one pass to write the row of estimate j.
+//   snr:    P = |t|^2,          N = |e - t|^2
+//   sdsdr:  P = alpha^2 |t|^2,  N = |e - t|^2              alpha = <e,t> / (|t|^2 + eps)
+//   sisdr:  P = alpha^2 |t|^2,  N = |e - alpha t|^2
+//   loss = -10 log10(P / (N + eps) + eps)  (or -P / (N + eps) without the log); upstream gradient dmin[b] / n_src.
+__global__ __launch_bounds__(256) void pit_sdr_bwd_kernel(const float* __restrict__ est, const float* __restrict__ tgt,
+                                                          const int* __restrict__ perm, const float* __restrict__ dmin, float* __restrict__ dest,
+                                                          int n, int L, int kind, int zero_mean, int take_log) {
+    __shared__ double red[4];
+    const int b = blockIdx.x / n, i = blockIdx.x % n, tid = threadIdx.x;
+    const int j = perm[b * n + i];
+    const float* e = est + ((size_t)b * n + j) * L;
+    const float* t = tgt + ((size_t)b * n + i) * L;
+    double se = 0, st = 0, see = 0, stt = 0, set = 0;
+    for (int l = tid; l < L; l += 256) {
+        const double ev = e[l], tv = t[l];
+        se += ev; st += tv; see += ev * ev; stt += tv * tv; set += ev * tv;
+    }
+    se = block_sum_d(se, red, tid);
+    st = block_sum_d(st, red, tid);
+    see = block_sum_d(see, red, tid);
+    stt = block_sum_d(stt, red, tid);
+    set = block_sum_d(set, red, tid);
+    const double eps = 1e-8;
+    double me = 0, mt = 0;
+    if (zero_mean) {
+        me = se / L; mt = st / L;
+        see -= L * me * me; stt -= L * mt * mt; set -= L * me * mt;
+    }
+    const double Et = stt + eps, alpha = set / Et;
+    double P, N, p_t, n_t;
+    if (kind == 0) {         // snr
+        P = stt; N = see - 2 * set + stt; p_t = 0; n_t = -2;
+    } else if (kind == 2) {  // sdsdr
+        P = alpha * alpha * stt; N = see - 2 * set + stt; p_t = 2 * alpha * stt / Et; n_t = -2;
+    } else {                 // sisdr
+        P = alpha * alpha * stt; N = see - 2 * alpha * set + alpha * alpha * stt; p_t = 2 * alpha * stt / Et;
+        n_t = -2 * alpha - 2 * (set - alpha * stt) / Et;
+    }
+    if (N < 0) N = 0;
+    const double Ne = N + eps, r = P / Ne;
+    const double g0 = (take_log ? -(10.0 / 2.302585092994046) / (r + eps) : -1.0) * (double)dmin[b] / n;
+    const float ce = (float)(g0 * (-P / (Ne * Ne)) * 2.0), ct = (float)(g0 * (p_t / Ne - P / (Ne * Ne) * n_t));
+    const float fme = (float)me, fmt = (float)mt;
+    float* d = dest + ((size_t)b * n + j) * L;
+    for (int l = tid; l < L; l += 256) d[l] = ce * (e[l] - fme) + ct * (t[l] - fmt);
+}
+
+int launch_pit_sdr_bwd(const float* est, const float* tgt, const int* perm, const float* dmin, float* dest, int B, int n, int L, int kind,
+                       int zero_mean, int take_log, hipStream_t st) {
+    if (n < 1 || n > LOSS_MAXN || L < 1) return RTFS_ERR_SHAPE;
+    hipLaunchKernelGGL(pit_sdr_bwd_kernel, dim3(B * n), dim3(256), 0, st, est, tgt, perm, dmin, dest, n, L, kind, zero_mean, take_log);
+    return rtfs_launch_status();
+}
+
 int launch_pit_pairwise(const float* est, const float* tgt, int B, int n, int L, int kind, int zero_mean, int take_log, float* pw,
                         float* min_loss, int* perm, hipStream_t st) {
     if (B < 1 || n < 1 || n > LOSS_MAXN || L < 1 || kind < 0 || kind > 2) return RTFS_ERR_SHAPE;

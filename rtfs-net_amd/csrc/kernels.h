@@ -320,3 +320,5 @@ int launch_caf_combine(const float* key, const float* value, const float* r, con
                        hipStream_t st);
 int launch_caf_combine_bwd(const float* dout, const float* key, const float* value, const float* r, const float* att, float* dkey,
                            float* dvalue, float* dr, float* datt, size_t N, int T, int F, int Tv, hipStream_t st);
+int launch_pit_sdr_bwd(const float* est, const float* tgt, const int* perm, const float* dmin, float* dest, int B, int n, int L, int kind,
+                       int zero_mean, int take_log, hipStream_t st);

@@ -1,7 +1,8 @@
 """Evaluation-side losses of the reference on the device (forward only): ``src/losses/matrix.py`` ``PairwiseNegSDR`` and
 ``src/losses/pit_wrapper.py`` ``PITLossWrapper`` (``pit_from="pw_mtx"``, factorial search), same class names, constructor
 keywords and return values.  The arithmetic runs in ``librtfs_amd.so`` (``rtfs_pit_pairwise_sdr_f32``: one pass over the
-signals, float64 moments, permutation search in the same kernel); there is no CPU fallback.
+signals, float64 moments, permutation search in the same kernel; ``rtfs_pit_sdr_backward_f32`` for the gradient w.r.t. the
+estimates when autograd is recording); there is no CPU fallback.
 """
 from __future__ import annotations
 
@@ -29,6 +30,30 @@ def _pairwise(ests, targets, kind, zero_mean, take_log):
                                              _lib.ptr(pw), _lib.ptr(min_loss), _lib.ptr(perm), _lib.stream_of(ests)),
                "rtfs_pit_pairwise_sdr_f32")
     return pw, min_loss, perm
+
+
+class _PitLossFn(torch.autograd.Function):
+    """min over permutations of the mean pairwise loss, per batch element, with its gradient w.r.t. the estimates."""
+
+    @staticmethod
+    def forward(ctx, ests, targets, kind, zero_mean, take_log):
+        pw, min_loss, perm = _pairwise(ests, targets, kind, zero_mean, take_log)
+        ctx.save_for_backward(ests.contiguous().float(), targets.contiguous().float(), perm)
+        ctx.cfg = (kind, zero_mean, take_log)
+        ctx.mark_non_differentiable(perm)
+        return min_loss, perm
+
+    @staticmethod
+    def backward(ctx, dmin, _dperm):
+        lib = _lib.load()
+        ests, targets, perm = ctx.saved_tensors
+        kind, zero_mean, take_log = ctx.cfg
+        B, n, L = ests.shape
+        dmin = dmin.contiguous().float()
+        dests = torch.empty_like(ests)
+        _lib.check(lib.rtfs_pit_sdr_backward_f32(_lib.ptr(ests), _lib.ptr(targets), _lib.ptr(perm), _lib.ptr(dmin), _lib.ptr(dests), B, n, L,
+                                                 _KIND[kind], int(zero_mean), int(take_log), _lib.stream_of(ests)), "rtfs_pit_sdr_backward_f32")
+        return dests, None, None, None, None
 
 
 class PairwiseNegSDR(nn.Module):
@@ -59,7 +84,10 @@ class PITLossWrapper(nn.Module):
 
     def forward(self, ests, targets, return_ests=False, reduce_kwargs=None, **kwargs):
         f = self.loss_func
-        _, min_loss, perm = _pairwise(ests, targets, f.sdr_type, f.zero_mean, f.take_log)
+        if torch.is_grad_enabled() and ests.requires_grad:  # training: the HIP backward kernel hangs off min_loss
+            min_loss, perm = _PitLossFn.apply(ests, targets, f.sdr_type, f.zero_mean, f.take_log)
+        else:
+            _, min_loss, perm = _pairwise(ests, targets, f.sdr_type, f.zero_mean, f.take_log)
         mean_loss = torch.mean(min_loss)
         if not return_ests:
             return mean_loss

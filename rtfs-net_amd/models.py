@@ -560,8 +560,11 @@ class AVNet(BaseAVModel):
             return self.forward_modular(audio_mixture, mouth_embedding)
         wav = STFTEncoder.unsqueeze_to_2D(audio_mixture)
         _lib.need_gpu(wav, mouth_embedding)
+        if L_recording(self):
+            return self.forward_train(audio_mixture, mouth_embedding)
         if self.training:
-            raise RuntimeError("AVNet: only the eval-mode forward is implemented on the MI355X path")
+            raise RuntimeError("AVNet: in .train() mode only the gradient-recording forward exists (see forward_train); "
+                               "call .eval() for inference")
         lib = _lib.load()
         wav = wav.contiguous()
         B, L = wav.shape
@@ -601,6 +604,43 @@ class AVNet(BaseAVModel):
         refined = self.refinement_module(audio, video)
         sep = self.mask_generator(refined, emb)
         return self.decoder(sep, STFTEncoder.unsqueeze_to_2D(audio_mixture).shape)
+
+    def forward_train(self, audio_mixture, mouth_embedding):
+        """The separator inside a training step (reference tdavnet.py:86-97 called from src/system/core.py:94-123): every audio-side
+        module runs its HIP forward-with-saved-state and hands autograd its HIP backward.  Two things are frozen in this version
+        (SURVEY 8f rank 1 is not finished): BatchNorm layers use their running statistics (put them in eval mode - ``freeze_for_finetune``
+        does) and the video-side VP block is evaluated without a graph on the inference kernel, so its parameters get no gradient."""
+        rm = self.refinement_module
+        vp_block = rm.video_net.get_block(0)
+        if vp_block.training or self.video_bottleneck.training:
+            raise RuntimeError("AVNet.forward_train: the video-side VP block has no backward yet; call model.freeze_for_finetune() "
+                               "(VP block and BatchNorm layers in eval mode) before taking gradients")
+        with torch.no_grad():
+            video = vp_block(self.video_bottleneck(mouth_embedding))
+        emb = self.encoder(audio_mixture)
+        audio = self.audio_bottleneck(emb)
+        a_res = audio
+        blk = rm.audio_net.get_block(0)
+        audio = blk(audio)
+        audio, _ = rm.crossmodal_fusion.get_fusion_block(0)(audio, video)
+        for _ in range(rm.audio_repeats):
+            audio = blk(audio, a_res)
+        sep = self.mask_generator(audio, emb)
+        return self.decoder(sep, STFTEncoder.unsqueeze_to_2D(audio_mixture).shape)
+
+    def freeze_for_finetune(self):
+        """Training configuration this version supports: everything in train mode except BatchNorm layers (frozen running statistics)
+        and the video-side VP block (eval mode, requires_grad False).  Returns self."""
+        self.train()
+        for m in self.modules():
+            if isinstance(m, (nn.BatchNorm1d, nn.BatchNorm2d, nn.BatchNorm3d)):
+                m.eval()
+        vp = self.refinement_module.video_net
+        vp.eval()
+        for p in vp.parameters():
+            p.requires_grad_(False)
+        self.video_bottleneck.eval()
+        return self
 
     def get_config(self):
         return dict(encoder=self.encoder.get_config(), audio_bottleneck=self.audio_bottleneck.get_config(),

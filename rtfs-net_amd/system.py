@@ -1,8 +1,11 @@
-"""Inference-side mirror of the reference's ``System`` (``src/system/core.py:50-123``) and its on-disk formats
-(SURVEY 8f rank 4): ``forward(wav, mouth)`` chains the video front-end, the separator and -- in ``validation_step`` -- the
-PIT loss, all on the HIP path; ``load_lightning_checkpoint`` reads a Lightning ``.ckpt`` (``state_dict`` with
-``audio_model.`` / ``video_model.`` prefixes, ``core.py:178-181``) and ``load_best_model`` the ``best_model.pth`` that
-``train.py:156-160`` writes, both with non-executing loaders.  No training loop (no backward yet).
+"""Mirror of the reference's ``System`` (``src/system/core.py:50-123``) and its on-disk formats (SURVEY 8f rank 4 + the start of
+rank 1): ``forward(wav, mouth)`` chains the video front-end and the separator; ``validation_step`` / ``training_step`` add the PIT
+loss, all on the HIP path.  ``optimization_step`` is what Lightning does around ``training_step`` in the reference (``train.py:135-148``:
+backward, gradient all-reduce over the data-parallel ranks, ``gradient_clip_val`` 5.0, optimizer step) written out, because Lightning is
+not a dependency here; the gradient exchange is ONE all-reduce of one flattened buffer (RCCL when the process group is ``nccl``).
+Training covers what ``AVNet.forward_train`` covers (frozen BatchNorm statistics, frozen video-side VP block).
+``load_lightning_checkpoint`` reads a Lightning ``.ckpt`` (``state_dict`` with ``audio_model.`` / ``video_model.`` prefixes,
+``core.py:178-181``) and ``load_best_model`` the ``best_model.pth`` that ``train.py:156-160`` writes, both with non-executing loaders.
 """
 from __future__ import annotations
 
@@ -18,9 +21,10 @@ class System(nn.Module):
     def __init__(self, audio_model=None, video_model=None, optimizer=None, loss_func=None, train_loader=None, val_loader=None,
                  scheduler=None, config=None, train_video_model=False):
         super().__init__()
-        if optimizer is not None or scheduler is not None or train_video_model:
-            raise ValueError("MI355X System is inference-only (no backward pass yet): no optimizer / scheduler / video training")
+        if train_video_model:
+            raise ValueError("MI355X System: the video front-end is inference-only (the reference freezes it too: yaml videonet)")
         self.audio_model, self.video_model, self.loss_func = audio_model, video_model, loss_func
+        self.optimizer, self.scheduler = optimizer, scheduler
         self.train_loader, self.val_loader = train_loader, val_loader
         self.config = {} if config is None else config
 
@@ -32,11 +36,12 @@ class System(nn.Module):
             mouth_emb = self.video_model(mouth.type_as(wav))
         return self.audio_model(wav, mouth_emb)
 
-    def common_step(self, batch, batch_nb, is_train=False):
-        """core.py:94-118, validation side."""
-        if is_train:
-            raise RuntimeError("MI355X System: training_step needs the backward pass, which is not built yet")
-        if self.video_model is None:
+    def common_step(self, batch, batch_nb, is_train=True):
+        """core.py:94-118."""
+        if self.video_model is None and len(batch) == 4:  # extension: pre-computed lip embeddings in the mouth slot
+            inputs, targets, mouth_emb, _ = batch
+            est_targets = self.audio_model(inputs, mouth_emb)
+        elif self.video_model is None:
             inputs, targets, _ = batch
             est_targets = self(inputs)
         else:
@@ -44,10 +49,51 @@ class System(nn.Module):
             est_targets = self(inputs, target_mouths)
         if targets.ndim == 2:
             targets = targets.unsqueeze(1)
-        return self.loss_func["val"](est_targets, targets)
+        return self.loss_func["train" if is_train else "val"](est_targets, targets)
+
+    def training_step(self, batch, batch_nb):
+        """core.py:119-123: the loss tensor carries the HIP backward graph (AVNet.forward_train + the PIT loss gradient kernel)."""
+        return {"loss": self.common_step(batch, batch_nb, is_train=True)}
 
     def validation_step(self, batch, batch_nb):
-        return {"val_loss": self.common_step(batch, batch_nb, is_train=False)}
+        with torch.no_grad():
+            return {"val_loss": self.common_step(batch, batch_nb, is_train=False)}
+
+    # ---------------------------------------------------------------- what Lightning does around training_step (train.py:135-148)
+    def trainable_parameters(self):
+        return [p for p in self.audio_model.parameters() if p.requires_grad]
+
+    def allreduce_gradients(self):
+        """Average the gradients over the data-parallel ranks with ONE collective on one flattened buffer (739,952 floats for
+        RTFS-Net; backend nccl = RCCL over xGMI on the GPU box, gloo in the CPU tests).  No-op without a process group."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return 0
+        params = [p for p in self.trainable_parameters()]
+        if not params:
+            return 0
+        flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat.div_(dist.get_world_size())
+        off = 0
+        for p in params:
+            n = p.numel()
+            p.grad = flat[off:off + n].view_as(p).clone()
+            off += n
+        return flat.numel()
+
+    def optimization_step(self, batch, batch_nb=0, gradient_clip_val=5.0):
+        """zero_grad -> training_step -> backward -> gradient all-reduce -> clip (train.py:142 gradient_clip_val 5.0) -> optimizer step."""
+        if self.optimizer is None:
+            raise RuntimeError("System.optimization_step needs an optimizer")
+        self.optimizer.zero_grad(set_to_none=True)
+        loss = self.training_step(batch, batch_nb)["loss"]
+        loss.backward()
+        self.allreduce_gradients()
+        if gradient_clip_val:
+            torch.nn.utils.clip_grad_norm_(self.trainable_parameters(), gradient_clip_val)
+        self.optimizer.step()
+        return loss.detach()
 
     # ---------------------------------------------------------------- on-disk formats
     def load_lightning_checkpoint(self, path, strict=True):
