@@ -241,8 +241,11 @@ def test_system_checkpoint_formats(tmp_path):
     a1 = R.system.load_best_model(str(best), **copy.deepcopy(cfg))
     for k, v in a0.state_dict().items():
         assert torch.equal(v, a1.state_dict()[k]), k
-    with pytest.raises(ValueError):
-        R.System(audio_model=a0, optimizer=object())
+    with pytest.raises(ValueError):  # the video front-end stays frozen (as in the reference's yaml)
+        R.System(audio_model=a0, train_video_model=True)
+    assert R.System(audio_model=a0, optimizer=object()).optimizer is not None  # an optimizer is accepted since the backward exists
+    with pytest.raises(RuntimeError):
+        R.System(audio_model=a0).optimization_step(None)  # ... and required for optimization_step
 
 
 # ---------------------------------------------------------------------------------------------- training side (host logic)
