@@ -50,6 +50,25 @@ class PackedModule(nn.Module):
             )
 
 
+def _recording(*tensors_and_modules):
+    """True when a module call has to take the training kernels: autograd is recording, the module is in train() mode and a
+    gradient is wanted (an input or a parameter requires grad).  In eval() mode the inference kernels run and return graph-less
+    tensors whatever the grad mode, exactly as before the backward pass existed."""
+    if not torch.is_grad_enabled():
+        return False
+    wanted = False
+    for o in tensors_and_modules:
+        if o is None:
+            continue
+        if isinstance(o, torch.Tensor):
+            wanted = wanted or o.requires_grad
+        else:
+            if not o.training:
+                return False
+            wanted = wanted or any(p.requires_grad for p in o.parameters())
+    return wanted
+
+
 # ----------------------------------------------------------------------------- normalisations / activations
 class GlobalLayerNorm(nn.Module):
     """gLN = GroupNorm(1, C) (reference normalizations.py:8-17); parameter keys ``norm.weight/bias``."""
@@ -189,7 +208,7 @@ class ConvNormAct(nn.Module):
         self.full_layer = nn.Sequential(*stages)
 
     def forward(self, x):
-        if x.is_cuda and torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+        if x.is_cuda and _recording(x, self):
             return self._forward_train(x)
         return self.full_layer(x)
 
@@ -367,7 +386,7 @@ class SRU(PackedModule):
     def forward(self, x):
         _lib.need_gpu(x)  # no train/eval difference in this operator (no dropout at the reference call site)
         lib = _lib.load()
-        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+        if _recording(x, self):
             params = [p for cell in self.rnn_lst for p in (cell.weight, cell.weight_c, cell.bias)]
             return _SRUTrainFn.apply(x, *params), None
         x = x.contiguous()
@@ -450,7 +469,7 @@ class DualPathRNN(PackedModule):
         B, C, T, Fq = x.shape
         if (T if self.dim == 3 else Fq) < self.kernel_size:
             raise ValueError(f"sweep axis shorter than kernel_size {self.kernel_size}")  # nn.Unfold raises in the reference
-        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+        if _recording(x, self):
             if self.rnn_type != "SRU":
                 raise RuntimeError("DualPathRNN: the backward pass is built for the SRU cell only")
             sru = [p for cell in self.rnn.rnn_lst for p in (cell.weight, cell.weight_c, cell.bias)]
@@ -522,7 +541,7 @@ class MultiHeadSelfAttention2D(PackedModule):
         B, C, T, Fq = x.shape
         if C != 64 or Fq != 64:
             raise ValueError("expected (B, 64, T, 64)")
-        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+        if _recording(x, self):
             names, params = zip(*self.named_parameters())
             return _AttentionTrainFn.apply(x, names, *params)
         out = torch.empty_like(x)
@@ -595,16 +614,6 @@ def adaptive_avg_pool(x, size):
     return _AdaptivePoolFn.apply(x, tuple(size))
 
 
-def _recording(*tensors_and_modules):
-    if not torch.is_grad_enabled():
-        return False
-    for o in tensors_and_modules:
-        if isinstance(o, torch.Tensor):
-            if o.requires_grad:
-                return True
-        elif any(p.requires_grad for p in o.parameters()):
-            return True
-    return False
 
 
 class InjectionMultiSum(PackedModule):

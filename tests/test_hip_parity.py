@@ -466,7 +466,10 @@ def test_caf_training_forward_backward(B, T, F, Tv, seed):
             p[k] = (p[k] * (1 + 0.5 * rng.random(p[k].shape))).astype(np.float32)
     cell = R.layers.ATTNFusionCell(256, 512, kernel_size=4, is2d=True)
     cell.load_state_dict({k: torch.from_numpy(v) for k, v in p.items()})
-    cell = cell.cuda().eval()  # frozen BatchNorm; autograd still records
+    cell = cell.cuda().train()
+    for mod_ in cell.modules():  # frozen BatchNorm statistics; everything else in train mode, so autograd takes the training kernels
+        if isinstance(mod_, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+            mod_.eval()
     a, v = rand((B, 256, T, F), seed), rand((B, 512, Tv), seed + 1)
     dout = rand((B, 256, T, F), seed + 2)
     at, vt = dev(a).requires_grad_(True), dev(v).requires_grad_(True)
@@ -487,8 +490,7 @@ def test_caf_training_forward_backward(B, T, F, Tv, seed):
             assert float(np.abs(host(g)).max()) <= 1e-5 * gscale
             continue
         close(f"caf d {k}", host(g), pt[k].grad.numpy(), tol=2e-4)
-    with torch.no_grad():
-        close("caf inference vs training forward", host(cell(dev(a), dev(v))), host(out))
+    close("caf inference vs training forward", host(cell.eval()(dev(a), dev(v))), host(out))  # eval mode: inference kernels, no graph
 
 
 @pytest.mark.parametrize("kind,zero_mean,take_log,n", [("snr", True, True, 1), ("sisdr", True, True, 2), ("sdsdr", False, True, 3),
