@@ -164,9 +164,9 @@ int rtfs_dualpath_backward_f32(const float* x, const float* tpack, const float* 
                                float* dparams, int B, int T, int F, int dim, void* ws, size_t ws_bytes, void* stream);
 /* ConvNormAct.forward / backward for training (src/models/layers/conv_layers.py:65-129: pre_norm -> pre_act -> conv -> norm -> act),
  * 1x1 dense (channels up to 1024) or depthwise k x k (taps up to 4 x 5, stride 1 "same" or stride 2 symmetric), norms: none | gLN |
- * BatchNorm with frozen running statistics (post-norm only), acts: none | ReLU | PReLU | Sigmoid.
+ * BatchNorm (post-norm only; frozen running statistics, or train mode = statistics of the batch), acts: none | ReLU | PReLU | Sigmoid.
  * cfg (HOST int[11]): Cin, Cout, k, stride, depthwise, pre_norm (0/1), pre_act (0 none, 1 ReLU, 2 PReLU, 3 Sigmoid), norm (0 none, 1 gLN,
- *   2 frozen BatchNorm), act, has_bias, is2d.  x (B,Cin,H,W) -> out (B,Cout,Ho,Wo) (rtfs_cna_out_shape).
+ *   2 frozen BatchNorm, 3 train-mode BatchNorm), act, has_bias, is2d.  x (B,Cin,H,W) -> out (B,Cout,Ho,Wo) (rtfs_cna_out_shape).
  * params (rtfs_cna_param_floats, packing.py:pack_cna_train; every slot padded to 64 floats, unused slots ignored):
  *   pre gamma | pre beta | pre slope | W (Cout,Cin) or (C,kh*kw) | W^T (dense only) | bias | gamma | beta | slope | running mean | running var.
  * dparams (rtfs_cna_grad_floats, overwritten): the slots pre gamma ... slope without W^T. */
@@ -179,6 +179,10 @@ int rtfs_cna_forward_train_f32(const float* x, const float* params, float* out, 
                                void* ws, size_t ws_bytes, void* stream);
 int rtfs_cna_backward_f32(const float* params, const float* saved, const float* dout, float* dx, float* dparams, const int* cfg,
                           int B, int H, int W, void* ws, size_t ws_bytes, void* stream);
+/* after a forward with norm = 3: nn.BatchNorm's running_mean / running_var update (momentum, unbiased variance) from the batch
+ * statistics kept in `saved`; the two pointers are the module's buffers on the device. */
+int rtfs_cna_bn_update_f32(const float* saved, const int* cfg, int B, int H, int W, float* running_mean, float* running_var,
+                           float momentum, void* stream);
 /* MultiHeadSelfAttention2D.forward / backward for training (src/models/layers/attention.py:149-189; 4 heads, hid_chan 4, n_freqs 64).
  * x, out, dout, dx (B,64,T,64).  tpack (rtfs_tf_attention_train_pack_floats(), packing.py:pack_attention_train):
  *   W_qkv (128,64) rows [Q h0..3 (4 each) | K h0..3 | V h0..3 (16 each) | 32 zero rows] | its transpose | bias (128) | PReLU slope per

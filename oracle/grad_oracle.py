@@ -238,7 +238,7 @@ def audio_chain_torch(wav, p):
     return stft_decoder_torch(s[:, 0], p["decoder.decoder.weight"], wav.shape[-1])
 
 
-def caf_torch(a, v, p):
+def caf_torch(a, v, p, bn_train=False):
     """ATTNFusionCell.forward (reference layers/fusion.py:252-274), is2d, kernel_size 4, BatchNorm in eval mode (running stats).
     a (B,256,T,F), v (B,512,Tv); p = the cell's state_dict (running statistics included, treated as constants)."""
     import torch.nn.functional as F
@@ -251,8 +251,9 @@ def caf_torch(a, v, p):
 
     def audio_conv(pre, relu):
         y = F.conv2d(a, p[pre + ".full_layer.2.weight"], None, groups=C)
+        # bn_train: statistics of the batch (and torch updates the two running tensors in place, momentum 0.1, as nn.BatchNorm2d does)
         y = F.batch_norm(y, p[pre + ".full_layer.3.running_mean"].detach(), p[pre + ".full_layer.3.running_var"].detach(),
-                         p[pre + ".full_layer.3.weight"], p[pre + ".full_layer.3.bias"], False, 0.0, 1e-5)
+                         p[pre + ".full_layer.3.weight"], p[pre + ".full_layer.3.bias"], bn_train, 0.1, 1e-5)
         return torch.relu(y) if relu else y
     b_t = F.interpolate(video_conv("resize"), size=T, mode="nearest").unsqueeze(-1)
     k1 = audio_conv("key_embed", True) * b_t

@@ -65,6 +65,7 @@ SIGNATURES = {
     "rtfs_cna_workspace_bytes": (_z, [_p, _i, _i, _i]),
     "rtfs_cna_out_shape": (None, [_p, _i, _i, _p, _p]),
     "rtfs_cna_forward_train_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p, _z, _p]),
+    "rtfs_cna_bn_update_f32": (_i, [_p, _p, _i, _i, _i, _p, _p, C.c_float, _p]),
     "rtfs_cna_backward_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _z, _p]),
     "rtfs_tf_attention_train_pack_floats": (_z, []),
     "rtfs_tf_attention_grad_floats": (_z, []),

@@ -1189,7 +1189,7 @@ struct CnaCfg {
         ok = pow2(Cin, depthwise ? 256 : 1024) && pow2(Cout, depthwise ? 256 : 1024) && k >= 1 && kh <= 4 && kw <= 5 &&
              (stride == 1 || stride == 2) && Ho >= 1 && Wo >= 1 &&
              (depthwise ? Cin == Cout : (k == 1 && stride == 1 && Cin % 16 == 0 && Cout % 64 == 0 && Cin % 64 == 0)) &&
-             pre_norm >= 0 && pre_norm <= 1 && norm >= 0 && norm <= 2 && pre_act >= 0 && pre_act <= 3 && act >= 0 && act <= 3 &&
+             pre_norm >= 0 && pre_norm <= 1 && norm >= 0 && norm <= 3 && pre_act >= 0 && pre_act <= 3 && act >= 0 && act <= 3 &&
              rows_in * (size_t)(Cin > Cout ? Cin : Cout) < 0x7fffffffu;
     }
     bool pre() const { return pre_norm || pre_act; }
@@ -1197,7 +1197,7 @@ struct CnaCfg {
 };
 struct CnaSaved {
     float *r0, *r2, *r3;
-    double *st0, *st3;
+    double *st0, *st3, *cst;
     size_t floats;
     CnaSaved(float* p, const CnaCfg& c) {
         float* p0 = p;
@@ -1206,6 +1206,7 @@ struct CnaSaved {
         r3 = p; p += c.rows_out * c.Cout;
         st0 = (double*)p; p += 4 * c.B;
         st3 = (double*)p; p += 4 * c.B;
+        cst = (double*)p; p += 4 * c.Cout;  // BatchNorm batch statistics (norm 3)
         floats = (size_t)(p - p0);
     }
 };
@@ -1265,7 +1266,11 @@ int rtfs_cna_forward_train_f32(const float* x, const float* params, float* out, 
         ClStageArgs a;
         a.x = sv.r3; a.y = r5; a.n = n_out; a.C = c.Cout; a.norm = c.norm; a.act = c.act;
         a.gamma = params + c.o_g; a.beta = params + c.o_be; a.slope = params + c.o_s; a.stats = sv.st3;
-        a.rmean = params + c.o_rm; a.rvar = params + c.o_rv;
+        a.rmean = params + c.o_rm; a.rvar = params + c.o_rv; a.cstats = sv.cst; a.inv_rows = 1.0 / (double)c.rows_out;
+        if (c.norm == 3) {
+            if (hipMemsetAsync(sv.cst, 0, sizeof(double) * 2 * c.Cout, st) != hipSuccess) return RTFS_ERR_LAUNCH;
+            CHECK(launch_cl_chan_stats(sv.r3, sv.cst, c.rows_out * c.Cout, c.Cout, st));
+        }
         if (c.norm == 1) {
             if (hipMemsetAsync(sv.st3, 0, sizeof(double) * 2 * B, st) != hipSuccess) return RTFS_ERR_LAUNCH;
             CHECK(launch_stats(sv.r3, sv.st3, B, n_out, st));
@@ -1273,6 +1278,17 @@ int rtfs_cna_forward_train_f32(const float* x, const float* params, float* out, 
         CHECK(launch_cl_norm_act_fwd(a, B, st));
     }
     return launch_transpose(r5, out, B, c.Ho * c.Wo, c.Cout, st);  // (B, P, C) -> (B, C, P)
+}
+
+// nn.BatchNorm's running-statistics update for a forward that ran with norm = 3 (train-mode BatchNorm): reads the batch statistics the
+// forward left in `saved`, updates running_mean / running_var (DEVICE pointers to the module's buffers) in place
+int rtfs_cna_bn_update_f32(const float* saved, const int* cfg, int B, int H, int W, float* running_mean, float* running_var, float momentum,
+                           void* stream) {
+    RTFS_RETURN_IF(!saved || !cfg || !running_mean || !running_var, RTFS_ERR_ARG);
+    CnaCfg c(cfg, B, H, W);
+    RTFS_RETURN_IF(!c.ok || c.norm != 3, RTFS_ERR_SHAPE);
+    CnaSaved sv((float*)align_up((size_t)saved, 16), c);
+    return launch_bn_update(sv.cst, running_mean, running_var, c.Cout, (double)c.rows_out, momentum, S(stream));
 }
 
 int rtfs_cna_backward_f32(const float* params, const float* saved, const float* dout, float* dx, float* dparams, const int* cfg, int B,
@@ -1299,7 +1315,7 @@ int rtfs_cna_backward_f32(const float* params, const float* saved, const float* 
         ClStageArgs a;
         a.x = sv.r3; a.dy = d5; a.dx = d3b; a.n = n_out; a.C = c.Cout; a.norm = c.norm; a.act = c.act;
         a.gamma = params + c.o_g; a.beta = params + c.o_be; a.slope = params + c.o_s; a.stats = sv.st3; a.S = Sb;
-        a.rmean = params + c.o_rm; a.rvar = params + c.o_rv;
+        a.rmean = params + c.o_rm; a.rvar = params + c.o_rv; a.cstats = sv.cst; a.inv_rows = 1.0 / (double)c.rows_out;
         a.dgamma = dparams + c.g_g; a.dbeta = dparams + c.g_be; a.dslope = dparams + c.g_s;
         CHECK(launch_cl_norm_act_bwd(a, B, st));
         d3 = d3b;

@@ -538,12 +538,20 @@ __device__ __forceinline__ float act_bwd(float z, float dy, int act, float slope
 
 // grid (chunks, B): each workgroup a strided share of one sample's n = rows*C elements.
 // norm: 0 none, 1 gLN (per-sample statistics), 2 BatchNorm with frozen running statistics (per-channel mean / variance; the
-// eval-mode arithmetic of conv_layers.py's BatchNorm stages, used when a model is fine-tuned with its BN layers in eval mode).
+// eval-mode arithmetic of conv_layers.py's BatchNorm stages, used when a model is fine-tuned with its BN layers in eval mode),
+// 3 BatchNorm in train mode (per-channel statistics of the batch, cl_chan_stats_kernel; dx = gamma*rstd*(da - dbeta/n - xhat*dgamma/n),
+// where dgamma, dbeta are exactly the per-channel sums the reduction pass produces anyway).
 namespace {
 __device__ __forceinline__ void norm_of(const ClStageArgs& a, int b, int c, float& mean, float& rstd) {
     if (a.norm == 2) {
         mean = a.rmean[c];
         rstd = 1.0f / sqrtf(a.rvar[c] + RTFS_EPS);
+    } else if (a.norm == 3) {  // BatchNorm in train mode: statistics of this batch, per channel (biased variance)
+        const double m = a.cstats[2 * c] * a.inv_rows;
+        double var = a.cstats[2 * c + 1] * a.inv_rows - m * m;
+        var = var < 0 ? 0 : var;
+        mean = (float)m;
+        rstd = (float)(1.0 / sqrt(var + (double)RTFS_EPS));
     }
 }
 }  // namespace
@@ -631,8 +639,54 @@ __global__ __launch_bounds__(256) void cl_norm_act_bwd_apply_kernel(ClStageArgs 
         const float xh = a.norm ? (xv - mean) * rstd : xv;
         const float z = a.norm ? fmaf(xh, g, a.beta[c]) : xv;
         const float da = act_bwd(z, a.dy[base + i], a.act, slope, dummy);
-        a.dx[base + i] = a.norm == 1 ? rstd * (da * g - m1 - xh * m2) : (a.norm == 2 ? da * g * rstd : da);
+        float out = da;
+        if (a.norm == 1) out = rstd * (da * g - m1 - xh * m2);
+        else if (a.norm == 2) out = da * g * rstd;
+        else if (a.norm == 3) out = g * rstd * (da - (float)a.inv_rows * (a.dbeta[c] + xh * a.dgamma[c]));
+        a.dx[base + i] = out;
     }
+}
+
+// per-channel sum and sum of squares over all rows (BatchNorm batch statistics), f64 atomics; grid stride a multiple of C
+__global__ __launch_bounds__(256) void cl_chan_stats_kernel(const float* __restrict__ x, double* __restrict__ st, size_t n, int C) {
+    __shared__ double part[2][256];
+    const int tid = threadIdx.x;
+    double s = 0, ss = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + tid; i < n; i += (size_t)gridDim.x * 256) {
+        const double v = x[i];
+        s += v;
+        ss += v * v;
+    }
+    if (C >= 256) {
+        const size_t c = ((size_t)blockIdx.x * 256 + tid) & (C - 1);
+        atomicAdd(st + 2 * c, s);
+        atomicAdd(st + 2 * c + 1, ss);
+        return;
+    }
+    part[0][tid] = s;
+    part[1][tid] = ss;
+    __syncthreads();
+    if (tid < C) {
+        double a = 0, b = 0;
+        for (int j = tid; j < 256; j += C) {
+            a += part[0][j];
+            b += part[1][j];
+        }
+        atomicAdd(st + 2 * tid, a);
+        atomicAdd(st + 2 * tid + 1, b);
+    }
+}
+// running_mean / running_var update of nn.BatchNorm (momentum m, unbiased variance for the running estimate)
+__global__ void bn_update_kernel(const double* __restrict__ st, float* __restrict__ rmean, float* __restrict__ rvar, int C, double rows,
+                                 float momentum) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const double m = st[2 * c] / rows;
+    double var = st[2 * c + 1] / rows - m * m;
+    var = var < 0 ? 0 : var;
+    const double unb = rows > 1 ? var * rows / (rows - 1) : var;
+    rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)m;
+    rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
 }
 
 // out[c] += sum over rows of d[row][c]   (bias gradients); grid stride a multiple of C
@@ -785,6 +839,15 @@ int launch_cl_norm_act_bwd(const ClStageArgs& a, int B, hipStream_t st) {
         hipLaunchKernelGGL(cl_norm_act_bwd_reduce_kernel, dim3(grid4(a.n, 256), B), dim3(256), 0, st, a);
     }
     hipLaunchKernelGGL(cl_norm_act_bwd_apply_kernel, dim3(grid_for(a.n, 2048), B), dim3(256), 0, st, a);
+    return rtfs_launch_status();
+}
+int launch_cl_chan_stats(const float* x, double* stats, size_t n, int C, hipStream_t st) {
+    if (!cl_c_ok(C)) return RTFS_ERR_SHAPE;
+    hipLaunchKernelGGL(cl_chan_stats_kernel, dim3(grid4(n, 1024)), dim3(256), 0, st, x, stats, n, C);
+    return rtfs_launch_status();
+}
+int launch_bn_update(const double* stats, float* rmean, float* rvar, int C, double rows, float momentum, hipStream_t st) {
+    hipLaunchKernelGGL(bn_update_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, stats, rmean, rvar, C, rows, momentum);
     return rtfs_launch_status();
 }
 int launch_cl_colsum(const float* d, float* out, size_t n, int C, hipStream_t st) {

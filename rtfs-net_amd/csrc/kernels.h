@@ -272,6 +272,8 @@ struct ClStageArgs {  // y = act(gLN(x)) over rows x C, per-sample statistics
     const double* stats = nullptr;  // (B, 2) sum, sum of squares of x per sample (norm only)
     const float *gamma = nullptr, *beta = nullptr, *slope = nullptr;
     const float *rmean = nullptr, *rvar = nullptr;  // norm 2: BatchNorm running statistics (per channel)
+    const double* cstats = nullptr;                 // norm 3: per-channel (sum, sum of squares) of this batch
+    double inv_rows = 0;                            // norm 3: 1 / (rows over the whole batch)
     const float* dy = nullptr;  // backward
     float* dx = nullptr;
     double* S = nullptr;        // backward scratch (B, 2)
@@ -289,6 +291,8 @@ struct ClDwArgs {
 int launch_cl_norm_act_fwd(const ClStageArgs& a, int B, hipStream_t st);
 int launch_cl_norm_act_bwd(const ClStageArgs& a, int B, hipStream_t st);
 int launch_cl_colsum(const float* d, float* out, size_t n, int C, hipStream_t st);
+int launch_cl_chan_stats(const float* x, double* stats, size_t n, int C, hipStream_t st);
+int launch_bn_update(const double* stats, float* rmean, float* rvar, int C, double rows, float momentum, hipStream_t st);
 int launch_cl_dw(const ClDwArgs& a, int what /* 0 fwd, 1 bwd data, 2 wgrad */, hipStream_t st);
 // TF attention training kernels (k_train.hip)
 struct LngArgs {  // PReLU + LayerNormalization4D((C_group, 64)) over rows (b,t,f) x CZ

@@ -146,8 +146,8 @@ class _CNATrainFn(torch.autograd.Function):
         x = x.contiguous()
         B, H, W = x.shape[0], (x.shape[2] if x.dim() == 4 else 1), x.shape[-1]
         carr = (ctypes.c_int * 11)(*cfg)
-        params, running = params[:8], params[8:]  # optional: BatchNorm running mean / var (constants)
-        pk = packing.pack_cna_train(cfg, *params, *running)
+        params, running = params[:8], params[8:]  # optional: BatchNorm running mean / var (+ momentum in train mode)
+        pk = packing.pack_cna_train(cfg, *params, *running[:2])
         ho, wo = ctypes.c_int(), ctypes.c_int()
         lib.rtfs_cna_out_shape(carr, H, W, ctypes.byref(ho), ctypes.byref(wo))
         out = torch.empty((B, cfg[1], ho.value, wo.value) if x.dim() == 4 else (B, cfg[1], wo.value), device=x.device, dtype=torch.float32)
@@ -155,6 +155,10 @@ class _CNATrainFn(torch.autograd.Function):
         ws = _lib.workspace(lib.rtfs_cna_workspace_bytes(carr, B, H, W), x.device)
         _lib.check(lib.rtfs_cna_forward_train_f32(_lib.ptr(x), _lib.ptr(pk), _lib.ptr(out), _lib.ptr(saved), carr, B, H, W, _lib.ptr(ws), ws.numel(),
                                                   _lib.stream_of(x)), "rtfs_cna_forward_train_f32")
+        if cfg[7] == 3:  # train-mode BatchNorm: nn.BatchNorm's side effect on its buffers (momentum None = cumulative average is not built)
+            rm, rv, momentum = running
+            _lib.check(lib.rtfs_cna_bn_update_f32(_lib.ptr(saved), carr, B, H, W, _lib.ptr(rm), _lib.ptr(rv), float(momentum), _lib.stream_of(x)),
+                       "rtfs_cna_bn_update_f32")
         ctx.save_for_backward(pk, saved)
         ctx.cfg, ctx.geom, ctx.xshape = cfg, (B, H, W), x.shape
         ctx.pshapes = [None if p is None else p.shape for p in params]
@@ -220,9 +224,8 @@ class ConvNormAct(nn.Module):
         if not isinstance(pre_n, (nn.Identity, GlobalLayerNorm)):
             raise RuntimeError(f"ConvNormAct: the training kernels implement gLN as pre-norm only, not {type(pre_n).__name__}")
         bn = isinstance(nrm, (nn.BatchNorm1d, nn.BatchNorm2d))
-        if bn and nrm.training:
-            raise RuntimeError("ConvNormAct: BatchNorm batch statistics are not built; put the BatchNorm layers in eval mode "
-                               "(frozen running statistics) to take gradients through them")
+        if bn and nrm.training and (nrm.momentum is None or not nrm.track_running_stats):
+            raise RuntimeError("ConvNormAct: train-mode BatchNorm needs track_running_stats and a momentum")
         if not bn and not isinstance(nrm, (nn.Identity, GlobalLayerNorm)):
             raise RuntimeError(f"ConvNormAct: norm {type(nrm).__name__} has no training kernel")
         for m in (pre_a, act):
@@ -243,13 +246,16 @@ class ConvNormAct(nn.Module):
             weight = weight.reshape(cout, conv.in_channels, *([1] * (conv.weight.dim() - 2)))
         is2d = isinstance(conv, nn.Conv2d)
         cfg = (conv.in_channels, conv.out_channels, self.kernel_size, self.stride, int(depthwise), int(isinstance(pre_n, GlobalLayerNorm)),
-               _ACT_CODE[type(pre_a)], 2 if bn else int(isinstance(nrm, GlobalLayerNorm)), _ACT_CODE[type(act)], int(conv.bias is not None),
-               int(is2d))
+               _ACT_CODE[type(pre_a)], (3 if nrm.training else 2) if bn else int(isinstance(nrm, GlobalLayerNorm)), _ACT_CODE[type(act)],
+               int(conv.bias is not None), int(is2d))
         gn = lambda m, a: getattr(m.norm, a) if isinstance(m, GlobalLayerNorm) else (getattr(m, a) if isinstance(m, (nn.BatchNorm1d, nn.BatchNorm2d)) else None)
         sl = lambda m: m.weight if isinstance(m, nn.PReLU) else None
-        running = (nrm.running_mean, nrm.running_var) if bn else ()
-        return _CNATrainFn.apply(x, cfg, gn(pre_n, "weight"), gn(pre_n, "bias"), sl(pre_a), weight, conv.bias, gn(nrm, "weight"),
-                                 gn(nrm, "bias"), sl(act), *running)
+        running = ((nrm.running_mean, nrm.running_var) + ((nrm.momentum,) if nrm.training else ())) if bn else ()
+        out = _CNATrainFn.apply(x, cfg, gn(pre_n, "weight"), gn(pre_n, "bias"), sl(pre_a), weight, conv.bias, gn(nrm, "weight"),
+                                gn(nrm, "bias"), sl(act), *running)
+        if bn and nrm.training:
+            nrm.num_batches_tracked += 1
+        return out
 
     def get_config(self):
         return _config_of(self)

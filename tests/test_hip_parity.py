@@ -450,8 +450,9 @@ def test_encoder_bottleneck_s3_decoder_training(B, L, seed, smooth):
         assert max(e for e, _ in errs.values()) <= 2e-4, errs
 
 
-@pytest.mark.parametrize("B,T,F,Tv,seed", [(2, 9, 5, 4, 71), (1, 33, 129, 7, 72), (2, 20, 16, 20, 73)])
-def test_caf_training_forward_backward(B, T, F, Tv, seed):
+@pytest.mark.parametrize("B,T,F,Tv,seed,bn_train", [(2, 9, 5, 4, 71, False), (1, 33, 129, 7, 72, False), (2, 20, 16, 20, 73, False),
+                                                     (2, 9, 5, 4, 74, True), (3, 33, 129, 7, 75, True)])
+def test_caf_training_forward_backward(B, T, F, Tv, seed, bn_train):
     """CAF cell inside a training step with its BatchNorm layers frozen (eval-mode statistics): grouped video-side convolutions +
     gLN, depthwise audio-side convolutions + BatchNorm (+ReLU), attention softmax, nearest up-sampling; all gradients (audio input,
     video input, 14 parameter tensors) against the autograd oracle."""
@@ -467,8 +468,8 @@ def test_caf_training_forward_backward(B, T, F, Tv, seed):
     cell = R.layers.ATTNFusionCell(256, 512, kernel_size=4, is2d=True)
     cell.load_state_dict({k: torch.from_numpy(v) for k, v in p.items()})
     cell = cell.cuda().train()
-    for mod_ in cell.modules():  # frozen BatchNorm statistics; everything else in train mode, so autograd takes the training kernels
-        if isinstance(mod_, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+    for mod_ in cell.modules():  # bn_train False: frozen BatchNorm statistics (eval), everything else in train mode
+        if isinstance(mod_, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)) and not bn_train:
             mod_.eval()
     a, v = rand((B, 256, T, F), seed), rand((B, 512, Tv), seed + 1)
     dout = rand((B, 256, T, F), seed + 2)
@@ -477,8 +478,14 @@ def test_caf_training_forward_backward(B, T, F, Tv, seed):
     out.backward(dev(dout))
     pt = {k: torch.tensor(val, dtype=torch.float64, requires_grad=("running" not in k)) for k, val in p.items() if "num_batches" not in k}
     ar, vr = torch.tensor(a, dtype=torch.float64, requires_grad=True), torch.tensor(v, dtype=torch.float64, requires_grad=True)
-    o_ref = G.caf_torch(ar, vr, pt)
+    o_ref = G.caf_torch(ar, vr, pt, bn_train=bn_train)
     o_ref.backward(torch.tensor(dout, dtype=torch.float64))
+    if bn_train:  # nn.BatchNorm2d's side effects: running statistics (momentum 0.1, unbiased variance) and the batch counter
+        for pre in ("key_embed", "value_embed"):
+            bnm = getattr(cell, pre).full_layer[3]
+            close(f"caf {pre} running_mean", host(bnm.running_mean), pt[pre + ".full_layer.3.running_mean"].numpy(), tol=1e-5)
+            close(f"caf {pre} running_var", host(bnm.running_var), pt[pre + ".full_layer.3.running_var"].numpy(), tol=1e-5)
+            assert int(bnm.num_batches_tracked) == 1
     close("caf train forward", host(out), o_ref.detach().numpy())
     close("caf d audio", host(at.grad), ar.grad.numpy(), tol=2e-4)
     close("caf d video", host(vt.grad), vr.grad.numpy(), tol=2e-4)
@@ -490,7 +497,8 @@ def test_caf_training_forward_backward(B, T, F, Tv, seed):
             assert float(np.abs(host(g)).max()) <= 1e-5 * gscale
             continue
         close(f"caf d {k}", host(g), pt[k].grad.numpy(), tol=2e-4)
-    close("caf inference vs training forward", host(cell.eval()(dev(a), dev(v))), host(out))  # eval mode: inference kernels, no graph
+    if not bn_train:
+        close("caf inference vs training forward", host(cell.eval()(dev(a), dev(v))), host(out))  # eval mode: inference kernels, no graph
 
 
 @pytest.mark.parametrize("kind,zero_mean,take_log,n", [("snr", True, True, 1), ("sisdr", True, True, 2), ("sdsdr", False, True, 3),
