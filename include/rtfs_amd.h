@@ -235,6 +235,19 @@ int rtfs_caf_combine_backward_f32(const float* dout, const float* key, const flo
  * rtfs_pit_pairwise_sdr_f32 -> dests (B, n_src, L).  (The targets are data.) */
 int rtfs_pit_sdr_backward_f32(const float* ests, const float* targets, const int* perm, const float* dmin_loss, float* dests, int B,
                               int n_src, int L, int sdr_type, int zero_mean, int take_log, void* stream);
+/* Pieces of the video-side MultiHeadSelfAttention (src/models/layers/attention.py:28-73) with their adjoints, on rows (b, t) x C:
+ * nn.LayerNorm over C; nn.Linear (in_proj / out_proj of nn.MultiheadAttention; N, K multiples of 64); the attention core
+ * softmax(q k^T / sqrt(head_dim)) v on the packed projections [q | k | v] (T <= 256, head_dim <= 16), with an optional keep-mask
+ * (B*n_head, T, T), already scaled by 1/(1-p), for the dropout nn.MultiheadAttention applies to the attention weights in train mode. */
+int rtfs_layernorm_rows_f32(const float* x, const float* gamma, const float* beta, float* y, int N, int C, void* stream);
+int rtfs_layernorm_rows_backward_f32(const float* x, const float* gamma, const float* dy, float* dx, float* dgamma, float* dbeta, int N,
+                                     int C, void* stream);
+int rtfs_linear_rows_f32(const float* x, const float* W, const float* bias, float* y, int M, int N, int K, void* stream);
+int rtfs_linear_rows_backward_f32(const float* x, const float* W, const float* dy, float* dx, float* dW, float* dbias, int M, int N, int K,
+                                  void* ws, size_t ws_bytes, void* stream);
+int rtfs_mha_core_f32(const float* qkv, const float* pmask, float* o, int B, int T, int n_head, int head_dim, void* stream);
+int rtfs_mha_core_backward_f32(const float* qkv, const float* pmask, const float* dout, float* dqkv, int B, int T, int n_head, int head_dim,
+                               void* stream);
 /* The two GEMM forms of the training path (bf16x3 split on the matrix cores), exposed for tests:
  * kind 0: C (M,N) = A (M,K) . B (N,K)^T (accumulate != 0: C += ...), N % 64 == 0, K % 16 == 0;
  * kind 1: C (M,N) += A (K,M)^T . B (K,N), M % 64 == 0, N % 64 == 0. */

@@ -290,3 +290,78 @@ def pit_loss_torch(est, tgt, kind="snr", zero_mean=True, take_log=True, eps=1e-8
     if take_log:
         sdr = 10 * torch.log10(sdr + eps)
     return (-sdr).mean()
+
+
+def _cna1d(x, p, *, k=1, stride=1, depthwise=False, norm=None, act=0, bn_train=False):
+    """1-D ConvNormAct from its state_dict sub-dict; norm in {None, "gLN", "BN"} (BN: running statistics, or the batch's if bn_train)."""
+    import torch.nn.functional as F
+    y = F.conv1d(x, p["full_layer.2.weight"], p.get("full_layer.2.bias"), stride=stride, padding=(k - 1) // 2,
+                 groups=x.shape[1] if depthwise else 1)
+    if norm == "gLN":
+        y = F.group_norm(y, 1, p["full_layer.3.norm.weight"], p["full_layer.3.norm.bias"], 1e-5)
+    elif norm == "BN":
+        y = F.batch_norm(y, p["full_layer.3.running_mean"].detach(), p["full_layer.3.running_var"].detach(), p["full_layer.3.weight"],
+                         p["full_layer.3.bias"], bn_train, 0.1, 1e-5)
+    if act == 1:
+        y = torch.relu(y)
+    elif act == 2:
+        y = F.prelu(y, p["full_layer.4.weight"])
+    elif act == 3:
+        y = torch.sigmoid(y)
+    return y
+
+
+def mhsa_1d_torch(x, p, n_head=8, pmask=None):
+    """rtfs_oracle.mhsa_1d in torch (reference attention.py:57-73), dropout / DropPath off; pmask: optional keep-mask (B*n_head, T, T)
+    multiplying the attention weights (what nn.MultiheadAttention's dropout does in train mode)."""
+    import math
+    import torch.nn.functional as F
+    res = x
+    y = x.transpose(1, 2)
+    C = y.shape[-1]
+    y = F.layer_norm(y, (C,), p["norm1.weight"], p["norm1.bias"], 1e-5) + p["pos_enc.pe"][0, : y.shape[1]].detach()
+    residual = y
+    B, T, _ = y.shape
+    hd = C // n_head
+    qkv = y @ p["attention.in_proj_weight"].t() + p["attention.in_proj_bias"]
+    q, k, v = [t.reshape(B, T, n_head, hd).transpose(1, 2) for t in qkv.split(C, -1)]
+    a = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(hd), -1)
+    if pmask is not None:
+        a = a * pmask.reshape(B, n_head, T, T)
+    o = (a @ v).transpose(1, 2).reshape(B, T, C) @ p["attention.out_proj.weight"].t() + p["attention.out_proj.bias"]
+    y = F.layer_norm(o + residual, (C,), p["norm2.weight"], p["norm2.bias"], 1e-5)
+    return y.transpose(1, 2) + res
+
+
+def vp_block_torch(v, p, depth=4, bn_train=False):
+    """rtfs_oracle.vp_block in torch (reference separators/tdanet.py:104-131 with yaml video_params), dropout / DropPath off."""
+    import torch.nn.functional as F
+    residual = _cna1d(v, _sub(p, "gateway"), depthwise=True, act=2)
+    x_enc = _cna1d(residual, _sub(p, "projection"))
+    kw = dict(k=3, depthwise=True, norm="BN", bn_train=bn_train)
+    downs = [_cna1d(x_enc, _sub(p, "downsample_layers.0"), **kw)]
+    for i in range(1, depth):
+        downs.append(_cna1d(downs[-1], _sub(p, f"downsample_layers.{i}"), stride=2, **kw))
+    tgt = downs[-1].shape[-1]
+    g = sum(F.adaptive_avg_pool1d(d, tgt) for d in downs)
+    g = mhsa_1d_torch(g, _sub(p, "globalatt.0.MHSA"))
+    f = _sub(p, "globalatt.0.FFN")
+    y = _cna1d(g, _sub(f, "encoder"), norm="gLN")
+    y = _cna1d(y, _sub(f, "refiner"), k=f["refiner.full_layer.2.weight"].shape[-1], depthwise=True, act=1)
+    g = _cna1d(y, _sub(f, "decoder"), norm="gLN") + g
+
+    def ims(loc, glo, name):
+        q = _sub(p, name)
+        le = _cna1d(loc, _sub(q, "local_embedding"), **kw)
+        if loc.shape[-1] > glo.shape[-1]:
+            ge = F.interpolate(_cna1d(glo, _sub(q, "global_embedding"), **kw), size=loc.shape[-1], mode="nearest")
+            gate = F.interpolate(_cna1d(glo, _sub(q, "global_gate"), act=3, **kw), size=loc.shape[-1], mode="nearest")
+        else:
+            gi = F.interpolate(glo, size=loc.shape[-1], mode="nearest")
+            ge, gate = _cna1d(gi, _sub(q, "global_embedding"), **kw), _cna1d(gi, _sub(q, "global_gate"), act=3, **kw)
+        return le * gate + ge
+    xf = [ims(downs[i], g, f"fusion_layers.{i}") for i in range(depth)]
+    expanded = ims(xf[-2], xf[-1], f"concat_layers.{depth - 2}") + downs[-2]
+    for i in range(depth - 3, -1, -1):
+        expanded = ims(xf[i], expanded, f"concat_layers.{i}") + downs[i]
+    return _cna1d(expanded, _sub(p, "residual_conv")) + residual

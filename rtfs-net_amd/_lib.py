@@ -87,6 +87,12 @@ SIGNATURES = {
     "rtfs_caf_combine_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "rtfs_caf_combine_backward_f32": (_i, [_p] * 9 + [_i, _i, _i, _i, _p]),
     "rtfs_pit_sdr_backward_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "rtfs_layernorm_rows_f32": (_i, [_p, _p, _p, _p, _i, _i, _p]),
+    "rtfs_layernorm_rows_backward_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _p]),
+    "rtfs_linear_rows_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
+    "rtfs_linear_rows_backward_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _z, _p]),
+    "rtfs_mha_core_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
+    "rtfs_mha_core_backward_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "rtfs_debug_gemm_f32": (_i, [_i, _p, _p, _p, _i, _i, _i, _i, _p]),
     "rtfs_debug_sweep_stamps": (_i, [_p, _p, _p, _i, _i, _i, _p, _p]),
     "rtfs_selftest_mfma_f16": (_i, [_p, _p, _p, _p]),

@@ -1186,7 +1186,7 @@ struct CnaCfg {
         g_pg = o; o += pad64(Cin); g_pb = o; o += pad64(Cin); g_ps = o; o += 64; g_w = o; o += pad64(wn);
         g_b = o; o += pad64(Cout); g_g = o; o += pad64(Cout); g_be = o; o += pad64(Cout); g_s = o; o += 64; g_end = o;
         auto pow2 = [](int v, int cap) { return v >= 1 && v <= cap && !(v & (v - 1)); };
-        ok = pow2(Cin, depthwise ? 256 : 1024) && pow2(Cout, depthwise ? 256 : 1024) && k >= 1 && kh <= 4 && kw <= 5 &&
+        ok = pow2(Cin, 1024) && pow2(Cout, 1024) && k >= 1 && kh <= 4 && kw <= 5 &&
              (stride == 1 || stride == 2) && Ho >= 1 && Wo >= 1 &&
              (depthwise ? Cin == Cout : (k == 1 && stride == 1 && Cin % 16 == 0 && Cout % 64 == 0 && Cin % 64 == 0)) &&
              pre_norm >= 0 && pre_norm <= 1 && norm >= 0 && norm <= 3 && pre_act >= 0 && pre_act <= 3 && act >= 0 && act <= 3 &&
@@ -1609,6 +1609,54 @@ int rtfs_pit_sdr_backward_f32(const float* ests, const float* targets, const int
     RTFS_RETURN_IF(!ests || !targets || !perm || !dmin_loss || !dests || B < 1, RTFS_ERR_ARG);
     RTFS_RETURN_IF(sdr_type < 0 || sdr_type > 2, RTFS_ERR_ARG);
     return launch_pit_sdr_bwd(ests, targets, perm, dmin_loss, dests, B, n_src, L, sdr_type, zero_mean, take_log, S(stream));
+}
+
+// ------------------------------------------------------------ video-side attention pieces (rows = (b, t), channels last)
+// nn.LayerNorm over the last axis of (N, C) rows
+int rtfs_layernorm_rows_f32(const float* x, const float* gamma, const float* beta, float* y, int N, int C, void* stream) {
+    RTFS_RETURN_IF(!x || !gamma || !beta || !y || N < 1, RTFS_ERR_ARG);
+    return launch_ln_rows(x, gamma, beta, y, nullptr, nullptr, nullptr, nullptr, (size_t)N, C, false, S(stream));
+}
+int rtfs_layernorm_rows_backward_f32(const float* x, const float* gamma, const float* dy, float* dx, float* dgamma, float* dbeta, int N, int C,
+                                     void* stream) {
+    RTFS_RETURN_IF(!x || !gamma || !dy || !dx || !dgamma || !dbeta || N < 1, RTFS_ERR_ARG);
+    hipStream_t st = S(stream);
+    if (hipMemsetAsync(dgamma, 0, sizeof(float) * C, st) != hipSuccess || hipMemsetAsync(dbeta, 0, sizeof(float) * C, st) != hipSuccess)
+        return RTFS_ERR_LAUNCH;
+    return launch_ln_rows(x, gamma, nullptr, nullptr, dy, dx, dgamma, dbeta, (size_t)N, C, true, st);
+}
+// nn.Linear on rows: y (M,N) = x (M,K) . W (N,K)^T + bias;  backward: dx = dy . W, dW = dy^T . x, dbias = column sums of dy.
+// N % 64 == 0, K % 64 == 0.  ws (backward): N*K floats for W^T.
+int rtfs_linear_rows_f32(const float* x, const float* W, const float* bias, float* y, int M, int N, int K, void* stream) {
+    RTFS_RETURN_IF(!x || !W || !y || M < 1, RTFS_ERR_ARG);
+    return launch_gemm_nt(x, K, W, K, y, N, M, N, K, 0, S(stream), bias);
+}
+int rtfs_linear_rows_backward_f32(const float* x, const float* W, const float* dy, float* dx, float* dW, float* dbias, int M, int N, int K,
+                                  void* ws, size_t ws_bytes, void* stream) {
+    RTFS_RETURN_IF(!x || !W || !dy || !dx || !dW || M < 1, RTFS_ERR_ARG);
+    RTFS_RETURN_IF((N & 63) || (K & 63), RTFS_ERR_SHAPE);
+    RTFS_RETURN_IF(!ws || ws_bytes < (size_t)N * K * sizeof(float), RTFS_ERR_WORKSPACE);
+    hipStream_t st = S(stream);
+    float* Wt = (float*)ws;
+    CHECK(launch_transpose(W, Wt, 1, N, K, st));  // (N, K) -> (K, N)
+    CHECK(launch_gemm_nt(dy, N, Wt, N, dx, K, M, K, N, 0, st));
+    if (hipMemsetAsync(dW, 0, sizeof(float) * N * K, st) != hipSuccess) return RTFS_ERR_LAUNCH;
+    CHECK(launch_gemm_tn(dy, N, x, K, dW, K, N, K, (long)M, st));
+    if (dbias) {
+        if (hipMemsetAsync(dbias, 0, sizeof(float) * N, st) != hipSuccess) return RTFS_ERR_LAUNCH;
+        CHECK(launch_cl_colsum(dy, dbias, (size_t)M * N, N, st));
+    }
+    return RTFS_OK;
+}
+// softmax(q k^T / sqrt(hd)) v per (batch, head) on packed projections qkv (B*T, 3*nh*hd) -> o (B*T, nh*hd); pmask optional
+int rtfs_mha_core_f32(const float* qkv, const float* pmask, float* o, int B, int T, int n_head, int head_dim, void* stream) {
+    RTFS_RETURN_IF(!qkv || !o || B < 1, RTFS_ERR_ARG);
+    return launch_mha_core(qkv, pmask, o, nullptr, nullptr, B, T, n_head, head_dim, false, S(stream));
+}
+int rtfs_mha_core_backward_f32(const float* qkv, const float* pmask, const float* dout, float* dqkv, int B, int T, int n_head, int head_dim,
+                               void* stream) {
+    RTFS_RETURN_IF(!qkv || !dout || !dqkv || B < 1, RTFS_ERR_ARG);
+    return launch_mha_core(qkv, pmask, nullptr, dout, dqkv, B, T, n_head, head_dim, true, S(stream));
 }
 
 // C = A . Bt^T (kind 0; accumulate adds to C) or C += A^T . B (kind 1): the two GEMM forms of the training path, exposed for tests

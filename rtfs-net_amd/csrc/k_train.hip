@@ -725,10 +725,10 @@ __global__ __launch_bounds__(256) void cl_dw_fwd_kernel(ClDwArgs a) {
             for (int kj = 0; kj < a.kw; ++kj) {
                 const int w = wo * a.s - a.pl + kj;
                 if (w < 0 || w >= a.W) continue;
-                acc = fmaf(a.w[c * a.kh * a.kw + ki * a.kw + kj], a.x[(((size_t)b * a.H + h) * a.W + w) * a.C + c], acc);
+                acc = fmaf(a.w[c * a.kh * a.kw + ki * a.kw + kj], a.x[(((size_t)b * a.H + h) * a.W + w) * a.Cp + c], acc);
             }
         }
-        a.y[i] = acc;
+        a.y[(size_t)(i / (unsigned)a.C) * a.Cp + c] = acc;
     }
 }
 
@@ -752,10 +752,10 @@ __global__ __launch_bounds__(256) void cl_dw_bwd_data_kernel(ClDwArgs a) {
                 if (wn < 0 || wn % a.s) continue;
                 const int wo = wn / a.s;
                 if (wo >= a.Wo) continue;
-                acc = fmaf(a.w[c * a.kh * a.kw + ki * a.kw + kj], a.dy[(((size_t)b * a.Ho + ho) * a.Wo + wo) * a.C + c], acc);
+                acc = fmaf(a.w[c * a.kh * a.kw + ki * a.kw + kj], a.dy[(((size_t)b * a.Ho + ho) * a.Wo + wo) * a.Cp + c], acc);
             }
         }
-        a.dx[i] = acc;
+        a.dx[(size_t)(i / (unsigned)a.C) * a.Cp + c] = acc;
     }
 }
 
@@ -773,9 +773,9 @@ __global__ __launch_bounds__(256) void cl_dw_wgrad_kernel(ClDwArgs a) {
     for (unsigned r = blockIdx.x * lanes + rl; r < rows; r += gridDim.x * lanes) {
         const unsigned b = r / HoWo, q = r - b * HoWo;
         const int ho = (int)(q / (unsigned)a.Wo), wo = (int)(q - (unsigned)ho * a.Wo);
-        const float d = a.dy[(size_t)r * a.C + c];
+        const float d = a.dy[(size_t)r * a.Cp + c];
         const int hb = ho * a.s - a.pt, wb = wo * a.s - a.pl;
-        const float* xb = a.x + ((size_t)b * a.H * a.W) * a.C + c;
+        const float* xb = a.x + ((size_t)b * a.H * a.W) * a.Cp + c;
 #pragma unroll
         for (int ki = 0; ki < 4; ++ki) {
             const int h = hb + ki;
@@ -783,7 +783,7 @@ __global__ __launch_bounds__(256) void cl_dw_wgrad_kernel(ClDwArgs a) {
 #pragma unroll
                 for (int kj = 0; kj < 5; ++kj) {
                     const int w = wb + kj;
-                    if (kj < a.kw && w >= 0 && w < a.W) acc[ki][kj] = fmaf(d, xb[((size_t)h * a.W + w) * a.C], acc[ki][kj]);
+                    if (kj < a.kw && w >= 0 && w < a.W) acc[ki][kj] = fmaf(d, xb[((size_t)h * a.W + w) * a.Cp], acc[ki][kj]);
                 }
             }
         }
@@ -850,13 +850,28 @@ int launch_bn_update(const double* stats, float* rmean, float* rvar, int C, doub
     hipLaunchKernelGGL(bn_update_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, stats, rmean, rvar, C, rows, momentum);
     return rtfs_launch_status();
 }
+// any C: thread = column, workgroup = a chunk of rows
+__global__ __launch_bounds__(256) void cl_colsum_any_kernel(const float* __restrict__ d, float* __restrict__ out, size_t rows, int C, int chunk) {
+    const size_t r0 = (size_t)blockIdx.x * chunk, r1 = min(rows, r0 + chunk);
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float s = 0.f;
+        for (size_t r = r0; r < r1; ++r) s += d[r * C + c];
+        unsafeAtomicAdd(out + c, s);
+    }
+}
 int launch_cl_colsum(const float* d, float* out, size_t n, int C, hipStream_t st) {
+    if (C >= 1 && !cl_c_ok(C)) {
+        const size_t rows = n / C;
+        const int chunk = 64;
+        hipLaunchKernelGGL(cl_colsum_any_kernel, dim3((unsigned)((rows + chunk - 1) / chunk)), dim3(256), 0, st, d, out, rows, C, chunk);
+        return rtfs_launch_status();
+    }
     if (!cl_c_ok(C)) return RTFS_ERR_SHAPE;
     hipLaunchKernelGGL(cl_colsum_kernel, dim3(grid4(n, 1024)), dim3(256), 0, st, d, out, n, C);
     return rtfs_launch_status();
 }
-int launch_cl_dw(const ClDwArgs& a, int what, hipStream_t st) {
-    if (a.kh > 4 || a.kw > 5 || a.C < 1 || a.C > 256 || (256 % a.C) || (size_t)a.B * a.H * a.W * a.C >= 0x7fffffffu) return RTFS_ERR_SHAPE;
+namespace {
+int launch_cl_dw_chunk(const ClDwArgs& a, int what, hipStream_t st) {
     if (what == 0) hipLaunchKernelGGL(cl_dw_fwd_kernel, dim3(grid_for((size_t)a.B * a.Ho * a.Wo * a.C)), dim3(256), 0, st, a);
     else if (what == 1) hipLaunchKernelGGL(cl_dw_bwd_data_kernel, dim3(grid_for((size_t)a.B * a.H * a.W * a.C)), dim3(256), 0, st, a);
     else {
@@ -865,9 +880,37 @@ int launch_cl_dw(const ClDwArgs& a, int what, hipStream_t st) {
         g = g < 1 ? 1 : (g > CL_DW_WGRAD_MAX_WG ? CL_DW_WGRAD_MAX_WG : g);
         if (!a.scratch) return RTFS_ERR_WORKSPACE;
         hipLaunchKernelGGL(cl_dw_wgrad_kernel, dim3((unsigned)g), dim3(256), 0, st, a);
-        hipLaunchKernelGGL(cl_dw_wgrad_reduce_kernel, dim3(cdiv(a.kh * a.kw * a.C, 256), g >= 64 ? 64 : (unsigned)g), dim3(256), 0, st, a.scratch, a.dw, (int)g, a.kh * a.kw, a.C);
+        hipLaunchKernelGGL(cl_dw_wgrad_reduce_kernel, dim3(cdiv(a.kh * a.kw * a.C, 256), g >= 64 ? 64 : (unsigned)g), dim3(256), 0, st,
+                           a.scratch, a.dw, (int)g, a.kh * a.kw, a.C);
     }
     return rtfs_launch_status();
+}
+}  // namespace
+// C up to 256 in one launch; wider tensors (the VP block's 512-channel gateway) go through in slices of 256 channels of the same rows
+int launch_cl_dw(const ClDwArgs& a0, int what, hipStream_t st) {
+    ClDwArgs a = a0;
+    a.Cp = a.C;
+    if (a.kh > 4 || a.kw > 5 || a.C < 1 || (size_t)a.B * a.H * a.W * a.C >= 0x7fffffffu) return RTFS_ERR_SHAPE;
+    if (a.C <= 256) {
+        if (256 % a.C) return RTFS_ERR_SHAPE;
+        return launch_cl_dw_chunk(a, what, st);
+    }
+    if (a.C % 256) return RTFS_ERR_SHAPE;
+    const int taps = a.kh * a.kw;
+    for (int c0 = 0; c0 < a0.C; c0 += 256) {
+        ClDwArgs b = a;
+        b.C = 256;
+        if (b.x) b.x += c0;
+        if (b.y) b.y += c0;
+        if (b.dy) b.dy += c0;
+        if (b.dx) b.dx += c0;
+        if (b.w) b.w += (size_t)c0 * taps;
+        if (b.bias) b.bias += c0;
+        if (b.dw) b.dw += (size_t)c0 * taps;
+        int rc = launch_cl_dw_chunk(b, what, st);
+        if (rc) return rc;
+    }
+    return RTFS_OK;
 }
 
 // ------------------------------------------------------------------------------------------------ TF attention, training side
@@ -1395,5 +1438,177 @@ int launch_caf_combine_bwd(const float* dout, const float* key, const float* val
     if (Tv < 1 || Tv > T) return RTFS_ERR_SHAPE;
     hipLaunchKernelGGL(caf_combine_bwd_kernel, dim3((unsigned)((N * Tv + 3) / 4)), dim3(256), 0, st, dout, key, value, r, att, dkey, dvalue, dr,
                        datt, N, T, F, Tv);
+    return rtfs_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------ video-side attention (1-D) kernels
+// nn.LayerNorm(C) over the last axis of rows (N, C), C in {64, 128, ..., 1024 with C % 64 == 0}; one wave per row.
+// bwd: dx = rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat)); dgamma += dy*xhat, dbeta += dy (per-workgroup LDS sums, then atomics)
+__global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      float* __restrict__ y, const float* __restrict__ dy, float* __restrict__ dx,
+                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, size_t N, int C, int bwd) {
+    __shared__ float pg[1024], pb[1024];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, per = C >> 6;
+    if (bwd)
+        for (int i = threadIdx.x; i < C; i += 256) pg[i] = pb[i] = 0.f;
+    __syncthreads();
+    for (size_t row = (size_t)blockIdx.x * 4 + wave; row < N; row += (size_t)gridDim.x * 4) {
+        const float* xr = x + row * C;
+        float v[16], s = 0.f;
+        for (int k = 0; k < per; ++k) {
+            v[k] = xr[lane + 64 * k];
+            s += v[k];
+        }
+        const float mean = wave_sum(s) / C;
+        float q = 0.f;
+        for (int k = 0; k < per; ++k) {
+            v[k] -= mean;
+            q = fmaf(v[k], v[k], q);
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) / C + RTFS_EPS);
+        if (!bwd) {
+            for (int k = 0; k < per; ++k) y[row * C + lane + 64 * k] = fmaf(v[k] * rstd, gamma[lane + 64 * k], beta[lane + 64 * k]);
+        } else {
+            float gd[16], s1 = 0.f, s2 = 0.f;
+            for (int k = 0; k < per; ++k) {
+                const float d = dy[row * C + lane + 64 * k];
+                v[k] *= rstd;  // xhat
+                gd[k] = gamma[lane + 64 * k] * d;
+                s1 += gd[k];
+                s2 = fmaf(gd[k], v[k], s2);
+                atomicAdd(&pg[lane + 64 * k], d * v[k]);
+                atomicAdd(&pb[lane + 64 * k], d);
+            }
+            s1 = wave_sum(s1) / C;
+            s2 = wave_sum(s2) / C;
+            for (int k = 0; k < per; ++k) dx[row * C + lane + 64 * k] = rstd * (gd[k] - s1 - v[k] * s2);
+        }
+    }
+    if (bwd) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < C; i += 256) {
+            unsafeAtomicAdd(dgamma + i, pg[i]);
+            unsafeAtomicAdd(dbeta + i, pb[i]);
+        }
+    }
+}
+
+// nn.MultiheadAttention's core for self-attention on packed projections: qkv rows (B*T, 3E) = [q | k | v], E = nh * hd, hd <= 16,
+// T <= 256.  One workgroup per (b, head); thread t owns query row t (forward, dq) and key/value row t (dk, dv).
+// pmask (optional, (B*nh, T, T)): dropout keep-mask on the attention probabilities already scaled by 1/(1-p) (train mode).
+__global__ __launch_bounds__(256) void mha_core_kernel(const float* __restrict__ qkv, const float* __restrict__ pmask, float* __restrict__ o,
+                                                       const float* __restrict__ dout, float* __restrict__ dqkv, int T, int nh, int hd, int bwd) {
+    extern __shared__ float sm[];  // q, k, v [T][hd]; bwd: do [T][hd], m [T], l [T], D [T]
+    const int bh = blockIdx.x, b = bh / nh, h = bh % nh, t = threadIdx.x, E = nh * hd;
+    float* q = sm;
+    float* k = q + T * hd;
+    float* v = k + T * hd;
+    float* dO = v + T * hd;
+    float* rm = dO + T * hd;
+    float* rl = rm + T;
+    float* rD = rl + T;
+    const float scale = rsqrtf((float)hd);
+    for (int i = t; i < T * hd; i += 256) {
+        const int tt = i / hd, d = i - tt * hd;
+        const size_t base = ((size_t)b * T + tt) * 3 * E + h * hd + d;
+        q[i] = qkv[base];
+        k[i] = qkv[base + E];
+        v[i] = qkv[base + 2 * E];
+        if (bwd) dO[i] = dout[((size_t)b * T + tt) * E + h * hd + d];
+    }
+    __syncthreads();
+    const float* pm = pmask ? pmask + (size_t)bh * T * T : nullptr;
+    float qt[16], acc[16];
+    if (t < T) {
+        for (int d = 0; d < hd; ++d) qt[d] = q[t * hd + d];
+        float m = -INFINITY;
+        for (int j = 0; j < T; ++j) {
+            float sc = 0.f;
+            for (int d = 0; d < hd; ++d) sc = fmaf(qt[d], k[j * hd + d], sc);
+            m = fmaxf(m, sc * scale);
+        }
+        float l = 0.f;
+        for (int d = 0; d < hd; ++d) acc[d] = 0.f;
+        float D = 0.f;
+        for (int j = 0; j < T; ++j) {
+            float sc = 0.f;
+            for (int d = 0; d < hd; ++d) sc = fmaf(qt[d], k[j * hd + d], sc);
+            const float e = __expf(sc * scale - m);
+            l += e;
+            const float w = pm ? e * pm[(size_t)t * T + j] : e;
+            for (int d = 0; d < hd; ++d) acc[d] = fmaf(w, v[j * hd + d], acc[d]);
+            if (bwd) {
+                float dp = 0.f;
+                for (int d = 0; d < hd; ++d) dp = fmaf(dO[t * hd + d], v[j * hd + d], dp);
+                D = fmaf(w, dp, D);  // sum_j p_tj * mask_tj * dP_tj  (unnormalised by l here)
+            }
+        }
+        const float inv = 1.0f / l;
+        if (!bwd) {
+            for (int d = 0; d < hd; ++d) o[((size_t)b * T + t) * E + h * hd + d] = acc[d] * inv;
+        } else {
+            rm[t] = m;
+            rl[t] = inv;
+            rD[t] = D * inv;
+            // dq_t = scale * sum_j dS_tj k_j,  dS_tj = p_tj * (mask_tj * dP_tj - D_t)
+            float dq[16];
+            for (int d = 0; d < hd; ++d) dq[d] = 0.f;
+            for (int j = 0; j < T; ++j) {
+                float sc = 0.f, dp = 0.f;
+                for (int d = 0; d < hd; ++d) {
+                    sc = fmaf(qt[d], k[j * hd + d], sc);
+                    dp = fmaf(dO[t * hd + d], v[j * hd + d], dp);
+                }
+                const float p = __expf(sc * scale - m) * inv;
+                const float ds = p * ((pm ? pm[(size_t)t * T + j] : 1.f) * dp - D * inv);
+                for (int d = 0; d < hd; ++d) dq[d] = fmaf(ds, k[j * hd + d], dq[d]);
+            }
+            for (int d = 0; d < hd; ++d) dqkv[((size_t)b * T + t) * 3 * E + h * hd + d] = dq[d] * scale;
+        }
+    }
+    if (!bwd) return;
+    __syncthreads();
+    if (t < T) {  // thread t now owns key / value row j = t
+        const int j = t;
+        float kj[16], vj[16], dk[16], dv[16];
+        for (int d = 0; d < hd; ++d) {
+            kj[d] = k[j * hd + d];
+            vj[d] = v[j * hd + d];
+            dk[d] = dv[d] = 0.f;
+        }
+        for (int tt = 0; tt < T; ++tt) {
+            float sc = 0.f, dp = 0.f;
+            for (int d = 0; d < hd; ++d) {
+                sc = fmaf(q[tt * hd + d], kj[d], sc);
+                dp = fmaf(dO[tt * hd + d], vj[d], dp);
+            }
+            const float p = __expf(sc * scale - rm[tt]) * rl[tt];
+            const float mk = pm ? pm[(size_t)tt * T + j] : 1.f;
+            const float ds = p * (mk * dp - rD[tt]);
+            for (int d = 0; d < hd; ++d) {
+                dk[d] = fmaf(ds, q[tt * hd + d], dk[d]);
+                dv[d] = fmaf(p * mk, dO[tt * hd + d], dv[d]);
+            }
+        }
+        for (int d = 0; d < hd; ++d) {
+            dqkv[((size_t)b * T + j) * 3 * E + E + h * hd + d] = dk[d] * scale;
+            dqkv[((size_t)b * T + j) * 3 * E + 2 * E + h * hd + d] = dv[d];
+        }
+    }
+}
+
+int launch_ln_rows(const float* x, const float* gamma, const float* beta, float* y, const float* dy, float* dx, float* dgamma, float* dbeta,
+                   size_t N, int C, bool bwd, hipStream_t st) {
+    if (C < 64 || C > 1024 || (C & 63)) return RTFS_ERR_SHAPE;
+    size_t g = (N + 3) / 4;
+    g = g < 1 ? 1 : (g > 1024 ? 1024 : g);
+    hipLaunchKernelGGL(ln_rows_kernel, dim3((unsigned)g), dim3(256), 0, st, x, gamma, beta, y, dy, dx, dgamma, dbeta, N, C, bwd ? 1 : 0);
+    return rtfs_launch_status();
+}
+int launch_mha_core(const float* qkv, const float* pmask, float* o, const float* dout, float* dqkv, int B, int T, int nh, int hd, bool bwd,
+                    hipStream_t st) {
+    if (T < 1 || T > 256 || hd < 1 || hd > 16 || nh < 1) return RTFS_ERR_SHAPE;
+    const size_t lds = ((size_t)4 * T * hd + 3 * T) * sizeof(float);
+    hipLaunchKernelGGL(mha_core_kernel, dim3(B * nh), dim3(256), lds, st, qkv, pmask, o, dout, dqkv, T, nh, hd, bwd ? 1 : 0);
     return rtfs_launch_status();
 }

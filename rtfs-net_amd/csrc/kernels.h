@@ -287,6 +287,7 @@ struct ClDwArgs {
     float *y = nullptr, *dx = nullptr, *dw = nullptr;
     float* scratch = nullptr;  // wgrad: CL_DW_WGRAD_MAX_WG x kh*kw x C per-workgroup partial sums
     int B = 0, H = 0, W = 0, C = 0, Ho = 0, Wo = 0, kh = 0, kw = 0, s = 1, pt = 0, pl = 0;
+    int Cp = 0;  // row pitch in channels (set by the launcher; C is the slice a launch covers)
 };
 int launch_cl_norm_act_fwd(const ClStageArgs& a, int B, hipStream_t st);
 int launch_cl_norm_act_bwd(const ClStageArgs& a, int B, hipStream_t st);
@@ -326,3 +327,7 @@ int launch_caf_combine_bwd(const float* dout, const float* key, const float* val
                            float* dvalue, float* dr, float* datt, size_t N, int T, int F, int Tv, hipStream_t st);
 int launch_pit_sdr_bwd(const float* est, const float* tgt, const int* perm, const float* dmin, float* dest, int B, int n, int L, int kind,
                        int zero_mean, int take_log, hipStream_t st);
+int launch_ln_rows(const float* x, const float* gamma, const float* beta, float* y, const float* dy, float* dx, float* dgamma, float* dbeta,
+                   size_t N, int C, bool bwd, hipStream_t st);
+int launch_mha_core(const float* qkv, const float* pmask, float* o, const float* dout, float* dqkv, int B, int T, int nh, int hd, bool bwd,
+                    hipStream_t st);

@@ -301,6 +301,10 @@ class FeedForwardNetwork(nn.Module):
         self.dropout_layer = nn.Identity()  # DropPath: identity in eval, the only supported mode
 
     def forward(self, x):
+        if x.is_cuda and _recording(x, self):  # conv_layers.py:252-259 with its two DropPath applications
+            p = float(self.dropout)
+            y = _drop_path(self.refiner(self.encoder(x)), p, True)
+            return _drop_path(self.decoder(y), p, True) + x
         return self.decoder(self.refiner(self.encoder(x))) + x
 
 
@@ -786,8 +790,106 @@ class PositionalEncoding(nn.Module):
         return x + self.pe[:, : x.size(1)]
 
 
+class _LnRowsFn(torch.autograd.Function):
+    """nn.LayerNorm over the last axis of (..., C) rows on the HIP kernels."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta):
+        lib = _lib.load()
+        x = x.contiguous()
+        C = x.shape[-1]
+        N = x.numel() // C
+        y = torch.empty_like(x)
+        _lib.check(lib.rtfs_layernorm_rows_f32(_lib.ptr(x), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(y), N, C, _lib.stream_of(x)), "rtfs_layernorm_rows_f32")
+        ctx.save_for_backward(x, gamma)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, gamma = ctx.saved_tensors
+        C = x.shape[-1]
+        N = x.numel() // C
+        dy = dy.contiguous()
+        dx, dg, db = torch.empty_like(x), torch.empty_like(gamma), torch.empty_like(gamma)
+        _lib.check(lib.rtfs_layernorm_rows_backward_f32(_lib.ptr(x), _lib.ptr(gamma), _lib.ptr(dy), _lib.ptr(dx), _lib.ptr(dg), _lib.ptr(db), N, C,
+                                                        _lib.stream_of(x)), "rtfs_layernorm_rows_backward_f32")
+        return dx, dg, db
+
+
+class _LinearRowsFn(torch.autograd.Function):
+    """nn.Linear on (..., K) rows: bf16x3 GEMMs forward and for both gradients."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        lib = _lib.load()
+        x, w = x.contiguous(), weight.contiguous()
+        N, K = w.shape
+        M = x.numel() // K
+        y = torch.empty(x.shape[:-1] + (N,), device=x.device, dtype=torch.float32)
+        _lib.check(lib.rtfs_linear_rows_f32(_lib.ptr(x), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(y), M, N, K, _lib.stream_of(x)), "rtfs_linear_rows_f32")
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, w = ctx.saved_tensors
+        N, K = w.shape
+        M = x.numel() // K
+        dy = dy.contiguous()
+        dx, dw = torch.empty_like(x), torch.empty_like(w)
+        db = torch.empty(N, device=x.device, dtype=torch.float32) if ctx.has_bias else None
+        ws = _lib.workspace(N * K * 4, x.device)
+        _lib.check(lib.rtfs_linear_rows_backward_f32(_lib.ptr(x), _lib.ptr(w), _lib.ptr(dy), _lib.ptr(dx), _lib.ptr(dw), _lib.ptr(db), M, N, K,
+                                                     _lib.ptr(ws), ws.numel(), _lib.stream_of(x)), "rtfs_linear_rows_backward_f32")
+        return dx, dw, db
+
+
+class _MhaCoreFn(torch.autograd.Function):
+    """softmax(q k^T / sqrt(hd)) v per (batch, head) on packed projections (B, T, 3E); optional keep-mask on the attention weights."""
+
+    @staticmethod
+    def forward(ctx, qkv, n_head, pmask):
+        lib = _lib.load()
+        qkv = qkv.contiguous()
+        B, T, E3 = qkv.shape
+        E = E3 // 3
+        o = torch.empty(B, T, E, device=qkv.device, dtype=torch.float32)
+        pm = None if pmask is None else pmask.contiguous()
+        _lib.check(lib.rtfs_mha_core_f32(_lib.ptr(qkv), _lib.ptr(pm), _lib.ptr(o), B, T, n_head, E // n_head, _lib.stream_of(qkv)), "rtfs_mha_core_f32")
+        ctx.save_for_backward(qkv, pm)
+        ctx.n_head = n_head
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        lib = _lib.load()
+        qkv, pm = ctx.saved_tensors
+        B, T, E3 = qkv.shape
+        E = E3 // 3
+        do = do.contiguous()
+        dqkv = torch.empty_like(qkv)
+        _lib.check(lib.rtfs_mha_core_backward_f32(_lib.ptr(qkv), _lib.ptr(pm), _lib.ptr(do), _lib.ptr(dqkv), B, T, ctx.n_head, E // ctx.n_head,
+                                                  _lib.stream_of(qkv)), "rtfs_mha_core_backward_f32")
+        return dqkv, None, None
+
+
+def _drop_path(x, p, training):
+    """timm's DropPath (stochastic depth per sample, scale_by_keep) as used at attention.py:54,71 and conv_layers.py:250,256-258."""
+    if p == 0.0 or not training:
+        return x
+    keep = 1.0 - p
+    mask = x.new_empty((x.shape[0],) + (1,) * (x.dim() - 1)).bernoulli_(keep)
+    if keep > 0.0:
+        mask.div_(keep)
+    return x * mask
+
+
 class MultiHeadSelfAttention(nn.Module):
-    """reference attention.py:28-73 (eval mode: dropout / DropPath are identities)."""
+    """reference attention.py:28-73.  eval(): torch ops (the fused VP kernel covers the whole video block in inference); train() with
+    autograd recording: LayerNorm / in_proj / attention core / out_proj on the HIP training kernels, dropout masks from torch's RNG."""
 
     def __init__(self, in_chan, n_head=8, dropout=0.1, positional_encoding=True, batch_first=True, *args, **kwargs):
         super().__init__()
@@ -800,7 +902,28 @@ class MultiHeadSelfAttention(nn.Module):
         self.norm2 = nn.LayerNorm(in_chan)
         self.drop_path_layer = nn.Identity()
 
+    def _forward_train(self, x):
+        att = self.attention
+        if not (self.batch_first and att._qkv_same_embed_dim and att.in_proj_bias is not None and att.bias_k is None and not att.add_zero_attn):
+            raise RuntimeError("MultiHeadSelfAttention training kernels: batch_first self-attention with packed in_proj and biases")
+        p = float(self.dropout)
+        res = x
+        y = x.transpose(1, 2).contiguous()                                   # (B, T, C)
+        B, T, _ = y.shape
+        y = _LnRowsFn.apply(y, self.norm1.weight, self.norm1.bias)
+        y = self.pos_enc(y)
+        qkv = _LinearRowsFn.apply(y, att.in_proj_weight, att.in_proj_bias)
+        pmask = None
+        if p > 0.0:  # nn.MultiheadAttention drops attention weights in train mode
+            pmask = (torch.rand(B * self.n_head, T, T, device=x.device) >= p).to(torch.float32) / (1.0 - p)
+        o = _MhaCoreFn.apply(qkv, self.n_head, pmask)
+        o = _LinearRowsFn.apply(o, att.out_proj.weight, att.out_proj.bias)
+        y = _LnRowsFn.apply(self.dropout_layer(o) + y, self.norm2.weight, self.norm2.bias)
+        return _drop_path(y.transpose(2, 1), p, True) + res
+
     def forward(self, x):
+        if x.is_cuda and _recording(x, self):
+            return self._forward_train(x)
         res = x
         y = x.transpose(1, 2) if self.batch_first else x
         y = self.pos_enc(self.norm1(y))

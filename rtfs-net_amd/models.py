@@ -299,7 +299,7 @@ class TDANetBlock(PackedModule):
         return self.residual_conv(expanded) + residual
 
     def forward(self, x, x_res=None):
-        if self._hip and x.is_cuda and L_recording(x, x_res, self):
+        if x.is_cuda and L_recording(x, x_res, self):  # audio (2-D) and video (1-D) blocks alike
             return self._forward_train(x, x_res)
         if not self._hip:
             x = x if x_res is None else x + x_res

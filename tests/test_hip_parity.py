@@ -585,6 +585,102 @@ def test_avnet_training_step_end_to_end(smooth):
     assert after < before
 
 
+VP = O._sub(SD, "refinement_module.video_net.blocks")
+
+
+@pytest.mark.parametrize("B,T,masked", [(2, 7, False), (3, 50, False), (2, 13, True)])
+def test_video_mhsa_training_forward_backward(B, T, masked):
+    """Video-side MultiHeadSelfAttention (LayerNorm, PE, nn.MultiheadAttention 8 heads, LayerNorm) inside a training step: with
+    dropout 0 the module against the autograd oracle; with an explicit keep-mask the attention core alone against the same formula."""
+    import rtfs_net_amd as R
+    from oracle import grad_oracle as G
+    p = {k: v.copy() for k, v in O._sub(VP, "globalatt.0.MHSA").items()}
+    rng = np.random.default_rng(T)
+    for k in p:
+        if "norm" in k or "bias" in k:
+            p[k] = (p[k] + 0.3 * rng.standard_normal(p[k].shape)).astype(np.float32)
+    x, dout = rand((B, 64, T), 5), rand((B, 64, T), 6)
+    if not masked:
+        mod = R.layers.MultiHeadSelfAttention(64, n_head=8, dropout=0.0)
+        mod.load_state_dict({k: torch.from_numpy(v) for k, v in p.items()})
+        mod = mod.cuda().train()
+        xt = dev(x).requires_grad_(True)
+        out = mod(xt)
+        out.backward(dev(dout))
+        pt = {k: torch.tensor(v, dtype=torch.float64, requires_grad=(k != "pos_enc.pe")) for k, v in p.items()}
+        xr = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+        o_ref = G.mhsa_1d_torch(xr, pt)
+        o_ref.backward(torch.tensor(dout, dtype=torch.float64))
+        close("video mhsa train forward", host(out), o_ref.detach().numpy())
+        close("video mhsa dx", host(xt.grad), xr.grad.numpy(), tol=2e-4)
+        for k, v in mod.named_parameters():
+            close(f"video mhsa d {k}", host(v.grad), pt[k].grad.numpy(), tol=2e-4)
+        close("video mhsa eval vs train forward", host(mod.eval()(dev(x))), host(out))
+    else:
+        qkv = rand((B, T, 192), 7)
+        mask = (rng.random((B * 8, T, T)) >= 0.3).astype(np.float32) / 0.7
+        do = rand((B, T, 64), 8)
+        qt = dev(qkv).requires_grad_(True)
+        o = R.layers._MhaCoreFn.apply(qt, 8, dev(mask))
+        o.backward(dev(do))
+        qr = torch.tensor(qkv, dtype=torch.float64, requires_grad=True)
+        q, k_, v_ = [t.reshape(B, T, 8, 8).transpose(1, 2) for t in qr.split(64, -1)]
+        a = torch.softmax(q @ k_.transpose(-1, -2) / np.sqrt(8.0), -1) * torch.tensor(mask, dtype=torch.float64).reshape(B, 8, T, T)
+        o_ref = (a @ v_).transpose(1, 2).reshape(B, T, 64)
+        o_ref.backward(torch.tensor(do, dtype=torch.float64))
+        close("mha core (masked) forward", host(o), o_ref.detach().numpy(), tol=1e-5)
+        close("mha core (masked) d qkv", host(qt.grad), qr.grad.numpy(), tol=1e-5)
+
+
+@pytest.mark.parametrize("B,Tv,bn_train,seed", [(2, 50, False, 91), (3, 50, True, 92), (2, 17, True, 93)])
+def test_vp_block_training_forward_backward(B, Tv, bn_train, seed):
+    """The video-side VP block (1-D TDANetBlock depth 4, BatchNorm1d frozen or in train mode, GlobalAttention = MHSA + FFN; dropout 0)
+    inside a training step against the autograd oracle: output, input gradient, 150 parameter tensors, BatchNorm running statistics."""
+    import copy
+    from oracle import grad_oracle as G
+    blk = copy.deepcopy(model().refinement_module.video_net.get_block(0))
+    blk.globalatt[0].MHSA.dropout = 0.0
+    blk.globalatt[0].MHSA.dropout_layer.p = 0.0
+    blk.globalatt[0].FFN.dropout = 0.0
+    rng = np.random.default_rng(seed)
+    with torch.no_grad():  # BatchNorm statistics / affines away from their init values
+        for k, v in blk.state_dict().items():
+            if k.endswith("running_mean") or (k.endswith(".bias") and "full_layer.3" in k):
+                v.add_(torch.from_numpy(0.3 * rng.standard_normal(tuple(v.shape))).to(v))
+            if k.endswith("running_var") or (k.endswith("full_layer.3.weight")):
+                v.mul_(torch.from_numpy(1 + 0.5 * rng.random(tuple(v.shape))).to(v))
+    p = {k: v.detach().cpu().numpy().copy() for k, v in blk.state_dict().items() if "num_batches" not in k}
+    blk.train()
+    if not bn_train:
+        for m_ in blk.modules():
+            if isinstance(m_, torch.nn.BatchNorm1d):
+                m_.eval()
+    x, dout = rand((B, 512, Tv), seed), rand((B, 512, Tv), seed + 1)
+    xt = dev(x).requires_grad_(True)
+    out = blk(xt)
+    out.backward(dev(dout))
+    pt = {k: torch.tensor(v, dtype=torch.float64, requires_grad=("running" not in k and k != "globalatt.0.MHSA.pos_enc.pe")) for k, v in p.items()}
+    xr = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    o_ref = G.vp_block_torch(xr, pt, bn_train=bn_train)
+    o_ref.backward(torch.tensor(dout, dtype=torch.float64))
+    close("vp block train forward", host(out), o_ref.detach().numpy())
+    print(f"[parity] vp block dx: max-rel {rel_err(host(xt.grad), xr.grad.numpy()):.3e} l2-rel {l2_rel(host(xt.grad), xr.grad.numpy()):.3e}")
+    assert l2_rel(host(xt.grad), xr.grad.numpy()) <= 2e-3
+    got = {k: v.grad for k, v in blk.named_parameters()}
+    gsc = max(float(pt[k].grad.abs().max()) for k in got)
+    l2 = {k: l2_rel(host(g), pt[k].grad.numpy()) for k, g in got.items() if float(pt[k].grad.abs().max()) > 1e-7 * gsc}
+    worst = sorted(l2.items(), key=lambda kv: -kv[1])[:3]
+    print(f"[parity] vp block {len(got)} parameter gradients: median l2-rel {np.median(list(l2.values())):.3e}, worst {worst}")
+    assert np.median(list(l2.values())) <= 1e-4 and worst[0][1] <= 5e-2, worst  # PReLU kinks: see test_block_training_forward_backward
+    if bn_train:
+        sd = blk.state_dict()
+        for k in p:
+            if "running" in k:
+                close(f"vp {k}", host(sd[k]), pt[k].numpy(), tol=1e-5)
+    else:
+        close("vp block inference kernel vs training forward", host(blk.eval()(dev(x))), host(out))
+
+
 @pytest.mark.parametrize("shape,seed", [((2, 64, 12, 64), 103), ((1, 64, 125, 64), 5), ((1, 64, 250, 64), 6), ((2, 64, 33, 64), 8)])
 def test_mhsa2d(shape, seed):
     m = model()
