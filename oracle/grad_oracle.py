@@ -263,14 +263,17 @@ def caf_torch(a, v, p, bn_train=False):
     return k1 + att * val
 
 
-def avnet_torch(wav, video_vp, p, repeats):
-    """AVNet.forward (reference tdavnet.py:86-97 + refinement_module.py:45-62) in float64 torch ops, with the video-side VP block's
-    output given as a constant: encoder -> bottleneck -> block -> CAF -> (repeats-1) x block(x + a1) -> S^3 -> decoder."""
+def avnet_torch(wav, video_vp, p, repeats, vp_trainable=False, bn_train=False):
+    """AVNet.forward (reference tdavnet.py:86-97 + refinement_module.py:45-62) in float64 torch ops: encoder -> bottleneck -> block ->
+    CAF -> (repeats-1) x block(x + a1) -> S^3 -> decoder.  video_vp: the VP block's output (a constant), or with vp_trainable the lip
+    embedding the VP block (dropout off) is applied to; bn_train: BatchNorm layers on batch statistics."""
+    if vp_trainable:
+        video_vp = vp_block_torch(video_vp, _sub(p, "refinement_module.video_net.blocks"), bn_train=bn_train)
     a0 = stft_encoder_torch(wav, p["encoder.conv.full_layer.2.weight"])
     a1 = conv_norm_act_torch(a0, _sub(p, "audio_bottleneck"), (256, 256, 1, 1, 0, 1, 1, 0, 0, 1, 1))
     blk = _sub(p, "refinement_module.audio_net.blocks")
     x = rtfs_block_torch(a1, blk)
-    x = caf_torch(x, video_vp, _sub(p, "refinement_module.crossmodal_fusion.fusion_module.audio_lstm"))
+    x = caf_torch(x, video_vp, _sub(p, "refinement_module.crossmodal_fusion.fusion_module.audio_lstm"), bn_train=bn_train)
     for _ in range(repeats - 1):
         x = rtfs_block_torch(x + a1, blk)
     s = s3_torch(x, a0, _sub(p, "mask_generator"))

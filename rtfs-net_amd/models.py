@@ -606,17 +606,18 @@ class AVNet(BaseAVModel):
         return self.decoder(sep, STFTEncoder.unsqueeze_to_2D(audio_mixture).shape)
 
     def forward_train(self, audio_mixture, mouth_embedding):
-        """The separator inside a training step (reference tdavnet.py:86-97 called from src/system/core.py:94-123): every audio-side
-        module runs its HIP forward-with-saved-state and hands autograd its HIP backward.  Two things are frozen in this version
-        (SURVEY 8f rank 1 is not finished): BatchNorm layers use their running statistics (put them in eval mode - ``freeze_for_finetune``
-        does) and the video-side VP block is evaluated without a graph on the inference kernel, so its parameters get no gradient."""
+        """The separator inside a training step (reference tdavnet.py:86-97 called from src/system/core.py:94-123): every module runs
+        its HIP forward-with-saved-state and hands autograd its HIP backward.  BatchNorm layers follow their own mode (train: statistics
+        of this rank's batch; eval: running statistics), the video-side VP block is differentiated when it is in train mode and has
+        trainable parameters, and evaluated without a graph on its inference kernel otherwise (``freeze_for_finetune``)."""
         rm = self.refinement_module
         vp_block = rm.video_net.get_block(0)
-        if vp_block.training or self.video_bottleneck.training:
-            raise RuntimeError("AVNet.forward_train: the video-side VP block has no backward yet; call model.freeze_for_finetune() "
-                               "(VP block and BatchNorm layers in eval mode) before taking gradients")
-        with torch.no_grad():
-            video = vp_block(self.video_bottleneck(mouth_embedding))
+        video = self.video_bottleneck(mouth_embedding)
+        if vp_block.training and any(p.requires_grad for p in vp_block.parameters()):
+            video = vp_block(video)
+        else:
+            with torch.no_grad():
+                video = vp_block(video)
         emb = self.encoder(audio_mixture)
         audio = self.audio_bottleneck(emb)
         a_res = audio
@@ -629,8 +630,9 @@ class AVNet(BaseAVModel):
         return self.decoder(sep, STFTEncoder.unsqueeze_to_2D(audio_mixture).shape)
 
     def freeze_for_finetune(self):
-        """Training configuration this version supports: everything in train mode except BatchNorm layers (frozen running statistics)
-        and the video-side VP block (eval mode, requires_grad False).  Returns self."""
+        """Fine-tuning configuration: everything in train mode except BatchNorm layers (frozen running statistics) and the video-side VP
+        block (eval mode, requires_grad False; it then runs on its fused inference kernel).  Plain ``.train()`` trains everything, with
+        BatchNorm on the batch statistics of the local rank and the VP block's dropout / DropPath drawn from torch's RNG.  Returns self."""
         self.train()
         for m in self.modules():
             if isinstance(m, (nn.BatchNorm1d, nn.BatchNorm2d, nn.BatchNorm3d)):

@@ -527,15 +527,21 @@ def test_pit_loss_gradient(kind, zero_mean, take_log, n):
     close(f"pit loss {kind} d est", host(et.grad), er.grad.numpy(), tol=2e-5)
 
 
-@pytest.mark.parametrize("smooth", [True, False])
-def test_avnet_training_step_end_to_end(smooth):
+@pytest.mark.parametrize("smooth,full", [(True, False), (False, False), (True, True)])
+def test_avnet_training_step_end_to_end(smooth, full):
     """AVNet.forward_train + PIT loss + backward through every audio-side module (encoder, bottleneck, shared RTFS block x R, CAF,
     S^3, decoder), frozen BatchNorm / VP block, against the float64 autograd oracle of the whole separator.  R = 2, 0.26 s input.
     Tolerances as in test_block_training_forward_backward (activation kinks); then one optimizer step through System."""
     import copy
     import rtfs_net_amd as R
     from oracle import grad_oracle as G
-    m = copy.deepcopy(model(2)).freeze_for_finetune()
+    m = copy.deepcopy(model(2))
+    if full:  # everything trains: VP block differentiated (dropout 0 so the oracle can follow), BatchNorm on batch statistics
+        m.train()
+        ga = m.refinement_module.video_net.get_block(0).globalatt[0]
+        ga.MHSA.dropout, ga.MHSA.dropout_layer.p, ga.FFN.dropout = 0.0, 0.0, 0.0
+    else:
+        m.freeze_for_finetune()
     if smooth:  # take the activation kinks out of reach (see test_encoder_bottleneck_s3_decoder_training): every PReLU slope 1, mask ReLU inactive
         with torch.no_grad():
             for k, v in m.named_parameters():
@@ -546,16 +552,20 @@ def test_avnet_training_step_end_to_end(smooth):
     wav, emb = make_inputs(B, L, Tv, seed=5)
     tgt = rand((B, 1, L), 6) * 0.05
     wt, vt = dev(wav), dev(emb)
+    p0 = {k: v.detach().cpu().numpy().copy() for k, v in m.state_dict().items() if "num_batches" not in k}  # before BatchNorm's running update
     out = m(wt, vt)
     loss_mod = R.losses.PITLossWrapper(R.losses.PairwiseNegSDR("snr"), pit_from="pw_mtx")
     loss = loss_mod(out, dev(tgt))
     loss.backward()
-    with torch.no_grad():
-        vp = host(m.refinement_module.video_net.get_block(0)(vt))
-    skip = ("refinement_module.video_net.",)
-    p = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items() if not k.startswith(skip) and "num_batches" not in k}
-    pt = {k: torch.tensor(v, dtype=torch.float64, requires_grad=("running" not in k)) for k, v in p.items()}
-    o_ref = G.avnet_torch(torch.tensor(wav, dtype=torch.float64), torch.tensor(vp, dtype=torch.float64), pt, 2)
+    if full:
+        vp = emb
+    else:
+        with torch.no_grad():
+            vp = host(m.refinement_module.video_net.get_block(0)(vt))
+    skip = () if full else ("refinement_module.video_net.",)
+    p = {k: v for k, v in p0.items() if not (skip and k.startswith(skip))}
+    pt = {k: torch.tensor(v, dtype=torch.float64, requires_grad=("running" not in k and not k.endswith("pos_enc.pe"))) for k, v in p.items()}
+    o_ref = G.avnet_torch(torch.tensor(wav, dtype=torch.float64), torch.tensor(vp, dtype=torch.float64), pt, 2, vp_trainable=full, bn_train=full)
     l_ref = G.pit_loss_torch(o_ref, torch.tensor(tgt, dtype=torch.float64), "snr")
     l_ref.backward()
     close("avnet train forward", host(out), o_ref.detach().numpy())
