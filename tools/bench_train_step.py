@@ -16,12 +16,15 @@ def main():
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--repeats", type=int, default=4)
     ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--full", action="store_true", help="train everything (VP block with dropout, BatchNorm on batch statistics) instead of "
+                    "the fine-tuning configuration (frozen BatchNorm statistics and VP block)")
     a = ap.parse_args()
     from tests.test_host import RTFS4_AUDIONET
     conf = copy.deepcopy(RTFS4_AUDIONET)
     conf["audio_params"]["repeats"] = a.repeats
     torch.manual_seed(0)
-    m = R.AVNet(print_macs=False, **conf).cuda().freeze_for_finetune()
+    m = R.AVNet(print_macs=False, **conf).cuda()
+    m = m.train() if a.full else m.freeze_for_finetune()
     loss_mod = R.losses.PITLossWrapper(R.losses.PairwiseNegSDR("snr"), pit_from="pw_mtx")
     opt = torch.optim.AdamW([p for p in m.parameters() if p.requires_grad], lr=1e-3)
     system = R.System(audio_model=m, loss_func={"train": loss_mod, "val": loss_mod}, optimizer=opt)
@@ -39,7 +42,7 @@ def main():
     ev[1].record()
     torch.cuda.synchronize()
     ms = ev[0].elapsed_time(ev[1]) / a.iters
-    print(f"RTFS-Net-{a.repeats} training step, batch {a.batch} x 2 s: {ms:.1f} ms/step = {a.batch / ms * 1e3:.1f} mixtures/s trained; "
+    print(f"RTFS-Net-{a.repeats} {'full' if a.full else 'fine-tune'} training step, batch {a.batch} x 2 s: {ms:.1f} ms/step = {a.batch / ms * 1e3:.1f} mixtures/s trained; "
           f"peak memory {torch.cuda.max_memory_allocated() / 2**30:.2f} GiB; loss {losses[0]:.3f} -> {losses[-1]:.3f}")
 
 
