@@ -147,7 +147,8 @@ class _CNATrainFn(torch.autograd.Function):
         B, H, W = x.shape[0], (x.shape[2] if x.dim() == 4 else 1), x.shape[-1]
         carr = (ctypes.c_int * 11)(*cfg)
         params, running = params[:8], params[8:]  # optional: BatchNorm running mean / var (+ momentum in train mode)
-        pk = packing.pack_cna_train(cfg, *params, *running[:2])
+        pk = packing.cached_train_pack(("cna", cfg), tuple(params) + ((None,) if cfg[7] else ()),
+                                       lambda: packing.pack_cna_train(cfg, *params, *running[:2])) if cfg[7] < 2 else packing.pack_cna_train(cfg, *params, *running[:2])
         ho, wo = ctypes.c_int(), ctypes.c_int()
         lib.rtfs_cna_out_shape(carr, H, W, ctypes.byref(ho), ctypes.byref(wo))
         out = torch.empty((B, cfg[1], ho.value, wo.value) if x.dim() == 4 else (B, cfg[1], wo.value), device=x.device, dtype=torch.float32)
@@ -354,7 +355,7 @@ class _SRUTrainFn(torch.autograd.Function):
         lib = _lib.load()
         x = x.contiguous()
         L, N, _ = x.shape
-        tpack = packing.pack_sru_train(params[0::3], params[1::3], params[2::3])
+        tpack = packing.cached_train_pack("sru", params, lambda: packing.pack_sru_train(params[0::3], params[1::3], params[2::3]))
         h = torch.empty(L, N, 64, device=x.device, dtype=torch.float32)
         saved = torch.empty(lib.rtfs_sru_saved_floats(L, N), device=x.device, dtype=torch.float32)
         _lib.check(lib.rtfs_sru_forward_train_f32(_lib.ptr(x), _lib.ptr(tpack), _lib.ptr(h), _lib.ptr(saved), L, N, _lib.stream_of(x)),
@@ -418,7 +419,8 @@ class _DualPathTrainFn(torch.autograd.Function):
         x = x.contiguous()
         B, _, T, Fq = x.shape
         sru, lin_w, lin_b = rest[:12], rest[12], rest[13]
-        tpack = packing.pack_dualpath_train(gamma, beta, sru[0::3], sru[1::3], sru[2::3], lin_w, lin_b)
+        tpack = packing.cached_train_pack("dualpath", (gamma, beta) + tuple(rest),
+                                          lambda: packing.pack_dualpath_train(gamma, beta, sru[0::3], sru[1::3], sru[2::3], lin_w, lin_b))
         out = torch.empty_like(x)
         saved = torch.empty(lib.rtfs_dualpath_saved_floats(B, T, Fq, dim), device=x.device, dtype=torch.float32)
         ws = _lib.workspace(lib.rtfs_dualpath_train_workspace_bytes(B, T, Fq, dim), x.device)
@@ -501,7 +503,7 @@ class _AttentionTrainFn(torch.autograd.Function):
         lib = _lib.load()
         x = x.contiguous()
         B, _, T, _ = x.shape
-        tpack = packing.pack_attention_train(dict(zip(names, params)))
+        tpack = packing.cached_train_pack("attention", params, lambda: packing.pack_attention_train(dict(zip(names, params))))
         out = torch.empty_like(x)
         saved = torch.empty(lib.rtfs_tf_attention_saved_floats(B, T), device=x.device, dtype=torch.float32)
         ws = _lib.workspace(lib.rtfs_tf_attention_train_workspace_bytes(B, T), x.device)

@@ -83,6 +83,25 @@ def _dualpath_parts(sd):
     return parts
 
 
+def cached_train_pack(kind, tensors, build):
+    """The training kernels take re-ordered copies of the live parameters.  Within one step the shared RTFS block is applied R times
+    with unchanged parameters, so the copy is cached - ON the first parameter object (it dies with the module, so a new module that
+    happens to reuse the addresses cannot see it), keyed by (storage address, version counter) of every parameter: an optimizer step
+    bumps the versions.  Only genuine nn.Parameters are cached (a temporary may reuse an address with different contents)."""
+    if not all(t is None or isinstance(t, torch.nn.Parameter) for t in tensors):
+        return build()
+    anchor = next((t for t in tensors if t is not None), None)
+    if anchor is None:
+        return build()
+    store = anchor.__dict__.setdefault("_rtfs_train_pack", {})
+    key = (kind,) + tuple(None if t is None else (id(t), t.data_ptr(), t._version) for t in tensors)
+    pk = store.get(key)
+    if pk is None:
+        store.clear()  # one live entry per (anchor): older versions are dead weight
+        pk = store[key] = build()
+    return pk
+
+
 def pack_sru_train(weights, weight_cs, biases):
     """Training-side pack of sru.SRU(512, 32, 4 layers, bidirectional) (layout contract: include/rtfs_amd.h,
     rtfs_sru_forward_train_f32): projections re-ordered to column m*64 + dir*32 + j, once K-major (Wt) and once as is (Wp)."""
