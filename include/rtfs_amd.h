@@ -165,8 +165,12 @@ int rtfs_dualpath_backward_f32(const float* x, const float* tpack, const float* 
 /* ConvNormAct.forward / backward for training (src/models/layers/conv_layers.py:65-129: pre_norm -> pre_act -> conv -> norm -> act),
  * 1x1 dense (channels up to 1024) or depthwise k x k (taps up to 4 x 5, stride 1 "same" or stride 2 symmetric), norms: none | gLN |
  * BatchNorm (post-norm only; frozen running statistics, or train mode = statistics of the batch), acts: none | ReLU | PReLU | Sigmoid.
- * cfg (HOST int[11]): Cin, Cout, k, stride, depthwise, pre_norm (0/1), pre_act (0 none, 1 ReLU, 2 PReLU, 3 Sigmoid), norm (0 none, 1 gLN,
- *   2 frozen BatchNorm, 3 train-mode BatchNorm), act, has_bias, is2d.  x (B,Cin,H,W) -> out (B,Cout,Ho,Wo) (rtfs_cna_out_shape).
+ * cfg (HOST int[13]): Cin, Cout, k, stride, depthwise, pre_norm (0/1), pre_act (0 none, 1 ReLU, 2 PReLU, 3 Sigmoid), norm (0 none, 1 gLN,
+ *   2 frozen BatchNorm, 3 train-mode BatchNorm), act, has_bias, is2d, phase, world.
+ *   phase / world serve SyncBatchNorm (norm 3 only): phase 1 runs the forward up to the batch statistics (rtfs_cna_saved_stats_offset:
+ *   2*Cout doubles inside `saved`, which the caller all-reduces), phase 2 resumes with the normalisation over rows * world samples; the
+ *   backward likewise stops after the dgamma / dbeta sums (rtfs_cna_grad_norm_offsets) and resumes with the input gradient; phase 0 =
+ *   everything in one call, world = 1.  x (B,Cin,H,W) -> out (B,Cout,Ho,Wo) (rtfs_cna_out_shape).
  * params (rtfs_cna_param_floats, packing.py:pack_cna_train; every slot padded to 64 floats, unused slots ignored):
  *   pre gamma | pre beta | pre slope | W (Cout,Cin) or (C,kh*kw) | W^T (dense only) | bias | gamma | beta | slope | running mean | running var.
  * dparams (rtfs_cna_grad_floats, overwritten): the slots pre gamma ... slope without W^T. */
@@ -175,6 +179,8 @@ size_t rtfs_cna_grad_floats(const int* cfg);
 size_t rtfs_cna_saved_floats(const int* cfg, int B, int H, int W);
 size_t rtfs_cna_workspace_bytes(const int* cfg, int B, int H, int W);
 void rtfs_cna_out_shape(const int* cfg, int H, int W, int* Ho, int* Wo);
+size_t rtfs_cna_saved_stats_offset(const int* cfg, int B, int H, int W);
+void rtfs_cna_grad_norm_offsets(const int* cfg, size_t* dgamma, size_t* dbeta);
 int rtfs_cna_forward_train_f32(const float* x, const float* params, float* out, float* saved, const int* cfg, int B, int H, int W,
                                void* ws, size_t ws_bytes, void* stream);
 int rtfs_cna_backward_f32(const float* params, const float* saved, const float* dout, float* dx, float* dparams, const int* cfg,

@@ -63,6 +63,8 @@ SIGNATURES = {
     "rtfs_cna_grad_floats": (_z, [_p]),
     "rtfs_cna_saved_floats": (_z, [_p, _i, _i, _i]),
     "rtfs_cna_workspace_bytes": (_z, [_p, _i, _i, _i]),
+    "rtfs_cna_saved_stats_offset": (_z, [_p, _i, _i, _i]),
+    "rtfs_cna_grad_norm_offsets": (None, [_p, _p, _p]),
     "rtfs_cna_out_shape": (None, [_p, _i, _i, _p, _p]),
     "rtfs_cna_forward_train_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p, _z, _p]),
     "rtfs_cna_bn_update_f32": (_i, [_p, _p, _i, _i, _i, _p, _p, C.c_float, _p]),

@@ -1155,7 +1155,7 @@ int rtfs_dualpath_backward_f32(const float* x, const float* tpack, const float* 
 // ------------------------------------------------------------ ConvNormAct, training side (channel-last rows inside)
 namespace {
 struct CnaCfg {
-    int Cin, Cout, k, stride, depthwise, pre_norm, pre_act, norm, act, has_bias, is2d;
+    int Cin, Cout, k, stride, depthwise, pre_norm, pre_act, norm, act, has_bias, is2d, phase, world;
     int kh, kw, pt, pl, H, W, Ho, Wo, B;
     size_t rows_in, rows_out;
     // parameter / gradient layout (floats)
@@ -1164,7 +1164,7 @@ struct CnaCfg {
     bool ok;
     CnaCfg(const int* c, int B_, int H_, int W_) {
         Cin = c[0]; Cout = c[1]; k = c[2]; stride = c[3]; depthwise = c[4]; pre_norm = c[5]; pre_act = c[6]; norm = c[7]; act = c[8];
-        has_bias = c[9]; is2d = c[10];
+        has_bias = c[9]; is2d = c[10]; phase = c[11]; world = c[12] < 1 ? 1 : c[12];
         B = B_; H = H_; W = W_;
         kh = is2d ? k : 1;
         kw = k;
@@ -1189,7 +1189,7 @@ struct CnaCfg {
         ok = pow2(Cin, 1024) && pow2(Cout, 1024) && k >= 1 && kh <= 4 && kw <= 5 &&
              (stride == 1 || stride == 2) && Ho >= 1 && Wo >= 1 &&
              (depthwise ? Cin == Cout : (k == 1 && stride == 1 && Cin % 16 == 0 && Cout % 64 == 0 && Cin % 64 == 0)) &&
-             pre_norm >= 0 && pre_norm <= 1 && norm >= 0 && norm <= 3 && pre_act >= 0 && pre_act <= 3 && act >= 0 && act <= 3 &&
+             pre_norm >= 0 && pre_norm <= 1 && norm >= 0 && norm <= 3 && phase >= 0 && phase <= 2 && (phase == 0 || norm == 3) && pre_act >= 0 && pre_act <= 3 && act >= 0 && act <= 3 &&
              rows_in * (size_t)(Cin > Cout ? Cin : Cout) < 0x7fffffffu;
     }
     bool pre() const { return pre_norm || pre_act; }
@@ -1222,6 +1222,18 @@ size_t rtfs_cna_workspace_bytes(const int* cfg, int B, int H, int W) {
     CnaCfg c(cfg, B, H, W);
     return (2 * c.rows_out * c.Cout + 2 * c.rows_in * c.Cin + 4 * (size_t)B + (size_t)CL_DW_WGRAD_MAX_WG * 20 * 256) * sizeof(float) + 8 * 256;
 }
+// float offset, inside `saved`, of the 2 * Cout doubles (sum, sum of squares per channel) a norm = 3 forward accumulates; the gradient
+// buffer's dgamma / dbeta float offsets for the matching exchange in the backward
+size_t rtfs_cna_saved_stats_offset(const int* cfg, int B, int H, int W) {
+    CnaCfg c(cfg, B, H, W);
+    CnaSaved sv(nullptr, c);
+    return (size_t)((float*)sv.cst - (float*)nullptr);
+}
+void rtfs_cna_grad_norm_offsets(const int* cfg, size_t* dgamma, size_t* dbeta) {
+    CnaCfg c(cfg, 1, 8, 8);
+    *dgamma = c.g_g;
+    *dbeta = c.g_be;
+}
 void rtfs_cna_out_shape(const int* cfg, int H, int W, int* Ho, int* Wo) {
     CnaCfg c(cfg, 1, H, W);
     *Ho = c.Ho;
@@ -1239,6 +1251,8 @@ int rtfs_cna_forward_train_f32(const float* x, const float* params, float* out, 
     float* r5 = ar.take<float>(c.rows_out * c.Cout);
     hipStream_t st = S(stream);
     const size_t n_in = (size_t)H * W * c.Cin, n_out = (size_t)c.Ho * c.Wo * c.Cout;
+    // phase 1 stops once the BatchNorm batch statistics are in `saved`; phase 2 resumes there (the caller all-reduced them in between)
+    if (c.phase != 2) {
     CHECK(launch_transpose(x, sv.r0, B, c.Cin, H * W, st));  // (B, C, P) -> (B, P, C)
     const float* conv_in = sv.r0;
     if (c.pre()) {
@@ -1262,15 +1276,17 @@ int rtfs_cna_forward_train_f32(const float* x, const float* params, float* out, 
         CHECK(launch_gemm_nt(conv_in, c.Cin, params + c.o_w, c.Cin, conv_out, c.Cout, (int)c.rows_in, c.Cout, c.Cin, 0, st,
                              c.has_bias ? params + c.o_b : nullptr));
     }
+    if (c.norm == 3) {
+        if (hipMemsetAsync(sv.cst, 0, sizeof(double) * 2 * c.Cout, st) != hipSuccess) return RTFS_ERR_LAUNCH;
+        CHECK(launch_cl_chan_stats(sv.r3, sv.cst, c.rows_out * c.Cout, c.Cout, st));
+    }
+    }  // phase != 2
+    if (c.phase == 1) return RTFS_OK;
     if (c.post()) {
         ClStageArgs a;
         a.x = sv.r3; a.y = r5; a.n = n_out; a.C = c.Cout; a.norm = c.norm; a.act = c.act;
         a.gamma = params + c.o_g; a.beta = params + c.o_be; a.slope = params + c.o_s; a.stats = sv.st3;
-        a.rmean = params + c.o_rm; a.rvar = params + c.o_rv; a.cstats = sv.cst; a.inv_rows = 1.0 / (double)c.rows_out;
-        if (c.norm == 3) {
-            if (hipMemsetAsync(sv.cst, 0, sizeof(double) * 2 * c.Cout, st) != hipSuccess) return RTFS_ERR_LAUNCH;
-            CHECK(launch_cl_chan_stats(sv.r3, sv.cst, c.rows_out * c.Cout, c.Cout, st));
-        }
+        a.rmean = params + c.o_rm; a.rvar = params + c.o_rv; a.cstats = sv.cst; a.inv_rows = 1.0 / ((double)c.rows_out * c.world);
         if (c.norm == 1) {
             if (hipMemsetAsync(sv.st3, 0, sizeof(double) * 2 * B, st) != hipSuccess) return RTFS_ERR_LAUNCH;
             CHECK(launch_stats(sv.r3, sv.st3, B, n_out, st));
@@ -1288,7 +1304,7 @@ int rtfs_cna_bn_update_f32(const float* saved, const int* cfg, int B, int H, int
     CnaCfg c(cfg, B, H, W);
     RTFS_RETURN_IF(!c.ok || c.norm != 3, RTFS_ERR_SHAPE);
     CnaSaved sv((float*)align_up((size_t)saved, 16), c);
-    return launch_bn_update(sv.cst, running_mean, running_var, c.Cout, (double)c.rows_out, momentum, S(stream));
+    return launch_bn_update(sv.cst, running_mean, running_var, c.Cout, (double)c.rows_out * c.world, momentum, S(stream));
 }
 
 int rtfs_cna_backward_f32(const float* params, const float* saved, const float* dout, float* dx, float* dparams, const int* cfg, int B,
@@ -1308,16 +1324,21 @@ int rtfs_cna_backward_f32(const float* params, const float* saved, const float* 
     RTFS_RETURN_IF(!ar.ok(), RTFS_ERR_WORKSPACE);
     hipStream_t st = S(stream);
     const size_t n_in = (size_t)H * W * c.Cin, n_out = (size_t)c.Ho * c.Wo * c.Cout;
-    if (hipMemsetAsync(dparams, 0, c.g_end * sizeof(float), st) != hipSuccess) return RTFS_ERR_LAUNCH;
-    CHECK(launch_transpose(dout, d5, B, c.Cout, c.Ho * c.Wo, st));
+    // phase 1 (SyncBatchNorm): stop after the post-stage's reduction (dgamma / dbeta in dparams); phase 2: resume with the apply pass.
+    // The workspace must be the same buffer in both calls (d5 lives there).
+    if (c.phase != 2) {
+        if (hipMemsetAsync(dparams, 0, c.g_end * sizeof(float), st) != hipSuccess) return RTFS_ERR_LAUNCH;
+        CHECK(launch_transpose(dout, d5, B, c.Cout, c.Ho * c.Wo, st));
+    }
     const float* d3 = d5;
     if (c.post()) {
         ClStageArgs a;
         a.x = sv.r3; a.dy = d5; a.dx = d3b; a.n = n_out; a.C = c.Cout; a.norm = c.norm; a.act = c.act;
         a.gamma = params + c.o_g; a.beta = params + c.o_be; a.slope = params + c.o_s; a.stats = sv.st3; a.S = Sb;
-        a.rmean = params + c.o_rm; a.rvar = params + c.o_rv; a.cstats = sv.cst; a.inv_rows = 1.0 / (double)c.rows_out;
+        a.rmean = params + c.o_rm; a.rvar = params + c.o_rv; a.cstats = sv.cst; a.inv_rows = 1.0 / ((double)c.rows_out * c.world);
         a.dgamma = dparams + c.g_g; a.dbeta = dparams + c.g_be; a.dslope = dparams + c.g_s;
-        CHECK(launch_cl_norm_act_bwd(a, B, st));
+        CHECK(launch_cl_norm_act_bwd(a, B, st, c.phase));
+        if (c.phase == 1) return RTFS_OK;
         d3 = d3b;
     }
     const float* conv_in = c.pre() ? sv.r2 : sv.r0;

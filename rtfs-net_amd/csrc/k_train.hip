@@ -883,13 +883,14 @@ int launch_cl_norm_act_fwd(const ClStageArgs& a, int B, hipStream_t st) {
     hipLaunchKernelGGL(cl_norm_act_fwd_kernel, dim3(grid_for(a.n, 2048), B), dim3(256), 0, st, a);
     return rtfs_launch_status();
 }
-int launch_cl_norm_act_bwd(const ClStageArgs& a, int B, hipStream_t st) {
+// part 0: reduction + apply; 1: reduction only; 2: apply only (SyncBatchNorm all-reduces dgamma / dbeta in between)
+int launch_cl_norm_act_bwd(const ClStageArgs& a, int B, hipStream_t st, int part) {
     if (!cl_c_ok(a.C)) return RTFS_ERR_SHAPE;
-    if (a.norm || a.act == 2) {
+    if (part != 2 && (a.norm || a.act == 2)) {
         if (a.norm == 1 && hipMemsetAsync(a.S, 0, sizeof(double) * 2 * B, st) != hipSuccess) return RTFS_ERR_LAUNCH;
         hipLaunchKernelGGL(cl_norm_act_bwd_reduce_kernel, dim3(grid4(a.n, 256), B), dim3(256), 0, st, a);
     }
-    hipLaunchKernelGGL(cl_norm_act_bwd_apply_kernel, dim3(grid_for(a.n, 2048), B), dim3(256), 0, st, a);
+    if (part != 1) hipLaunchKernelGGL(cl_norm_act_bwd_apply_kernel, dim3(grid_for(a.n, 2048), B), dim3(256), 0, st, a);
     return rtfs_launch_status();
 }
 int launch_cl_chan_stats(const float* x, double* stats, size_t n, int C, hipStream_t st) {

@@ -290,7 +290,7 @@ struct ClDwArgs {
     int Cp = 0;  // row pitch in channels (set by the launcher; C is the slice a launch covers)
 };
 int launch_cl_norm_act_fwd(const ClStageArgs& a, int B, hipStream_t st);
-int launch_cl_norm_act_bwd(const ClStageArgs& a, int B, hipStream_t st);
+int launch_cl_norm_act_bwd(const ClStageArgs& a, int B, hipStream_t st, int part = 0);
 int launch_cl_colsum(const float* d, float* out, size_t n, int C, hipStream_t st);
 int launch_cl_chan_stats(const float* x, double* stats, size_t n, int C, hipStream_t st);
 int launch_bn_update(const double* stats, float* rmean, float* rvar, int C, double rows, float momentum, hipStream_t st);

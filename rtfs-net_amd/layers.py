@@ -135,9 +135,26 @@ def _config_of(module):
 _ACT_CODE = {nn.Identity: 0, nn.ReLU: 1, nn.PReLU: 2, nn.Sigmoid: 3}
 
 
+def _bn_world():
+    """Number of ranks a SyncBatchNorm layer synchronises over (hook: the tests emulate ranks with threads)."""
+    import torch.distributed as dist
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def _bn_all_reduce(t):
+    import torch.distributed as dist
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+
+
 class _CNATrainFn(torch.autograd.Function):
     """ConvNormAct forward/backward on the training kernels (csrc/k_train.hip, channel-last rows inside).
-    Inputs: x, cfg tuple, then pre_gamma, pre_beta, pre_slope, weight, bias, gamma, beta, slope (None where the stage is absent)."""
+    Inputs: x, cfg tuple (11 ints as in include/rtfs_amd.h + an optional 12th: synchronise the BatchNorm statistics across ranks), then
+    pre_gamma, pre_beta, pre_slope, weight, bias, gamma, beta, slope (None where the stage is absent) [, running mean, var, momentum]."""
+
+    @staticmethod
+    def _carr(cfg, phase, world):
+        import ctypes
+        return (ctypes.c_int * 13)(*(tuple(cfg[:11]) + (phase, world)))
 
     @staticmethod
     def forward(ctx, x, cfg, *params):
@@ -145,23 +162,33 @@ class _CNATrainFn(torch.autograd.Function):
         lib = _lib.load()
         x = x.contiguous()
         B, H, W = x.shape[0], (x.shape[2] if x.dim() == 4 else 1), x.shape[-1]
-        carr = (ctypes.c_int * 11)(*cfg)
+        world = _bn_world() if (len(cfg) > 11 and cfg[11] and cfg[7] == 3) else 1
+        carr = _CNATrainFn._carr(cfg, 0, world)
         params, running = params[:8], params[8:]  # optional: BatchNorm running mean / var (+ momentum in train mode)
-        pk = packing.cached_train_pack(("cna", cfg), tuple(params) + ((None,) if cfg[7] else ()),
+        pk = packing.cached_train_pack(("cna", tuple(cfg[:11])), tuple(params) + ((None,) if cfg[7] else ()),
                                        lambda: packing.pack_cna_train(cfg, *params, *running[:2])) if cfg[7] < 2 else packing.pack_cna_train(cfg, *params, *running[:2])
         ho, wo = ctypes.c_int(), ctypes.c_int()
         lib.rtfs_cna_out_shape(carr, H, W, ctypes.byref(ho), ctypes.byref(wo))
         out = torch.empty((B, cfg[1], ho.value, wo.value) if x.dim() == 4 else (B, cfg[1], wo.value), device=x.device, dtype=torch.float32)
         saved = torch.empty(lib.rtfs_cna_saved_floats(carr, B, H, W), device=x.device, dtype=torch.float32)
         ws = _lib.workspace(lib.rtfs_cna_workspace_bytes(carr, B, H, W), x.device)
-        _lib.check(lib.rtfs_cna_forward_train_f32(_lib.ptr(x), _lib.ptr(pk), _lib.ptr(out), _lib.ptr(saved), carr, B, H, W, _lib.ptr(ws), ws.numel(),
-                                                  _lib.stream_of(x)), "rtfs_cna_forward_train_f32")
+
+        def run(c):
+            _lib.check(lib.rtfs_cna_forward_train_f32(_lib.ptr(x), _lib.ptr(pk), _lib.ptr(out), _lib.ptr(saved), c, B, H, W, _lib.ptr(ws), ws.numel(),
+                                                      _lib.stream_of(x)), "rtfs_cna_forward_train_f32")
+        if world > 1:  # SyncBatchNorm: batch statistics summed over the ranks between the convolution and the normalisation
+            run(_CNATrainFn._carr(cfg, 1, world))
+            off = lib.rtfs_cna_saved_stats_offset(carr, B, H, W)
+            _bn_all_reduce(saved[off:off + 4 * cfg[1]].view(torch.float64))
+            run(_CNATrainFn._carr(cfg, 2, world))
+        else:
+            run(carr)
         if cfg[7] == 3:  # train-mode BatchNorm: nn.BatchNorm's side effect on its buffers (momentum None = cumulative average is not built)
             rm, rv, momentum = running
             _lib.check(lib.rtfs_cna_bn_update_f32(_lib.ptr(saved), carr, B, H, W, _lib.ptr(rm), _lib.ptr(rv), float(momentum), _lib.stream_of(x)),
                        "rtfs_cna_bn_update_f32")
         ctx.save_for_backward(pk, saved)
-        ctx.cfg, ctx.geom, ctx.xshape = cfg, (B, H, W), x.shape
+        ctx.cfg, ctx.geom, ctx.xshape, ctx.world = tuple(cfg[:11]), (B, H, W), x.shape, world
         ctx.pshapes = [None if p is None else p.shape for p in params]
         ctx.nrunning = len(running)
         return out
@@ -172,13 +199,32 @@ class _CNATrainFn(torch.autograd.Function):
         lib = _lib.load()
         pk, saved = ctx.saved_tensors
         B, H, W = ctx.geom
-        carr = (ctypes.c_int * 11)(*ctx.cfg)
+        world = ctx.world
+        carr = _CNATrainFn._carr(ctx.cfg, 0, world)
         dout = dout.contiguous().to(torch.float32)
         dx = torch.empty(ctx.xshape, device=dout.device, dtype=torch.float32)
         dpar = torch.empty(lib.rtfs_cna_grad_floats(carr), device=dout.device, dtype=torch.float32)
         ws = _lib.workspace(lib.rtfs_cna_workspace_bytes(carr, B, H, W), dout.device)
-        _lib.check(lib.rtfs_cna_backward_f32(_lib.ptr(pk), _lib.ptr(saved), _lib.ptr(dout), _lib.ptr(dx), _lib.ptr(dpar), carr, B, H, W,
-                                             _lib.ptr(ws), ws.numel(), _lib.stream_of(dout)), "rtfs_cna_backward_f32")
+
+        def run(c):
+            _lib.check(lib.rtfs_cna_backward_f32(_lib.ptr(pk), _lib.ptr(saved), _lib.ptr(dout), _lib.ptr(dx), _lib.ptr(dpar), c, B, H, W,
+                                                 _lib.ptr(ws), ws.numel(), _lib.stream_of(dout)), "rtfs_cna_backward_f32")
+        if world > 1:  # SyncBatchNorm backward: the input gradient needs the sums of dy and dy * xhat over every rank; the
+            # parameter gradients stay local (the gradient all-reduce averages them like every other parameter's)
+            run(_CNATrainFn._carr(ctx.cfg, 1, world))
+            og, ob = ctypes.c_size_t(), ctypes.c_size_t()
+            lib.rtfs_cna_grad_norm_offsets(carr, ctypes.byref(og), ctypes.byref(ob))
+            C = ctx.cfg[1]
+            local = (dpar[og.value:og.value + C].clone(), dpar[ob.value:ob.value + C].clone())
+            both = torch.cat(local)
+            _bn_all_reduce(both)
+            dpar[og.value:og.value + C] = both[:C]
+            dpar[ob.value:ob.value + C] = both[C:]
+            run(_CNATrainFn._carr(ctx.cfg, 2, world))
+            dpar[og.value:og.value + C] = local[0]
+            dpar[ob.value:ob.value + C] = local[1]
+        else:
+            run(carr)
         grads = packing.unpack_cna_grads(ctx.cfg, dpar, ctx.pshapes[3])
         out = (dx, None) + tuple(None if shp is None else g.reshape(shp) for g, shp in zip(grads, ctx.pshapes))
         return out + (None,) * ctx.nrunning
@@ -224,7 +270,7 @@ class ConvNormAct(nn.Module):
             return x
         if not isinstance(pre_n, (nn.Identity, GlobalLayerNorm)):
             raise RuntimeError(f"ConvNormAct: the training kernels implement gLN as pre-norm only, not {type(pre_n).__name__}")
-        bn = isinstance(nrm, (nn.BatchNorm1d, nn.BatchNorm2d))
+        bn = isinstance(nrm, (nn.BatchNorm1d, nn.BatchNorm2d, nn.SyncBatchNorm))  # SyncBatchNorm: what convert_sync_batchnorm leaves
         if bn and nrm.training and (nrm.momentum is None or not nrm.track_running_stats):
             raise RuntimeError("ConvNormAct: train-mode BatchNorm needs track_running_stats and a momentum")
         if not bn and not isinstance(nrm, (nn.Identity, GlobalLayerNorm)):
@@ -248,8 +294,8 @@ class ConvNormAct(nn.Module):
         is2d = isinstance(conv, nn.Conv2d)
         cfg = (conv.in_channels, conv.out_channels, self.kernel_size, self.stride, int(depthwise), int(isinstance(pre_n, GlobalLayerNorm)),
                _ACT_CODE[type(pre_a)], (3 if nrm.training else 2) if bn else int(isinstance(nrm, GlobalLayerNorm)), _ACT_CODE[type(act)],
-               int(conv.bias is not None), int(is2d))
-        gn = lambda m, a: getattr(m.norm, a) if isinstance(m, GlobalLayerNorm) else (getattr(m, a) if isinstance(m, (nn.BatchNorm1d, nn.BatchNorm2d)) else None)
+               int(conv.bias is not None), int(is2d), int(isinstance(nrm, nn.SyncBatchNorm)))
+        gn = lambda m, a: getattr(m.norm, a) if isinstance(m, GlobalLayerNorm) else (getattr(m, a) if bn and m is nrm else None)
         sl = lambda m: m.weight if isinstance(m, nn.PReLU) else None
         running = ((nrm.running_mean, nrm.running_var) + ((nrm.momentum,) if nrm.training else ())) if bn else ()
         out = _CNATrainFn.apply(x, cfg, gn(pre_n, "weight"), gn(pre_n, "bias"), sl(pre_a), weight, conv.bias, gn(nrm, "weight"),

@@ -635,7 +635,7 @@ class AVNet(BaseAVModel):
         BatchNorm on the batch statistics of the local rank and the VP block's dropout / DropPath drawn from torch's RNG.  Returns self."""
         self.train()
         for m in self.modules():
-            if isinstance(m, (nn.BatchNorm1d, nn.BatchNorm2d, nn.BatchNorm3d)):
+            if isinstance(m, (nn.BatchNorm1d, nn.BatchNorm2d, nn.BatchNorm3d, nn.SyncBatchNorm)):
                 m.eval()
         vp = self.refinement_module.video_net
         vp.eval()

@@ -60,6 +60,12 @@ class System(nn.Module):
             return {"val_loss": self.common_step(batch, batch_nb, is_train=False)}
 
     # ---------------------------------------------------------------- what Lightning does around training_step (train.py:135-148)
+    def convert_sync_batchnorm(self):
+        """What Lightning's ``sync_batchnorm=True`` (train.py:145) does: BatchNorm layers become nn.SyncBatchNorm, which the training
+        kernels synchronise with two small all-reduces per layer (batch statistics forward, dgamma / dbeta sums backward)."""
+        self.audio_model = nn.SyncBatchNorm.convert_sync_batchnorm(self.audio_model)
+        return self
+
     def trainable_parameters(self):
         return [p for p in self.audio_model.parameters() if p.requires_grad]
 

@@ -595,6 +595,62 @@ def test_avnet_training_step_end_to_end(smooth, full):
     assert after < before
 
 
+def test_sync_batchnorm_two_emulated_ranks():
+    """SyncBatchNorm (train.py:145 sync_batchnorm=True): two ranks each hold half a batch; outputs, input gradients and running
+    statistics must equal plain BatchNorm over the whole batch on one rank, and the two ranks' local parameter gradients must add up to
+    the whole-batch ones.  The ranks are emulated in one process by running them one after the other three times with an all-reduce hook
+    that first records each rank's contribution and then hands out the recorded sum (round 1 settles the forward statistics, round 2
+    the backward sums under the right forward, round 3 is the synchronised step that is checked)."""
+    import copy
+    import rtfs_net_amd as R
+    L = R.layers
+    torch.manual_seed(3)
+    ref = L.ConvNormAct(in_chan=256, out_chan=256, kernel_size=1, groups=256, norm_type="BatchNorm2d", act_type="ReLU", bias=False, is2d=True)
+    with torch.no_grad():
+        for k, v in ref.named_parameters():
+            v.add_(0.3 * torch.randn_like(v))
+    ref = ref.cuda().train()
+    init = copy.deepcopy(ref.state_dict())
+    x, dout = rand((4, 256, 9, 7), 1), rand((4, 256, 9, 7), 2)
+    ranks = [torch.nn.SyncBatchNorm.convert_sync_batchnorm(copy.deepcopy(ref)).train() for _ in range(2)]
+    assert isinstance(ranks[0].full_layer[3], torch.nn.SyncBatchNorm)
+    xt = dev(x).requires_grad_(True)
+    out = ref(xt)
+    out.backward(dev(dout))
+    state = {"rank": 0, "rec": {"fwd": [None, None], "bwd": [None, None]}, "use": {"fwd": False, "bwd": False}}
+
+    def all_reduce(t):
+        site = "fwd" if t.dtype == torch.float64 else "bwd"
+        if state["use"][site]:
+            t.copy_(state["rec"][site][0] + state["rec"][site][1])
+        else:
+            state["rec"][site][state["rank"]] = t.clone()
+    old = (L._bn_world, L._bn_all_reduce)
+    L._bn_world, L._bn_all_reduce = (lambda: 2), all_reduce
+    res = [None, None]
+    try:
+        for rnd in range(3):
+            state["use"] = {"fwd": rnd >= 1, "bwd": rnd >= 2}
+            for r in range(2):
+                state["rank"] = r
+                ranks[r].load_state_dict(init)
+                for q in ranks[r].parameters():
+                    q.grad = None
+                xr = dev(x[2 * r:2 * r + 2]).requires_grad_(True)
+                o = ranks[r](xr)
+                o.backward(dev(dout[2 * r:2 * r + 2]))
+                res[r] = (host(o), host(xr.grad))
+    finally:
+        L._bn_world, L._bn_all_reduce = old
+    close("syncbn output", np.concatenate([res[0][0], res[1][0]]), host(out), tol=1e-5)
+    close("syncbn dx", np.concatenate([res[0][1], res[1][1]]), host(xt.grad), tol=1e-5)
+    for (k, pr), (_, p0), (_, p1) in zip(ref.named_parameters(), ranks[0].named_parameters(), ranks[1].named_parameters()):
+        close(f"syncbn d {k} (sum of the local gradients)", host(p0.grad) + host(p1.grad), host(pr.grad), tol=1e-5)
+    for r in ranks:
+        close("syncbn running_mean", host(r.full_layer[3].running_mean), host(ref.full_layer[3].running_mean), tol=1e-6)
+        close("syncbn running_var", host(r.full_layer[3].running_var), host(ref.full_layer[3].running_var), tol=1e-6)
+
+
 VP = O._sub(SD, "refinement_module.video_net.blocks")
 
 
