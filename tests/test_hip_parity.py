@@ -1011,3 +1011,73 @@ def test_system_forward_and_validation_step():
     assert rel_err(est.cpu().numpy(), ref) < 1e-4
     ref_loss = LO.pit_from_pw_mtx(LO.pairwise_neg_sdr(ref, tgt, "snr"))[0]
     assert abs(float(out["val_loss"]) - float(ref_loss)) < 1e-3
+
+
+DDP_WORKER = r"""
+import json, os, sys, copy
+import numpy as np, torch
+import torch.distributed as dist
+sys.path.insert(0, os.environ["RTFS_ROOT"])
+import rtfs_net_amd as R
+from tests.test_host import RTFS4_AUDIONET
+from oracle.params import make_inputs
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+if world > 1:
+    dist.init_process_group("gloo", rank=rank, world_size=world)   # two ranks share the one GPU of the box: gloo moves the CUDA tensors
+conf = copy.deepcopy(RTFS4_AUDIONET); conf["audio_params"]["repeats"] = 2
+torch.manual_seed(0)
+m = R.AVNet(print_macs=False, **conf).cuda().train()
+ga = m.refinement_module.video_net.get_block(0).globalatt[0]
+ga.MHSA.dropout, ga.MHSA.dropout_layer.p, ga.FFN.dropout = 0.0, 0.0, 0.0           # no RNG in the comparison
+loss_mod = R.losses.PITLossWrapper(R.losses.PairwiseNegSDR("snr"), pit_from="pw_mtx")
+system = R.System(audio_model=m, loss_func={"train": loss_mod, "val": loss_mod})
+if world > 1:
+    system.convert_sync_batchnorm()
+    m = system.audio_model
+B = 2
+wav, emb = make_inputs(B, 4096, 7, seed=5)
+tgt = 0.05 * np.random.default_rng(6).standard_normal((B, 1, 4096)).astype(np.float32)
+sl = slice(rank * B // world, (rank + 1) * B // world)
+batch = tuple(torch.from_numpy(a[sl]).cuda() for a in (wav, tgt, emb)) + (None,)
+batch = (batch[0], batch[1], batch[2], None)
+loss = system.training_step(batch, 0)["loss"]
+loss.backward()
+n = system.allreduce_gradients()
+torch.cuda.synchronize()
+if rank == 0:
+    g = {k: p.grad.detach().double().cpu().numpy() for k, p in m.named_parameters()}
+    np.savez(os.environ["RTFS_OUT"], loss=float(loss), n=n, **{k.replace(".", "/"): v for k, v in g.items()})
+if world > 1:
+    dist.barrier(); dist.destroy_process_group()
+"""
+
+
+def test_two_process_training_step_matches_single_process(tmp_path):
+    """Data-parallel training step for real: two processes (gloo, sharing the box's GPU), each with half the batch, SyncBatchNorm and the
+    flattened gradient all-reduce, against one process with the whole batch: every averaged parameter gradient must agree."""
+    import socket
+    import subprocess
+    import sys
+    from tests.util import ROOT
+
+    def run(world, out):
+        s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
+        procs = []
+        for r in range(world):
+            env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                       RTFS_ROOT=ROOT, RTFS_OUT=str(out), HSA_ENABLE_IPC_MODE_LEGACY="0")
+            procs.append(subprocess.Popen([sys.executable, "-c", DDP_WORKER], env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+        for p_ in procs:
+            o_, e_ = p_.communicate(timeout=600)
+            assert p_.returncode == 0, e_[-3000:]
+        return dict(np.load(out))
+    one = run(1, tmp_path / "one.npz")
+    two = run(2, tmp_path / "two.npz")
+    assert int(two["n"]) == sum(v.size for k, v in two.items() if k not in ("loss", "n")) > 700000  # one flattened buffer, every parameter
+    gmax = max(np.abs(v).max() for k, v in one.items() if k not in ("loss", "n"))
+    # a bias in front of a BatchNorm and an additive constant in front of a softmax have an exactly zero gradient: noise, not compared
+    errs = {k: l2_rel(two[k], one[k]) for k in one if k not in ("loss", "n") and np.abs(one[k]).max() > 1e-6 * gmax}
+    assert abs(float(two["loss"]) - float(one["loss"])) < 10.0  # rank 0's loss is its own half batch's: not comparable beyond sanity
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:3]
+    print(f"[parity] 2-process vs 1-process gradients over {len(errs)} tensors: median l2-rel {np.median(list(errs.values())):.3e}, worst {worst}")
+    assert np.median(list(errs.values())) <= 1e-4 and worst[0][1] <= 2e-2, worst
