@@ -206,7 +206,7 @@ def rtfs_block_torch(x, p):
 def stft_encoder_torch(wav, w):
     """STFTEncoder.forward (reference TDAVNet/encoder.py:161-175): torch.stft -> (B,2,T,F) -> Conv2d 3x3 'same', no bias."""
     import torch.nn.functional as F
-    win = torch.hann_window(256, dtype=wav.dtype)
+    win = torch.hann_window(256, dtype=torch.float32).to(wav.dtype)  # the reference's buffer is float32 (encoder.py:159)
     spec = torch.stft(wav, n_fft=256, hop_length=128, window=win, return_complex=True)  # (B, F, T)
     x = torch.stack([spec.real, spec.imag], 1).transpose(2, 3).contiguous()
     return F.conv2d(x, w, padding=1)
@@ -217,7 +217,7 @@ def stft_decoder_torch(x, w, length):
     import torch.nn.functional as F
     y = F.conv_transpose2d(x, w, padding=1)  # (B, 2, T, F)
     spec = torch.complex(y[:, 0], y[:, 1]).transpose(1, 2)
-    win = torch.hann_window(256, dtype=x.dtype)
+    win = torch.hann_window(256, dtype=torch.float32).to(x.dtype)  # float32 buffer in the reference (decoder.py:108)
     return torch.istft(spec, n_fft=256, hop_length=128, window=win, length=length).unsqueeze(1)
 
 

@@ -1,6 +1,8 @@
 """CPU: pins oracle/rtfs_oracle.py against vectors captured from the reference itself
 (oracle/make_golden.py).  Everything but the SRU cell is the reference's own code in those
 vectors; the SRU arithmetic is the oracle's (third-party package absent -> parity unpinned)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -171,3 +173,44 @@ def test_video_oracle_matches_reference(k, B, T):
     for li in (1, 2, 3, 4):
         ref = g[f"c{k}_layer{li}"]
         assert np.abs(it[f"layer{li}"][:, ::16] - ref).max() / np.abs(ref).max() < 2e-5
+
+
+@pytest.mark.parametrize("case", ["eval", "train"])
+def test_gradient_oracle_against_reference_autograd(case):
+    """oracle/grad_oracle.py (the float64 torch restatement the HIP backward kernels are tested against) vs golden gradients produced by
+    the REFERENCE's own modules and loss under torch autograd (oracle/make_golden_grad.py -> tests/golden/grad_R2_L4096_B2.npz):
+    loss, output and every one of the 264 parameter gradients, with BatchNorm in eval mode and on batch statistics."""
+    import zlib
+    import torch
+    from oracle import grad_oracle as G
+    from oracle.params import make_inputs, make_state_dict
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "grad_R2_L4096_B2.npz"))
+    sd = make_state_dict(spec_R4(), 0)
+    B, Ls, Tv = 2, 4096, 7
+    wav, emb = make_inputs(B, Ls, Tv, seed=5)
+    tgt = (0.05 * np.random.default_rng(6).standard_normal((B, 1, Ls))).astype(np.float32)
+    pt = {k: torch.tensor(v, dtype=torch.float64, requires_grad=("running" not in k and not k.endswith("pos_enc.pe")))
+          for k, v in sd.items() if "num_batches" not in k}
+    out = G.avnet_torch(torch.tensor(wav, dtype=torch.float64), torch.tensor(emb, dtype=torch.float64), pt, 2, vp_trainable=True,
+                        bn_train=(case == "train"))
+    loss = G.pit_loss_torch(out, torch.tensor(tgt, dtype=torch.float64), "snr")
+    loss.backward()
+    # (the reference's float32 Hann / positional-encoding buffers cast to float64 vs float64 ones here: ~1e-8)
+    assert abs(float(loss) - float(gold[f"{case}/loss"])) <= 1e-7 * abs(float(gold[f"{case}/loss"]))
+    assert rel_err(out.detach().numpy(), gold[f"{case}/est"]) <= 1e-6
+    names = [k for k, v in pt.items() if v.requires_grad]
+    assert len(names) == 264
+    gscale = max(np.abs(gold[f"{case}/{k}"]).max() for k in names)
+    worst = 0.0
+    for k in names:
+        g = pt[k].grad.numpy().reshape(-1)
+        ref = gold[f"{case}/{k}"]
+        if g.size > 4096:
+            rs = np.random.RandomState(zlib.crc32(k.encode()) & 0x7FFFFFFF)
+            idx = rs.choice(g.size, 4096, replace=False).astype(np.int64)
+            assert abs(np.sqrt((g ** 2).sum()) - gold[f"{case}/{k}#l2"]) <= 1e-6 * max(gold[f"{case}/{k}#l2"], 1e-12 * gscale), k
+            g = g[idx]
+        err = np.abs(g - ref).max() / max(np.abs(ref).max(), 1e-9 * gscale)
+        worst = max(worst, err)
+        assert err <= 1e-6, (k, err)
+    print(f"gradient oracle vs reference autograd ({case}): worst relative error {worst:.2e} over {len(names)} tensors")
