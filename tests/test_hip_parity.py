@@ -1013,6 +1013,47 @@ def test_system_forward_and_validation_step():
     assert abs(float(out["val_loss"]) - float(ref_loss)) < 1e-3
 
 
+@pytest.mark.parametrize("case", ["eval", "train"])
+def test_training_gradients_vs_reference_golden(case):
+    """HIP training step directly against gradients the REFERENCE produced under torch autograd (tests/golden/grad_R2_L4096_B2.npz,
+    oracle/make_golden_grad.py): loss, separated waveform, and all 264 parameter gradients.  case "eval": BatchNorm frozen (here: BatchNorm
+    layers in eval mode inside a train()-mode model), "train": BatchNorm on batch statistics.  Bounds as in
+    test_avnet_training_step_end_to_end (activation kinks move single fp32 gradient elements; the tight bounds are the per-module tests)."""
+    import copy
+    import zlib
+    import rtfs_net_amd as R
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "grad_R2_L4096_B2.npz"))
+    m = copy.deepcopy(model(2)).train()
+    ga = m.refinement_module.video_net.get_block(0).globalatt[0]
+    ga.MHSA.dropout, ga.MHSA.dropout_layer.p, ga.FFN.dropout = 0.0, 0.0, 0.0
+    if case == "eval":
+        for mod_ in m.modules():
+            if isinstance(mod_, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+                mod_.eval()
+    B, L, Tv = 2, 4096, 7
+    wav, emb = make_inputs(B, L, Tv, seed=5)
+    tgt = (0.05 * np.random.default_rng(6).standard_normal((B, 1, L))).astype(np.float32)
+    out = m(dev(wav), dev(emb))
+    loss = R.losses.PITLossWrapper(R.losses.PairwiseNegSDR("snr"), pit_from="pw_mtx")(out, dev(tgt))
+    loss.backward()
+    close(f"hip vs reference ({case}) separated waveform", host(out), gold[f"{case}/est"])
+    assert abs(float(loss) - float(gold[f"{case}/loss"])) <= 1e-5 * abs(float(gold[f"{case}/loss"]))
+    errs = {}
+    gscale = max(np.abs(gold[f"{case}/{k}"]).max() for k, _ in m.named_parameters())
+    for k, p_ in m.named_parameters():
+        g = host(p_.grad).reshape(-1).astype(np.float64)
+        ref = gold[f"{case}/{k}"]
+        if g.size > 4096:
+            rs = np.random.RandomState(zlib.crc32(k.encode()) & 0x7FFFFFFF)
+            g = g[rs.choice(g.size, 4096, replace=False).astype(np.int64)]
+        if np.abs(ref).max() > 1e-6 * gscale:
+            errs[k] = l2_rel(g, ref)
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:3]
+    print(f"[parity] hip vs reference gradients ({case}), {len(errs)} tensors: median l2-rel {np.median(list(errs.values())):.3e}, worst {worst}")
+    assert np.median(list(errs.values())) <= 5e-3
+    assert np.mean([v <= 2e-2 for v in errs.values()]) >= 0.9, worst
+
+
 DDP_WORKER = r"""
 import json, os, sys, copy
 import numpy as np, torch
