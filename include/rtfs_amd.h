@@ -162,6 +162,20 @@ int rtfs_dualpath_forward_train_f32(const float* x, const float* tpack, float* o
                                     void* ws, size_t ws_bytes, void* stream);
 int rtfs_dualpath_backward_f32(const float* x, const float* tpack, const float* saved, const float* dout, float* dx,
                                float* dparams, int B, int T, int F, int dim, void* ws, size_t ws_bytes, void* stream);
+/* The same module with rnn_type LSTM (rnn_layers.py:116-122: nn.LSTM(512, 32, 4 layers, bidirectional)) in training.
+ * tpack (rtfs_dualpath_lstm_train_pack_floats(), packing.py:pack_dualpath_lstm_train): LN gamma | beta | per layer [W_ih both directions
+ *   (256, Din), rows dir*128 + gate*32 + j, layer-0 columns in k*64 + c order | its transpose | b_ih + b_hh (256) | W_hh (2,128,32)] |
+ *   ConvTranspose1d weight as (co, (7-k)*64 + ci) | as (ci, k*64 + co) | bias.
+ * dparams (rtfs_dualpath_lstm_grad_floats(), overwritten): dgamma | dbeta | per layer [dW_ih (256, Din) | d bias (256; the gradient of
+ *   b_ih and of b_hh alike) | dW_hh (2,128,32)] | d ConvTranspose1d weight ((7-k)*64 + ci, co) | d bias. */
+size_t rtfs_dualpath_lstm_train_pack_floats(void);
+size_t rtfs_dualpath_lstm_grad_floats(void);
+size_t rtfs_dualpath_lstm_saved_floats(int B, int T, int F, int dim);
+size_t rtfs_dualpath_lstm_train_workspace_bytes(int B, int T, int F, int dim);
+int rtfs_dualpath_lstm_forward_train_f32(const float* x, const float* tpack, float* out, float* saved, int B, int T, int F, int dim,
+                                         void* ws, size_t ws_bytes, void* stream);
+int rtfs_dualpath_lstm_backward_f32(const float* x, const float* tpack, const float* saved, const float* dout, float* dx,
+                                    float* dparams, int B, int T, int F, int dim, void* ws, size_t ws_bytes, void* stream);
 /* ConvNormAct.forward / backward for training (src/models/layers/conv_layers.py:65-129: pre_norm -> pre_act -> conv -> norm -> act),
  * 1x1 dense (channels up to 1024) or depthwise k x k (taps up to 4 x 5, stride 1 "same" or stride 2 symmetric), norms: none | gLN |
  * BatchNorm (post-norm only; frozen running statistics, or train mode = statistics of the batch), acts: none | ReLU | PReLU | Sigmoid.

@@ -368,3 +368,27 @@ def vp_block_torch(v, p, depth=4, bn_train=False):
     for i in range(depth - 3, -1, -1):
         expanded = ims(xf[i], expanded, f"concat_layers.{i}") + downs[i]
     return _cna1d(expanded, _sub(p, "residual_conv")) + residual
+
+
+def dualpath_lstm_torch(x, p, dim, kernel_size=8):
+    """DualPathRNN.forward with rnn_type LSTM (reference rnn_layers.py:116-122,136-162): the cell is stock
+    torch.nn.LSTM(512, 32, 4 layers, bidirectional), so this function is the reference's own arithmetic - forward and backward."""
+    if dim == 4:
+        x = x.permute(0, 1, 3, 2)
+    B, C, nT, nF = x.shape
+    res = x
+    mu = x.mean(1, keepdim=True)
+    var = ((x - mu) ** 2).mean(1, keepdim=True)
+    xn = (x - mu) / torch.sqrt(var + 1e-5) * p["norm.gamma"].reshape(1, C, 1, 1) + p["norm.beta"].reshape(1, C, 1, 1)
+    seq = xn.permute(0, 3, 1, 2).reshape(B * nF, C, nT)
+    Lr = nT - kernel_size + 1
+    unf = torch.stack([seq[:, :, kk:kk + Lr] for kk in range(kernel_size)], 2).reshape(B * nF, C * kernel_size, Lr).permute(2, 0, 1)
+    names = [k for k in p if k.startswith("rnn.")]
+    flat = [p[f"rnn.{n}_l{l}{suf}"] for l in range(4) for suf in ("", "_reverse") for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+    assert len(flat) == len(names)
+    h = torch._VF.lstm(unf, (unf.new_zeros(8, B * nF, 32), unf.new_zeros(8, B * nF, 32)), flat, True, 4, 0.0, False, True, False)[0]
+    y = torch.nn.functional.conv_transpose1d(h.permute(1, 2, 0), p["linear.weight"], p["linear.bias"])
+    y = y.reshape(B, nF, C, nT).permute(0, 2, 3, 1) + res
+    if dim == 4:
+        y = y.permute(0, 1, 3, 2)
+    return y

@@ -1668,3 +1668,125 @@ int launch_mha_core(const float* qkv, const float* pmask, float* o, const float*
     hipLaunchKernelGGL(mha_core_kernel, dim3(B * nh), dim3(256), lds, st, qkv, pmask, o, dout, dqkv, T, nh, hd, bwd ? 1 : 0);
     return rtfs_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------------ LSTM cell, training side
+// nn.LSTM(512, 32, 4 layers, bidirectional) as DualPathRNN's other cell (rnn_layers.py:116-122); gates i, f, g, o.
+// U = x . W_ih^T + (b_ih + b_hh) for both directions comes from the GEMM as rows x 256 (column dir*128 + gate*32 + j).  One wave per
+// (sequence, direction): lane l < 32 owns gate rows i_j and g_j (j = l), lane l >= 32 rows f_j and o_j (j = l - 32), each with its
+// 2 x 32 recurrent weights in registers; h_{t-1} is broadcast through LDS.  Saved for the backward: the four activated gates G
+// (rows x 256), c, h (in the zero-padded slot layout the windows read) and h_{t-1} (rows x 64, for the W_hh gradient GEMM).
+namespace {
+__device__ __forceinline__ float tanhf_(float x) { return 2.0f * sigmoidf_(2.0f * x) - 1.0f; }
+}
+__global__ __launch_bounds__(256) void lstm_scan_fwd_kernel(LstmScanArgs a) {
+    __shared__ float hs[4][32];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, hi = lane >> 5;
+    const long id = (long)blockIdx.x * 4 + wave;
+    const bool live = id < 2L * a.N;
+    const int n = live ? (int)(id >> 1) : 0, dir = (int)(id & 1);
+    const int r0 = hi ? 32 + j : j, r1 = hi ? 96 + j : 64 + j;  // i|f and g|o rows
+    float w0[32], w1[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+        w0[k] = a.whh[((size_t)dir * 128 + r0) * 32 + k];
+        w1[k] = a.whh[((size_t)dir * 128 + r1) * 32 + k];
+    }
+    const size_t nb = (size_t)n * a.ns;
+    float c = 0.f, hprev = 0.f;
+    if (lane < 32) hs[wave][j] = 0.f;
+    __syncthreads();
+    for (int s = 0; s < a.L; ++s) {
+        const int t = dir ? a.L - 1 - s : s;
+        const size_t row = (size_t)t * a.ts + nb;
+        float z0 = 0.f, z1 = 0.f;
+        if (live) {
+            z0 = a.U[row * 256 + dir * 128 + r0];
+            z1 = a.U[row * 256 + dir * 128 + r1];
+        }
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            const float hk = hs[wave][k];
+            z0 = fmaf(w0[k], hk, z0);
+            z1 = fmaf(w1[k], hk, z1);
+        }
+        const float a0 = sigmoidf_(z0), a1 = hi ? sigmoidf_(z1) : tanhf_(z1);
+        const float fg = __shfl(a0, j + 32, 64), og = __shfl(a1, j + 32, 64);
+        __syncthreads();  // every lane has read h_{t-1}
+        if (live) {
+            a.G[row * 256 + dir * 128 + r0] = a0;
+            a.G[row * 256 + dir * 128 + r1] = a1;
+        }
+        if (lane < 32) {
+            c = fg * c + a0 * a1;
+            const float h = og * tanhf_(c);
+            if (live) {
+                a.c[row * 64 + dir * 32 + j] = c;
+                a.h[row * 64 + dir * 32 + j] = h;
+                a.hprev[row * 64 + dir * 32 + j] = hprev;
+            }
+            hprev = h;
+            hs[wave][j] = h;
+        }
+        __syncthreads();
+    }
+    if (a.pad && live && dir == 0)
+        for (int i = 1; i <= 7; ++i) a.h[((long)nb - i) * 64 + lane] = 0.f;
+}
+
+// backward: reverse walk; carried: dc and the recurrent part of dh.  Writes dU (= gradient w.r.t. the gate pre-activations).
+__global__ __launch_bounds__(256) void lstm_scan_bwd_kernel(LstmScanArgs a) {
+    __shared__ float dzs[4][128];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, hi = lane >> 5;
+    const long id = (long)blockIdx.x * 4 + wave;
+    const bool live = id < 2L * a.N;
+    const int n = live ? (int)(id >> 1) : 0, dir = (int)(id & 1);
+    // W_hh^T: lane (k = j, half hi) holds W_hh[hi*64 + r][k] for r = 0..63
+    float wt[64];
+#pragma unroll
+    for (int r = 0; r < 64; ++r) wt[r] = a.whh[((size_t)dir * 128 + hi * 64 + r) * 32 + j];
+    const size_t nb = (size_t)n * a.ns;
+    float dc = 0.f, dh_rec = 0.f;
+    for (int s = a.L - 1; s >= 0; --s) {
+        const int t = dir ? a.L - 1 - s : s;
+        const size_t row = (size_t)t * a.ts + nb;
+        if (lane < 32) {
+            float dz[4] = {0.f, 0.f, 0.f, 0.f};
+            if (live) {
+                const float* g = a.G + row * 256 + dir * 128;
+                const float ig = g[j], fg = g[32 + j], gg = g[64 + j], og = g[96 + j];
+                const float ct = a.c[row * 64 + dir * 32 + j];
+                const int tp = dir ? t + 1 : t - 1;
+                const float cp = s > 0 ? a.c[((size_t)tp * a.ts + nb) * 64 + dir * 32 + j] : 0.f;
+                const float dh = a.g[row * 64 + dir * 32 + j] + dh_rec;
+                const float tc = tanhf_(ct);
+                const float d_o = dh * tc;
+                const float dct = fmaf(dh * og, 1.f - tc * tc, dc);
+                dz[0] = dct * gg * ig * (1.f - ig);
+                dz[1] = dct * cp * fg * (1.f - fg);
+                dz[2] = dct * ig * (1.f - gg * gg);
+                dz[3] = d_o * og * (1.f - og);
+                dc = dct * fg;
+                float* d = a.dU + row * 256 + dir * 128;
+                d[j] = dz[0]; d[32 + j] = dz[1]; d[64 + j] = dz[2]; d[96 + j] = dz[3];
+            }
+            dzs[wave][j] = dz[0]; dzs[wave][32 + j] = dz[1]; dzs[wave][64 + j] = dz[2]; dzs[wave][96 + j] = dz[3];
+        }
+        __syncthreads();
+        float acc = 0.f;
+#pragma unroll
+        for (int r = 0; r < 64; ++r) acc = fmaf(wt[r], dzs[wave][hi * 64 + r], acc);
+        acc += __shfl_xor(acc, 32, 64);
+        dh_rec = acc;
+        __syncthreads();
+    }
+    if (a.pad && live && dir == 0)
+        for (int i = 0; i < 7; ++i)
+            for (int m = 0; m < 256; m += 64) a.dU[(nb + a.L + i) * 256 + m + lane] = 0.f;
+}
+
+int launch_lstm_scan(const LstmScanArgs& a, bool bwd, hipStream_t st) {
+    const long waves = 2L * a.N;
+    if (bwd) hipLaunchKernelGGL(lstm_scan_bwd_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(lstm_scan_fwd_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, a);
+    return rtfs_launch_status();
+}

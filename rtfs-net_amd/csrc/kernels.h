@@ -331,3 +331,13 @@ int launch_ln_rows(const float* x, const float* gamma, const float* beta, float*
                    size_t N, int C, bool bwd, hipStream_t st);
 int launch_mha_core(const float* qkv, const float* pmask, float* o, const float* dout, float* dqkv, int B, int T, int nh, int hd, bool bwd,
                     hipStream_t st);
+struct LstmScanArgs {
+    const float* U = nullptr;     // forward: (rows, 256) pre-activations incl. both biases, column dir*128 + gate*32 + j
+    const float* whh = nullptr;   // (2, 128, 32)
+    float *G = nullptr, *c = nullptr, *h = nullptr, *hprev = nullptr;  // forward: written; backward: G, c read
+    const float* g = nullptr;     // backward: dL/dh (rows, 64)
+    float* dU = nullptr;          // backward: (rows, 256)
+    int L = 0, N = 0, pad = 0;
+    long ts = 0, ns = 0;
+};
+int launch_lstm_scan(const LstmScanArgs& a, bool bwd, hipStream_t st);

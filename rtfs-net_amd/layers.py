@@ -495,6 +495,43 @@ class _DualPathTrainFn(torch.autograd.Function):
         return tuple(out + [dlw, dlb])
 
 
+class _DualPathLstmTrainFn(torch.autograd.Function):
+    """DualPathRNN with the LSTM cell on the training kernels.  Inputs: x, dim, gamma, beta, the 32 nn.LSTM parameters in
+    packing.lstm_param_names() order, ConvTranspose1d weight, bias."""
+
+    @staticmethod
+    def forward(ctx, x, dim, gamma, beta, *rest):
+        lib = _lib.load()
+        x = x.contiguous()
+        B, _, T, Fq = x.shape
+        names = packing.lstm_param_names()
+        lstm, lin_w, lin_b = dict(zip(names, rest[:len(names)])), rest[len(names)], rest[len(names) + 1]
+        tpack = packing.cached_train_pack("dualpath_lstm", (gamma, beta) + tuple(rest),
+                                          lambda: packing.pack_dualpath_lstm_train(gamma, beta, lstm, lin_w, lin_b))
+        out = torch.empty_like(x)
+        saved = torch.empty(lib.rtfs_dualpath_lstm_saved_floats(B, T, Fq, dim), device=x.device, dtype=torch.float32)
+        ws = _lib.workspace(lib.rtfs_dualpath_lstm_train_workspace_bytes(B, T, Fq, dim), x.device)
+        _lib.check(lib.rtfs_dualpath_lstm_forward_train_f32(_lib.ptr(x), _lib.ptr(tpack), _lib.ptr(out), _lib.ptr(saved), B, T, Fq, dim,
+                                                            _lib.ptr(ws), ws.numel(), _lib.stream_of(x)), "rtfs_dualpath_lstm_forward_train_f32")
+        ctx.save_for_backward(x, tpack, saved)
+        ctx.dim, ctx.shapes, ctx.names = dim, (gamma.shape, beta.shape), names
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        x, tpack, saved = ctx.saved_tensors
+        B, _, T, Fq = x.shape
+        dout = dout.contiguous().to(torch.float32)
+        dx = torch.empty_like(x)
+        dpar = torch.empty(lib.rtfs_dualpath_lstm_grad_floats(), device=x.device, dtype=torch.float32)
+        ws = _lib.workspace(lib.rtfs_dualpath_lstm_train_workspace_bytes(B, T, Fq, ctx.dim), x.device)
+        _lib.check(lib.rtfs_dualpath_lstm_backward_f32(_lib.ptr(x), _lib.ptr(tpack), _lib.ptr(saved), _lib.ptr(dout), _lib.ptr(dx), _lib.ptr(dpar),
+                                                       B, T, Fq, ctx.dim, _lib.ptr(ws), ws.numel(), _lib.stream_of(x)), "rtfs_dualpath_lstm_backward_f32")
+        dg, db, dl, dlw, dlb = packing.unpack_dualpath_lstm_grads(dpar)
+        return (dx, None, dg.reshape(ctx.shapes[0]), db.reshape(ctx.shapes[1])) + tuple(dl[n] for n in ctx.names) + (dlw, dlb)
+
+
 class DualPathRNN(PackedModule):
     """reference rnn_layers.py:62-162 with rnn_type SRU.  x (B,64,T,F) -> same shape."""
 
@@ -528,8 +565,9 @@ class DualPathRNN(PackedModule):
         if (T if self.dim == 3 else Fq) < self.kernel_size:
             raise ValueError(f"sweep axis shorter than kernel_size {self.kernel_size}")  # nn.Unfold raises in the reference
         if _recording(x, self):
-            if self.rnn_type != "SRU":
-                raise RuntimeError("DualPathRNN: the backward pass is built for the SRU cell only")
+            if self.rnn_type == "LSTM":
+                lstm = [getattr(self.rnn, n) for n in packing.lstm_param_names()]
+                return _DualPathLstmTrainFn.apply(x, self.dim, self.norm.gamma, self.norm.beta, *lstm, self.linear.weight, self.linear.bias)
             sru = [p for cell in self.rnn.rnn_lst for p in (cell.weight, cell.weight_c, cell.bias)]
             return _DualPathTrainFn.apply(x, self.dim, self.norm.gamma, self.norm.beta, *sru, self.linear.weight, self.linear.bias)
         out = torch.empty_like(x)

@@ -227,6 +227,50 @@ def unpack_attention_grads(flat):
     return out
 
 
+_LSTM_SUFFIX = ("", "_reverse")
+
+
+def lstm_param_names(num_layers=4):
+    """nn.LSTM's parameter names in the order the training pack / gradient buffer uses: per layer, per direction, (w_ih, w_hh, b_ih, b_hh)."""
+    return [f"{n}_l{l}{suf}" for l in range(num_layers) for suf in _LSTM_SUFFIX for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+
+
+def pack_dualpath_lstm_train(gamma, beta, lstm, lin_w, lin_b):
+    """Training-side pack of DualPathRNN with nn.LSTM(512, 32, 4 layers, bidirectional) (layout contract: include/rtfs_amd.h,
+    rtfs_dualpath_lstm_forward_train_f32).  lstm: name -> tensor with nn.LSTM's names."""
+    f32 = lambda t: t.detach().to(torch.float32)
+    parts = [gamma.reshape(64), beta.reshape(64)]
+    for l in range(4):
+        wih = torch.cat([f32(lstm[f"weight_ih_l{l}{suf}"]) for suf in _LSTM_SUFFIX])  # (256, Din), rows dir*128 + gate*32 + j
+        if l == 0:
+            wih = wih.reshape(256, 64, 8).permute(0, 2, 1).reshape(256, 512)  # Unfold feature c*8 + k -> window order k*64 + c
+        bias = torch.cat([f32(lstm[f"bias_ih_l{l}{suf}"]) + f32(lstm[f"bias_hh_l{l}{suf}"]) for suf in _LSTM_SUFFIX])
+        whh = torch.stack([f32(lstm[f"weight_hh_l{l}{suf}"]) for suf in _LSTM_SUFFIX])
+        parts += [wih.contiguous(), wih.t().contiguous(), bias, whh.contiguous()]
+    lw = f32(lin_w)
+    parts += [lw.flip(2).permute(1, 2, 0).reshape(64, 512).contiguous(), lw.permute(0, 2, 1).reshape(64, 512).contiguous(), lin_b]
+    return _cat(parts)
+
+
+def unpack_dualpath_lstm_grads(flat):
+    """rtfs_dualpath_lstm_backward_f32's gradient buffer -> (dgamma, dbeta, {lstm name: grad}, dlin_w, dlin_b)."""
+    out, o = {}, 128
+    for l in range(4):
+        din = 512 if l == 0 else 64
+        dwih = flat[o:o + 256 * din].reshape(256, din); o += 256 * din
+        if l == 0:
+            dwih = dwih.reshape(256, 8, 64).permute(0, 2, 1).reshape(256, 512)
+        db = flat[o:o + 256]; o += 256
+        dwhh = flat[o:o + 2 * 128 * 32].reshape(2, 128, 32); o += 2 * 128 * 32
+        for d, suf in enumerate(_LSTM_SUFFIX):
+            out[f"weight_ih_l{l}{suf}"] = dwih[d * 128:(d + 1) * 128]
+            out[f"weight_hh_l{l}{suf}"] = dwhh[d]
+            out[f"bias_ih_l{l}{suf}"] = db[d * 128:(d + 1) * 128]
+            out[f"bias_hh_l{l}{suf}"] = db[d * 128:(d + 1) * 128]
+    dlw = flat[o:o + 512 * 64].reshape(8, 64, 64).flip(0).permute(1, 2, 0)
+    return flat[0:64], flat[64:128], out, dlw, flat[o + 512 * 64:o + 512 * 64 + 64]
+
+
 def _dualpath_lstm_parts(sd):
     """DualPathRNN with rnn_type LSTM (nn.LSTM(512, 32, 4 layers, bidirectional)).  Columns of the input projections:
     dir*128 + gate*32 + j (gates i,f,g,o); bias = b_ih + b_hh; recurrent weights as [layer][dir][k][gate*32 + j]."""

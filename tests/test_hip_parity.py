@@ -595,6 +595,38 @@ def test_avnet_training_step_end_to_end(smooth, full):
     assert after < before
 
 
+@pytest.mark.parametrize("idx,shape,seed", [(0, (2, 64, 11, 13), 131), (1, (2, 64, 11, 13), 132), (0, (1, 64, 5, 64), 133), (1, (1, 64, 125, 9), 134)])
+def test_dualpath_lstm_training_forward_backward(idx, shape, seed):
+    """DualPathRNN with the LSTM cell inside a training step.  Its oracle is stock torch.nn.LSTM in float64, i.e. the reference's own
+    arithmetic forward AND backward (rnn_layers.py:116-122): the fully pinned training parity for the dual-path module."""
+    import json
+    import rtfs_net_amd as R
+    from oracle import grad_oracle as G
+    from tests.util import ROOT
+    spec = json.load(open(os.path.join(ROOT, "tests", "golden", "state_spec_R4_lstm.json")))
+    p = O._sub(O._sub(make_state_dict(spec, 0), "refinement_module.audio_net.blocks"), f"globalatt.{idx}")
+    dim = 4 if idx == 0 else 3
+    mod = R.layers.DualPathRNN(64, 32, dim, kernel_size=8, stride=1, rnn_type="LSTM", num_layers=4, bidirectional=True)
+    mod.load_state_dict({k: torch.from_numpy(v) for k, v in p.items()})
+    mod = mod.cuda().train()
+    x, dout = rand(shape, seed), rand(shape, seed + 100)
+    xt = dev(x).requires_grad_(True)
+    out = mod(xt)
+    out.backward(dev(dout))
+    o_ref, dx_ref, g_ref = G.module_grads(lambda a, b: G.dualpath_lstm_torch(a, b, dim), x, p, dout)
+    close("dualpath lstm train forward", host(out), o_ref)
+    close("dualpath lstm dx", host(xt.grad), dx_ref, tol=2e-4)
+    got = {k: v.grad for k, v in mod.named_parameters()}
+    assert set(got) == set(g_ref)
+    worst = 0.0
+    for k in sorted(g_ref):
+        e = rel_err(host(got[k]).reshape(g_ref[k].shape), g_ref[k])
+        worst = max(worst, e)
+        assert e <= 2e-4, (k, e)
+    print(f"[parity] dualpath lstm {len(g_ref)} parameter gradients: worst max-rel {worst:.3e}")
+    close("dualpath lstm eval vs train forward", host(mod.eval()(dev(x))), host(out))
+
+
 def test_sync_batchnorm_two_emulated_ranks():
     """SyncBatchNorm (train.py:145 sync_batchnorm=True): two ranks each hold half a batch; outputs, input gradients and running
     statistics must equal plain BatchNorm over the whole batch on one rank, and the two ranks' local parameter gradients must add up to
