@@ -194,8 +194,9 @@ def rtfs_block_torch(x, p):
     d0 = _cna(x_enc, _sub(p, "downsample_layers.0"), k=4, depthwise=True, norm=True)
     d1 = _cna(d0, _sub(p, "downsample_layers.1"), k=4, stride=2, depthwise=True, norm=True)
     g = F.adaptive_avg_pool2d(d0, d1.shape[-2:]) + d1
-    g = dualpath_rnn_torch(g, _sub(p, "globalatt.0"), 4)
-    g = dualpath_rnn_torch(g, _sub(p, "globalatt.1"), 3)
+    dp = dualpath_lstm_torch if "globalatt.0.rnn.weight_ih_l0" in p else dualpath_rnn_torch  # yaml rnn_type LSTM / SRU
+    g = dp(g, _sub(p, "globalatt.0"), 4)
+    g = dp(g, _sub(p, "globalatt.1"), 3)
     g = mhsa2d_torch(g, _sub(p, "globalatt.2"))
     xf0 = injection_multi_sum_torch(d0, g, _sub(p, "fusion_layers.0"))
     xf1 = injection_multi_sum_torch(d1, g, _sub(p, "fusion_layers.1"))

@@ -372,18 +372,23 @@ def test_pool_and_tfar_combine_adjoints():
             close(f"tfar combine {nm}", host(t.grad), r.grad.numpy(), tol=2e-6)
 
 
-@pytest.mark.parametrize("shape,seed,with_res", [((1, 256, 17, 129), 51, False), ((2, 256, 21, 129), 52, True)])
-def test_block_training_forward_backward(shape, seed, with_res):
+@pytest.mark.parametrize("shape,seed,with_res,cell", [((1, 256, 17, 129), 51, False, "SRU"), ((2, 256, 21, 129), 52, True, "SRU"),
+                                                      ((1, 256, 17, 129), 53, True, "LSTM")])
+def test_block_training_forward_backward(shape, seed, with_res, cell):
     """The whole RTFS block inside a training step (gateway, projection, 2-level pyramid, pooling, both sweeps, TF attention,
     three TFAR fusions, residual convolution; 139 parameter tensors) against the autograd oracle.  Tolerances are loose by design:
     PReLU's derivative jumps at 0 and a handful of the ~10^5 pre-activations land within fp32 rounding of 0, which moves single
     gradient elements by O(1) of their size (the per-module tests pin the kernels to ~1e-5 with the kinks taken out)."""
     import rtfs_net_amd as R
     from oracle import grad_oracle as G
-    p = {k: v.copy() for k, v in BLK.items()}
-    blk = model().refinement_module.audio_net.get_block(0)
     import copy
-    blk = copy.deepcopy(blk).train()
+    if cell == "LSTM":  # the block with rnn_type LSTM in both sweeps (legacy yamls): stock nn.LSTM, fully reference arithmetic
+        lm, lsd = lstm_model()
+        p = {k: v.copy() for k, v in O._sub(lsd, "refinement_module.audio_net.blocks").items()}
+        blk = copy.deepcopy(lm.refinement_module.audio_net.get_block(0)).train()
+    else:
+        p = {k: v.copy() for k, v in BLK.items()}
+        blk = copy.deepcopy(model().refinement_module.audio_net.get_block(0)).train()
     x = rand(shape, seed)
     res = rand(shape, seed + 1) if with_res else None
     dout = rand(shape, seed + 100)
