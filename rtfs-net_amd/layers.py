@@ -165,8 +165,9 @@ class _CNATrainFn(torch.autograd.Function):
         world = _bn_world() if (len(cfg) > 11 and cfg[11] and cfg[7] == 3) else 1
         carr = _CNATrainFn._carr(cfg, 0, world)
         params, running = params[:8], params[8:]  # optional: BatchNorm running mean / var (+ momentum in train mode)
-        pk = packing.cached_train_pack(("cna", tuple(cfg[:11])), tuple(params) + ((None,) if cfg[7] else ()),
-                                       lambda: packing.pack_cna_train(cfg, *params, *running[:2])) if cfg[7] < 2 else packing.pack_cna_train(cfg, *params, *running[:2])
+        build = lambda: packing.pack_cna_train(cfg, *params, *running[:2])
+        # BatchNorm's running statistics are buffers that change without a version bump the cache could see: pack those afresh
+        pk = packing.cached_train_pack(("cna", tuple(cfg[:11])), tuple(params), build) if cfg[7] < 2 else build()
         ho, wo = ctypes.c_int(), ctypes.c_int()
         lib.rtfs_cna_out_shape(carr, H, W, ctypes.byref(ho), ctypes.byref(wo))
         out = torch.empty((B, cfg[1], ho.value, wo.value) if x.dim() == 4 else (B, cfg[1], wo.value), device=x.device, dtype=torch.float32)
