@@ -147,7 +147,8 @@ int rtfs_sru_forward_train_f32(const float* x, const float* tpack, float* h, flo
 int rtfs_sru_backward_f32(const float* x, const float* tpack, const float* saved, const float* dh, float* dx, float* dparams,
                           int L, int N, void* ws, size_t ws_bytes, void* stream);
 /* DualPathRNN.forward / backward for training (src/models/layers/rnn_layers.py:136-162 with rnn_type SRU).
- * x, out, dout, dx (B,64,T,F); dim as in the reference (4: sweep along F, 3: along T).  `saved` (rtfs_dualpath_saved_floats)
+ * x, out, dout, dx (B,64,T,F); dim as in the reference (4: sweep along F, 3: along T); dim 14 / 13: the same sweeps with x, out, dout, dx
+ * as rows (B,T,F,64) (the layout the training kernels of a block hand each other; size queries take the plain 4 / 3).  `saved` (rtfs_dualpath_saved_floats)
  * is written by the forward and read by the backward; the same workspace size serves both.
  * tpack (rtfs_dualpath_train_pack_floats(), packing.py:pack_dualpath_train):
  *   LN gamma (64) | LN beta (64) | SRU training pack with layer-0 rows in k*64 + c order | ConvTranspose1d weight as
@@ -179,8 +180,11 @@ int rtfs_dualpath_lstm_backward_f32(const float* x, const float* tpack, const fl
 /* ConvNormAct.forward / backward for training (src/models/layers/conv_layers.py:65-129: pre_norm -> pre_act -> conv -> norm -> act),
  * 1x1 dense (channels up to 1024) or depthwise k x k (taps up to 4 x 5, stride 1 "same" or stride 2 symmetric), norms: none | gLN |
  * BatchNorm (post-norm only; frozen running statistics, or train mode = statistics of the batch), acts: none | ReLU | PReLU | Sigmoid.
- * cfg (HOST int[13]): Cin, Cout, k, stride, depthwise, pre_norm (0/1), pre_act (0 none, 1 ReLU, 2 PReLU, 3 Sigmoid), norm (0 none, 1 gLN,
- *   2 frozen BatchNorm, 3 train-mode BatchNorm), act, has_bias, is2d, phase, world.
+ * cfg (HOST int[15]): Cin, Cout, k, stride, depthwise, pre_norm (0/1), pre_act (0 none, 1 ReLU, 2 PReLU, 3 Sigmoid), norm (0 none, 1 gLN,
+ *   2 frozen BatchNorm, 3 train-mode BatchNorm), act, has_bias, is2d, phase, world, in_rows, out_rows.
+ *   in_rows / out_rows: the input / output (and their gradients) are (B, H, W, C) rows instead of (B, C, H, W): modules chained inside a
+ *   training step hand rows to each other and skip the layout changes; a rows input is not copied into `saved`, the backward takes it
+ *   again as `x` (NULL otherwise).
  *   phase / world serve SyncBatchNorm (norm 3 only): phase 1 runs the forward up to the batch statistics (rtfs_cna_saved_stats_offset:
  *   2*Cout doubles inside `saved`, which the caller all-reduces), phase 2 resumes with the normalisation over rows * world samples; the
  *   backward likewise stops after the dgamma / dbeta sums (rtfs_cna_grad_norm_offsets) and resumes with the input gradient; phase 0 =
@@ -197,8 +201,8 @@ size_t rtfs_cna_saved_stats_offset(const int* cfg, int B, int H, int W);
 void rtfs_cna_grad_norm_offsets(const int* cfg, size_t* dgamma, size_t* dbeta);
 int rtfs_cna_forward_train_f32(const float* x, const float* params, float* out, float* saved, const int* cfg, int B, int H, int W,
                                void* ws, size_t ws_bytes, void* stream);
-int rtfs_cna_backward_f32(const float* params, const float* saved, const float* dout, float* dx, float* dparams, const int* cfg,
-                          int B, int H, int W, void* ws, size_t ws_bytes, void* stream);
+int rtfs_cna_backward_f32(const float* x, const float* params, const float* saved, const float* dout, float* dx, float* dparams,
+                          const int* cfg, int B, int H, int W, void* ws, size_t ws_bytes, void* stream);
 /* after a forward with norm = 3: nn.BatchNorm's running_mean / running_var update (momentum, unbiased variance) from the batch
  * statistics kept in `saved`; the two pointers are the module's buffers on the device. */
 int rtfs_cna_bn_update_f32(const float* saved, const int* cfg, int B, int H, int W, float* running_mean, float* running_var,
@@ -213,20 +217,27 @@ size_t rtfs_tf_attention_train_pack_floats(void);
 size_t rtfs_tf_attention_grad_floats(void);
 size_t rtfs_tf_attention_saved_floats(int B, int T);
 size_t rtfs_tf_attention_train_workspace_bytes(int B, int T);
-int rtfs_tf_attention_forward_train_f32(const float* x, const float* tpack, float* out, float* saved, int B, int T, void* ws,
+/* rows != 0: x, out, dout, dx are rows (B, T, 64 f, 64 c) instead of (B, 64, T, 64); a rows input is read in place and handed to the
+ * backward again as `x` (NULL otherwise). */
+int rtfs_tf_attention_forward_train_f32(const float* x, const float* tpack, float* out, float* saved, int B, int T, int rows, void* ws,
                                         size_t ws_bytes, void* stream);
-int rtfs_tf_attention_backward_f32(const float* tpack, const float* saved, const float* dout, float* dx, float* dparams, int B, int T,
-                                   void* ws, size_t ws_bytes, void* stream);
-/* Glue of the RTFS block with its adjoints (training side).  Planes are (N = B*C, H, W) contiguous.
+int rtfs_tf_attention_backward_f32(const float* x, const float* tpack, const float* saved, const float* dout, float* dx, float* dparams,
+                                   int B, int T, int rows, void* ws, size_t ws_bytes, void* stream);
+/* Layout change between the reference's (B, C, P) and the rows (B, P, C) the training kernels hand each other (to_rows != 0: the
+ * former to the latter); each direction is the other's adjoint. */
+int rtfs_layout_f32(const float* x, float* y, int B, int C, int P, int to_rows, void* stream);
+
+/* Glue of the RTFS block with its adjoints (training side).  inner = 1: channel-first planes (N = B*C, H, W); inner = C > 1: rows
+ * (N = B, H, W, C), channels fastest (what the training kernels hand each other inside a block).
  * F.adaptive_avg_pool2d as called at separators/tdanet.py:116 and its adjoint;
  * the last line of InjectionMultiSum.forward (layers/fusion.py:54-69): out = local * up(gate) + up(glob), up = nearest
- * interpolation (Hg, Wg) -> (H, W) (identity when equal), and its adjoint (dlocal (N,H,W); dgate, dglob (N,Hg,Wg)). */
-int rtfs_adaptive_avg_pool2d_f32(const float* x, float* y, int N, int H, int W, int Ho, int Wo, void* stream);
-int rtfs_adaptive_avg_pool2d_backward_f32(const float* dy, float* dx, int N, int H, int W, int Ho, int Wo, void* stream);
+ * interpolation (Hg, Wg) -> (H, W) (identity when equal), and its adjoint (dlocal like local; dgate, dglob like gate). */
+int rtfs_adaptive_avg_pool2d_f32(const float* x, float* y, int N, int H, int W, int Ho, int Wo, int inner, void* stream);
+int rtfs_adaptive_avg_pool2d_backward_f32(const float* dy, float* dx, int N, int H, int W, int Ho, int Wo, int inner, void* stream);
 int rtfs_tfar_combine_f32(const float* local, const float* gate, const float* glob, float* out, int N, int H, int W, int Hg, int Wg,
-                          void* stream);
+                          int inner, void* stream);
 int rtfs_tfar_combine_backward_f32(const float* dout, const float* local, const float* gate, float* dlocal, float* dgate, float* dglob,
-                                   int N, int H, int W, int Hg, int Wg, void* stream);
+                                   int N, int H, int W, int Hg, int Wg, int inner, void* stream);
 /* Training side of STFTEncoder / STFTDecoder / the S^3 multiply.
  * Encoder (encoder.py:161-175): the waveform is data, so only the Conv2d(2->256, 3x3) weight has a gradient: dw (256,2,3,3) from
  *   wav (B,L) and da0 (B,256,T,129).
@@ -240,6 +251,7 @@ size_t rtfs_istft_decoder_backward_workspace_bytes(int B, int T);
 int rtfs_istft_decoder_backward_f32(const float* x, const float* w, const float* dwav, float* dx, float* dw, int B, int T, int L, void* ws,
                                     size_t ws_bytes, void* stream);
 int rtfs_s3_cmul_f32(const float* a, const float* b, float* out, int B, int P, int conj_first, void* stream);
+
 /* Glue of ATTNFusionCell.forward (layers/fusion.py:252-274) with its adjoints (training side).
  * attention: att_embed (B, 4C, Tv) -> reshape (B, C, 4, Tv) -> mean over the 4 -> softmax over Tv -> att (B, C, Tv).
  * combine: fused = key * up(resized) + up(att) * value with key/value/fused (N = B*C, T, F), resized/att (N, Tv), up = nearest

@@ -74,17 +74,18 @@ SIGNATURES = {
     "rtfs_cna_out_shape": (None, [_p, _i, _i, _p, _p]),
     "rtfs_cna_forward_train_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p, _z, _p]),
     "rtfs_cna_bn_update_f32": (_i, [_p, _p, _i, _i, _i, _p, _p, C.c_float, _p]),
-    "rtfs_cna_backward_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _z, _p]),
+    "rtfs_cna_backward_f32": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _z, _p]),
     "rtfs_tf_attention_train_pack_floats": (_z, []),
     "rtfs_tf_attention_grad_floats": (_z, []),
     "rtfs_tf_attention_saved_floats": (_z, [_i, _i]),
     "rtfs_tf_attention_train_workspace_bytes": (_z, [_i, _i]),
-    "rtfs_tf_attention_forward_train_f32": (_i, [_p, _p, _p, _p, _i, _i, _p, _z, _p]),
-    "rtfs_tf_attention_backward_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _p, _z, _p]),
-    "rtfs_adaptive_avg_pool2d_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
-    "rtfs_adaptive_avg_pool2d_backward_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
-    "rtfs_tfar_combine_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
-    "rtfs_tfar_combine_backward_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "rtfs_tf_attention_forward_train_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _z, _p]),
+    "rtfs_tf_attention_backward_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _z, _p]),
+    "rtfs_layout_f32": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "rtfs_adaptive_avg_pool2d_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "rtfs_adaptive_avg_pool2d_backward_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "rtfs_tfar_combine_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "rtfs_tfar_combine_backward_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "rtfs_stft_encoder_backward_workspace_bytes": (_z, [_i, _i]),
     "rtfs_stft_encoder_backward_f32": (_i, [_p, _p, _p, _i, _i, _p, _z, _p]),
     "rtfs_istft_decoder_backward_workspace_bytes": (_z, [_i, _i]),

@@ -120,8 +120,12 @@ size_t rtfs_dualpath_train_workspace_bytes(int B, int T, int F, int dim) {
     return (fwd > bwd ? fwd : bwd) * sizeof(float) + 16 * 256;
 }
 
+// dim 3 / 4: x, out (B,64,T,F) as in the reference; dim 13 / 14: the same sweeps on rows (B,T,F,64) (what the training kernels of a block
+// hand each other): the F-sweep's slots then ARE the rows, the T-sweep goes through a row permutation instead of two tiled transposes.
 int rtfs_dualpath_forward_train_f32(const float* x, const float* tpack, float* out, float* saved, int B, int T, int F, int dim, void* ws,
                                     size_t ws_bytes, void* stream) {
+    const bool rows = dim >= 10;
+    dim = rows ? dim - 10 : dim;
     RTFS_RETURN_IF(!x || !tpack || !out || !saved || B < 1 || (dim != 3 && dim != 4), RTFS_ERR_ARG);
     DpGeom g(B, T, F, dim);
     RTFS_RETURN_IF(!g.ok(), RTFS_ERR_SHAPE);
@@ -135,14 +139,16 @@ int rtfs_dualpath_forward_train_f32(const float* x, const float* tpack, float* o
     const int M = (int)g.rows;
     const float* src = x;
     if (dim == 3) {
-        CHECK(launch_transpose(x, xt, B * CH, T, F, st));
+        if (rows) CHECK(launch_rows_permute(x, xt, B, T, F, CH, st));
+        else CHECK(launch_transpose(x, xt, B * CH, T, F, st));
         src = xt;
     }
     // rows past the last slot are read by the last windows: keep them zero
     if (hipMemsetAsync(sv.xn + g.rows * 64, 0, 8 * 64 * sizeof(float), st) != hipSuccess) return RTFS_ERR_LAUNCH;
     for (int l = 0; l < 4; ++l)
         if (hipMemsetAsync(sv.hpad[l] + g.rows * 64, 0, 8 * 64 * sizeof(float), st) != hipSuccess) return RTFS_ERR_LAUNCH;
-    CHECK(launch_dp_ln_fwd(src, tpack + DT_G, tpack + DT_B, sv.xn, g.nseq, g.R, g.Ls, st));
+    if (rows) CHECK(launch_ln_rows(src, tpack + DT_G, tpack + DT_B, sv.xn, nullptr, nullptr, nullptr, nullptr, g.rows, CH, false, st));
+    else CHECK(launch_dp_ln_fwd(src, tpack + DT_G, tpack + DT_B, sv.xn, g.nseq, g.R, g.Ls, st));
     const float* sp = tpack + DT_SRU;
     for (int l = 0; l < 4; ++l) {
         const float* xin = l == 0 ? sv.xn : sv.hpad[l - 1] + 7 * 64;
@@ -156,6 +162,11 @@ int rtfs_dualpath_forward_train_f32(const float* x, const float* tpack, float* o
     }
     // ConvTranspose1d as a GEMM over the 8-row windows of the zero-padded hidden sequence (rnn_layers.py:129,153)
     CHECK(launch_gemm_nt(sv.hpad[3], 64, tpack + DT_WCF, 512, y, 64, M, 64, 512, 0, st));
+    if (rows) {
+        CHECK(launch_rows_bias_res(y, tpack + DT_BT, src, dim == 4 ? out : ot, g.rows * 64, CH, st));
+        if (dim == 3) CHECK(launch_rows_permute(ot, out, B, F, T, CH, st));
+        return RTFS_OK;
+    }
     CHECK(launch_dp_out(y, tpack + DT_BT, src, dim == 4 ? out : ot, g.nseq, g.R, g.Ls, st));
     if (dim == 3) CHECK(launch_transpose(ot, out, B * CH, F, T, st));
     return RTFS_OK;
@@ -163,6 +174,8 @@ int rtfs_dualpath_forward_train_f32(const float* x, const float* tpack, float* o
 
 int rtfs_dualpath_backward_f32(const float* x, const float* tpack, const float* saved, const float* dout, float* dx, float* dparams, int B,
                                int T, int F, int dim, void* ws, size_t ws_bytes, void* stream) {
+    const bool rows = dim >= 10;
+    dim = rows ? dim - 10 : dim;
     RTFS_RETURN_IF(!x || !tpack || !saved || !dout || !dx || !dparams || B < 1 || (dim != 3 && dim != 4), RTFS_ERR_ARG);
     DpGeom g(B, T, F, dim);
     RTFS_RETURN_IF(!g.ok(), RTFS_ERR_SHAPE);
@@ -181,15 +194,25 @@ int rtfs_dualpath_backward_f32(const float* x, const float* tpack, const float* 
     const int M = (int)g.rows;
     const float *srcx = x, *srcd = dout;
     if (dim == 3) {
-        CHECK(launch_transpose(x, xt, B * CH, T, F, st));
-        CHECK(launch_transpose(dout, dt, B * CH, T, F, st));
+        if (rows) {
+            CHECK(launch_rows_permute(x, xt, B, T, F, CH, st));
+            CHECK(launch_rows_permute(dout, dt, B, T, F, CH, st));
+        } else {
+            CHECK(launch_transpose(x, xt, B * CH, T, F, st));
+            CHECK(launch_transpose(dout, dt, B * CH, T, F, st));
+        }
         srcx = xt;
         srcd = dt;
     }
     if (hipMemsetAsync(dparams, 0, DG_END * sizeof(float), st) != hipSuccess) return RTFS_ERR_LAUNCH;
     if (hipMemsetAsync(dy + g.rows * 64, 0, 8 * 64 * sizeof(float), st) != hipSuccess) return RTFS_ERR_LAUNCH;
     if (hipMemsetAsync(dxn, 0, (g.rows + 8) * 64 * sizeof(float), st) != hipSuccess) return RTFS_ERR_LAUNCH;
-    CHECK(launch_dp_dy(srcd, dy, dparams + DG_BT, g.nseq, g.R, g.Ls, st));
+    if (rows) {  // the gradient already is rows: copy it next to its zero tail (the windows read 7 rows past the end), bias gradient = column sums
+        if (hipMemcpyAsync(dy, srcd, g.rows * 64 * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) return RTFS_ERR_LAUNCH;
+        CHECK(launch_cl_colsum(srcd, dparams + DG_BT, g.rows * 64, 64, st));
+    } else {
+        CHECK(launch_dp_dy(srcd, dy, dparams + DG_BT, g.nseq, g.R, g.Ls, st));
+    }
     // ConvTranspose1d: weight gradient = (windows of h)^T . dy, input gradient = windows of dy . W
     CHECK(launch_gemm_tn(sv.hpad[3], 64, dy, 64, dparams + DG_WCT, 64, 512, 64, (long)M, st));
     CHECK(launch_gemm_nt(dy, 64, tpack + DT_WCB, 512, gbuf[0], 64, M, 64, 512, 0, st));
@@ -211,6 +234,11 @@ int rtfs_dualpath_backward_f32(const float* x, const float* tpack, const float* 
         else CHECK(launch_gemm_nt(dU, KC, Wp, KC, gnext, 64, M, 64, KC, 1, st));
         CHECK(launch_gemm_tn(xin, 64, dU, KC, dWp, KC, K, KC, (long)M, st));
         gcur = gnext;
+    }
+    if (rows) {
+        CHECK(launch_ln_rows(srcx, tpack + DT_G, nullptr, nullptr, dxn, dim == 4 ? dx : dxt, dparams + DG_G, dparams + DG_B, g.rows, CH, true, st, srcd));
+        if (dim == 3) CHECK(launch_rows_permute(dxt, dx, B, F, T, CH, st));
+        return RTFS_OK;
     }
     CHECK(launch_dp_ln_bwd(srcx, dxn, srcd, tpack + DT_G, dim == 4 ? dx : dxt, dparams + DG_G, dparams + DG_B, g.nseq, g.R, g.Ls, st));
     if (dim == 3) CHECK(launch_transpose(dxt, dx, B * CH, F, T, st));
@@ -373,7 +401,7 @@ int rtfs_dualpath_lstm_backward_f32(const float* x, const float* tpack, const fl
 // ------------------------------------------------------------ ConvNormAct, training side (channel-last rows inside)
 namespace {
 struct CnaCfg {
-    int Cin, Cout, k, stride, depthwise, pre_norm, pre_act, norm, act, has_bias, is2d, phase, world;
+    int Cin, Cout, k, stride, depthwise, pre_norm, pre_act, norm, act, has_bias, is2d, phase, world, in_rows, out_rows;
     int kh, kw, pt, pl, H, W, Ho, Wo, B;
     size_t rows_in, rows_out;
     // parameter / gradient layout (floats)
@@ -382,7 +410,7 @@ struct CnaCfg {
     bool ok;
     CnaCfg(const int* c, int B_, int H_, int W_) {
         Cin = c[0]; Cout = c[1]; k = c[2]; stride = c[3]; depthwise = c[4]; pre_norm = c[5]; pre_act = c[6]; norm = c[7]; act = c[8];
-        has_bias = c[9]; is2d = c[10]; phase = c[11]; world = c[12] < 1 ? 1 : c[12];
+        has_bias = c[9]; is2d = c[10]; phase = c[11]; world = c[12] < 1 ? 1 : c[12]; in_rows = c[13]; out_rows = c[14];
         B = B_; H = H_; W = W_;
         kh = is2d ? k : 1;
         kw = k;
@@ -471,20 +499,22 @@ int rtfs_cna_forward_train_f32(const float* x, const float* params, float* out, 
     const size_t n_in = (size_t)H * W * c.Cin, n_out = (size_t)c.Ho * c.Wo * c.Cout;
     // phase 1 stops once the BatchNorm batch statistics are in `saved`; phase 2 resumes there (the caller all-reduced them in between)
     if (c.phase != 2) {
-    CHECK(launch_transpose(x, sv.r0, B, c.Cin, H * W, st));  // (B, C, P) -> (B, P, C)
-    const float* conv_in = sv.r0;
+    // in_rows: x already is (B, P, C) rows (the producer was another training kernel); it is then read in place, forward and backward
+    const float* r0 = c.in_rows ? x : sv.r0;
+    if (!c.in_rows) CHECK(launch_transpose(x, sv.r0, B, c.Cin, H * W, st));  // (B, C, P) -> (B, P, C)
+    const float* conv_in = r0;
     if (c.pre()) {
         ClStageArgs a;
-        a.x = sv.r0; a.y = sv.r2; a.n = n_in; a.C = c.Cin; a.norm = c.pre_norm; a.act = c.pre_act;
+        a.x = r0; a.y = sv.r2; a.n = n_in; a.C = c.Cin; a.norm = c.pre_norm; a.act = c.pre_act;
         a.gamma = params + c.o_pg; a.beta = params + c.o_pb; a.slope = params + c.o_ps; a.stats = sv.st0;
         if (c.pre_norm) {
             if (hipMemsetAsync(sv.st0, 0, sizeof(double) * 2 * B, st) != hipSuccess) return RTFS_ERR_LAUNCH;
-            CHECK(launch_stats(sv.r0, sv.st0, B, n_in, st));
+            CHECK(launch_stats(r0, sv.st0, B, n_in, st));
         }
         CHECK(launch_cl_norm_act_fwd(a, B, st));
         conv_in = sv.r2;
     }
-    float* conv_out = c.post() ? sv.r3 : r5;
+    float* conv_out = c.post() ? sv.r3 : (c.out_rows ? out : r5);
     if (c.depthwise) {
         ClDwArgs d;
         d.x = conv_in; d.w = params + c.o_w; d.bias = c.has_bias ? params + c.o_b : nullptr; d.y = conv_out;
@@ -502,7 +532,7 @@ int rtfs_cna_forward_train_f32(const float* x, const float* params, float* out, 
     if (c.phase == 1) return RTFS_OK;
     if (c.post()) {
         ClStageArgs a;
-        a.x = sv.r3; a.y = r5; a.n = n_out; a.C = c.Cout; a.norm = c.norm; a.act = c.act;
+        a.x = sv.r3; a.y = c.out_rows ? out : r5; a.n = n_out; a.C = c.Cout; a.norm = c.norm; a.act = c.act;
         a.gamma = params + c.o_g; a.beta = params + c.o_be; a.slope = params + c.o_s; a.stats = sv.st3;
         a.rmean = params + c.o_rm; a.rvar = params + c.o_rv; a.cstats = sv.cst; a.inv_rows = 1.0 / ((double)c.rows_out * c.world);
         if (c.norm == 1) {
@@ -511,6 +541,7 @@ int rtfs_cna_forward_train_f32(const float* x, const float* params, float* out, 
         }
         CHECK(launch_cl_norm_act_fwd(a, B, st));
     }
+    if (c.out_rows) return RTFS_OK;
     return launch_transpose(r5, out, B, c.Ho * c.Wo, c.Cout, st);  // (B, P, C) -> (B, C, P)
 }
 
@@ -525,11 +556,12 @@ int rtfs_cna_bn_update_f32(const float* saved, const int* cfg, int B, int H, int
     return launch_bn_update(sv.cst, running_mean, running_var, c.Cout, (double)c.rows_out * c.world, momentum, S(stream));
 }
 
-int rtfs_cna_backward_f32(const float* params, const float* saved, const float* dout, float* dx, float* dparams, const int* cfg, int B,
-                          int H, int W, void* ws, size_t ws_bytes, void* stream) {
+int rtfs_cna_backward_f32(const float* x, const float* params, const float* saved, const float* dout, float* dx, float* dparams,
+                          const int* cfg, int B, int H, int W, void* ws, size_t ws_bytes, void* stream) {
     RTFS_RETURN_IF(!params || !saved || !dout || !dx || !dparams || !cfg || B < 1, RTFS_ERR_ARG);
     CnaCfg c(cfg, B, H, W);
     RTFS_RETURN_IF(!c.ok, RTFS_ERR_SHAPE);
+    RTFS_RETURN_IF(c.in_rows && !x, RTFS_ERR_ARG);  // rows input is not copied into `saved`: the caller hands it back
     RTFS_RETURN_IF(!ws || ws_bytes < rtfs_cna_workspace_bytes(cfg, B, H, W), RTFS_ERR_WORKSPACE);
     CnaSaved sv((float*)align_up((size_t)saved, 16), c);
     Arena ar(ws, ws_bytes);
@@ -544,9 +576,11 @@ int rtfs_cna_backward_f32(const float* params, const float* saved, const float* 
     const size_t n_in = (size_t)H * W * c.Cin, n_out = (size_t)c.Ho * c.Wo * c.Cout;
     // phase 1 (SyncBatchNorm): stop after the post-stage's reduction (dgamma / dbeta in dparams); phase 2: resume with the apply pass.
     // The workspace must be the same buffer in both calls (d5 lives there).
+    const float* r0 = c.in_rows ? x : sv.r0;
+    if (c.out_rows) d5 = const_cast<float*>(dout);  // gradient arrives as rows
     if (c.phase != 2) {
         if (hipMemsetAsync(dparams, 0, c.g_end * sizeof(float), st) != hipSuccess) return RTFS_ERR_LAUNCH;
-        CHECK(launch_transpose(dout, d5, B, c.Cout, c.Ho * c.Wo, st));
+        if (!c.out_rows) CHECK(launch_transpose(dout, d5, B, c.Cout, c.Ho * c.Wo, st));
     }
     const float* d3 = d5;
     if (c.post()) {
@@ -559,7 +593,8 @@ int rtfs_cna_backward_f32(const float* params, const float* saved, const float* 
         if (c.phase == 1) return RTFS_OK;
         d3 = d3b;
     }
-    const float* conv_in = c.pre() ? sv.r2 : sv.r0;
+    const float* conv_in = c.pre() ? sv.r2 : r0;
+    if (!c.pre() && c.in_rows) d2 = dx;  // the convolution's input gradient is the module's
     if (c.has_bias) CHECK(launch_cl_colsum(d3, dparams + c.g_b, c.rows_out * c.Cout, c.Cout, st));
     if (c.depthwise) {
         ClDwArgs d;
@@ -574,12 +609,14 @@ int rtfs_cna_backward_f32(const float* params, const float* saved, const float* 
     const float* dfirst = d2;
     if (c.pre()) {
         ClStageArgs a;
-        a.x = sv.r0; a.dy = d2; a.dx = d0; a.n = n_in; a.C = c.Cin; a.norm = c.pre_norm; a.act = c.pre_act;
+        if (c.in_rows) d0 = dx;
+        a.x = r0; a.dy = d2; a.dx = d0; a.n = n_in; a.C = c.Cin; a.norm = c.pre_norm; a.act = c.pre_act;
         a.gamma = params + c.o_pg; a.beta = params + c.o_pb; a.slope = params + c.o_ps; a.stats = sv.st0; a.S = Sb;
         a.dgamma = dparams + c.g_pg; a.dbeta = dparams + c.g_pb; a.dslope = dparams + c.g_ps;
         CHECK(launch_cl_norm_act_bwd(a, B, st));
         dfirst = d0;
     }
+    if (c.in_rows) return RTFS_OK;
     return launch_transpose(dfirst, dx, B, H * W, c.Cin, st);
 }
 
@@ -643,7 +680,9 @@ size_t rtfs_tf_attention_train_workspace_bytes(int B, int T) {
     return (g.R * (64 + 64 + 64 + 128 + 128) + 2 * g.v + g.sc + 3 * g.qk) * sizeof(float) + 16 * 256;
 }
 
-int rtfs_tf_attention_forward_train_f32(const float* x, const float* tpack, float* out, float* saved, int B, int T, void* ws,
+// rows != 0: x / out (and their gradients) are rows (B, T, 64 f, 64 c) instead of (B, 64, T, 64); the rows input is then used in place
+// and handed to the backward again as `x`.
+int rtfs_tf_attention_forward_train_f32(const float* x, const float* tpack, float* out, float* saved, int B, int T, int rows, void* ws,
                                         size_t ws_bytes, void* stream) {
     RTFS_RETURN_IF(!x || !tpack || !out || !saved || B < 1 || T < 1, RTFS_ERR_ARG);
     RTFS_RETURN_IF(T > 256 || (size_t)B * T * 64 * 128 >= 0x7fffffffu, RTFS_ERR_SHAPE);
@@ -657,8 +696,9 @@ int rtfs_tf_attention_forward_train_f32(const float* x, const float* tpack, floa
     float* rout = ar.take<float>(g.R * 64);
     hipStream_t st = S(stream);
     const int R = (int)g.R;
-    CHECK(launch_transpose(x, sv.r0, B, 64, T * 64, st));
-    CHECK(launch_gemm_nt(sv.r0, 64, tpack + AT_W, 64, sv.Z, 128, R, 128, 64, 0, st, tpack + AT_B));
+    const float* r0 = rows ? x : sv.r0;
+    if (!rows) CHECK(launch_transpose(x, sv.r0, B, 64, T * 64, st));
+    CHECK(launch_gemm_nt(r0, 64, tpack + AT_W, 64, sv.Z, 128, R, 128, 64, 0, st, tpack + AT_B));
     LngArgs a;
     att_groups(a, true);
     a.Z = sv.Z; a.Y = Y; a.stats = sv.st; a.slope = tpack + AT_SL; a.gamma = tpack + AT_G; a.beta = tpack + AT_BE;
@@ -676,14 +716,15 @@ int rtfs_tf_attention_forward_train_f32(const float* x, const float* tpack, floa
     CHECK(launch_gemm_nt(sv.ratt, 64, tpack + AT_WP, 64, sv.Z2, 64, R, 64, 64, 0, st, tpack + AT_BP));
     LngArgs b;
     att_groups(b, false);
-    b.Z = sv.Z2; b.Y = rout; b.res = sv.r0; b.stats = sv.st2; b.slope = tpack + AT_SLP; b.gamma = tpack + AT_GP; b.beta = tpack + AT_BEP;
+    b.Z = sv.Z2; b.Y = rows ? out : rout; b.res = r0; b.stats = sv.st2; b.slope = tpack + AT_SLP; b.gamma = tpack + AT_GP; b.beta = tpack + AT_BEP;
     CHECK(launch_att_lng(b, B * T, false, st));
+    if (rows) return RTFS_OK;
     return launch_transpose(rout, out, B, T * 64, 64, st);
 }
 
-int rtfs_tf_attention_backward_f32(const float* tpack, const float* saved, const float* dout, float* dx, float* dparams, int B, int T,
-                                   void* ws, size_t ws_bytes, void* stream) {
-    RTFS_RETURN_IF(!tpack || !saved || !dout || !dx || !dparams || B < 1 || T < 1, RTFS_ERR_ARG);
+int rtfs_tf_attention_backward_f32(const float* x, const float* tpack, const float* saved, const float* dout, float* dx, float* dparams, int B,
+                                   int T, int rows, void* ws, size_t ws_bytes, void* stream) {
+    RTFS_RETURN_IF(!tpack || !saved || !dout || !dx || !dparams || B < 1 || T < 1 || (rows && !x), RTFS_ERR_ARG);
     RTFS_RETURN_IF(T > 256 || (size_t)B * T * 64 * 128 >= 0x7fffffffu, RTFS_ERR_SHAPE);
     RTFS_RETURN_IF(!ws || ws_bytes < rtfs_tf_attention_train_workspace_bytes(B, T), RTFS_ERR_WORKSPACE);
     AttGeom g(B, T);
@@ -705,7 +746,12 @@ int rtfs_tf_attention_backward_f32(const float* tpack, const float* saved, const
     const int R = (int)g.R;
     const size_t sQ = (size_t)g.Tp * 256, sV = (size_t)g.Tp * 1024, sS = (size_t)g.Tp * g.Tp;
     if (hipMemsetAsync(dparams, 0, AG_END * sizeof(float), st) != hipSuccess) return RTFS_ERR_LAUNCH;
-    CHECK(launch_transpose(dout, drow, B, 64, T * 64, st));
+    const float* r0 = rows ? x : sv.r0;
+    if (rows) {
+        if (hipMemcpyAsync(drow, dout, g.R * 64 * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) return RTFS_ERR_LAUNCH;
+    } else {
+        CHECK(launch_transpose(dout, drow, B, 64, T * 64, st));
+    }
     // concat projection ConvActNorm: LNG, then the 1x1 convolution
     LngArgs b;
     att_groups(b, false);
@@ -734,29 +780,36 @@ int rtfs_tf_attention_backward_f32(const float* tpack, const float* saved, const
     a.dgamma = dparams + AG_G; a.dbeta = dparams + AG_BE; a.dslope = dparams + AG_SL;
     CHECK(launch_att_lng(a, B * T, true, st));
     CHECK(launch_cl_colsum(dZ, dparams + AG_B, g.R * 128, 128, st));
-    CHECK(launch_gemm_tn(dZ, 128, sv.r0, 64, dparams + AG_W, 64, 128, 64, (long)R, st));
+    CHECK(launch_gemm_tn(dZ, 128, r0, 64, dparams + AG_W, 64, 128, 64, (long)R, st));
     CHECK(launch_gemm_nt(dZ, 128, tpack + AT_WT, 128, drow, 64, R, 64, 128, 1, st));  // + the residual's gradient already in drow
+    if (rows) return hipMemcpyAsync(dx, drow, g.R * 64 * sizeof(float), hipMemcpyDeviceToDevice, st) == hipSuccess ? RTFS_OK : RTFS_ERR_LAUNCH;
     return launch_transpose(drow, dx, B, T * 64, 64, st);
 }
 
-// ------------------------------------------------------------ block glue with gradients: pooling, TFAR combine
-int rtfs_adaptive_avg_pool2d_f32(const float* x, float* y, int N, int H, int W, int Ho, int Wo, void* stream) {
-    RTFS_RETURN_IF(!x || !y || N < 1, RTFS_ERR_ARG);
-    return launch_pool2d(x, y, (size_t)N, H, W, Ho, Wo, false, S(stream));
+// ------------------------------------------------------------ layout change between (B, C, P) and rows (B, P, C)
+int rtfs_layout_f32(const float* x, float* y, int B, int C, int P, int to_rows, void* stream) {
+    RTFS_RETURN_IF(!x || !y || B < 1 || C < 1 || P < 1, RTFS_ERR_ARG);
+    return to_rows ? launch_transpose(x, y, B, C, P, S(stream)) : launch_transpose(x, y, B, P, C, S(stream));
 }
-int rtfs_adaptive_avg_pool2d_backward_f32(const float* dy, float* dx, int N, int H, int W, int Ho, int Wo, void* stream) {
+
+// ------------------------------------------------------------ block glue with gradients: pooling, TFAR combine
+int rtfs_adaptive_avg_pool2d_f32(const float* x, float* y, int N, int H, int W, int Ho, int Wo, int inner, void* stream) {
+    RTFS_RETURN_IF(!x || !y || N < 1, RTFS_ERR_ARG);
+    return launch_pool2d(x, y, (size_t)N, H, W, Ho, Wo, false, S(stream), inner);
+}
+int rtfs_adaptive_avg_pool2d_backward_f32(const float* dy, float* dx, int N, int H, int W, int Ho, int Wo, int inner, void* stream) {
     RTFS_RETURN_IF(!dy || !dx || N < 1, RTFS_ERR_ARG);
-    return launch_pool2d(dy, dx, (size_t)N, H, W, Ho, Wo, true, S(stream));
+    return launch_pool2d(dy, dx, (size_t)N, H, W, Ho, Wo, true, S(stream), inner);
 }
 int rtfs_tfar_combine_f32(const float* local, const float* gate, const float* glob, float* out, int N, int H, int W, int Hg, int Wg,
-                          void* stream) {
+                          int inner, void* stream) {
     RTFS_RETURN_IF(!local || !gate || !glob || !out || N < 1, RTFS_ERR_ARG);
-    return launch_tfar_combine(local, gate, glob, out, (size_t)N, H, W, Hg, Wg, S(stream));
+    return launch_tfar_combine(local, gate, glob, out, (size_t)N, H, W, Hg, Wg, S(stream), inner);
 }
 int rtfs_tfar_combine_backward_f32(const float* dout, const float* local, const float* gate, float* dlocal, float* dgate, float* dglob, int N,
-                                   int H, int W, int Hg, int Wg, void* stream) {
+                                   int H, int W, int Hg, int Wg, int inner, void* stream) {
     RTFS_RETURN_IF(!dout || !local || !gate || !dlocal || !dgate || !dglob || N < 1, RTFS_ERR_ARG);
-    return launch_tfar_combine_bwd(dout, local, gate, dlocal, dgate, dglob, (size_t)N, H, W, Hg, Wg, S(stream));
+    return launch_tfar_combine_bwd(dout, local, gate, dlocal, dgate, dglob, (size_t)N, H, W, Hg, Wg, S(stream), inner);
 }
 
 // ------------------------------------------------------------ encoder / decoder / S^3, training side

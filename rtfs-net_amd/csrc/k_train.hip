@@ -1213,25 +1213,31 @@ namespace {
 __device__ __forceinline__ int win_lo(int i, int n_in, int n_out) { return (int)(((long)i * n_in) / n_out); }
 __device__ __forceinline__ int win_hi(int i, int n_in, int n_out) { return (int)((((long)(i + 1)) * n_in + n_out - 1) / n_out); }
 }  // namespace
+// All four glue kernels take an inner channel count C: C = 1 is the channel-first case (N = B*C planes of (H, W)), C > 1 the rows case
+// (N = B maps of (H, W, C) with channels fastest): element (n, h, w, c) lives at ((n*H + h)*W + w)*C + c.
 __global__ __launch_bounds__(256) void pool2d_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, size_t N, int H, int W, int Ho,
-                                                         int Wo) {
-    const size_t total = N * Ho * Wo;
+                                                         int Wo, int C) {
+    const size_t total = N * Ho * Wo * C;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int wo = (int)(i % Wo), ho = (int)((i / Wo) % Ho);
-        const size_t n = i / ((size_t)Wo * Ho);
+        const int c = (int)(i % C);
+        const size_t p = i / C;
+        const int wo = (int)(p % Wo), ho = (int)((p / Wo) % Ho);
+        const size_t n = p / ((size_t)Wo * Ho);
         const int h0 = win_lo(ho, H, Ho), h1 = win_hi(ho, H, Ho), w0 = win_lo(wo, W, Wo), w1 = win_hi(wo, W, Wo);
         float s = 0.f;
         for (int h = h0; h < h1; ++h)
-            for (int w = w0; w < w1; ++w) s += x[(n * H + h) * W + w];
+            for (int w = w0; w < w1; ++w) s += x[((n * H + h) * W + w) * C + c];
         y[i] = s / (float)((h1 - h0) * (w1 - w0));
     }
 }
 __global__ __launch_bounds__(256) void pool2d_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, size_t N, int H, int W, int Ho,
-                                                         int Wo) {
-    const size_t total = N * H * W;
+                                                         int Wo, int C) {
+    const size_t total = N * H * W * C;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int w = (int)(i % W), h = (int)((i / W) % H);
-        const size_t n = i / ((size_t)W * H);
+        const int c = (int)(i % C);
+        const size_t p = i / C;
+        const int w = (int)(p % W), h = (int)((p / W) % H);
+        const size_t n = p / ((size_t)W * H);
         // candidate windows around floor(h * out / in): window starts are non-decreasing and each is at most in/out + 1 long
         const int hc = (int)(((long)h * Ho) / H), wc = (int)(((long)w * Wo) / W);
         float s = 0.f;
@@ -1241,7 +1247,7 @@ __global__ __launch_bounds__(256) void pool2d_bwd_kernel(const float* __restrict
             for (int wo = max(wc - 1, 0); wo <= min(wc + 1, Wo - 1); ++wo) {
                 const int w0 = win_lo(wo, W, Wo), w1 = win_hi(wo, W, Wo);
                 if (w < w0 || w >= w1) continue;
-                s += dy[(n * Ho + ho) * Wo + wo] / (float)((h1 - h0) * (w1 - w0));
+                s += dy[((n * Ho + ho) * Wo + wo) * C + c] / (float)((h1 - h0) * (w1 - w0));
             }
         }
         dx[i] = s;
@@ -1250,24 +1256,28 @@ __global__ __launch_bounds__(256) void pool2d_bwd_kernel(const float* __restrict
 // InjectionMultiSum's last line (fusion.py:54-69): out = local * up(gate) + up(global), up = F.interpolate(mode="nearest")
 __global__ __launch_bounds__(256) void tfar_combine_fwd_kernel(const float* __restrict__ le, const float* __restrict__ gate,
                                                                const float* __restrict__ ge, float* __restrict__ out, size_t N, int H, int W,
-                                                               int Hg, int Wg) {
-    const size_t total = N * H * W;
+                                                               int Hg, int Wg, int C) {
+    const size_t total = N * H * W * C;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int w = (int)(i % W), h = (int)((i / W) % H);
-        const size_t n = i / ((size_t)W * H);
-        const size_t j = (n * Hg + nearest_src(h, Hg, H)) * Wg + nearest_src(w, Wg, W);
+        const int c = (int)(i % C);
+        const size_t p = i / C;
+        const int w = (int)(p % W), h = (int)((p / W) % H);
+        const size_t n = p / ((size_t)W * H);
+        const size_t j = ((n * Hg + nearest_src(h, Hg, H)) * Wg + nearest_src(w, Wg, W)) * C + c;
         out[i] = fmaf(le[i], gate[j], ge[j]);
     }
 }
 __global__ __launch_bounds__(256) void tfar_combine_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ le,
                                                                const float* __restrict__ gate, float* __restrict__ dle,
                                                                float* __restrict__ dgate, float* __restrict__ dge, size_t N, int H, int W, int Hg,
-                                                               int Wg) {
-    // one thread per GLOBAL pixel: it owns the local pixels that read it (a contiguous block of rows x columns)
-    const size_t total = N * Hg * Wg;
+                                                               int Wg, int C) {
+    // one thread per GLOBAL element: it owns the local pixels that read it (a contiguous block of rows x columns)
+    const size_t total = N * Hg * Wg * C;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int wg = (int)(i % Wg), hg = (int)((i / Wg) % Hg);
-        const size_t n = i / ((size_t)Wg * Hg);
+        const int c = (int)(i % C);
+        const size_t p = i / C;
+        const int wg = (int)(p % Wg), hg = (int)((p / Wg) % Hg);
+        const size_t n = p / ((size_t)Wg * Hg);
         // local h reads global floor(h * Hg / H) == hg  <=>  h in [ceil(hg*H/Hg), ceil((hg+1)*H/Hg))
         const int h0 = (int)(((long)hg * H + Hg - 1) / Hg), h1 = min(H, (int)(((long)(hg + 1) * H + Hg - 1) / Hg));
         const int w0 = (int)(((long)wg * W + Wg - 1) / Wg), w1 = min(W, (int)(((long)(wg + 1) * W + Wg - 1) / Wg));
@@ -1275,7 +1285,7 @@ __global__ __launch_bounds__(256) void tfar_combine_bwd_kernel(const float* __re
         float sg = 0.f, se = 0.f;
         for (int h = h0; h < h1; ++h)
             for (int w = w0; w < w1; ++w) {
-                const size_t k = (n * H + h) * W + w;
+                const size_t k = ((n * H + h) * W + w) * C + c;
                 const float d = dout[k];
                 dle[k] = d * g;
                 sg = fmaf(d, le[k], sg);
@@ -1285,21 +1295,22 @@ __global__ __launch_bounds__(256) void tfar_combine_bwd_kernel(const float* __re
         dge[i] = se;
     }
 }
-int launch_pool2d(const float* x, float* y, size_t N, int H, int W, int Ho, int Wo, bool bwd, hipStream_t st) {
-    if (H < 1 || W < 1 || Ho < 1 || Wo < 1 || Ho > H || Wo > W) return RTFS_ERR_SHAPE;
-    if (bwd) hipLaunchKernelGGL(pool2d_bwd_kernel, dim3(grid_for(N * H * W)), dim3(256), 0, st, x, y, N, H, W, Ho, Wo);
-    else hipLaunchKernelGGL(pool2d_fwd_kernel, dim3(grid_for(N * Ho * Wo)), dim3(256), 0, st, x, y, N, H, W, Ho, Wo);
+int launch_pool2d(const float* x, float* y, size_t N, int H, int W, int Ho, int Wo, bool bwd, hipStream_t st, int C) {
+    if (H < 1 || W < 1 || Ho < 1 || Wo < 1 || Ho > H || Wo > W || C < 1) return RTFS_ERR_SHAPE;
+    if (bwd) hipLaunchKernelGGL(pool2d_bwd_kernel, dim3(grid_for(N * H * W * C)), dim3(256), 0, st, x, y, N, H, W, Ho, Wo, C);
+    else hipLaunchKernelGGL(pool2d_fwd_kernel, dim3(grid_for(N * Ho * Wo * C)), dim3(256), 0, st, x, y, N, H, W, Ho, Wo, C);
     return rtfs_launch_status();
 }
-int launch_tfar_combine(const float* le, const float* gate, const float* ge, float* out, size_t N, int H, int W, int Hg, int Wg, hipStream_t st) {
-    if (Hg < 1 || Wg < 1 || Hg > H || Wg > W) return RTFS_ERR_SHAPE;
-    hipLaunchKernelGGL(tfar_combine_fwd_kernel, dim3(grid_for(N * H * W)), dim3(256), 0, st, le, gate, ge, out, N, H, W, Hg, Wg);
+int launch_tfar_combine(const float* le, const float* gate, const float* ge, float* out, size_t N, int H, int W, int Hg, int Wg, hipStream_t st,
+                        int C) {
+    if (Hg < 1 || Wg < 1 || Hg > H || Wg > W || C < 1) return RTFS_ERR_SHAPE;
+    hipLaunchKernelGGL(tfar_combine_fwd_kernel, dim3(grid_for(N * H * W * C)), dim3(256), 0, st, le, gate, ge, out, N, H, W, Hg, Wg, C);
     return rtfs_launch_status();
 }
 int launch_tfar_combine_bwd(const float* dout, const float* le, const float* gate, float* dle, float* dgate, float* dge, size_t N, int H, int W,
-                            int Hg, int Wg, hipStream_t st) {
-    if (Hg < 1 || Wg < 1 || Hg > H || Wg > W) return RTFS_ERR_SHAPE;
-    hipLaunchKernelGGL(tfar_combine_bwd_kernel, dim3(grid_for(N * Hg * Wg)), dim3(256), 0, st, dout, le, gate, dle, dgate, dge, N, H, W, Hg, Wg);
+                            int Hg, int Wg, hipStream_t st, int C) {
+    if (Hg < 1 || Wg < 1 || Hg > H || Wg > W || C < 1) return RTFS_ERR_SHAPE;
+    hipLaunchKernelGGL(tfar_combine_bwd_kernel, dim3(grid_for(N * Hg * Wg * C)), dim3(256), 0, st, dout, le, gate, dle, dgate, dge, N, H, W, Hg, Wg, C);
     return rtfs_launch_status();
 }
 
@@ -1502,49 +1513,67 @@ int launch_caf_combine_bwd(const float* dout, const float* key, const float* val
 // bwd: dx = rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat)); dgamma += dy*xhat, dbeta += dy (per-workgroup LDS sums, then atomics)
 __global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                       float* __restrict__ y, const float* __restrict__ dy, float* __restrict__ dx,
-                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, size_t N, int C, int bwd) {
-    __shared__ float pg[1024], pb[1024];
+                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, size_t N, int C, int bwd,
+                                                      const float* __restrict__ res) {
+    __shared__ float pg[4][1024], pb[4][1024];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, per = C >> 6;
-    if (bwd)
-        for (int i = threadIdx.x; i < C; i += 256) pg[i] = pb[i] = 0.f;
-    __syncthreads();
+    // a lane owns channels lane + 64k in every row: the affine's gradients accumulate in registers
+    float ag[16], ab[16], gm[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        ag[k] = ab[k] = 0.f;
+        gm[k] = k < per ? gamma[lane + 64 * k] : 0.f;
+    }
     for (size_t row = (size_t)blockIdx.x * 4 + wave; row < N; row += (size_t)gridDim.x * 4) {
         const float* xr = x + row * C;
         float v[16], s = 0.f;
-        for (int k = 0; k < per; ++k) {
-            v[k] = xr[lane + 64 * k];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            v[k] = k < per ? xr[lane + 64 * k] : 0.f;
             s += v[k];
         }
         const float mean = wave_sum(s) / C;
         float q = 0.f;
-        for (int k = 0; k < per; ++k) {
-            v[k] -= mean;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            v[k] = k < per ? v[k] - mean : 0.f;
             q = fmaf(v[k], v[k], q);
         }
         const float rstd = 1.0f / sqrtf(wave_sum(q) / C + RTFS_EPS);
         if (!bwd) {
-            for (int k = 0; k < per; ++k) y[row * C + lane + 64 * k] = fmaf(v[k] * rstd, gamma[lane + 64 * k], beta[lane + 64 * k]);
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                if (k < per) y[row * C + lane + 64 * k] = fmaf(v[k] * rstd, gm[k], beta[lane + 64 * k]);
         } else {
             float gd[16], s1 = 0.f, s2 = 0.f;
-            for (int k = 0; k < per; ++k) {
-                const float d = dy[row * C + lane + 64 * k];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const float d = k < per ? dy[row * C + lane + 64 * k] : 0.f;
                 v[k] *= rstd;  // xhat
-                gd[k] = gamma[lane + 64 * k] * d;
+                gd[k] = gm[k] * d;
                 s1 += gd[k];
                 s2 = fmaf(gd[k], v[k], s2);
-                atomicAdd(&pg[lane + 64 * k], d * v[k]);
-                atomicAdd(&pb[lane + 64 * k], d);
+                ag[k] = fmaf(d, v[k], ag[k]);
+                ab[k] += d;
             }
             s1 = wave_sum(s1) / C;
             s2 = wave_sum(s2) / C;
-            for (int k = 0; k < per; ++k) dx[row * C + lane + 64 * k] = rstd * (gd[k] - s1 - v[k] * s2);
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                if (k < per) dx[row * C + lane + 64 * k] = rstd * (gd[k] - s1 - v[k] * s2) + (res ? res[row * C + lane + 64 * k] : 0.f);
         }
     }
     if (bwd) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            if (k < per) {
+                pg[wave][lane + 64 * k] = ag[k];
+                pb[wave][lane + 64 * k] = ab[k];
+            }
         __syncthreads();
         for (int i = threadIdx.x; i < C; i += 256) {
-            unsafeAtomicAdd(dgamma + i, pg[i]);
-            unsafeAtomicAdd(dbeta + i, pb[i]);
+            unsafeAtomicAdd(dgamma + i, pg[0][i] + pg[1][i] + pg[2][i] + pg[3][i]);
+            unsafeAtomicAdd(dbeta + i, pb[0][i] + pb[1][i] + pb[2][i] + pb[3][i]);
         }
     }
 }
@@ -1654,11 +1683,11 @@ __global__ __launch_bounds__(256) void mha_core_kernel(const float* __restrict__
 }
 
 int launch_ln_rows(const float* x, const float* gamma, const float* beta, float* y, const float* dy, float* dx, float* dgamma, float* dbeta,
-                   size_t N, int C, bool bwd, hipStream_t st) {
+                   size_t N, int C, bool bwd, hipStream_t st, const float* res) {
     if (C < 64 || C > 1024 || (C & 63)) return RTFS_ERR_SHAPE;
     size_t g = (N + 3) / 4;
     g = g < 1 ? 1 : (g > 1024 ? 1024 : g);
-    hipLaunchKernelGGL(ln_rows_kernel, dim3((unsigned)g), dim3(256), 0, st, x, gamma, beta, y, dy, dx, dgamma, dbeta, N, C, bwd ? 1 : 0);
+    hipLaunchKernelGGL(ln_rows_kernel, dim3((unsigned)g), dim3(256), 0, st, x, gamma, beta, y, dy, dx, dgamma, dbeta, N, C, bwd ? 1 : 0, res);
     return rtfs_launch_status();
 }
 int launch_mha_core(const float* qkv, const float* pmask, float* o, const float* dout, float* dqkv, int B, int T, int nh, int hd, bool bwd,
@@ -1788,5 +1817,33 @@ int launch_lstm_scan(const LstmScanArgs& a, bool bwd, hipStream_t st) {
     const long waves = 2L * a.N;
     if (bwd) hipLaunchKernelGGL(lstm_scan_bwd_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(lstm_scan_fwd_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, a);
+    return rtfs_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------ rows-layout helpers
+// out = y + bias[c] + x over rows of C floats (the dual path's output in rows layout)
+__global__ __launch_bounds__(256) void rows_bias_res_kernel(const float* __restrict__ y, const float* __restrict__ bias, const float* __restrict__ x,
+                                                            float* __restrict__ out, size_t n, int C) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = y[i] + bias[i & (C - 1)] + x[i];
+}
+// (B, H, W, C) -> (B, W, H, C): the T-sweep's sequences become contiguous runs of rows
+__global__ __launch_bounds__(256) void rows_permute_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int H, int W, int C) {
+    const size_t total = (size_t)B * H * W * C;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        size_t p = i / C;
+        const int w = (int)(p % W);
+        p /= W;
+        const int h = (int)(p % H), b = (int)(p / H);
+        y[(((size_t)b * W + w) * H + h) * C + c] = x[i];
+    }
+}
+int launch_rows_bias_res(const float* y, const float* bias, const float* x, float* out, size_t n, int C, hipStream_t st) {
+    if (C < 1 || (C & (C - 1))) return RTFS_ERR_SHAPE;
+    hipLaunchKernelGGL(rows_bias_res_kernel, dim3(grid_for(n)), dim3(256), 0, st, y, bias, x, out, n, C);
+    return rtfs_launch_status();
+}
+int launch_rows_permute(const float* x, float* y, int B, int H, int W, int C, hipStream_t st) {
+    hipLaunchKernelGGL(rows_permute_kernel, dim3(grid_for((size_t)B * H * W * C)), dim3(256), 0, st, x, y, B, H, W, C);
     return rtfs_launch_status();
 }

@@ -313,10 +313,11 @@ int launch_att_lng(const LngArgs& a, int nbt, bool bwd, hipStream_t st);
 int launch_att_pack_qkv(float* rows, float* Qp, float* Kp, float* Vp, int B, int T, int Tp, int dir, hipStream_t st);
 int launch_att_pack_o(float* rows, float* Op, int B, int T, int Tp, int dir, hipStream_t st);
 int launch_att_softmax(float* S, const float* P, int nbatch, int T, int Tp, float scale, bool bwd, hipStream_t st);
-int launch_pool2d(const float* x, float* y, size_t N, int H, int W, int Ho, int Wo, bool bwd, hipStream_t st);
-int launch_tfar_combine(const float* le, const float* gate, const float* ge, float* out, size_t N, int H, int W, int Hg, int Wg, hipStream_t st);
+int launch_pool2d(const float* x, float* y, size_t N, int H, int W, int Ho, int Wo, bool bwd, hipStream_t st, int C = 1);
+int launch_tfar_combine(const float* le, const float* gate, const float* ge, float* out, size_t N, int H, int W, int Hg, int Wg, hipStream_t st,
+                        int C = 1);
 int launch_tfar_combine_bwd(const float* dout, const float* le, const float* gate, float* dle, float* dgate, float* dge, size_t N, int H, int W,
-                            int Hg, int Wg, hipStream_t st);
+                            int Hg, int Wg, hipStream_t st, int C = 1);
 int launch_patch3x3_rows(const float* z, float* rows, int B, int T, int F, hipStream_t st);
 int launch_istft_adjoint(const float* dwav, float* dspec, int B, int T, int L, hipStream_t st);
 int launch_cmul(const float* a, const float* b, float* out, int B, size_t half, int conj_a, hipStream_t st);
@@ -328,7 +329,7 @@ int launch_caf_combine_bwd(const float* dout, const float* key, const float* val
 int launch_pit_sdr_bwd(const float* est, const float* tgt, const int* perm, const float* dmin, float* dest, int B, int n, int L, int kind,
                        int zero_mean, int take_log, hipStream_t st);
 int launch_ln_rows(const float* x, const float* gamma, const float* beta, float* y, const float* dy, float* dx, float* dgamma, float* dbeta,
-                   size_t N, int C, bool bwd, hipStream_t st);
+                   size_t N, int C, bool bwd, hipStream_t st, const float* res = nullptr);
 int launch_mha_core(const float* qkv, const float* pmask, float* o, const float* dout, float* dqkv, int B, int T, int nh, int hd, bool bwd,
                     hipStream_t st);
 struct LstmScanArgs {
@@ -341,3 +342,5 @@ struct LstmScanArgs {
     long ts = 0, ns = 0;
 };
 int launch_lstm_scan(const LstmScanArgs& a, bool bwd, hipStream_t st);
+int launch_rows_bias_res(const float* y, const float* bias, const float* x, float* out, size_t n, int C, hipStream_t st);
+int launch_rows_permute(const float* x, float* y, int B, int H, int W, int C, hipStream_t st);

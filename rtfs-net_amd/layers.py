@@ -154,14 +154,19 @@ class _CNATrainFn(torch.autograd.Function):
     @staticmethod
     def _carr(cfg, phase, world):
         import ctypes
-        return (ctypes.c_int * 13)(*(tuple(cfg[:11]) + (phase, world)))
+        lay = tuple(int(v) for v in cfg[12:14]) if len(cfg) >= 14 else (0, 0)  # (in_rows, out_rows)
+        return (ctypes.c_int * 15)(*(tuple(cfg[:11]) + (phase, world) + lay))
 
     @staticmethod
     def forward(ctx, x, cfg, *params):
         import ctypes
         lib = _lib.load()
         x = x.contiguous()
-        B, H, W = x.shape[0], (x.shape[2] if x.dim() == 4 else 1), x.shape[-1]
+        in_rows, out_rows = (bool(cfg[12]), bool(cfg[13])) if len(cfg) >= 14 else (False, False)
+        if in_rows:  # (B, H, W, C) / (B, W, C)
+            B, H, W = x.shape[0], (x.shape[1] if x.dim() == 4 else 1), x.shape[-2]
+        else:
+            B, H, W = x.shape[0], (x.shape[2] if x.dim() == 4 else 1), x.shape[-1]
         world = _bn_world() if (len(cfg) > 11 and cfg[11] and cfg[7] == 3) else 1
         carr = _CNATrainFn._carr(cfg, 0, world)
         params, running = params[:8], params[8:]  # optional: BatchNorm running mean / var (+ momentum in train mode)
@@ -170,7 +175,11 @@ class _CNATrainFn(torch.autograd.Function):
         pk = packing.cached_train_pack(("cna", tuple(cfg[:11])), tuple(params), build) if cfg[7] < 2 else build()
         ho, wo = ctypes.c_int(), ctypes.c_int()
         lib.rtfs_cna_out_shape(carr, H, W, ctypes.byref(ho), ctypes.byref(wo))
-        out = torch.empty((B, cfg[1], ho.value, wo.value) if x.dim() == 4 else (B, cfg[1], wo.value), device=x.device, dtype=torch.float32)
+        if out_rows:
+            oshape = (B, ho.value, wo.value, cfg[1]) if x.dim() == 4 else (B, wo.value, cfg[1])
+        else:
+            oshape = (B, cfg[1], ho.value, wo.value) if x.dim() == 4 else (B, cfg[1], wo.value)
+        out = torch.empty(oshape, device=x.device, dtype=torch.float32)
         saved = torch.empty(lib.rtfs_cna_saved_floats(carr, B, H, W), device=x.device, dtype=torch.float32)
         ws = _lib.workspace(lib.rtfs_cna_workspace_bytes(carr, B, H, W), x.device)
 
@@ -188,8 +197,8 @@ class _CNATrainFn(torch.autograd.Function):
             rm, rv, momentum = running
             _lib.check(lib.rtfs_cna_bn_update_f32(_lib.ptr(saved), carr, B, H, W, _lib.ptr(rm), _lib.ptr(rv), float(momentum), _lib.stream_of(x)),
                        "rtfs_cna_bn_update_f32")
-        ctx.save_for_backward(pk, saved)
-        ctx.cfg, ctx.geom, ctx.xshape, ctx.world = tuple(cfg[:11]), (B, H, W), x.shape, world
+        ctx.save_for_backward(pk, saved, x if in_rows else None)
+        ctx.cfg, ctx.geom, ctx.xshape, ctx.world = tuple(cfg[:11]) + (0, int(in_rows), int(out_rows)), (B, H, W), x.shape, world
         ctx.pshapes = [None if p is None else p.shape for p in params]
         ctx.nrunning = len(running)
         return out
@@ -198,7 +207,7 @@ class _CNATrainFn(torch.autograd.Function):
     def backward(ctx, dout):
         import ctypes
         lib = _lib.load()
-        pk, saved = ctx.saved_tensors
+        pk, saved, xrows = ctx.saved_tensors
         B, H, W = ctx.geom
         world = ctx.world
         carr = _CNATrainFn._carr(ctx.cfg, 0, world)
@@ -208,8 +217,8 @@ class _CNATrainFn(torch.autograd.Function):
         ws = _lib.workspace(lib.rtfs_cna_workspace_bytes(carr, B, H, W), dout.device)
 
         def run(c):
-            _lib.check(lib.rtfs_cna_backward_f32(_lib.ptr(pk), _lib.ptr(saved), _lib.ptr(dout), _lib.ptr(dx), _lib.ptr(dpar), c, B, H, W,
-                                                 _lib.ptr(ws), ws.numel(), _lib.stream_of(dout)), "rtfs_cna_backward_f32")
+            _lib.check(lib.rtfs_cna_backward_f32(_lib.ptr(xrows), _lib.ptr(pk), _lib.ptr(saved), _lib.ptr(dout), _lib.ptr(dx), _lib.ptr(dpar), c,
+                                                 B, H, W, _lib.ptr(ws), ws.numel(), _lib.stream_of(dout)), "rtfs_cna_backward_f32")
         if world > 1:  # SyncBatchNorm backward: the input gradient needs the sums of dy and dy * xhat over every rank; the
             # parameter gradients stay local (the gradient all-reduce averages them like every other parameter's)
             run(_CNATrainFn._carr(ctx.cfg, 1, world))
@@ -264,8 +273,9 @@ class ConvNormAct(nn.Module):
             return self._forward_train(x)
         return self.full_layer(x)
 
-    def _forward_train(self, x):
-        """The module inside a training step: HIP forward-with-saved-state + backward (rtfs_cna_*_f32)."""
+    def _forward_train(self, x, rows=(False, False)):
+        """The module inside a training step: HIP forward-with-saved-state + backward (rtfs_cna_*_f32).  rows = (input, output) are
+        (B, H, W, C) rows instead of (B, C, H, W): how the modules of a block hand tensors to each other without layout changes."""
         pre_n, pre_a, conv, nrm, act = self.full_layer
         if not isinstance(conv, (nn.Conv1d, nn.Conv2d)):
             return x
@@ -295,7 +305,7 @@ class ConvNormAct(nn.Module):
         is2d = isinstance(conv, nn.Conv2d)
         cfg = (conv.in_channels, conv.out_channels, self.kernel_size, self.stride, int(depthwise), int(isinstance(pre_n, GlobalLayerNorm)),
                _ACT_CODE[type(pre_a)], (3 if nrm.training else 2) if bn else int(isinstance(nrm, GlobalLayerNorm)), _ACT_CODE[type(act)],
-               int(conv.bias is not None), int(is2d), int(isinstance(nrm, nn.SyncBatchNorm)))
+               int(conv.bias is not None), int(is2d), int(isinstance(nrm, nn.SyncBatchNorm)), int(rows[0]), int(rows[1]))
         gn = lambda m, a: getattr(m.norm, a) if isinstance(m, GlobalLayerNorm) else (getattr(m, a) if bn and m is nrm else None)
         sl = lambda m: m.weight if isinstance(m, nn.PReLU) else None
         running = ((nrm.running_mean, nrm.running_var) + ((nrm.momentum,) if nrm.training else ())) if bn else ()
@@ -464,17 +474,20 @@ class _DualPathTrainFn(torch.autograd.Function):
     def forward(ctx, x, dim, gamma, beta, *rest):
         lib = _lib.load()
         x = x.contiguous()
-        B, _, T, Fq = x.shape
+        if dim >= 10:  # rows layout (B, T, F, 64)
+            B, T, Fq, _ = x.shape
+        else:
+            B, _, T, Fq = x.shape
         sru, lin_w, lin_b = rest[:12], rest[12], rest[13]
         tpack = packing.cached_train_pack("dualpath", (gamma, beta) + tuple(rest),
                                           lambda: packing.pack_dualpath_train(gamma, beta, sru[0::3], sru[1::3], sru[2::3], lin_w, lin_b))
         out = torch.empty_like(x)
-        saved = torch.empty(lib.rtfs_dualpath_saved_floats(B, T, Fq, dim), device=x.device, dtype=torch.float32)
-        ws = _lib.workspace(lib.rtfs_dualpath_train_workspace_bytes(B, T, Fq, dim), x.device)
+        saved = torch.empty(lib.rtfs_dualpath_saved_floats(B, T, Fq, dim % 10), device=x.device, dtype=torch.float32)
+        ws = _lib.workspace(lib.rtfs_dualpath_train_workspace_bytes(B, T, Fq, dim % 10), x.device)
         _lib.check(lib.rtfs_dualpath_forward_train_f32(_lib.ptr(x), _lib.ptr(tpack), _lib.ptr(out), _lib.ptr(saved), B, T, Fq, dim,
                                                        _lib.ptr(ws), ws.numel(), _lib.stream_of(x)), "rtfs_dualpath_forward_train_f32")
         ctx.save_for_backward(x, tpack, saved)
-        ctx.dim = dim
+        ctx.dim, ctx.geom = dim, (B, T, Fq)
         ctx.shapes = (gamma.shape, beta.shape)
         return out
 
@@ -482,11 +495,11 @@ class _DualPathTrainFn(torch.autograd.Function):
     def backward(ctx, dout):
         lib = _lib.load()
         x, tpack, saved = ctx.saved_tensors
-        B, _, T, Fq = x.shape
+        B, T, Fq = ctx.geom
         dout = dout.contiguous().to(torch.float32)
         dx = torch.empty_like(x)
         dpar = torch.empty(lib.rtfs_dualpath_grad_floats(), device=x.device, dtype=torch.float32)
-        ws = _lib.workspace(lib.rtfs_dualpath_train_workspace_bytes(B, T, Fq, ctx.dim), x.device)
+        ws = _lib.workspace(lib.rtfs_dualpath_train_workspace_bytes(B, T, Fq, ctx.dim % 10), x.device)
         _lib.check(lib.rtfs_dualpath_backward_f32(_lib.ptr(x), _lib.ptr(tpack), _lib.ptr(saved), _lib.ptr(dout), _lib.ptr(dx), _lib.ptr(dpar),
                                                   B, T, Fq, ctx.dim, _lib.ptr(ws), ws.numel(), _lib.stream_of(x)), "rtfs_dualpath_backward_f32")
         dg, db, dws, dwcs, dbs, dlw, dlb = packing.unpack_dualpath_grads(dpar)
@@ -584,33 +597,34 @@ class _AttentionTrainFn(torch.autograd.Function):
     """MultiHeadSelfAttention2D forward/backward on the training kernels.  Inputs: x, names (tuple), then the parameters in that order."""
 
     @staticmethod
-    def forward(ctx, x, names, *params):
+    def forward(ctx, x, names, rows, *params):
         lib = _lib.load()
         x = x.contiguous()
-        B, _, T, _ = x.shape
+        B, T = (x.shape[0], x.shape[1]) if rows else (x.shape[0], x.shape[2])
         tpack = packing.cached_train_pack("attention", params, lambda: packing.pack_attention_train(dict(zip(names, params))))
         out = torch.empty_like(x)
         saved = torch.empty(lib.rtfs_tf_attention_saved_floats(B, T), device=x.device, dtype=torch.float32)
         ws = _lib.workspace(lib.rtfs_tf_attention_train_workspace_bytes(B, T), x.device)
-        _lib.check(lib.rtfs_tf_attention_forward_train_f32(_lib.ptr(x), _lib.ptr(tpack), _lib.ptr(out), _lib.ptr(saved), B, T, _lib.ptr(ws),
-                                                           ws.numel(), _lib.stream_of(x)), "rtfs_tf_attention_forward_train_f32")
-        ctx.save_for_backward(tpack, saved)
-        ctx.names, ctx.geom = names, (B, T)
+        _lib.check(lib.rtfs_tf_attention_forward_train_f32(_lib.ptr(x), _lib.ptr(tpack), _lib.ptr(out), _lib.ptr(saved), B, T, int(rows),
+                                                           _lib.ptr(ws), ws.numel(), _lib.stream_of(x)), "rtfs_tf_attention_forward_train_f32")
+        ctx.save_for_backward(tpack, saved, x if rows else None)
+        ctx.names, ctx.geom, ctx.rows = names, (B, T), bool(rows)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         lib = _lib.load()
-        tpack, saved = ctx.saved_tensors
+        tpack, saved, xrows = ctx.saved_tensors
         B, T = ctx.geom
         dout = dout.contiguous().to(torch.float32)
         dx = torch.empty_like(dout)
         dpar = torch.empty(lib.rtfs_tf_attention_grad_floats(), device=dout.device, dtype=torch.float32)
         ws = _lib.workspace(lib.rtfs_tf_attention_train_workspace_bytes(B, T), dout.device)
-        _lib.check(lib.rtfs_tf_attention_backward_f32(_lib.ptr(tpack), _lib.ptr(saved), _lib.ptr(dout), _lib.ptr(dx), _lib.ptr(dpar), B, T,
-                                                      _lib.ptr(ws), ws.numel(), _lib.stream_of(dout)), "rtfs_tf_attention_backward_f32")
+        _lib.check(lib.rtfs_tf_attention_backward_f32(_lib.ptr(xrows), _lib.ptr(tpack), _lib.ptr(saved), _lib.ptr(dout), _lib.ptr(dx), _lib.ptr(dpar),
+                                                      B, T, int(ctx.rows), _lib.ptr(ws), ws.numel(), _lib.stream_of(dout)),
+                   "rtfs_tf_attention_backward_f32")
         g = packing.unpack_attention_grads(dpar)
-        return (dx, None) + tuple(g[n] for n in ctx.names)
+        return (dx, None, None) + tuple(g[n] for n in ctx.names)
 
 
 class MultiHeadSelfAttention2D(PackedModule):
@@ -640,7 +654,7 @@ class MultiHeadSelfAttention2D(PackedModule):
             raise ValueError("expected (B, 64, T, 64)")
         if _recording(x, self):
             names, params = zip(*self.named_parameters())
-            return _AttentionTrainFn.apply(x, names, *params)
+            return _AttentionTrainFn.apply(x, names, False, *params)
         out = torch.empty_like(x)
         ws = _lib.workspace(lib.rtfs_tf_attention_workspace_bytes(B, T), x.device)
         _lib.check(lib.rtfs_tf_attention_f32(_lib.ptr(x), _lib.ptr(self.pack()), _lib.ptr(out), B, T, _lib.ptr(ws), ws.numel(),
@@ -649,66 +663,98 @@ class MultiHeadSelfAttention2D(PackedModule):
 
 
 # ----------------------------------------------------------------------------- TFAR
-def _planes(t):
-    """(B, C, H, W) or (B, C, W) -> (N = B*C, H, W) geometry of a contiguous tensor."""
-    return t.shape[0] * t.shape[1], (t.shape[2] if t.dim() == 4 else 1), t.shape[-1]
+def _geom(t, rows):
+    """(N, H, W, inner C) of a contiguous tensor: channel-first (B, C, H, W) / (B, C, W) -> N = B*C planes, inner 1;
+    rows (B, H, W, C) / (B, W, C) -> N = B, inner C."""
+    if rows:
+        return t.shape[0], (t.shape[1] if t.dim() == 4 else 1), t.shape[-2], t.shape[-1]
+    return t.shape[0] * t.shape[1], (t.shape[2] if t.dim() == 4 else 1), t.shape[-1], 1
 
 
 class _AdaptivePoolFn(torch.autograd.Function):
     """F.adaptive_avg_pool2d / 1d with its adjoint on the HIP kernels (reference call site separators/tdanet.py:116)."""
 
     @staticmethod
-    def forward(ctx, x, size):
+    def forward(ctx, x, size, rows=False):
         lib = _lib.load()
         x = x.contiguous()
-        N, H, W = _planes(x)
+        N, H, W, C = _geom(x, rows)
         Ho, Wo = (size[0], size[1]) if x.dim() == 4 else (1, size[-1])
-        y = torch.empty(x.shape[:2] + ((Ho, Wo) if x.dim() == 4 else (Wo,)), device=x.device, dtype=torch.float32)
-        _lib.check(lib.rtfs_adaptive_avg_pool2d_f32(_lib.ptr(x), _lib.ptr(y), N, H, W, Ho, Wo, _lib.stream_of(x)), "rtfs_adaptive_avg_pool2d_f32")
-        ctx.geom, ctx.xshape = (N, H, W, Ho, Wo), x.shape
+        if rows:
+            y = torch.empty((x.shape[0], Ho, Wo, C) if x.dim() == 4 else (x.shape[0], Wo, C), device=x.device, dtype=torch.float32)
+        else:
+            y = torch.empty(x.shape[:2] + ((Ho, Wo) if x.dim() == 4 else (Wo,)), device=x.device, dtype=torch.float32)
+        _lib.check(lib.rtfs_adaptive_avg_pool2d_f32(_lib.ptr(x), _lib.ptr(y), N, H, W, Ho, Wo, C, _lib.stream_of(x)), "rtfs_adaptive_avg_pool2d_f32")
+        ctx.geom, ctx.xshape = (N, H, W, Ho, Wo, C), x.shape
         return y
 
     @staticmethod
     def backward(ctx, dy):
         lib = _lib.load()
-        N, H, W, Ho, Wo = ctx.geom
+        N, H, W, Ho, Wo, C = ctx.geom
         dy = dy.contiguous()
         dx = torch.empty(ctx.xshape, device=dy.device, dtype=torch.float32)
-        _lib.check(lib.rtfs_adaptive_avg_pool2d_backward_f32(_lib.ptr(dy), _lib.ptr(dx), N, H, W, Ho, Wo, _lib.stream_of(dy)),
+        _lib.check(lib.rtfs_adaptive_avg_pool2d_backward_f32(_lib.ptr(dy), _lib.ptr(dx), N, H, W, Ho, Wo, C, _lib.stream_of(dy)),
                    "rtfs_adaptive_avg_pool2d_backward_f32")
-        return dx, None
+        return dx, None, None
 
 
 class _TfarCombineFn(torch.autograd.Function):
     """local * up(gate) + up(glob) with nearest up-sampling, and its adjoint (layers/fusion.py:54-69)."""
 
     @staticmethod
-    def forward(ctx, local, gate, glob):
+    def forward(ctx, local, gate, glob, rows=False):
         lib = _lib.load()
         local, gate, glob = local.contiguous(), gate.contiguous(), glob.contiguous()
-        N, H, W = _planes(local)
-        _, Hg, Wg = _planes(gate)
+        N, H, W, C = _geom(local, rows)
+        _, Hg, Wg, _ = _geom(gate, rows)
         out = torch.empty_like(local)
-        _lib.check(lib.rtfs_tfar_combine_f32(_lib.ptr(local), _lib.ptr(gate), _lib.ptr(glob), _lib.ptr(out), N, H, W, Hg, Wg, _lib.stream_of(local)),
-                   "rtfs_tfar_combine_f32")
+        _lib.check(lib.rtfs_tfar_combine_f32(_lib.ptr(local), _lib.ptr(gate), _lib.ptr(glob), _lib.ptr(out), N, H, W, Hg, Wg, C,
+                                             _lib.stream_of(local)), "rtfs_tfar_combine_f32")
         ctx.save_for_backward(local, gate)
-        ctx.geom = (N, H, W, Hg, Wg)
+        ctx.geom = (N, H, W, Hg, Wg, C)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         lib = _lib.load()
         local, gate = ctx.saved_tensors
-        N, H, W, Hg, Wg = ctx.geom
+        N, H, W, Hg, Wg, C = ctx.geom
         dout = dout.contiguous()
         dl, dg, de = torch.empty_like(local), torch.empty_like(gate), torch.empty_like(gate)
         _lib.check(lib.rtfs_tfar_combine_backward_f32(_lib.ptr(dout), _lib.ptr(local), _lib.ptr(gate), _lib.ptr(dl), _lib.ptr(dg), _lib.ptr(de),
-                                                      N, H, W, Hg, Wg, _lib.stream_of(dout)), "rtfs_tfar_combine_backward_f32")
-        return dl, dg, de
+                                                      N, H, W, Hg, Wg, C, _lib.stream_of(dout)), "rtfs_tfar_combine_backward_f32")
+        return dl, dg, de, None
 
 
-def adaptive_avg_pool(x, size):
-    return _AdaptivePoolFn.apply(x, tuple(size))
+class _LayoutFn(torch.autograd.Function):
+    """(B, C, *spatial) <-> rows (B, *spatial, C) on the tiled transpose kernel; the backward is the opposite change (and hands
+    autograd a contiguous gradient, which a permuted view would not)."""
+
+    @staticmethod
+    def forward(ctx, x, to_rows):
+        lib = _lib.load()
+        x = x.contiguous()
+        if to_rows:
+            B, C, sp = x.shape[0], x.shape[1], tuple(x.shape[2:])
+            y = torch.empty((B,) + sp + (C,), device=x.device, dtype=torch.float32)
+        else:
+            B, C, sp = x.shape[0], x.shape[-1], tuple(x.shape[1:-1])
+            y = torch.empty((B, C) + sp, device=x.device, dtype=torch.float32)
+        P = 1
+        for d in sp:
+            P *= d
+        _lib.check(lib.rtfs_layout_f32(_lib.ptr(x), _lib.ptr(y), B, C, P, int(to_rows), _lib.stream_of(x)), "rtfs_layout_f32")
+        ctx.to_rows = to_rows
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return _LayoutFn.apply(dy, not ctx.to_rows), None
+
+
+def adaptive_avg_pool(x, size, rows=False):
+    return _AdaptivePoolFn.apply(x, tuple(size), rows)
 
 
 
@@ -726,11 +772,17 @@ class InjectionMultiSum(PackedModule):
         self.global_embedding = mk()
         self.global_gate = mk("Sigmoid")
 
-    def _forward_train(self, loc, glo):
+    def _forward_train(self, loc, glo, rows=False):
         """Inside a training step: the three ConvNormActs on their training kernels + the combine kernel.  When the global map is
-        not smaller than the local one the reference interpolates first (an identity at equal sizes, the only such case on the path)."""
-        if tuple(loc.shape[2:]) != tuple(glo.shape[2:]) and all(a <= b for a, b in zip(loc.shape[2:], glo.shape[2:])):
+        not smaller than the local one the reference interpolates first (an identity at equal sizes, the only such case on the path).
+        rows: inputs and output are (B, H, W, C) rows."""
+        sl, sg = (loc.shape[1:-1], glo.shape[1:-1]) if rows else (loc.shape[2:], glo.shape[2:])
+        if tuple(sl) != tuple(sg) and all(a <= b for a, b in zip(sl, sg)):
             raise RuntimeError("InjectionMultiSum: a global map larger than the local one does not occur on the RTFS path")
+        if rows:
+            r = (True, True)
+            return _TfarCombineFn.apply(self.local_embedding._forward_train(loc, r), self.global_gate._forward_train(glo, r),
+                                        self.global_embedding._forward_train(glo, r), True)
         return _TfarCombineFn.apply(self.local_embedding(loc), self.global_gate(glo), self.global_embedding(glo))
 
     def forward(self, local_features, global_features):

@@ -8,6 +8,8 @@ arithmetic runs in ``librtfs_amd.so``.
 """
 from __future__ import annotations
 
+import os
+
 import ctypes
 import sys
 
@@ -278,10 +280,40 @@ class TDANetBlock(PackedModule):
         _lib.check(lib.rtfs_vp_block_f32(_lib.ptr(x), _lib.ptr(pk), _lib.ptr(out), B, Tv, _lib.stream_of(x)), "rtfs_vp_block_f32")
         return out
 
+    def _forward_train_rows(self, x, x_res=None):
+        """The audio block inside a training step with rows (B, T, F, C) between its modules: the same composition as _forward_train,
+        but only the block's input and output change layout (every module converting at its own boundary costs 10 % of a step)."""
+        from . import layers as L
+        if x_res is not None:
+            x = x + x_res
+        rr = (True, True)
+        residual = self.gateway._forward_train(x, (False, True))
+        x_enc = self.projection._forward_train(residual, rr)
+        down = [self.downsample_layers[0]._forward_train(x_enc, rr)]
+        for i in range(1, self.upsampling_depth):
+            down.append(self.downsample_layers[i]._forward_train(down[-1], rr))
+        size = down[-1].shape[1:3]
+        g = down[-1] + sum(L.adaptive_avg_pool(f, size, True) for f in down[:-1])
+        for m in self.globalatt:
+            if isinstance(m, L.DualPathRNN):
+                sru = [p for cell in m.rnn.rnn_lst for p in (cell.weight, cell.weight_c, cell.bias)]
+                g = L._DualPathTrainFn.apply(g, m.dim + 10, m.norm.gamma, m.norm.beta, *sru, m.linear.weight, m.linear.bias)
+            else:
+                names, params = zip(*m.named_parameters())
+                g = L._AttentionTrainFn.apply(g, names, True, *params)
+        fused = [self.fusion_layers[i]._forward_train(down[i], g, True) for i in range(self.upsampling_depth)]
+        expanded = self.concat_layers[-1]._forward_train(fused[-2], fused[-1], True) + down[-2]
+        for i in range(self.upsampling_depth - 3, -1, -1):
+            expanded = self.concat_layers[i]._forward_train(fused[i], expanded, True) + down[i]
+        out = self.residual_conv._forward_train(expanded, rr) + residual
+        return L._LayoutFn.apply(out, False)
+
     def _forward_train(self, x, x_res=None):
         """The block inside a training step (reference separators/tdanet.py:104-131, line by line): every module runs its HIP
         forward-with-saved-state and hands autograd its HIP backward; tensor additions are the only torch ops."""
         from . import layers as L
+        if self._hip and self.rnn_kind == 0 and not os.environ.get("RTFS_TRAIN_CF"):
+            return self._forward_train_rows(x, x_res)
         if x_res is not None:
             x = x + x_res
         residual = self.gateway(x)

@@ -16,6 +16,7 @@ def main():
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--repeats", type=int, default=4)
     ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--seconds", type=float, default=2.0)
     ap.add_argument("--full", action="store_true", help="train everything (VP block with dropout, BatchNorm on batch statistics) instead of "
                     "the fine-tuning configuration (frozen BatchNorm statistics and VP block)")
     a = ap.parse_args()
@@ -29,8 +30,9 @@ def main():
     opt = torch.optim.AdamW([p for p in m.parameters() if p.requires_grad], lr=1e-3)
     system = R.System(audio_model=m, loss_func={"train": loss_mod, "val": loss_mod}, optimizer=opt)
     g = torch.Generator().manual_seed(1234)
-    s1, s2 = 0.05 * torch.randn(a.batch, 32000, generator=g), 0.05 * torch.randn(a.batch, 32000, generator=g)
-    wav, tgt, emb = (s1 + s2).cuda(), s1.cuda(), torch.randn(a.batch, 512, 50, generator=g).cuda()
+    L = int(16000 * a.seconds)
+    s1, s2 = 0.05 * torch.randn(a.batch, L, generator=g), 0.05 * torch.randn(a.batch, L, generator=g)
+    wav, tgt, emb = (s1 + s2).cuda(), s1.cuda(), torch.randn(a.batch, 512, int(25 * a.seconds), generator=g).cuda()
     batch = (wav, tgt, emb, None)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     losses = []
@@ -42,7 +44,7 @@ def main():
     ev[1].record()
     torch.cuda.synchronize()
     ms = ev[0].elapsed_time(ev[1]) / a.iters
-    print(f"RTFS-Net-{a.repeats} {'full' if a.full else 'fine-tune'} training step, batch {a.batch} x 2 s: {ms:.1f} ms/step = {a.batch / ms * 1e3:.1f} mixtures/s trained; "
+    print(f"RTFS-Net-{a.repeats} {'full' if a.full else 'fine-tune'} training step, batch {a.batch} x {a.seconds:g} s: {ms:.1f} ms/step = {a.batch / ms * 1e3:.1f} mixtures/s trained; "
           f"peak memory {torch.cuda.max_memory_allocated() / 2**30:.2f} GiB; loss {losses[0]:.3f} -> {losses[-1]:.3f}")
 
 
