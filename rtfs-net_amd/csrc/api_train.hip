@@ -677,7 +677,7 @@ size_t rtfs_tf_attention_saved_floats(int B, int T) { return AttSaved(nullptr, A
 size_t rtfs_tf_attention_train_workspace_bytes(int B, int T) {
     AttGeom g(B, T);
     // backward is the larger: d rows (64), dZ2/dratt (64), dY/dZ (128 x 2), dO (v), dVp (v), dP (sc), Kt (qk), dQp, dKp (qk x 2)
-    return (g.R * (64 + 64 + 64 + 128 + 128) + 2 * g.v + g.sc + 3 * g.qk) * sizeof(float) + 16 * 256;
+    return (g.R * (64 + 64 + 64 + 128 + 128) + 2 * g.v + g.sc + 3 * g.qk + att_lng_scratch_floats(B * T)) * sizeof(float) + 16 * 256;
 }
 
 // rows != 0: x / out (and their gradients) are rows (B, T, 64 f, 64 c) instead of (B, 64, T, 64); the rows input is then used in place
@@ -741,6 +741,7 @@ int rtfs_tf_attention_backward_f32(const float* x, const float* tpack, const flo
     float* Kt = ar.take<float>(g.qk);
     float* dQp = ar.take<float>(g.qk);
     float* dKp = ar.take<float>(g.qk);
+    float* lng_scratch = ar.take<float>(att_lng_scratch_floats(B * T));
     RTFS_RETURN_IF(!ar.ok(), RTFS_ERR_WORKSPACE);
     hipStream_t st = S(stream);
     const int R = (int)g.R;
@@ -756,7 +757,7 @@ int rtfs_tf_attention_backward_f32(const float* x, const float* tpack, const flo
     LngArgs b;
     att_groups(b, false);
     b.Z = sv.Z2; b.stats = sv.st2; b.slope = tpack + AT_SLP; b.gamma = tpack + AT_GP; b.beta = tpack + AT_BEP; b.dY = drow; b.dZ = dZ2;
-    b.dgamma = dparams + AG_GP; b.dbeta = dparams + AG_BEP; b.dslope = dparams + AG_SLP;
+    b.dgamma = dparams + AG_GP; b.dbeta = dparams + AG_BEP; b.dslope = dparams + AG_SLP; b.scratch = lng_scratch;
     CHECK(launch_att_lng(b, B * T, true, st));
     CHECK(launch_cl_colsum(dZ2, dparams + AG_BP, g.R * 64, 64, st));
     CHECK(launch_gemm_tn(dZ2, 64, sv.ratt, 64, dparams + AG_WP, 64, 64, 64, (long)R, st));
@@ -777,7 +778,7 @@ int rtfs_tf_attention_backward_f32(const float* x, const float* tpack, const flo
     LngArgs a;
     att_groups(a, true);
     a.Z = sv.Z; a.stats = sv.st; a.slope = tpack + AT_SL; a.gamma = tpack + AT_G; a.beta = tpack + AT_BE; a.dY = dY; a.dZ = dZ;
-    a.dgamma = dparams + AG_G; a.dbeta = dparams + AG_BE; a.dslope = dparams + AG_SL;
+    a.dgamma = dparams + AG_G; a.dbeta = dparams + AG_BE; a.dslope = dparams + AG_SL; a.scratch = lng_scratch;
     CHECK(launch_att_lng(a, B * T, true, st));
     CHECK(launch_cl_colsum(dZ, dparams + AG_B, g.R * 128, 128, st));
     CHECK(launch_gemm_tn(dZ, 128, r0, 64, dparams + AG_W, 64, 128, 64, (long)R, st));

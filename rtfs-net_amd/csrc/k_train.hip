@@ -970,7 +970,7 @@ int launch_cl_dw(const ClDwArgs& a0, int what, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------------ TF attention, training side
-#define LNG_BT 8  // (b,t) slices per workgroup of the LNG backward
+#define LNG_BT 1  // (b,t) slices per workgroup of the LNG backward
 // MultiHeadSelfAttention2D (attention.py:149-189) on channel-last rows (b, t, f) x CZ.  "LNG" = the tail of a ConvActNorm
 // (conv_layers.py:201-205): PReLU, then LayerNormalization4D((C_out, F)) = statistics over (channels of the module, F) per (b, t)
 // with a (C_out, F) affine (normalizations.py:26,33-37).  The twelve Q/K/V modules are evaluated side by side: their channels are
@@ -1091,13 +1091,27 @@ __global__ __launch_bounds__(256) void att_lng_bwd_kernel(LngArgs a) {
         if (k < per) {
             const int idx = tid + 256 * k;
             const int f = idx / CZ, c = idx - f * CZ;
-            if (a.gof[c] < 16) {
-                unsafeAtomicAdd(a.dgamma + c * 64 + f, acc_g[k]);
-                unsafeAtomicAdd(a.dbeta + c * 64 + f, acc_b[k]);
-            }
+            // per-workgroup partial sums; att_lng_reduce_kernel adds them up (atomics from every workgroup onto the (C, F) affine's
+            // 2 x 8192 addresses serialise: 346 -> 60 us)
+            float* sc = a.scratch + (size_t)blockIdx.x * 2 * CZ * 64;
+            sc[c * 64 + f] = a.gof[c] < 16 ? acc_g[k] : 0.f;
+            sc[CZ * 64 + c * 64 + f] = a.gof[c] < 16 ? acc_b[k] : 0.f;
         }
     }
     if (tid < a.ngroups && gsl[tid] != 0.f) unsafeAtomicAdd(a.dslope + tid, gsl[tid]);
+}
+
+__global__ __launch_bounds__(256) void att_lng_reduce_kernel(const float* __restrict__ scratch, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                             int nwg, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;  // element of the (CZ, 64) affine
+    if (i >= n) return;
+    float g = 0.f, b = 0.f;
+    for (int w = blockIdx.y; w < nwg; w += gridDim.y) {
+        g += scratch[(size_t)w * 2 * n + i];
+        b += scratch[(size_t)w * 2 * n + n + i];
+    }
+    unsafeAtomicAdd(dgamma + i, g);
+    unsafeAtomicAdd(dbeta + i, b);
 }
 
 // Y rows (b,t,f) x 128 <-> Qp, Kp (4B, Tp, 256 = f*4 + e), Vp (4B, Tp, 1024 = f*16 + c); head-major batch index h*B + b
@@ -1179,6 +1193,7 @@ __global__ __launch_bounds__(256) void att_softmax_kernel(float* __restrict__ S,
     }
 }
 
+size_t att_lng_scratch_floats(int nbt) { return (size_t)cdiv(nbt, LNG_BT) * 2 * 128 * 64; }
 int launch_att_lng(const LngArgs& a, int nbt, bool bwd, hipStream_t st) {
     if (a.CZ != 64 && a.CZ != 128) return RTFS_ERR_SHAPE;
     const size_t lds = (size_t)(bwd ? 2 : 1) * 64 * (a.CZ + 1) * sizeof(float);
@@ -1187,7 +1202,11 @@ int launch_att_lng(const LngArgs& a, int nbt, bool bwd, hipStream_t st) {
     if (bwd) {
         LngArgs b = a;
         b.nbt = nbt;
-        hipLaunchKernelGGL(att_lng_bwd_kernel, dim3(cdiv(nbt, LNG_BT)), dim3(256), lds, st, b);
+        if (!b.scratch) return RTFS_ERR_WORKSPACE;
+        const int nwg = cdiv(nbt, LNG_BT);
+        hipLaunchKernelGGL(att_lng_bwd_kernel, dim3(nwg), dim3(256), lds, st, b);
+        hipLaunchKernelGGL(att_lng_reduce_kernel, dim3(cdiv(a.CZ * 64, 256), nwg >= 16 ? 16 : nwg), dim3(256), 0, st, b.scratch, a.dgamma, a.dbeta, nwg,
+                           a.CZ * 64);
     }
     else hipLaunchKernelGGL(att_lng_fwd_kernel, dim3(nbt), dim3(256), lds, st, a);
     return rtfs_launch_status();

@@ -305,6 +305,7 @@ struct LngArgs {  // PReLU + LayerNormalization4D((C_group, 64)) over rows (b,t,
     const float* dY = nullptr;     // backward
     float* dZ = nullptr;
     float *dgamma = nullptr, *dbeta = nullptr, *dslope = nullptr;      // (CZ,64), (CZ,64), (ngroups)
+    float* scratch = nullptr;      // backward: (workgroups, 2, CZ*64) partial sums of dgamma | dbeta
     int CZ = 0, ngroups = 0, nbt = 0;
     int gstart[17] = {0};
     unsigned char gof[128] = {0};  // channel -> group, 255 = padding channel
@@ -344,3 +345,4 @@ struct LstmScanArgs {
 int launch_lstm_scan(const LstmScanArgs& a, bool bwd, hipStream_t st);
 int launch_rows_bias_res(const float* y, const float* bias, const float* x, float* out, size_t n, int C, hipStream_t st);
 int launch_rows_permute(const float* x, float* y, int B, int H, int W, int C, hipStream_t st);
+size_t att_lng_scratch_floats(int nbt);
