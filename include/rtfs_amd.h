@@ -177,6 +177,21 @@ int rtfs_dualpath_lstm_forward_train_f32(const float* x, const float* tpack, flo
                                          void* ws, size_t ws_bytes, void* stream);
 int rtfs_dualpath_lstm_backward_f32(const float* x, const float* tpack, const float* saved, const float* dout, float* dx,
                                     float* dparams, int B, int T, int F, int dim, void* ws, size_t ws_bytes, void* stream);
+/* The same module with rnn_type GRU (rnn_layers.py:116-122: nn.GRU(512, 32, 4 layers, bidirectional); gates r, z, n).  There is no fused
+ * inference kernel for this cell (no reference yaml uses it in a DualPathRNN): the forward below also serves inference.
+ * tpack (rtfs_dualpath_gru_train_pack_floats(), packing.py:pack_dualpath_gru_train): LN gamma | beta | per layer [W_ih both directions
+ *   (192, Din), rows dir*96 + gate*32 + j, layer-0 columns in k*64 + c order | its transpose | b_ih (192) | W_hh (2,96,32) | b_hh (192)] |
+ *   ConvTranspose1d weight as (co, (7-k)*64 + ci) | as (ci, k*64 + co) | bias.
+ * dparams (rtfs_dualpath_gru_grad_floats(), overwritten): dgamma | dbeta | per layer [dW_ih | db_ih | dW_hh | db_hh] | d ConvTranspose1d
+ *   weight ((7-k)*64 + ci, co) | d bias. */
+size_t rtfs_dualpath_gru_train_pack_floats(void);
+size_t rtfs_dualpath_gru_grad_floats(void);
+size_t rtfs_dualpath_gru_saved_floats(int B, int T, int F, int dim);
+size_t rtfs_dualpath_gru_train_workspace_bytes(int B, int T, int F, int dim);
+int rtfs_dualpath_gru_forward_train_f32(const float* x, const float* tpack, float* out, float* saved, int B, int T, int F, int dim,
+                                        void* ws, size_t ws_bytes, void* stream);
+int rtfs_dualpath_gru_backward_f32(const float* x, const float* tpack, const float* saved, const float* dout, float* dx, float* dparams,
+                                   int B, int T, int F, int dim, void* ws, size_t ws_bytes, void* stream);
 /* ConvNormAct.forward / backward for training (src/models/layers/conv_layers.py:65-129: pre_norm -> pre_act -> conv -> norm -> act),
  * 1x1 dense (channels up to 1024) or depthwise k x k (taps up to 4 x 5, stride 1 "same" or stride 2 symmetric), norms: none | gLN |
  * BatchNorm (post-norm only; frozen running statistics, or train mode = statistics of the batch), acts: none | ReLU | PReLU | Sigmoid.

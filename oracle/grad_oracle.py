@@ -372,8 +372,9 @@ def vp_block_torch(v, p, depth=4, bn_train=False):
 
 
 def dualpath_lstm_torch(x, p, dim, kernel_size=8):
-    """DualPathRNN.forward with rnn_type LSTM (reference rnn_layers.py:116-122,136-162): the cell is stock
-    torch.nn.LSTM(512, 32, 4 layers, bidirectional), so this function is the reference's own arithmetic - forward and backward."""
+    """DualPathRNN.forward with rnn_type LSTM or GRU (reference rnn_layers.py:116-122,136-162): the cell is stock
+    torch.nn.LSTM / nn.GRU (512, 32, 4 layers, bidirectional; told apart by the 128 / 96 rows of weight_hh), so this function is the
+    reference's own arithmetic - forward and backward."""
     if dim == 4:
         x = x.permute(0, 1, 3, 2)
     B, C, nT, nF = x.shape
@@ -387,7 +388,10 @@ def dualpath_lstm_torch(x, p, dim, kernel_size=8):
     names = [k for k in p if k.startswith("rnn.")]
     flat = [p[f"rnn.{n}_l{l}{suf}"] for l in range(4) for suf in ("", "_reverse") for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
     assert len(flat) == len(names)
-    h = torch._VF.lstm(unf, (unf.new_zeros(8, B * nF, 32), unf.new_zeros(8, B * nF, 32)), flat, True, 4, 0.0, False, True, False)[0]
+    if p["rnn.weight_hh_l0"].shape[0] == 128:
+        h = torch._VF.lstm(unf, (unf.new_zeros(8, B * nF, 32), unf.new_zeros(8, B * nF, 32)), flat, True, 4, 0.0, False, True, False)[0]
+    else:
+        h = torch._VF.gru(unf, unf.new_zeros(8, B * nF, 32), flat, True, 4, 0.0, False, True, False)[0]
     y = torch.nn.functional.conv_transpose1d(h.permute(1, 2, 0), p["linear.weight"], p["linear.bias"])
     y = y.reshape(B, nF, C, nT).permute(0, 2, 3, 1) + res
     if dim == 4:

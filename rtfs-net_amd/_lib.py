@@ -65,6 +65,12 @@ SIGNATURES = {
     "rtfs_dualpath_lstm_train_workspace_bytes": (_z, [_i, _i, _i, _i]),
     "rtfs_dualpath_lstm_forward_train_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _z, _p]),
     "rtfs_dualpath_lstm_backward_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _z, _p]),
+    "rtfs_dualpath_gru_train_pack_floats": (_z, []),
+    "rtfs_dualpath_gru_grad_floats": (_z, []),
+    "rtfs_dualpath_gru_saved_floats": (_z, [_i, _i, _i, _i]),
+    "rtfs_dualpath_gru_train_workspace_bytes": (_z, [_i, _i, _i, _i]),
+    "rtfs_dualpath_gru_forward_train_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _z, _p]),
+    "rtfs_dualpath_gru_backward_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _z, _p]),
     "rtfs_cna_param_floats": (_z, [_p]),
     "rtfs_cna_grad_floats": (_z, [_p]),
     "rtfs_cna_saved_floats": (_z, [_p, _i, _i, _i]),

@@ -398,6 +398,161 @@ int rtfs_dualpath_lstm_backward_f32(const float* x, const float* tpack, const fl
     return RTFS_OK;
 }
 
+// ------------------------------------------------------------ DualPathRNN with the GRU cell (forward with saved state + backward)
+namespace {
+struct GruLayout {
+    size_t wih[4], wiht[4], bih[4], whh[4], bhh[4], wcf, wcb, bt, end;   // pack
+    size_t g_wih[4], g_bih[4], g_whh[4], g_bhh[4], g_wct, g_bt, g_end;   // gradients
+    GruLayout() {
+        size_t o = 128;
+        for (int l = 0; l < 4; ++l) {
+            const size_t din = l == 0 ? 512 : 64;
+            wih[l] = o; o += 192 * din;
+            wiht[l] = o; o += din * 192;
+            bih[l] = o; o += 192;
+            whh[l] = o; o += 2 * 96 * 32;
+            bhh[l] = o; o += 192;
+        }
+        wcf = o; o += 64 * 512; wcb = o; o += 64 * 512; bt = o; o += 64; end = o;
+        o = 128;
+        for (int l = 0; l < 4; ++l) {
+            const size_t din = l == 0 ? 512 : 64;
+            g_wih[l] = o; o += 192 * din;
+            g_bih[l] = o; o += 192;
+            g_whh[l] = o; o += 2 * 96 * 32;
+            g_bhh[l] = o; o += 192;
+        }
+        g_wct = o; o += 512 * 64; g_bt = o; o += 64; g_end = o;
+    }
+};
+struct GruSaved {
+    float *xn, *Sg[4], *hpad[4], *hprev[4];
+    size_t floats;
+    GruSaved(float* p, size_t rows) {
+        float* p0 = p;
+        xn = p; p += (rows + 8) * 64;
+        for (int l = 0; l < 4; ++l) { Sg[l] = p; p += rows * 256; }
+        for (int l = 0; l < 4; ++l) { hpad[l] = p; p += (rows + 8) * 64; }
+        for (int l = 0; l < 4; ++l) { hprev[l] = p; p += rows * 64; }
+        floats = (size_t)(p - p0);
+    }
+};
+}  // namespace
+
+size_t rtfs_dualpath_gru_train_pack_floats(void) { return GruLayout().end; }
+size_t rtfs_dualpath_gru_grad_floats(void) { return GruLayout().g_end; }
+size_t rtfs_dualpath_gru_saved_floats(int B, int T, int F, int dim) {
+    DpGeom g(B, T, F, dim);
+    return GruSaved(nullptr, g.rows).floats;
+}
+size_t rtfs_dualpath_gru_train_workspace_bytes(int B, int T, int F, int dim) {
+    DpGeom g(B, T, F, dim);
+    return rtfs_dualpath_train_workspace_bytes(B, T, F, dim) + (g.rows * 2 * 192 + 192 * 64) * sizeof(float) + 4 * 256;
+}
+
+int rtfs_dualpath_gru_forward_train_f32(const float* x, const float* tpack, float* out, float* saved, int B, int T, int F, int dim, void* ws,
+                                        size_t ws_bytes, void* stream) {
+    RTFS_RETURN_IF(!x || !tpack || !out || !saved || B < 1 || (dim != 3 && dim != 4), RTFS_ERR_ARG);
+    DpGeom g(B, T, F, dim);
+    RTFS_RETURN_IF(!g.ok(), RTFS_ERR_SHAPE);
+    RTFS_RETURN_IF(!ws || ws_bytes < rtfs_dualpath_gru_train_workspace_bytes(B, T, F, dim), RTFS_ERR_WORKSPACE);
+    Arena ar(ws, ws_bytes);
+    float* xt = ar.take<float>(g.elems);
+    float* ot = ar.take<float>(g.elems);
+    float* y = ar.take<float>(g.rows * 64);
+    float* U = ar.take<float>(g.rows * 192);
+    RTFS_RETURN_IF(!ar.ok(), RTFS_ERR_WORKSPACE);
+    GruSaved sv(saved, g.rows);
+    GruLayout lo;
+    hipStream_t st = S(stream);
+    const int M = (int)g.rows;
+    const float* src = x;
+    if (dim == 3) {
+        CHECK(launch_transpose(x, xt, B * CH, T, F, st));
+        src = xt;
+    }
+    if (hipMemsetAsync(sv.xn + g.rows * 64, 0, 8 * 64 * sizeof(float), st) != hipSuccess) return RTFS_ERR_LAUNCH;
+    for (int l = 0; l < 4; ++l) {
+        if (hipMemsetAsync(sv.hpad[l] + g.rows * 64, 0, 8 * 64 * sizeof(float), st) != hipSuccess) return RTFS_ERR_LAUNCH;
+        if (hipMemsetAsync(sv.hprev[l], 0, g.rows * 64 * sizeof(float), st) != hipSuccess) return RTFS_ERR_LAUNCH;
+    }
+    CHECK(launch_dp_ln_fwd(src, tpack + DT_G, tpack + DT_B, sv.xn, g.nseq, g.R, g.Ls, st));
+    for (int l = 0; l < 4; ++l) {
+        const float* xin = l == 0 ? sv.xn : sv.hpad[l - 1] + 7 * 64;
+        const int K = l == 0 ? 512 : 64;
+        CHECK(launch_gemm_nt(xin, 64, tpack + lo.wih[l], K, U, 192, M, 192, K, 0, st, tpack + lo.bih[l]));
+        GruScanArgs a;
+        a.U = U; a.whh = tpack + lo.whh[l]; a.bhh = tpack + lo.bhh[l]; a.S = sv.Sg[l]; a.h = sv.hpad[l] + 7 * 64; a.hprev = sv.hprev[l];
+        a.L = g.L; a.N = g.nseq; a.ts = 1; a.ns = g.Ls; a.pad = 1;
+        CHECK(launch_gru_scan(a, false, st));
+    }
+    CHECK(launch_gemm_nt(sv.hpad[3], 64, tpack + lo.wcf, 512, y, 64, M, 64, 512, 0, st));
+    CHECK(launch_dp_out(y, tpack + lo.bt, src, dim == 4 ? out : ot, g.nseq, g.R, g.Ls, st));
+    if (dim == 3) CHECK(launch_transpose(ot, out, B * CH, F, T, st));
+    return RTFS_OK;
+}
+
+int rtfs_dualpath_gru_backward_f32(const float* x, const float* tpack, const float* saved, const float* dout, float* dx, float* dparams,
+                                   int B, int T, int F, int dim, void* ws, size_t ws_bytes, void* stream) {
+    RTFS_RETURN_IF(!x || !tpack || !saved || !dout || !dx || !dparams || B < 1 || (dim != 3 && dim != 4), RTFS_ERR_ARG);
+    DpGeom g(B, T, F, dim);
+    RTFS_RETURN_IF(!g.ok(), RTFS_ERR_SHAPE);
+    RTFS_RETURN_IF(!ws || ws_bytes < rtfs_dualpath_gru_train_workspace_bytes(B, T, F, dim), RTFS_ERR_WORKSPACE);
+    Arena ar(ws, ws_bytes);
+    float* xt = ar.take<float>(g.elems);
+    float* dt = ar.take<float>(g.elems);
+    float* dxt = ar.take<float>(g.elems);
+    float* dy = ar.take<float>((g.rows + 8) * 64);
+    float* dxn = ar.take<float>((g.rows + 8) * 64);
+    float* dU = ar.take<float>(g.rows * 192);
+    float* dHR = ar.take<float>(g.rows * 192);
+    float* gbuf[2] = {ar.take<float>(g.rows * 64), ar.take<float>(g.rows * 64)};
+    float* whh64 = ar.take<float>(192 * 64);
+    RTFS_RETURN_IF(!ar.ok(), RTFS_ERR_WORKSPACE);
+    GruSaved sv(const_cast<float*>(saved), g.rows);
+    GruLayout lo;
+    hipStream_t st = S(stream);
+    const int M = (int)g.rows;
+    const float *srcx = x, *srcd = dout;
+    if (dim == 3) {
+        CHECK(launch_transpose(x, xt, B * CH, T, F, st));
+        CHECK(launch_transpose(dout, dt, B * CH, T, F, st));
+        srcx = xt;
+        srcd = dt;
+    }
+    if (hipMemsetAsync(dparams, 0, lo.g_end * sizeof(float), st) != hipSuccess) return RTFS_ERR_LAUNCH;
+    if (hipMemsetAsync(dy + g.rows * 64, 0, 8 * 64 * sizeof(float), st) != hipSuccess) return RTFS_ERR_LAUNCH;
+    if (hipMemsetAsync(dxn, 0, (g.rows + 8) * 64 * sizeof(float), st) != hipSuccess) return RTFS_ERR_LAUNCH;
+    CHECK(launch_dp_dy(srcd, dy, dparams + lo.g_bt, g.nseq, g.R, g.Ls, st));
+    CHECK(launch_gemm_tn(sv.hpad[3], 64, dy, 64, dparams + lo.g_wct, 64, 512, 64, (long)M, st));
+    CHECK(launch_gemm_nt(dy, 64, tpack + lo.wcb, 512, gbuf[0], 64, M, 64, 512, 0, st));
+    const float* gcur = gbuf[0];
+    for (int l = 3; l >= 0; --l) {
+        const int K = l == 0 ? 512 : 64;
+        const float* xin = l == 0 ? sv.xn : sv.hpad[l - 1] + 7 * 64;
+        float* gnext = gcur == gbuf[0] ? gbuf[1] : gbuf[0];
+        GruScanArgs a;
+        a.whh = tpack + lo.whh[l]; a.bhh = tpack + lo.bhh[l]; a.S = sv.Sg[l]; a.hprev = sv.hprev[l]; a.g = gcur; a.dU = dU; a.dHR = dHR;
+        a.L = g.L; a.N = g.nseq; a.ts = 1; a.ns = g.Ls; a.pad = 1;
+        CHECK(launch_gru_scan(a, true, st));
+        CHECK(launch_cl_colsum(dU, dparams + lo.g_bih[l], g.rows * 192, 192, st));
+        CHECK(launch_cl_colsum(dHR, dparams + lo.g_bhh[l], g.rows * 192, 192, st));
+        if (hipMemsetAsync(whh64, 0, 192 * 64 * sizeof(float), st) != hipSuccess) return RTFS_ERR_LAUNCH;
+        CHECK(launch_gemm_tn(dHR, 192, sv.hprev[l], 64, whh64, 64, 192, 64, (long)M, st));
+        for (int d = 0; d < 2; ++d)
+            if (hipMemcpy2DAsync(dparams + lo.g_whh[l] + (size_t)d * 96 * 32, 32 * sizeof(float), whh64 + (size_t)d * 96 * 64 + d * 32,
+                                 64 * sizeof(float), 32 * sizeof(float), 96, hipMemcpyDeviceToDevice, st) != hipSuccess)
+                return RTFS_ERR_LAUNCH;
+        if (l == 0) CHECK(launch_gemm_nt(dU, 192, tpack + lo.wiht[l], 192, dxn, 64, M, 512, 192, 2, st));
+        else CHECK(launch_gemm_nt(dU, 192, tpack + lo.wiht[l], 192, gnext, 64, M, 64, 192, 0, st));
+        CHECK(launch_gemm_tn(dU, 192, xin, 64, dparams + lo.g_wih[l], K, 192, K, (long)M, st));
+        gcur = gnext;
+    }
+    CHECK(launch_dp_ln_bwd(srcx, dxn, srcd, tpack + DT_G, dim == 4 ? dx : dxt, dparams + DG_G, dparams + DG_B, g.nseq, g.R, g.Ls, st));
+    if (dim == 3) CHECK(launch_transpose(dxt, dx, B * CH, F, T, st));
+    return RTFS_OK;
+}
+
 // ------------------------------------------------------------ ConvNormAct, training side (channel-last rows inside)
 namespace {
 struct CnaCfg {

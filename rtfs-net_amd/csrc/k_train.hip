@@ -1866,3 +1866,120 @@ int launch_rows_permute(const float* x, float* y, int B, int H, int W, int C, hi
     hipLaunchKernelGGL(rows_permute_kernel, dim3(grid_for((size_t)B * H * W * C)), dim3(256), 0, st, x, y, B, H, W, C);
     return rtfs_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------------ GRU cell (forward with saved state + backward)
+// nn.GRU(512, 32, 4 layers, bidirectional): DualPathRNN's third cell (rnn_layers.py:116-122, rnn_type "GRU"); gates r, z, n:
+//   r = s(U_r + hr_r), z = s(U_z + hr_z), n = tanh(U_n + r * hr_n), h' = (1 - z) n + z h,   hr = W_hh h + b_hh,  U = W_ih x + b_ih.
+// U comes from the GEMM as rows x 192 (column dir*96 + gate*32 + j).  One wave per (sequence, direction): lane j < 32 owns rows r_j and
+// n_j, lane 32 + j row z_j.  Saved: r, z, n, hr_n as S (rows x 256, column dir*128 + q*32 + j), h (slot layout), h_{t-1}.
+__global__ __launch_bounds__(256) void gru_scan_fwd_kernel(GruScanArgs a) {
+    __shared__ float hs[4][32];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, hi = lane >> 5;
+    const long id = (long)blockIdx.x * 4 + wave;
+    const bool live = id < 2L * a.N;
+    const int n = live ? (int)(id >> 1) : 0, dir = (int)(id & 1);
+    const int r0 = hi ? 32 + j : j, r1 = 64 + j;  // r|z row, n row (lanes < 32 only)
+    float w0[32], w1[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+        w0[k] = a.whh[((size_t)dir * 96 + r0) * 32 + k];
+        w1[k] = a.whh[((size_t)dir * 96 + r1) * 32 + k];
+    }
+    const float b0 = a.bhh[dir * 96 + r0], b1 = a.bhh[dir * 96 + r1];
+    const size_t nb = (size_t)n * a.ns;
+    float h = 0.f;
+    if (lane < 32) hs[wave][j] = 0.f;
+    __syncthreads();
+    for (int s = 0; s < a.L; ++s) {
+        const int t = dir ? a.L - 1 - s : s;
+        const size_t row = (size_t)t * a.ts + nb;
+        float z0 = b0, z1 = b1;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            const float hk = hs[wave][k];
+            z0 = fmaf(w0[k], hk, z0);
+            z1 = fmaf(w1[k], hk, z1);
+        }
+        const float u0 = live ? a.U[row * 192 + dir * 96 + r0] : 0.f;
+        const float un = (live && !hi) ? a.U[row * 192 + dir * 96 + r1] : 0.f;
+        const float g0 = sigmoidf_(u0 + z0);             // r (lanes < 32) or z (lanes >= 32)
+        const float zg = __shfl(g0, j + 32, 64);
+        __syncthreads();  // every lane has read h_{t-1}
+        if (lane < 32) {
+            const float ng = tanhf_(fmaf(g0, z1, un));
+            const float hn = fmaf(1.f - zg, ng, zg * h);
+            if (live) {
+                float* sv = a.S + row * 256 + dir * 128;
+                sv[j] = g0; sv[32 + j] = zg; sv[64 + j] = ng; sv[96 + j] = z1;
+                a.hprev[row * 64 + dir * 32 + j] = h;
+                a.h[row * 64 + dir * 32 + j] = hn;
+            }
+            h = hn;
+            hs[wave][j] = hn;
+        }
+        __syncthreads();
+    }
+    if (a.pad && live && dir == 0)
+        for (int i = 1; i <= 7; ++i) a.h[((long)nb - i) * 64 + lane] = 0.f;
+}
+
+// backward: writes dU (gradient w.r.t. W_ih x + b_ih) and dHR (w.r.t. W_hh h + b_hh), both rows x 192
+__global__ __launch_bounds__(256) void gru_scan_bwd_kernel(GruScanArgs a) {
+    __shared__ float dhr[4][96];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, hi = lane >> 5;
+    const long id = (long)blockIdx.x * 4 + wave;
+    const bool live = id < 2L * a.N;
+    const int n = live ? (int)(id >> 1) : 0, dir = (int)(id & 1);
+    // W_hh^T: lane (k = j, half hi) holds W_hh[hi*48 + r][k] for r = 0..47
+    float wt[48];
+#pragma unroll
+    for (int r = 0; r < 48; ++r) wt[r] = a.whh[((size_t)dir * 96 + hi * 48 + r) * 32 + j];
+    const size_t nb = (size_t)n * a.ns;
+    float dh_rec = 0.f;
+    for (int s = a.L - 1; s >= 0; --s) {
+        const int t = dir ? a.L - 1 - s : s;
+        const size_t row = (size_t)t * a.ts + nb;
+        if (lane < 32) {
+            float d_r = 0.f, d_z = 0.f, d_n = 0.f, d_hn = 0.f;
+            if (live) {
+                const float* sv = a.S + row * 256 + dir * 128;
+                const float rg = sv[j], zg = sv[32 + j], ng = sv[64 + j], hrn = sv[96 + j];
+                const float hp = a.hprev[row * 64 + dir * 32 + j];
+                const float dh = a.g[row * 64 + dir * 32 + j] + dh_rec;
+                const float dn = dh * (1.f - zg);
+                d_z = dh * (hp - ng) * zg * (1.f - zg);
+                d_n = dn * (1.f - ng * ng);
+                d_r = d_n * hrn * rg * (1.f - rg);
+                d_hn = d_n * rg;
+                dh_rec = dh * zg;  // the direct path; the recurrent-matrix part is added below
+                float* du = a.dU + row * 192 + dir * 96;
+                du[j] = d_r; du[32 + j] = d_z; du[64 + j] = d_n;
+                float* dq = a.dHR + row * 192 + dir * 96;
+                dq[j] = d_r; dq[32 + j] = d_z; dq[64 + j] = d_hn;
+            } else {
+                dh_rec = 0.f;
+            }
+            dhr[wave][j] = d_r; dhr[wave][32 + j] = d_z; dhr[wave][64 + j] = d_hn;
+        }
+        __syncthreads();
+        float acc = 0.f;
+#pragma unroll
+        for (int r = 0; r < 48; ++r) acc = fmaf(wt[r], dhr[wave][hi * 48 + r], acc);
+        acc += __shfl_xor(acc, 32, 64);
+        if (lane < 32) dh_rec += acc;
+        __syncthreads();
+    }
+    if (a.pad && live && dir == 0)
+        for (int i = 0; i < 7; ++i)
+            for (int m = 0; m < 192; m += 64) {
+                a.dU[(nb + a.L + i) * 192 + m + lane] = 0.f;
+                a.dHR[(nb + a.L + i) * 192 + m + lane] = 0.f;
+            }
+}
+
+int launch_gru_scan(const GruScanArgs& a, bool bwd, hipStream_t st) {
+    const long waves = 2L * a.N;
+    if (bwd) hipLaunchKernelGGL(gru_scan_bwd_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(gru_scan_fwd_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, a);
+    return rtfs_launch_status();
+}

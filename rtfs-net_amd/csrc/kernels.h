@@ -346,3 +346,14 @@ int launch_lstm_scan(const LstmScanArgs& a, bool bwd, hipStream_t st);
 int launch_rows_bias_res(const float* y, const float* bias, const float* x, float* out, size_t n, int C, hipStream_t st);
 int launch_rows_permute(const float* x, float* y, int B, int H, int W, int C, hipStream_t st);
 size_t att_lng_scratch_floats(int nbt);
+struct GruScanArgs {
+    const float* U = nullptr;     // forward: (rows, 192) = W_ih x + b_ih, column dir*96 + gate*32 + j (gates r, z, n)
+    const float* whh = nullptr;   // (2, 96, 32)
+    const float* bhh = nullptr;   // (2, 96)
+    float *S = nullptr, *h = nullptr, *hprev = nullptr;  // forward: written; backward: S, hprev read
+    const float* g = nullptr;     // backward: dL/dh (rows, 64)
+    float *dU = nullptr, *dHR = nullptr;  // backward: (rows, 192) each
+    int L = 0, N = 0, pad = 0;
+    long ts = 0, ns = 0;
+};
+int launch_gru_scan(const GruScanArgs& a, bool bwd, hipStream_t st);

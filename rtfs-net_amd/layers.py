@@ -50,10 +50,27 @@ class PackedModule(nn.Module):
             )
 
 
+_FORCE_TRAIN_KERNELS = [False]
+
+
+class force_train_kernels:
+    """Context manager: route every module through its unfused HIP kernels whatever the mode.  Used for configurations that have
+    no fused inference kernel (DualPathRNN with the GRU cell); BatchNorm layers still follow their own train / eval flag."""
+
+    def __enter__(self):
+        self.prev = _FORCE_TRAIN_KERNELS[0]
+        _FORCE_TRAIN_KERNELS[0] = True
+
+    def __exit__(self, *exc):
+        _FORCE_TRAIN_KERNELS[0] = self.prev
+
+
 def _recording(*tensors_and_modules):
     """True when a module call has to take the training kernels: autograd is recording, the module is in train() mode and a
     gradient is wanted (an input or a parameter requires grad).  In eval() mode the inference kernels run and return graph-less
     tensors whatever the grad mode, exactly as before the backward pass existed."""
+    if _FORCE_TRAIN_KERNELS[0]:
+        return True
     if not torch.is_grad_enabled():
         return False
     wanted = False
@@ -361,8 +378,8 @@ class FeedForwardNetwork(nn.Module):
     def forward(self, x):
         if x.is_cuda and _recording(x, self):  # conv_layers.py:252-259 with its two DropPath applications
             p = float(self.dropout)
-            y = _drop_path(self.refiner(self.encoder(x)), p, True)
-            return _drop_path(self.decoder(y), p, True) + x
+            y = _drop_path(self.refiner(self.encoder(x)), p, self.training)
+            return _drop_path(self.decoder(y), p, self.training) + x
         return self.decoder(self.refiner(self.encoder(x))) + x
 
 
@@ -510,25 +527,26 @@ class _DualPathTrainFn(torch.autograd.Function):
 
 
 class _DualPathLstmTrainFn(torch.autograd.Function):
-    """DualPathRNN with the LSTM cell on the training kernels.  Inputs: x, dim, gamma, beta, the 32 nn.LSTM parameters in
-    packing.lstm_param_names() order, ConvTranspose1d weight, bias."""
+    """DualPathRNN with a stock torch cell (kind "lstm" or "gru") on the GEMM + scan kernels.  Inputs: x, dim, kind, gamma, beta, the 32
+    nn.LSTM / nn.GRU parameters in packing.lstm_param_names() order, ConvTranspose1d weight, bias."""
 
     @staticmethod
-    def forward(ctx, x, dim, gamma, beta, *rest):
+    def forward(ctx, x, dim, kind, gamma, beta, *rest):
         lib = _lib.load()
         x = x.contiguous()
         B, _, T, Fq = x.shape
         names = packing.lstm_param_names()
-        lstm, lin_w, lin_b = dict(zip(names, rest[:len(names)])), rest[len(names)], rest[len(names) + 1]
-        tpack = packing.cached_train_pack("dualpath_lstm", (gamma, beta) + tuple(rest),
-                                          lambda: packing.pack_dualpath_lstm_train(gamma, beta, lstm, lin_w, lin_b))
+        cell, lin_w, lin_b = dict(zip(names, rest[:len(names)])), rest[len(names)], rest[len(names) + 1]
+        pack_fn = packing.pack_dualpath_lstm_train if kind == "lstm" else packing.pack_dualpath_gru_train
+        tpack = packing.cached_train_pack("dualpath_" + kind, (gamma, beta) + tuple(rest), lambda: pack_fn(gamma, beta, cell, lin_w, lin_b))
+        fn = lambda n: getattr(lib, f"rtfs_dualpath_{kind}_{n}")
         out = torch.empty_like(x)
-        saved = torch.empty(lib.rtfs_dualpath_lstm_saved_floats(B, T, Fq, dim), device=x.device, dtype=torch.float32)
-        ws = _lib.workspace(lib.rtfs_dualpath_lstm_train_workspace_bytes(B, T, Fq, dim), x.device)
-        _lib.check(lib.rtfs_dualpath_lstm_forward_train_f32(_lib.ptr(x), _lib.ptr(tpack), _lib.ptr(out), _lib.ptr(saved), B, T, Fq, dim,
-                                                            _lib.ptr(ws), ws.numel(), _lib.stream_of(x)), "rtfs_dualpath_lstm_forward_train_f32")
+        saved = torch.empty(fn("saved_floats")(B, T, Fq, dim), device=x.device, dtype=torch.float32)
+        ws = _lib.workspace(fn("train_workspace_bytes")(B, T, Fq, dim), x.device)
+        _lib.check(fn("forward_train_f32")(_lib.ptr(x), _lib.ptr(tpack), _lib.ptr(out), _lib.ptr(saved), B, T, Fq, dim, _lib.ptr(ws), ws.numel(),
+                                           _lib.stream_of(x)), f"rtfs_dualpath_{kind}_forward_train_f32")
         ctx.save_for_backward(x, tpack, saved)
-        ctx.dim, ctx.shapes, ctx.names = dim, (gamma.shape, beta.shape), names
+        ctx.dim, ctx.shapes, ctx.names, ctx.kind = dim, (gamma.shape, beta.shape), names, kind
         return out
 
     @staticmethod
@@ -536,14 +554,17 @@ class _DualPathLstmTrainFn(torch.autograd.Function):
         lib = _lib.load()
         x, tpack, saved = ctx.saved_tensors
         B, _, T, Fq = x.shape
+        kind = ctx.kind
+        fn = lambda n: getattr(lib, f"rtfs_dualpath_{kind}_{n}")
         dout = dout.contiguous().to(torch.float32)
         dx = torch.empty_like(x)
-        dpar = torch.empty(lib.rtfs_dualpath_lstm_grad_floats(), device=x.device, dtype=torch.float32)
-        ws = _lib.workspace(lib.rtfs_dualpath_lstm_train_workspace_bytes(B, T, Fq, ctx.dim), x.device)
-        _lib.check(lib.rtfs_dualpath_lstm_backward_f32(_lib.ptr(x), _lib.ptr(tpack), _lib.ptr(saved), _lib.ptr(dout), _lib.ptr(dx), _lib.ptr(dpar),
-                                                       B, T, Fq, ctx.dim, _lib.ptr(ws), ws.numel(), _lib.stream_of(x)), "rtfs_dualpath_lstm_backward_f32")
-        dg, db, dl, dlw, dlb = packing.unpack_dualpath_lstm_grads(dpar)
-        return (dx, None, dg.reshape(ctx.shapes[0]), db.reshape(ctx.shapes[1])) + tuple(dl[n] for n in ctx.names) + (dlw, dlb)
+        dpar = torch.empty(fn("grad_floats")(), device=x.device, dtype=torch.float32)
+        ws = _lib.workspace(fn("train_workspace_bytes")(B, T, Fq, ctx.dim), x.device)
+        _lib.check(fn("backward_f32")(_lib.ptr(x), _lib.ptr(tpack), _lib.ptr(saved), _lib.ptr(dout), _lib.ptr(dx), _lib.ptr(dpar), B, T, Fq, ctx.dim,
+                                      _lib.ptr(ws), ws.numel(), _lib.stream_of(x)), f"rtfs_dualpath_{kind}_backward_f32")
+        unpack = packing.unpack_dualpath_lstm_grads if kind == "lstm" else packing.unpack_dualpath_gru_grads
+        dg, db, dl, dlw, dlb = unpack(dpar)
+        return (dx, None, None, dg.reshape(ctx.shapes[0]), db.reshape(ctx.shapes[1])) + tuple(dl[n] for n in ctx.names) + (dlw, dlb)
 
 
 class DualPathRNN(PackedModule):
@@ -554,10 +575,10 @@ class DualPathRNN(PackedModule):
     def __init__(self, in_chan, hid_chan, dim, kernel_size=8, stride=1, rnn_type="LSTM", num_layers=1,
                  norm_type="LayerNormalization4D", act_type="Tanh", bidirectional=True, apply_ffn=False, *args, **kwargs):
         super().__init__()
-        if not (rnn_type in ("SRU", "LSTM") and in_chan == 64 and hid_chan == 32 and kernel_size == 8 and stride == 1 and num_layers == 4
+        if not (rnn_type in ("SRU", "LSTM", "GRU") and in_chan == 64 and hid_chan == 32 and kernel_size == 8 and stride == 1 and num_layers == 4
                 and bidirectional and norm_type == "LayerNormalization4D" and not apply_ffn and dim in (3, 4)):
             raise ValueError("MI355X DualPathRNN supports the RTFS-Net yaml configuration only "
-                             "(SRU or LSTM, in 64, hid 32, kernel 8, stride 1, 4 layers, bidirectional, LN4D)")
+                             "(SRU, LSTM or GRU, in 64, hid 32, kernel 8, stride 1, 4 layers, bidirectional, LN4D)")
         self.in_chan, self.hid_chan, self.dim, self.kernel_size, self.stride = in_chan, hid_chan, dim, kernel_size, stride
         self.rnn_type, self.num_layers, self.norm_type, self.act_type = rnn_type, num_layers, norm_type, act_type
         self.bidirectional, self.apply_ffn = bidirectional, apply_ffn
@@ -567,8 +588,8 @@ class DualPathRNN(PackedModule):
         self.norm = LayerNormalization4D((in_chan, 1))
         if rnn_type == "SRU":
             self.rnn = SRU(self.unfolded_chan, hid_chan, num_layers=num_layers, bidirectional=True)
-        else:  # parameter holder with nn.LSTM's names (weight_ih_l0, weight_hh_l0_reverse, ...); the arithmetic is the HIP kernel's
-            self.rnn = nn.LSTM(input_size=self.unfolded_chan, hidden_size=hid_chan, num_layers=num_layers, bidirectional=True)
+        else:  # parameter holder with nn.LSTM's / nn.GRU's names (weight_ih_l0, weight_hh_l0_reverse, ...); the arithmetic is the HIP kernels'
+            self.rnn = getattr(nn, rnn_type)(input_size=self.unfolded_chan, hidden_size=hid_chan, num_layers=num_layers, bidirectional=True)
         self.linear = nn.ConvTranspose1d(self.rnn_out_chan, in_chan, kernel_size, stride=stride)
 
     def forward(self, x):
@@ -578,10 +599,11 @@ class DualPathRNN(PackedModule):
         B, C, T, Fq = x.shape
         if (T if self.dim == 3 else Fq) < self.kernel_size:
             raise ValueError(f"sweep axis shorter than kernel_size {self.kernel_size}")  # nn.Unfold raises in the reference
-        if _recording(x, self):
-            if self.rnn_type == "LSTM":
-                lstm = [getattr(self.rnn, n) for n in packing.lstm_param_names()]
-                return _DualPathLstmTrainFn.apply(x, self.dim, self.norm.gamma, self.norm.beta, *lstm, self.linear.weight, self.linear.bias)
+        if _recording(x, self) or self.rnn_type == "GRU":  # GRU: no fused inference kernel, the GEMM + scan kernels serve both
+            if self.rnn_type in ("LSTM", "GRU"):
+                cell = [getattr(self.rnn, n) for n in packing.lstm_param_names()]
+                return _DualPathLstmTrainFn.apply(x, self.dim, self.rnn_type.lower(), self.norm.gamma, self.norm.beta, *cell, self.linear.weight,
+                                                  self.linear.bias)
             sru = [p for cell in self.rnn.rnn_lst for p in (cell.weight, cell.weight_c, cell.bias)]
             return _DualPathTrainFn.apply(x, self.dim, self.norm.gamma, self.norm.beta, *sru, self.linear.weight, self.linear.bias)
         out = torch.empty_like(x)
@@ -1045,7 +1067,7 @@ class MultiHeadSelfAttention(nn.Module):
         att = self.attention
         if not (self.batch_first and att._qkv_same_embed_dim and att.in_proj_bias is not None and att.bias_k is None and not att.add_zero_attn):
             raise RuntimeError("MultiHeadSelfAttention training kernels: batch_first self-attention with packed in_proj and biases")
-        p = float(self.dropout)
+        p = float(self.dropout) if self.training else 0.0  # (eval mode reaches here only under force_train_kernels)
         res = x
         y = x.transpose(1, 2).contiguous()                                   # (B, T, C)
         B, T, _ = y.shape
@@ -1058,7 +1080,7 @@ class MultiHeadSelfAttention(nn.Module):
         o = _MhaCoreFn.apply(qkv, self.n_head, pmask)
         o = _LinearRowsFn.apply(o, att.out_proj.weight, att.out_proj.bias)
         y = _LnRowsFn.apply(self.dropout_layer(o) + y, self.norm2.weight, self.norm2.bias)
-        return _drop_path(y.transpose(2, 1), p, True) + res
+        return _drop_path(y.transpose(2, 1), p, self.training) + res
 
     def forward(self, x):
         if x.is_cuda and _recording(x, self):

@@ -248,9 +248,9 @@ class TDANetBlock(PackedModule):
             cells = [getattr(m, "rnn_type", None) for m in self.globalatt][:2]
             if not (in_chan == 256 and hid_chan == 64 and kernel_size == 4 and stride == 2 and norm_type == "gLN" and act_type == "PReLU"
                     and upsampling_depth == 2 and kinds == ["DualPathRNN", "DualPathRNN", "MultiHeadSelfAttention2D"] and dims == [4, 3, 3]
-                    and cells in (["SRU", "SRU"], ["LSTM", "LSTM"])):
-                raise ValueError("MI355X RTFS block supports the RTFS-Net yaml audio_params only (both sweeps SRU, or both LSTM)")
-            self.rnn_kind = 1 if cells[0] == "LSTM" else 0
+                    and cells in (["SRU", "SRU"], ["LSTM", "LSTM"], ["GRU", "GRU"])):
+                raise ValueError("MI355X RTFS block supports the RTFS-Net yaml audio_params only (both sweeps SRU, both LSTM or both GRU)")
+            self.rnn_kind = {"SRU": 0, "LSTM": 1, "GRU": 2}[cells[0]]  # 2: no fused block kernel, the unfused HIP kernels serve inference too
 
     def _vp_supported(self):
         kinds = [type(m).__name__ for m in self.globalatt]
@@ -333,6 +333,10 @@ class TDANetBlock(PackedModule):
     def forward(self, x, x_res=None):
         if x.is_cuda and L_recording(x, x_res, self):  # audio (2-D) and video (1-D) blocks alike
             return self._forward_train(x, x_res)
+        if self._hip and self.rnn_kind == 2:
+            _lib.need_gpu(x, x_res)
+            with layers.force_train_kernels():
+                return self._forward_train(x, x_res)
         if not self._hip:
             x = x if x_res is None else x + x_res
             if x.is_cuda and not self.training and self._vp_supported() and x.shape[-1] <= 120:
@@ -594,6 +598,11 @@ class AVNet(BaseAVModel):
         _lib.need_gpu(wav, mouth_embedding)
         if L_recording(self):
             return self.forward_train(audio_mixture, mouth_embedding)
+        if self.refinement_module.audio_net.get_block(0).rnn_kind == 2:  # GRU cells: the separator composed from the unfused HIP kernels
+            if self.training:
+                raise RuntimeError("AVNet: call .eval() for inference")
+            with layers.force_train_kernels():
+                return self.forward_train(audio_mixture, mouth_embedding)
         if self.training:
             raise RuntimeError("AVNet: in .train() mode only the gradient-recording forward exists (see forward_train); "
                                "call .eval() for inference")

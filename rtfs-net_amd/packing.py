@@ -271,6 +271,44 @@ def unpack_dualpath_lstm_grads(flat):
     return flat[0:64], flat[64:128], out, dlw, flat[o + 512 * 64:o + 512 * 64 + 64]
 
 
+def pack_dualpath_gru_train(gamma, beta, gru, lin_w, lin_b):
+    """Pack of DualPathRNN with nn.GRU(512, 32, 4 layers, bidirectional) (layout contract: include/rtfs_amd.h,
+    rtfs_dualpath_gru_forward_train_f32).  gru: name -> tensor with nn.GRU's names (the same as nn.LSTM's)."""
+    f32 = lambda t: t.detach().to(torch.float32)
+    parts = [gamma.reshape(64), beta.reshape(64)]
+    for l in range(4):
+        wih = torch.cat([f32(gru[f"weight_ih_l{l}{suf}"]) for suf in _LSTM_SUFFIX])  # (192, Din), rows dir*96 + gate*32 + j
+        if l == 0:
+            wih = wih.reshape(192, 64, 8).permute(0, 2, 1).reshape(192, 512)
+        bih = torch.cat([f32(gru[f"bias_ih_l{l}{suf}"]) for suf in _LSTM_SUFFIX])
+        bhh = torch.cat([f32(gru[f"bias_hh_l{l}{suf}"]) for suf in _LSTM_SUFFIX])
+        whh = torch.stack([f32(gru[f"weight_hh_l{l}{suf}"]) for suf in _LSTM_SUFFIX])
+        parts += [wih.contiguous(), wih.t().contiguous(), bih, whh.contiguous(), bhh]
+    lw = f32(lin_w)
+    parts += [lw.flip(2).permute(1, 2, 0).reshape(64, 512).contiguous(), lw.permute(0, 2, 1).reshape(64, 512).contiguous(), lin_b]
+    return _cat(parts)
+
+
+def unpack_dualpath_gru_grads(flat):
+    """rtfs_dualpath_gru_backward_f32's gradient buffer -> (dgamma, dbeta, {gru name: grad}, dlin_w, dlin_b)."""
+    out, o = {}, 128
+    for l in range(4):
+        din = 512 if l == 0 else 64
+        dwih = flat[o:o + 192 * din].reshape(192, din); o += 192 * din
+        if l == 0:
+            dwih = dwih.reshape(192, 8, 64).permute(0, 2, 1).reshape(192, 512)
+        dbih = flat[o:o + 192]; o += 192
+        dwhh = flat[o:o + 2 * 96 * 32].reshape(2, 96, 32); o += 2 * 96 * 32
+        dbhh = flat[o:o + 192]; o += 192
+        for d, suf in enumerate(_LSTM_SUFFIX):
+            out[f"weight_ih_l{l}{suf}"] = dwih[d * 96:(d + 1) * 96]
+            out[f"weight_hh_l{l}{suf}"] = dwhh[d]
+            out[f"bias_ih_l{l}{suf}"] = dbih[d * 96:(d + 1) * 96]
+            out[f"bias_hh_l{l}{suf}"] = dbhh[d * 96:(d + 1) * 96]
+    dlw = flat[o:o + 512 * 64].reshape(8, 64, 64).flip(0).permute(1, 2, 0)
+    return flat[0:64], flat[64:128], out, dlw, flat[o + 512 * 64:o + 512 * 64 + 64]
+
+
 def _dualpath_lstm_parts(sd):
     """DualPathRNN with rnn_type LSTM (nn.LSTM(512, 32, 4 layers, bidirectional)).  Columns of the input projections:
     dir*128 + gate*32 + j (gates i,f,g,o); bias = b_ih + b_hh; recurrent weights as [layer][dir][k][gate*32 + j]."""

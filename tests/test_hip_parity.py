@@ -632,6 +632,67 @@ def test_dualpath_lstm_training_forward_backward(idx, shape, seed):
     close("dualpath lstm eval vs train forward", host(mod.eval()(dev(x))), host(out))
 
 
+@pytest.mark.parametrize("idx,shape,seed", [(0, (2, 64, 11, 13), 141), (1, (2, 64, 11, 13), 142), (1, (1, 64, 125, 9), 143)])
+def test_dualpath_gru_forward_and_backward(idx, shape, seed):
+    """DualPathRNN with the GRU cell (SURVEY 8 row a8': nn.LSTM/GRU): inference forward and training forward + backward on the GEMM +
+    scan kernels, against stock torch.nn.GRU in float64 = the reference's own arithmetic."""
+    import rtfs_net_amd as R
+    from oracle import grad_oracle as G
+    dim = 4 if idx == 0 else 3
+    torch.manual_seed(seed)
+    mod = R.layers.DualPathRNN(64, 32, dim, kernel_size=8, stride=1, rnn_type="GRU", num_layers=4, bidirectional=True)
+    with torch.no_grad():
+        mod.norm.gamma.add_(0.2 * torch.randn_like(mod.norm.gamma))
+        mod.norm.beta.add_(0.2 * torch.randn_like(mod.norm.beta))
+    p = {k: v.detach().numpy().copy() for k, v in mod.state_dict().items()}
+    mod = mod.cuda().train()
+    x, dout = rand(shape, seed), rand(shape, seed + 100)
+    xt = dev(x).requires_grad_(True)
+    out = mod(xt)
+    out.backward(dev(dout))
+    o_ref, dx_ref, g_ref = G.module_grads(lambda a, b: G.dualpath_lstm_torch(a, b, dim), x, p, dout)
+    close("dualpath gru train forward", host(out), o_ref)
+    close("dualpath gru dx", host(xt.grad), dx_ref, tol=2e-4)
+    got = {k: v.grad for k, v in mod.named_parameters()}
+    assert set(got) == set(g_ref)
+    worst = max(rel_err(host(got[k]).reshape(g_ref[k].shape), g_ref[k]) for k in g_ref)
+    print(f"[parity] dualpath gru {len(g_ref)} parameter gradients: worst max-rel {worst:.3e}")
+    assert worst <= 2e-4
+    with torch.no_grad():
+        close("dualpath gru inference forward", host(mod.eval()(dev(x))), o_ref)
+
+
+def test_avnet_gru_cells_inference_and_training_step():
+    """The whole separator with rnn_type GRU in both sweeps: there is no fused kernel for it, eval() composes the unfused HIP kernels;
+    checked against the float64 oracle (stock nn.GRU), then one training step through System."""
+    import copy
+    import rtfs_net_amd as R
+    from oracle import grad_oracle as G
+    conf = _conf(2)
+    for k in ("layer_1", "layer_2"):
+        conf["audio_params"]["layers"][k]["rnn_type"] = "GRU"
+    torch.manual_seed(7)
+    m = R.AVNet(print_macs=False, **conf).cuda().eval()
+    B, L, Tv = 2, 4096, 7
+    wav, emb = make_inputs(B, L, Tv, seed=5)
+    with torch.no_grad():
+        out = m(dev(wav), dev(emb))
+        vp = host(m.refinement_module.video_net.get_block(0)(dev(emb)))
+    p = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items() if "num_batches" not in k}
+    pt = {k: torch.tensor(v, dtype=torch.float64) for k, v in p.items()}
+    o_ref = G.avnet_torch(torch.tensor(wav, dtype=torch.float64), torch.tensor(vp, dtype=torch.float64), pt, 2)
+    close("avnet (GRU cells) inference", host(out), o_ref.numpy())
+    m.train()
+    loss_mod = R.losses.PITLossWrapper(R.losses.PairwiseNegSDR("snr"), pit_from="pw_mtx")
+    system = R.System(audio_model=m, loss_func={"train": loss_mod, "val": loss_mod}, optimizer=torch.optim.AdamW(m.parameters(), lr=1e-3))
+    tgt = dev(rand((B, 1, L), 6) * 0.05)
+    l0 = float(system.optimization_step((dev(wav), tgt, dev(emb), None)))
+    for _ in range(2):
+        l1 = float(system.optimization_step((dev(wav), tgt, dev(emb), None)))
+    print(f"[train] GRU-cell model: loss {l0:.4f} -> {l1:.4f}")
+    assert l1 < l0
+
+
 def test_sync_batchnorm_two_emulated_ranks():
     """SyncBatchNorm (train.py:145 sync_batchnorm=True): two ranks each hold half a batch; outputs, input gradients and running
     statistics must equal plain BatchNorm over the whole batch on one rank, and the two ranks' local parameter gradients must add up to
