@@ -166,9 +166,15 @@ def test_unsupported_configs_fail_loudly():
     import copy
     import rtfs_net_amd as R
     c = copy.deepcopy(RTFS4_AUDIONET)
-    c["audio_params"]["layers"]["layer_1"]["rnn_type"] = "GRU"
+    c["audio_params"]["layers"]["layer_1"]["rnn_type"] = "GRU"  # GRU in one sweep, SRU in the other: mixed cells are not on any yaml
     with pytest.raises(ValueError):
         R.AVNet(print_macs=False, **c)
+    c["audio_params"]["layers"]["layer_2"]["rnn_type"] = "GRU"  # both sweeps GRU (SURVEY 8 row a8'): builds, with nn.GRU's parameter names
+    g = R.AVNet(print_macs=False, **c)
+    names = [k for k in g.state_dict() if ".globalatt.0.rnn." in k]
+    assert len(names) == 32 and "refinement_module.audio_net.blocks.globalatt.0.rnn.weight_hh_l3_reverse" in names
+    assert g.state_dict()["refinement_module.audio_net.blocks.globalatt.0.rnn.weight_ih_l0"].shape == (96, 512)
+    c["audio_params"]["layers"]["layer_2"]["rnn_type"] = "SRU"
     c["audio_params"]["layers"]["layer_1"]["rnn_type"] = "LSTM"  # mixed cells are not on any yaml
     with pytest.raises(ValueError):
         R.AVNet(print_macs=False, **c)
