@@ -1152,6 +1152,40 @@ def test_training_gradients_vs_reference_golden(case):
     assert np.mean([v <= 2e-2 for v in errs.values()]) >= 0.9, worst
 
 
+def test_training_edge_shapes_and_gradient_accumulation():
+    """Smallest shapes the sweeps allow (B = 1, T' = 9 > kernel 8, R = 1) through a training step, and autograd's accumulation contract:
+    two forward/backward passes without zero_grad leave exactly twice the gradient of one."""
+    import copy
+    import rtfs_net_amd as R
+    conf = _conf(1)
+    mdl = R.AVNet(print_macs=False, **conf)
+    mdl.load_state_dict({k: torch.from_numpy(v) for k, v in SD.items()})
+    mdl = mdl.cuda().train()
+    ga = mdl.refinement_module.video_net.get_block(0).globalatt[0]
+    ga.MHSA.dropout, ga.MHSA.dropout_layer.p, ga.FFN.dropout = 0.0, 0.0, 0.0
+    for mod_ in mdl.modules():  # frozen statistics: a second pass must not see different BatchNorm buffers
+        if isinstance(mod_, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+            mod_.eval()
+    wav, emb = make_inputs(1, 2176, 4, seed=9)  # T = 18 frames -> T' = 9
+    tgt = dev(rand((1, 1, 2176), 10) * 0.05)
+    loss_mod = R.losses.PITLossWrapper(R.losses.PairwiseNegSDR("sisdr"), pit_from="pw_mtx")
+
+    def step():
+        out = mdl(dev(wav), dev(emb))
+        assert out.shape == (1, 1, 2176) and torch.isfinite(out).all()
+        loss_mod(out, tgt).backward()
+    step()
+    g1 = {k: v.grad.clone() for k, v in mdl.named_parameters()}
+    assert all(torch.isfinite(g).all() for g in g1.values()) and sum(float(g.abs().sum()) for g in g1.values()) > 0
+    step()
+    gmax = max(float(g.abs().max()) for g in g1.values())
+    dev_ = {k: float((v.grad - 2 * g1[k]).abs().max() / g1[k].abs().max()) for k, v in mdl.named_parameters()
+            if float(g1[k].abs().max()) > 1e-6 * gmax}  # exactly-zero gradients (bias before BatchNorm, ...) are rounding noise
+    worst = max(dev_.values())
+    print(f"[parity] accumulated gradient vs 2x single: worst relative deviation {worst:.2e} ({max(dev_, key=dev_.get)})")
+    assert worst <= 1e-3  # f32 atomics make single gradients reproducible only to rounding
+
+
 DDP_WORKER = r"""
 import json, os, sys, copy
 import numpy as np, torch
