@@ -719,13 +719,22 @@ __global__ __launch_bounds__(256) void cl_dw_fwd_kernel(ClDwArgs a) {
         r /= (unsigned)a.Wo;
         const int ho = (int)(r % (unsigned)a.Ho), b = (int)(r / (unsigned)a.Ho);
         float acc = a.bias ? a.bias[c] : 0.f;
-        for (int ki = 0; ki < a.kh; ++ki) {
-            const int h = ho * a.s - a.pt + ki;
-            if (h < 0 || h >= a.H) continue;
-            for (int kj = 0; kj < a.kw; ++kj) {
-                const int w = wo * a.s - a.pl + kj;
-                if (w < 0 || w >= a.W) continue;
-                acc = fmaf(a.w[c * a.kh * a.kw + ki * a.kw + kj], a.x[(((size_t)b * a.H + h) * a.W + w) * a.Cp + c], acc);
+        const float* xb = a.x + ((size_t)b * a.H * a.W) * a.Cp + c;
+        // taps unrolled to 4 x 5 with uniform predicates; loads unconditional on clamped addresses, masked afterwards
+#pragma unroll
+        for (int ki = 0; ki < 4; ++ki) {
+            if (ki < a.kh) {
+                const int h = ho * a.s - a.pt + ki;
+                const bool hok = h >= 0 && h < a.H;
+                const float* rowp = xb + (size_t)min(max(h, 0), a.H - 1) * a.W * a.Cp;
+                float v[5];
+#pragma unroll
+                for (int kj = 0; kj < 5; ++kj) v[kj] = kj < a.kw ? rowp[(size_t)min(max(wo * a.s - a.pl + kj, 0), a.W - 1) * a.Cp] : 0.f;
+#pragma unroll
+                for (int kj = 0; kj < 5; ++kj) {
+                    const int w = wo * a.s - a.pl + kj;
+                    if (kj < a.kw) acc = fmaf(a.w[c * a.kh * a.kw + ki * a.kw + kj], (hok && w >= 0 && w < a.W) ? v[kj] : 0.f, acc);
+                }
             }
         }
         a.y[(size_t)(i / (unsigned)a.C) * a.Cp + c] = acc;
@@ -801,17 +810,24 @@ __global__ __launch_bounds__(256) void cl_dw_bwd_data_kernel(ClDwArgs a) {
         r /= (unsigned)a.W;
         const int h = (int)(r % (unsigned)a.H), b = (int)(r / (unsigned)a.H);
         float acc = 0.f;
-        for (int ki = 0; ki < a.kh; ++ki) {
-            const int hn = h + a.pt - ki;
-            if (hn < 0 || hn % a.s) continue;
-            const int ho = hn / a.s;
-            if (ho >= a.Ho) continue;
-            for (int kj = 0; kj < a.kw; ++kj) {
-                const int wn = w + a.pl - kj;
-                if (wn < 0 || wn % a.s) continue;
-                const int wo = wn / a.s;
-                if (wo >= a.Wo) continue;
-                acc = fmaf(a.w[c * a.kh * a.kw + ki * a.kw + kj], a.dy[(((size_t)b * a.Ho + ho) * a.Wo + wo) * a.Cp + c], acc);
+        const float* db = a.dy + ((size_t)b * a.Ho * a.Wo) * a.Cp + c;
+#pragma unroll
+        for (int ki = 0; ki < 4; ++ki) {
+            if (ki < a.kh) {
+                const int hn = h + a.pt - ki, ho = hn / a.s;  // (a negative hn fails the first test)
+                const bool hok = hn >= 0 && hn - ho * a.s == 0 && ho < a.Ho;
+                const float* rowp = db + (size_t)min(max(ho, 0), a.Ho - 1) * a.Wo * a.Cp;
+                float v[5];
+                bool ok[5];
+#pragma unroll
+                for (int kj = 0; kj < 5; ++kj) {
+                    const int wn = w + a.pl - kj, wo = wn / a.s;
+                    ok[kj] = kj < a.kw && hok && wn >= 0 && wn - wo * a.s == 0 && wo < a.Wo;
+                    v[kj] = kj < a.kw ? rowp[(size_t)min(max(wo, 0), a.Wo - 1) * a.Cp] : 0.f;
+                }
+#pragma unroll
+                for (int kj = 0; kj < 5; ++kj)
+                    if (kj < a.kw) acc = fmaf(a.w[c * a.kh * a.kw + ki * a.kw + kj], ok[kj] ? v[kj] : 0.f, acc);
             }
         }
         a.dx[(size_t)(i / (unsigned)a.C) * a.Cp + c] = acc;
