@@ -45,8 +45,8 @@ class PackedModule(nn.Module):
         _lib.need_gpu(*tensors)
         if self.training:
             raise RuntimeError(
-                f"{type(self).__name__}: only the eval-mode forward is implemented on the MI355X path "
-                "(call .eval(); the backward pass is not built yet)"
+                f"{type(self).__name__}: in .train() mode this module runs only with autograd recording (its training kernels); "
+                "call .eval() for inference"
             )
 
 

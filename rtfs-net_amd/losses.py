@@ -1,4 +1,4 @@
-"""Evaluation-side losses of the reference on the device (forward only): ``src/losses/matrix.py`` ``PairwiseNegSDR`` and
+"""Losses of the reference on the device: ``src/losses/matrix.py`` ``PairwiseNegSDR`` and
 ``src/losses/pit_wrapper.py`` ``PITLossWrapper`` (``pit_from="pw_mtx"``, factorial search), same class names, constructor
 keywords and return values.  The arithmetic runs in ``librtfs_amd.so`` (``rtfs_pit_pairwise_sdr_f32``: one pass over the
 signals, float64 moments, permutation search in the same kernel; ``rtfs_pit_sdr_backward_f32`` for the gradient w.r.t. the
