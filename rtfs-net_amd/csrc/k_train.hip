@@ -222,6 +222,10 @@ int launch_gemm_tn(const float* A, int lda, const float* B, int ldb, float* C, i
 // upstream (L, N, .) order (ts = N, ns = 1); the dual-path layout is sequence-major with pitch Ls = L + 7 (ts = 1, ns = Ls),
 // where `pad` asks the wave to zero the 7 rows of its sequence that are not steps (see the layout notes further down).
 // forward with saved state: h and c of every step go to HBM (the backward reads c; h feeds the next layer)
+// Both scans are software-pipelined by hand: the loads of the next SRU_LOOK steps are issued into a second register set before the
+// current SRU_LOOK steps are computed and stored.  (Left to the compiler, every step's loads stay behind the previous step's stores -
+// it cannot prove they do not alias - and each step pays a full global-memory latency: 68 -> 30 us for the backward scan.)
+#define SRU_LOOK 4
 __global__ __launch_bounds__(256) void sru_scan_fwd_kernel(SruScanArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, dir = lane >> 5;
     const int n = blockIdx.x * 4 + wave;
@@ -229,18 +233,36 @@ __global__ __launch_bounds__(256) void sru_scan_fwd_kernel(SruScanArgs a) {
     const float vf = a.wc[lane], vr = a.wc[64 + lane], bf = a.bias[lane], br = a.bias[64 + lane];
     const int KC = a.KC, L = a.L;
     const size_t ts = a.ts, nb = (size_t)n * a.ns;
-    float c = 0.f;
-#pragma unroll 4
-    for (int s = 0; s < L; ++s) {
-        const int t = dir ? L - 1 - s : s;
-        const size_t row = (size_t)t * ts + nb;
+    auto row_of = [&](int s) { const int sc = min(s, L - 1); return (size_t)(dir ? L - 1 - sc : sc) * ts + nb; };
+    auto load = [&](int s, float (&v)[4]) {
+        const size_t row = row_of(s);
         const float* u = a.U + row * KC + lane;
-        const float u0 = u[0], u1 = u[64], u2 = u[128];
-        const float xp = a.xin ? a.xin[row * 64 + lane] : u[192];
-        const float f = sigmoidf_(u1 + vf * c + bf), rg = sigmoidf_(u2 + vr * c + br);
-        c = u0 + (c - u0) * f;
-        a.c[row * 64 + lane] = c;
-        a.h[row * 64 + lane] = xp + (c - xp) * rg;
+        v[0] = u[0]; v[1] = u[64]; v[2] = u[128];
+        v[3] = *(a.xin ? a.xin + row * 64 + lane : u + 192);
+    };
+    float cur[SRU_LOOK][4], nx[SRU_LOOK][4];
+#pragma unroll
+    for (int i = 0; i < SRU_LOOK; ++i) load(i, cur[i]);
+    float c = 0.f;
+    for (int s0 = 0; s0 < L; s0 += SRU_LOOK) {
+#pragma unroll
+        for (int i = 0; i < SRU_LOOK; ++i) load(s0 + SRU_LOOK + i, nx[i]);
+#pragma unroll
+        for (int i = 0; i < SRU_LOOK; ++i) {
+            const int s = s0 + i;
+            if (s < L) {
+                const float u0 = cur[i][0], xp = cur[i][3];
+                const float f = sigmoidf_(cur[i][1] + vf * c + bf), rg = sigmoidf_(cur[i][2] + vr * c + br);
+                c = u0 + (c - u0) * f;
+                const size_t row = row_of(s);
+                a.c[row * 64 + lane] = c;
+                a.h[row * 64 + lane] = xp + (c - xp) * rg;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < SRU_LOOK; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) cur[i][q] = nx[i][q];
     }
     if (a.pad)  // h is stored 7 rows into its sequence slot: rows -7..-1 are the zero steps the conv-transpose windows read
         for (int i = 1; i <= 7; ++i) a.h[((long)nb - i) * 64 + lane] = 0.f;
@@ -256,36 +278,53 @@ __global__ __launch_bounds__(256) void sru_scan_bwd_kernel(SruScanArgs a) {
     const size_t ts = a.ts, nb = (size_t)n * a.ns;
     float s_vf = 0.f, s_bf = 0.f, s_vr = 0.f, s_br = 0.f;
     if (n < a.N) {
-        float dc = 0.f;
-        float ct = a.c[((size_t)(dir ? 0 : L - 1) * ts + nb) * 64 + lane];
-#pragma unroll 2
-        for (int s = L - 1; s >= 0; --s) {
-            const int t = dir ? L - 1 - s : s;
-            const size_t row = (size_t)t * ts + nb;
-            const int tp = dir ? t + 1 : t - 1;
-            const int tpc = min(max(tp, 0), L - 1);
-            const float cpl = a.c[((size_t)tpc * ts + nb) * 64 + lane];
-            const float cp = s > 0 ? cpl : 0.f;
+        // step index s counts forward-scan order; the walk is s = L-1 .. 0.  k = L-1-s is the walk position.
+        auto row_at = [&](int s) { const int sc = min(max(s, 0), L - 1); return (size_t)(dir ? L - 1 - sc : sc) * ts + nb; };
+        auto load = [&](int k, float (&v)[6]) {  // walk position k -> step s = L-1-k (clamped: positions past the end are never used)
+            const int s = L - 1 - k;
+            const size_t row = row_at(s);
             const float* u = a.U + row * KC + lane;
-            const float u0 = u[0], u1 = u[64], u2 = u[128];
-            const float xp = a.xin ? a.xin[row * 64 + lane] : u[192];
-            const float gh = a.g[row * 64 + lane];
-            const float f = sigmoidf_(u1 + vf * cp + bf), rg = sigmoidf_(u2 + vr * cp + br);
-            const float dr = gh * (ct - xp), dct = dc + gh * rg, dxp = gh * (1.f - rg);
-            const float du0 = dct * (1.f - f), df = dct * (cp - u0);
-            const float dzf = df * f * (1.f - f), dzr = dr * rg * (1.f - rg);
-            dc = dct * f + dzf * vf + dzr * vr;
-            s_vf = fmaf(dzf, cp, s_vf);
-            s_bf += dzf;
-            s_vr = fmaf(dzr, cp, s_vr);
-            s_br += dzr;
-            float* d = a.dU + row * KC + lane;
-            d[0] = du0;
-            d[64] = dzf;
-            d[128] = dzr;
-            if (a.xin) a.dxp[row * 64 + lane] = dxp;
-            else d[192] = dxp;
-            ct = cp;
+            v[0] = u[0]; v[1] = u[64]; v[2] = u[128];
+            v[3] = *(a.xin ? a.xin + row * 64 + lane : u + 192);
+            v[4] = a.g[row * 64 + lane];
+            v[5] = a.c[row_at(s - 1) * 64 + lane];  // c of the step before (ignored at s = 0)
+        };
+        float cur[SRU_LOOK][6], nx[SRU_LOOK][6];
+#pragma unroll
+        for (int i = 0; i < SRU_LOOK; ++i) load(i, cur[i]);
+        float dc = 0.f;
+        float ct = a.c[row_at(L - 1) * 64 + lane];
+        for (int k0 = 0; k0 < L; k0 += SRU_LOOK) {
+#pragma unroll
+            for (int i = 0; i < SRU_LOOK; ++i) load(k0 + SRU_LOOK + i, nx[i]);
+#pragma unroll
+            for (int i = 0; i < SRU_LOOK; ++i) {
+                const int s = L - 1 - (k0 + i);
+                if (s >= 0) {
+                    const float u0 = cur[i][0], u1 = cur[i][1], u2 = cur[i][2], xp = cur[i][3], gh = cur[i][4];
+                    const float cp = s > 0 ? cur[i][5] : 0.f;
+                    const float f = sigmoidf_(u1 + vf * cp + bf), rg = sigmoidf_(u2 + vr * cp + br);
+                    const float dr = gh * (ct - xp), dct = dc + gh * rg, dxp = gh * (1.f - rg);
+                    const float du0 = dct * (1.f - f), df = dct * (cp - u0);
+                    const float dzf = df * f * (1.f - f), dzr = dr * rg * (1.f - rg);
+                    dc = dct * f + dzf * vf + dzr * vr;
+                    s_vf = fmaf(dzf, cp, s_vf);
+                    s_bf += dzf;
+                    s_vr = fmaf(dzr, cp, s_vr);
+                    s_br += dzr;
+                    const size_t row = row_at(s);
+                    float* d = a.dU + row * KC + lane;
+                    d[0] = du0;
+                    d[64] = dzf;
+                    d[128] = dzr;
+                    *(a.xin ? a.dxp + row * 64 + lane : d + 192) = dxp;
+                    ct = cp;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < SRU_LOOK; ++i)
+#pragma unroll
+                for (int q = 0; q < 6; ++q) cur[i][q] = nx[i][q];
         }
         if (a.pad)  // rows L..L+6 of the slot are not steps: the weight-gradient GEMMs sum over every row, so they must be zero
             for (int i = 0; i < 7; ++i) {
