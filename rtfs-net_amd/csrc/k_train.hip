@@ -225,7 +225,7 @@ int launch_gemm_tn(const float* A, int lda, const float* B, int ldb, float* C, i
 // Both scans are software-pipelined by hand: the loads of the next SRU_LOOK steps are issued into a second register set before the
 // current SRU_LOOK steps are computed and stored.  (Left to the compiler, every step's loads stay behind the previous step's stores -
 // it cannot prove they do not alias - and each step pays a full global-memory latency: 68 -> 30 us for the backward scan.)
-#define SRU_LOOK 4
+#define SRU_LOOK 8
 __global__ __launch_bounds__(256) void sru_scan_fwd_kernel(SruScanArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, dir = lane >> 5;
     const int n = blockIdx.x * 4 + wave;
