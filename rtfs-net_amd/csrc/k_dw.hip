@@ -714,6 +714,7 @@ __global__ __launch_bounds__(256) void stats_kernel(const float* __restrict__ x,
     const int b = blockIdx.y;
     float s = 0.f, ss = 0.f;
     const float* xb = x + (size_t)b * N;
+#pragma unroll 8
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < N; i += (size_t)gridDim.x * 256) {
         const float v = xb[i];
         s += v;
@@ -793,8 +794,9 @@ int launch_transpose(const float* x, float* y, int N, int H, int W, hipStream_t 
 }
 
 int launch_stats(const float* x, double* stats, int B, size_t N, hipStream_t st) {
-    int gx = (int)((N + 256 * 16 - 1) / (256 * 16));
-    gx = gx < 1 ? 1 : (gx > 1024 ? 1024 : gx);
+    // every workgroup ends in two f64 atomics on its sample's pair: a few hundred long workgroups per sample beat thousands of short ones
+    int gx = (int)((N + 256 * 32 - 1) / (256 * 32));
+    gx = gx < 1 ? 1 : (gx > 256 ? 256 : gx);
     hipLaunchKernelGGL(stats_kernel, dim3(gx, B), dim3(256), 0, st, x, stats, N);
     return rtfs_launch_status();
 }

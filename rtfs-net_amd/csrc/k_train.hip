@@ -733,6 +733,7 @@ __global__ __launch_bounds__(256) void cl_colsum_kernel(const float* __restrict_
     __shared__ float part[256];
     const int tid = threadIdx.x;
     float s = 0.f;
+#pragma unroll 8
     for (size_t i = (size_t)blockIdx.x * 256 + tid; i < n; i += (size_t)gridDim.x * 256) s += d[i];
     if (C >= 256) {
         unsafeAtomicAdd(out + (((size_t)blockIdx.x * 256 + tid) & (C - 1)), s);
