@@ -301,8 +301,9 @@ class ConvNormAct(nn.Module):
         bn = isinstance(nrm, (nn.BatchNorm1d, nn.BatchNorm2d, nn.SyncBatchNorm))  # SyncBatchNorm: what convert_sync_batchnorm leaves
         if bn and nrm.training and (nrm.momentum is None or not nrm.track_running_stats):
             raise RuntimeError("ConvNormAct: train-mode BatchNorm needs track_running_stats and a momentum")
-        if bn and nrm.training and x.numel() // conv.in_channels <= self.stride:  # one output value per channel: torch's own check
-            raise ValueError(f"Expected more than 1 value per channel when training, got input size {tuple(x.shape)}")
+        world = _bn_world() if isinstance(nrm, nn.SyncBatchNorm) else 1
+        if bn and nrm.training and world * (x.numel() // conv.in_channels) <= self.stride:  # one output value per channel (over all ranks
+            raise ValueError(f"Expected more than 1 value per channel when training, got input size {tuple(x.shape)}")  # if synchronised)
         if not bn and not isinstance(nrm, (nn.Identity, GlobalLayerNorm)):
             raise RuntimeError(f"ConvNormAct: norm {type(nrm).__name__} has no training kernel")
         for m in (pre_a, act):
