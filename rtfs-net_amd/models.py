@@ -653,17 +653,25 @@ class AVNet(BaseAVModel):
         trainable parameters, and evaluated without a graph on its inference kernel otherwise (``freeze_for_finetune``)."""
         rm = self.refinement_module
         vp_block = rm.video_net.get_block(0)
-        video = self.video_bottleneck(mouth_embedding)
-        if vp_block.training and any(p.requires_grad for p in vp_block.parameters()):
-            video = vp_block(video)
-        else:
-            with torch.no_grad():
+        # The VP block is ~1500 tiny launches that only feed the CAF block: it runs on the side stream under the encoder and the first RTFS
+        # block, and - autograd replays every node on the stream its forward ran on - its backward runs under theirs as well.
+        main = torch.cuda.current_stream(mouth_embedding.device)
+        side = self._side_stream(mouth_embedding.device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            video = self.video_bottleneck(mouth_embedding)
+            if vp_block.training and any(p.requires_grad for p in vp_block.parameters()):
                 video = vp_block(video)
+            else:
+                with torch.no_grad():
+                    video = vp_block(video)
         emb = self.encoder(audio_mixture)
         audio = self.audio_bottleneck(emb)
         a_res = audio
         blk = rm.audio_net.get_block(0)
         audio = blk(audio)
+        main.wait_stream(side)
+        video.record_stream(main)
         audio, _ = rm.crossmodal_fusion.get_fusion_block(0)(audio, video)
         for _ in range(rm.audio_repeats):
             audio = blk(audio, a_res)
