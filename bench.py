@@ -88,6 +88,65 @@ def throughput(world, B, steps, dt):
     return world * B * steps / dt
 
 
+def train_main(args):
+    """Training-step throughput, same timing protocol as the forward bench (W warm-up steps, K steps between barrier + synchronize on both
+    sides, MAX over ranks, whole-job aggregate).  Per-GPU batch defaults to the reference's training batch_size 4 unless --batch is given."""
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    import rtfs_net_amd as R
+    torch.manual_seed(0)
+    model = R.AVNet(print_macs=False, **audionet_config(args.repeats)).to(dev).train()
+    loss = R.losses.PITLossWrapper(R.losses.PairwiseNegSDR("snr"), pit_from="pw_mtx")
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=0.1)
+    system = R.System(audio_model=model, loss_func={"train": loss, "val": loss}, optimizer=opt)
+    if world > 1:
+        system.convert_sync_batchnorm()
+    B = args.batch if "--batch" in sys.argv else 4
+    L, Tv = int(args.seconds * 16000), int(args.seconds * 25)
+    wav, emb = rank_inputs(rank, B, L, Tv)
+    g = torch.Generator().manual_seed(4321 + rank)
+    tgt = wav - 0.05 * torch.randn(B, L, generator=g)  # one of the two synthetic sources
+    batch = (wav.to(dev), tgt.unsqueeze(1).to(dev), emb.to(dev), None)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        system.optimization_step(batch)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        last = system.optimization_step(batch)
+    barrier()
+    dt = max_over_ranks(time.perf_counter() - t0, dist, dev)
+    assert bool(torch.isfinite(last))
+    if rank == 0:
+        print(json.dumps({
+            "metric": f"mixtures/sec trained ({args.seconds:g} s@16 kHz) RTFS-Net-{args.repeats} training step", "value": round(throughput(world, B, args.steps, dt), 3),
+            "unit": "mixtures/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 (bf16x3 / f16x3 split-precision matrix products)", "data": "synthetic",
+            "config": {"workload": f"RTFS-Net-{args.repeats} training step (forward_train, PIT neg-SNR loss, HIP backward, AdamW), batch {B}/GPU, "
+                                   f"{args.seconds:g} s segments, every parameter trainable, BatchNorm on batch statistics"
+                                   + (", SyncBatchNorm" if world > 1 else ""),
+                       "per_gpu_batch": B, "global_batch": B * world, "samples": L,
+                       "parallelism": f"dp{world} (one flattened gradient all-reduce of {sum(p.numel() for p in model.parameters())} floats per step)"},
+            "peak_memory_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -97,7 +156,12 @@ def main():
     ap.add_argument("--repeats", type=int, default=4, help="RTFS-Net-R")
     ap.add_argument("--seconds", type=float, default=2.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--train", action="store_true",
+                    help="measure the training step instead (forward_train + PIT loss + HIP backward + one flattened gradient all-reduce "
+                         "over RCCL + clip + AdamW; SyncBatchNorm at N > 1); not the contract metric, a separate JSON line")
     args = ap.parse_args()
+    if args.train:
+        return train_main(args)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
