@@ -1,9 +1,9 @@
 // C-ABI layer, training side: forward-with-saved-state / backward entry points of every module, the packs and
-// saved-state layouts they use, and the launch sequences over the kernels of k_train.hip / k_loss.hip.
+// saved-state layouts they use, and the launch sequences over the kernels of k_train_{gemm,rnn,conv,attn}.hip / k_loss.hip.
 // See include/rtfs_amd.h for the contract and the reference interfaces each entry point replaces.
 #include "api_common.h"
 
-// ------------------------------------------------------------ SRU operator, training side (k_train.hip)
+// ------------------------------------------------------------ SRU operator, training side (k_train_gemm.hip, k_train_rnn.hip)
 namespace {
 constexpr size_t TP_WT0 = 0, TP_WTL = TP_WT0 + 256 * 512, TP_WP0 = TP_WTL + 3 * 192 * 64, TP_WPL = TP_WP0 + 512 * 256,
                  TP_WC = TP_WPL + 3 * 64 * 192, TP_BIAS = TP_WC + 512, TP_END = TP_BIAS + 512;
@@ -79,7 +79,7 @@ namespace {
 constexpr size_t DT_G = 0, DT_B = 64, DT_SRU = 128, DT_WCF = DT_SRU + TP_END, DT_WCB = DT_WCF + 64 * 512, DT_BT = DT_WCB + 64 * 512,
                  DT_END = DT_BT + 64;
 constexpr size_t DG_G = 0, DG_B = 64, DG_SRU = 128, DG_WCT = DG_SRU + GP_END, DG_BT = DG_WCT + 512 * 64, DG_END = DG_BT + 64;
-struct DpSaved {  // sequence-major training layout, see k_train.hip
+struct DpSaved {  // sequence-major training layout, see k_train_rnn.hip
     float *xn, *U[4], *c[4], *hpad[4];
     size_t floats;
     DpSaved(float* p, size_t rows) {

@@ -1,0 +1,216 @@
+// Training side, file 1 of 4: the two GEMM kernels every module's forward-with-saved-state and backward are built on.
+// (k_train_rnn.hip: SRU / LSTM / GRU scans + dual-path layout; k_train_conv.hip: ConvNormAct stages, depthwise convolutions, glue with
+// adjoints; k_train_attn.hip: the two attention modules; entry points: api_train.hip.)
+//
+// Unlike the inference sweep (k_dualpath16.hip), the training path materialises U = x.W - the backward needs it and the weight gradient
+// is a reduction over all rows anyway - so the structure is upstream sru's: GEMM, scan, GEMM; and with activations as rows (b, t, f) x C
+// every 1x1 convolution and its two adjoints are these same two kernels.
+//   bf16x3 split on the matrix cores (x = x1 + x2, both bf16: products x1.w1 + x2.w1 + x1.w2, error ~2^-17 per product).  bf16 keeps
+//   f32's exponent range, so gradients of any magnitude need no scaling; fragments are converted in registers straight from the f32
+//   operands in HBM/L2 (v_cvt_pk_bf16_f32).
+#include "train_common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+struct Frag {
+    bf16x8 hi, lo;
+};
+__device__ __forceinline__ Frag split_bf16(const f32x4& a, const f32x4& b) {
+    Frag f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const __bf16 h0 = (__bf16)a[j], h1 = (__bf16)b[j];
+        f.hi[j] = h0;
+        f.hi[4 + j] = h1;
+        f.lo[j] = (__bf16)(a[j] - (float)h0);
+        f.lo[4 + j] = (__bf16)(b[j] - (float)h1);
+    }
+    return f;
+}
+__device__ __forceinline__ void mfma3(f32x16& acc, const Frag& a, const Frag& b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.lo, b.hi, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.lo, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.hi, acc, 0, 0, 0);
+}
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ C = A . Bt^T
+// A (M, K) and Bt (N, K), both K-contiguous (lda, ldb multiples of 4 floats); C (M, N).  N % 64 == 0, K % 16 == 0, any M.
+// Workgroup = 4 waves stacked along M (256 rows x 64 columns), wave tile 64 x 64.  Workgroups that share the A rows
+// (the column blocks of one row block) share blockIdx % 8, i.e. one XCD's L2.
+// MODE 0: C = ..., 1: C += ... (read-modify-write), 2: fold form - column block j lands j rows further down in a 64-wide C
+// (C[(row + j) * ldc + col % 64] += ..., atomics: the adjoint of the unfold windows, see the dual-path backward).
+template <int MODE>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
+    g.A += (size_t)blockIdx.y * g.sA;
+    g.B += (size_t)blockIdx.y * g.sB;
+    g.C += (size_t)blockIdx.y * g.sC;
+    const int id = blockIdx.x;
+    const int rowblk = (id / (8 * g.ncb)) * 8 + (id & 7), colblk = (id >> 3) % g.ncb;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+    const int m0 = rowblk * 256 + wave * 64, n0 = colblk * 64;
+    if (m0 >= g.M) return;
+    const float *pa[2], *pb[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = min(m0 + 32 * i + r, g.M - 1);
+        pa[i] = g.A + (size_t)row * g.lda + 8 * h;
+        pb[i] = g.B + (size_t)(n0 + 32 * i + r) * g.ldb + 8 * h;
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+    f32x4 ra[2][2], rb[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        ra[i][0] = *(const f32x4*)(pa[i]);
+        ra[i][1] = *(const f32x4*)(pa[i] + 4);
+        rb[i][0] = *(const f32x4*)(pb[i]);
+        rb[i][1] = *(const f32x4*)(pb[i] + 4);
+    }
+    for (int k0 = 0; k0 < g.K; k0 += 16) {
+        const int kn = min(k0 + 16, g.K - 16);
+        f32x4 na[2][2], nb[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            na[i][0] = *(const f32x4*)(pa[i] + kn);
+            na[i][1] = *(const f32x4*)(pa[i] + kn + 4);
+            nb[i][0] = *(const f32x4*)(pb[i] + kn);
+            nb[i][1] = *(const f32x4*)(pb[i] + kn + 4);
+        }
+        Frag fa[2], fb[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            fa[i] = split_bf16(ra[i][0], ra[i][1]);
+            fb[i] = split_bf16(rb[i][0], rb[i][1]);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) mfma3(acc[i][j], fa[i], fb[j]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int x = 0; x < 2; ++x) {
+                ra[i][x] = na[i][x];
+                rb[i][x] = nb[i][x];
+            }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int row = m0 + 32 * i + (q & 3) + 8 * (q >> 2) + 4 * h;
+            if (row < g.M) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if (MODE == 2) {
+                        unsafeAtomicAdd(g.C + (size_t)(row + colblk) * g.ldc + 32 * j + r, acc[i][j][q]);
+                    } else {
+                        float* p = g.C + (size_t)row * g.ldc + n0 + 32 * j + r;
+                        const float v = acc[i][j][q] + (g.bias ? g.bias[n0 + 32 * j + r] : 0.f);
+                        *p = MODE == 1 ? *p + v : v;
+                    }
+                }
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------ C += A^T . B (split K)
+// A (K, M), B (K, N), both with K as the slow axis; C (M, N) must hold the running sum (zeroed by the caller).
+// M % 64 == 0, N % 64 == 0, any K.  One wave = one 64 x 64 tile of C over one K chunk; f32 atomics merge the chunks.
+__global__ __launch_bounds__(256) void gemm_tn_kernel(GemmArgs g) {
+    g.A += (size_t)blockIdx.y * g.sA;
+    g.B += (size_t)blockIdx.y * g.sB;
+    g.C += (size_t)blockIdx.y * g.sC;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+    const int tiles_n = g.N >> 6, tiles = (g.M >> 6) * tiles_n;
+    const long gw = (long)blockIdx.x * 4 + wave;
+    const int tile = (int)(gw % tiles), kc = (int)(gw / tiles);
+    const int m0 = (tile / tiles_n) * 64, n0 = (tile % tiles_n) * 64;
+    const long kbeg = (long)kc * g.kchunk, kend = min((long)g.K, kbeg + g.kchunk);
+    if (kbeg >= kend) return;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+    const float* pa = g.A + m0 + r;
+    const float* pb = g.B + n0 + r;
+    for (long k0 = kbeg; k0 < kend; k0 += 16) {
+        f32x4 va[2][2], vb[2][2];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const long kk = k0 + 8 * h + j;
+            const bool ok = kk < kend;
+            const long kr = ok ? kk : kend - 1;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float av = pa[kr * g.lda + 32 * i], bv = pb[kr * g.ldb + 32 * i];
+                va[i][j >> 2][j & 3] = ok ? av : 0.f;
+                vb[i][j >> 2][j & 3] = ok ? bv : 0.f;
+            }
+        }
+        Frag fa[2], fb[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            fa[i] = split_bf16(va[i][0], va[i][1]);
+            fb[i] = split_bf16(vb[i][0], vb[i][1]);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) mfma3(acc[i][j], fa[i], fb[j]);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int row = m0 + 32 * i + (q & 3) + 8 * (q >> 2) + 4 * h;
+                unsafeAtomicAdd(g.C + (size_t)row * g.ldc + n0 + 32 * j + r, acc[i][j][q]);
+            }
+}
+
+int launch_gemm_nt(const float* A, int lda, const float* Bt, int ldb, float* C, int ldc, int M, int N, int K, int mode,
+                   hipStream_t st, const float* bias, int batch, size_t sA, size_t sB, size_t sC) {
+    if (M < 1 || N < 64 || (N & 63) || K < 16 || (K & 15) || (lda & 3) || (ldb & 3)) return RTFS_ERR_SHAPE;
+    GemmArgs g;
+    g.A = A; g.B = Bt; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.bias = bias;
+    g.sA = sA; g.sB = sB; g.sC = sC;
+    g.ncb = N >> 6;
+    g.nrb = cdiv(M, 256);
+    const long grid = (long)cdiv(g.nrb, 8) * 8 * g.ncb;
+    if (grid > 0x7fffffffL) return RTFS_ERR_SHAPE;
+    if (mode == 2) hipLaunchKernelGGL(gemm_nt_kernel<2>, dim3((unsigned)grid, batch), dim3(256), 0, st, g);
+    else if (mode == 1) hipLaunchKernelGGL(gemm_nt_kernel<1>, dim3((unsigned)grid, batch), dim3(256), 0, st, g);
+    else hipLaunchKernelGGL(gemm_nt_kernel<0>, dim3((unsigned)grid, batch), dim3(256), 0, st, g);
+    return rtfs_launch_status();
+}
+
+int launch_gemm_tn(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, long K, hipStream_t st, int batch,
+                   size_t sA, size_t sB, size_t sC) {
+    if (M < 64 || (M & 63) || N < 64 || (N & 63) || K < 1 || K > 0x7fffffffL) return RTFS_ERR_SHAPE;
+    GemmArgs g;
+    g.A = A; g.B = B; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.M = M; g.N = N; g.K = (int)K;
+    g.sA = sA; g.sB = sB; g.sC = sC;
+    const int tiles = (M >> 6) * (N >> 6);
+    // enough waves to fill the chip several times over, chunks of at least 256 k
+    long splits = cdiv(8192, tiles);
+    long kchunk = (cdiv((int)cdiv((int)K, (int)splits), 16)) * 16;
+    if (kchunk < 256) kchunk = 256;
+    splits = (K + kchunk - 1) / kchunk;
+    g.kchunk = (int)kchunk;
+    const long waves = splits * tiles;
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)((waves + 3) / 4), batch), dim3(256), 0, st, g);
+    return rtfs_launch_status();
+}
+

@@ -224,7 +224,7 @@ size_t video_pack_floats();
 size_t video_workspace_bytes(int B, int T);
 int video_frontend(const float* lips, const float* pack, float* out, int B, int T, void* ws, size_t ws_bytes, hipStream_t st);
 
-// training side of the SRU operator (k_train.hip)
+// training-side GEMMs and SRU scans (k_train_gemm.hip, k_train_rnn.hip)
 struct GemmArgs {
     const float *A = nullptr, *B = nullptr;
     float* C = nullptr;
@@ -265,7 +265,7 @@ int launch_dp_out(const float* y, const float* bias, const float* x, float* out,
 int launch_dp_dy(const float* dout, float* dy, float* dbias, int nseq, int R, int Ls, hipStream_t st);
 int launch_dp_ln_bwd(const float* x, const float* dxn, const float* dout, const float* gamma, float* dx, float* dgamma, float* dbeta,
                      int nseq, int R, int Ls, hipStream_t st);
-// channel-last ConvNormAct training kernels (k_train.hip)
+// channel-last ConvNormAct training kernels (k_train_conv.hip)
 struct ClStageArgs {  // y = act(gLN(x)) over rows x C, per-sample statistics
     const float* x = nullptr;
     float* y = nullptr;
@@ -295,7 +295,7 @@ int launch_cl_colsum(const float* d, float* out, size_t n, int C, hipStream_t st
 int launch_cl_chan_stats(const float* x, double* stats, size_t n, int C, hipStream_t st);
 int launch_bn_update(const double* stats, float* rmean, float* rvar, int C, double rows, float momentum, hipStream_t st);
 int launch_cl_dw(const ClDwArgs& a, int what /* 0 fwd, 1 bwd data, 2 wgrad */, hipStream_t st);
-// TF attention training kernels (k_train.hip)
+// TF attention training kernels (k_train_attn.hip)
 struct LngArgs {  // PReLU + LayerNormalization4D((C_group, 64)) over rows (b,t,f) x CZ
     const float* Z = nullptr;      // pre-activation rows
     float* Y = nullptr;            // forward output rows

@@ -1,0 +1,21 @@
+// Helpers shared by the training-side kernel files (k_train_*.hip).
+#pragma once
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+// dynamic LDS above the default limit needs the attribute once per kernel
+template <typename K>
+int set_lds(K kernel, size_t bytes) {
+    if (bytes > 160 * 1024) return RTFS_ERR_SHAPE;
+    if (bytes > 48 * 1024 && hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess)
+        return RTFS_ERR_LAUNCH;
+    return RTFS_OK;
+}
+// grid of 256-thread workgroups for a grid-stride loop over n elements
+inline unsigned grid_for(size_t n, unsigned cap = 8192) {
+    size_t g = (n + 255) / 256;
+    return (unsigned)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+__device__ __forceinline__ float tanhf_(float x) { return 2.0f * sigmoidf_(2.0f * x) - 1.0f; }
+}  // namespace

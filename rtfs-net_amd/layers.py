@@ -164,7 +164,7 @@ def _bn_all_reduce(t):
 
 
 class _CNATrainFn(torch.autograd.Function):
-    """ConvNormAct forward/backward on the training kernels (csrc/k_train.hip, channel-last rows inside).
+    """ConvNormAct forward/backward on the training kernels (csrc/k_train_conv.hip, channel-last rows inside).
     Inputs: x, cfg tuple (11 ints as in include/rtfs_amd.h + an optional 12th: synchronise the BatchNorm statistics across ranks), then
     pre_gamma, pre_beta, pre_slope, weight, bias, gamma, beta, slope (None where the stage is absent) [, running mean, var, momentum]."""
 
@@ -425,7 +425,7 @@ def _sru_pack(sd):
 
 
 class _SRUTrainFn(torch.autograd.Function):
-    """sru.SRU forward/backward on the training kernels (csrc/k_train.hip).  Inputs: x, then (weight, weight_c, bias) x 4."""
+    """sru.SRU forward/backward on the training kernels (csrc/k_train_gemm.hip, k_train_rnn.hip).  Inputs: x, then (weight, weight_c, bias) x 4."""
 
     @staticmethod
     def forward(ctx, x, *params):
