@@ -708,15 +708,56 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
         if (w0 + r < W && h0 + tx < H) y[base + (size_t)(w0 + r) * H + h0 + tx] = t[tx][r];
 }
 
+// The same through a 64x64 tile with 16-byte accesses on both sides (4-byte-aligned multi-dword accesses run at full rate here, so odd
+// row pitches such as T*F = 32379 keep the wide form): the (B, 256, T*F) <-> (B, T*F, 256) layout changes of the training step.
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+__global__ __launch_bounds__(256) void transpose64_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W) {
+    __shared__ float t[64][65];
+    const size_t base = (size_t)blockIdx.z * H * W;
+    const int w0 = blockIdx.x * 64, h0 = blockIdx.y * 64;
+    const int tx = (threadIdx.x & 15) * 4, ty = threadIdx.x >> 4;
+    if (h0 + 64 <= H && w0 + 64 <= W) {
+        f32x4u v[4];
+#pragma unroll
+        for (int p = 0; p < 4; p++) v[p] = *reinterpret_cast<const f32x4u*>(x + base + (size_t)(h0 + ty + 16 * p) * W + w0 + tx);
+#pragma unroll
+        for (int p = 0; p < 4; p++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) t[ty + 16 * p][tx + k] = v[p][k];
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            const int r = ty + 16 * p;
+            f32x4u o = {t[tx][r], t[tx + 1][r], t[tx + 2][r], t[tx + 3][r]};
+            *reinterpret_cast<f32x4u*>(y + base + (size_t)(w0 + r) * H + h0 + tx) = o;
+        }
+        return;
+    }
+    for (int r = ty; r < 64; r += 16)
+        for (int k = 0; k < 4; k++)
+            if (h0 + r < H && w0 + tx + k < W) t[r][tx + k] = x[base + (size_t)(h0 + r) * W + w0 + tx + k];
+    __syncthreads();
+    for (int r = ty; r < 64; r += 16)
+        for (int k = 0; k < 4; k++)
+            if (w0 + r < W && h0 + tx + k < H) y[base + (size_t)(w0 + r) * H + h0 + tx + k] = t[tx + k][r];
+}
+
 // stats of an arbitrary (B, N) tensor (used when a module is called stand-alone)
 __global__ __launch_bounds__(256) void stats_kernel(const float* __restrict__ x, double* __restrict__ stats, size_t N) {
     __shared__ double red[8];
     const int b = blockIdx.y;
-    float s = 0.f, ss = 0.f;
     const float* xb = x + (size_t)b * N;
-#pragma unroll 8
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < N; i += (size_t)gridDim.x * 256) {
-        const float v = xb[i];
+    const size_t n4 = N >> 2;
+    f32x4u s4 = {0.f, 0.f, 0.f, 0.f}, q4 = {0.f, 0.f, 0.f, 0.f};  // 16-byte loads (a dword stream reads at 60 % of their rate)
+#pragma unroll 4
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const f32x4u v = reinterpret_cast<const f32x4u*>(xb)[i];
+        s4 += v;
+        q4 += v * v;
+    }
+    float s = (s4[0] + s4[1]) + (s4[2] + s4[3]), ss = (q4[0] + q4[1]) + (q4[2] + q4[3]);
+    if (blockIdx.x == 0 && threadIdx.x < (N & 3)) {
+        const float v = xb[(n4 << 2) + threadIdx.x];
         s += v;
         ss = fmaf(v, v, ss);
     }
@@ -789,13 +830,16 @@ int launch_g_combine(const GCombineArgs& a, int B, hipStream_t st) {
 }
 
 int launch_transpose(const float* x, float* y, int N, int H, int W, hipStream_t st) {
-    hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(W, 32), cdiv(H, 32), N), dim3(256), 0, st, x, y, H, W);
+    if (H >= 64 && W >= 64)
+        hipLaunchKernelGGL(transpose64_kernel, dim3(cdiv(W, 64), cdiv(H, 64), N), dim3(256), 0, st, x, y, H, W);
+    else
+        hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(W, 32), cdiv(H, 32), N), dim3(256), 0, st, x, y, H, W);
     return rtfs_launch_status();
 }
 
 int launch_stats(const float* x, double* stats, int B, size_t N, hipStream_t st) {
     // every workgroup ends in two f64 atomics on its sample's pair: a few hundred long workgroups per sample beat thousands of short ones
-    int gx = (int)((N + 256 * 32 - 1) / (256 * 32));
+    int gx = (int)((N / 4 + 256 * 8 - 1) / (256 * 8));
     gx = gx < 1 ? 1 : (gx > 256 ? 256 : gx);
     hipLaunchKernelGGL(stats_kernel, dim3(gx, B), dim3(256), 0, st, x, stats, N);
     return rtfs_launch_status();

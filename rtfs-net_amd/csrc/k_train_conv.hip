@@ -55,95 +55,164 @@ __device__ __forceinline__ void norm_of(const ClStageArgs& a, int b, int c, floa
     }
 }
 }  // namespace
+// The three stage kernels walk a sample in units of V adjacent channels per thread (V = 4: 16-byte accesses - a dword stream runs at
+// 60 % of their rate - whenever 4 | C; V = 1 for narrower tensors).  The grid stride is a multiple of C / V units, so a thread keeps
+// its channels and loads their gamma / beta / statistics once.
+typedef float f32x4u_t __attribute__((ext_vector_type(4), aligned(4)));
+namespace {
+template <int V>
+__device__ __forceinline__ void ldv(const float* __restrict__ p, size_t i, float (&o)[V]) {
+    if constexpr (V == 4) {
+        const f32x4u_t v = reinterpret_cast<const f32x4u_t*>(p)[i];
+        o[0] = v[0], o[1] = v[1], o[2] = v[2], o[3] = v[3];
+    } else {
+        o[0] = p[i];
+    }
+}
+template <int V>
+__device__ __forceinline__ void stv(float* __restrict__ p, size_t i, const float (&o)[V]) {
+    if constexpr (V == 4) {
+        const f32x4u_t v = {o[0], o[1], o[2], o[3]};
+        reinterpret_cast<f32x4u_t*>(p)[i] = v;
+    } else {
+        p[i] = o[0];
+    }
+}
+template <int V>
+struct ChanNorm {
+    float g[V], be[V], mean[V], rstd[V];
+    __device__ __forceinline__ ChanNorm(const ClStageArgs& a, int b, int c0) {
+        float m0 = 0.f, r0 = 1.f;
+        if (a.norm == 1) stats_of(a.stats, b, 1.0 / (double)a.n, m0, r0);
+#pragma unroll
+        for (int k = 0; k < V; k++) {
+            mean[k] = m0, rstd[k] = r0;
+            norm_of(a, b, c0 + k, mean[k], rstd[k]);
+            g[k] = a.norm ? a.gamma[c0 + k] : 1.f;
+            be[k] = a.norm ? a.beta[c0 + k] : 0.f;
+        }
+    }
+};
+}  // namespace
+template <int V>
 __global__ __launch_bounds__(256) void cl_norm_act_fwd_kernel(ClStageArgs a) {
     const int b = blockIdx.y;
-    float mean = 0.f, rstd = 1.f;
-    if (a.norm == 1) stats_of(a.stats, b, 1.0 / (double)a.n, mean, rstd);
+    const size_t i0 = (size_t)blockIdx.x * 256 + threadIdx.x, nv = a.n / V;
+    const ChanNorm<V> p(a, b, (int)((i0 * V) & (size_t)(a.C - 1)));
     const float slope = a.act == 2 ? a.slope[0] : 0.f;
-    const size_t base = (size_t)b * a.n;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (size_t)gridDim.x * 256) {
-        const int c = (int)(i & (a.C - 1));
-        float z = a.x[base + i];
-        norm_of(a, b, c, mean, rstd);
-        if (a.norm) z = fmaf((z - mean) * rstd, a.gamma[c], a.beta[c]);
-        a.y[base + i] = act_fwd(z, a.act, slope);
+    const float* __restrict__ x = a.x + (size_t)b * a.n;
+    float* __restrict__ y = a.y + (size_t)b * a.n;
+#pragma unroll 4
+    for (size_t i = i0; i < nv; i += (size_t)gridDim.x * 256) {
+        float v[V];
+        ldv<V>(x, i, v);
+#pragma unroll
+        for (int k = 0; k < V; k++) {
+            const float z = a.norm ? fmaf((v[k] - p.mean[k]) * p.rstd[k], p.g[k], p.be[k]) : v[k];
+            v[k] = act_fwd(z, a.act, slope);
+        }
+        stv<V>(y, i, v);
     }
 }
 
 // reductions of the stage's backward: per sample S1 = sum da*gamma, S2 = sum da*gamma*xhat (f64 atomics into S[2b..], gLN only);
-// per channel dgamma += sum da*xhat, dbeta += sum da; dslope.  The grid stride is a multiple of C, so a thread keeps one channel.
+// per channel dgamma += sum da*xhat, dbeta += sum da; dslope.
+template <int V>
 __global__ __launch_bounds__(256) void cl_norm_act_bwd_reduce_kernel(ClStageArgs a) {
     __shared__ double red[16];
-    __shared__ float part[3][256];
+    __shared__ float part[2 * V + 1][256];
     const int b = blockIdx.y, tid = threadIdx.x;
-    float mean = 0.f, rstd = 1.f;
-    if (a.norm == 1) stats_of(a.stats, b, 1.0 / (double)a.n, mean, rstd);
+    const size_t i0 = (size_t)blockIdx.x * 256 + tid, nv = a.n / V;
+    const int c0 = (int)((i0 * V) & (size_t)(a.C - 1));
+    const ChanNorm<V> p(a, b, c0);
     const float slope = a.act == 2 ? a.slope[0] : 0.f;
-    const size_t base = (size_t)b * a.n;
-    const int c = (int)(((size_t)blockIdx.x * 256 + tid) & (a.C - 1));
-    norm_of(a, b, c, mean, rstd);
-    const float g = a.norm ? a.gamma[c] : 1.f, be = a.norm ? a.beta[c] : 0.f;
-    float s1 = 0.f, s2 = 0.f, dg = 0.f, db = 0.f, dsl = 0.f;
-    for (size_t i = (size_t)blockIdx.x * 256 + tid; i < a.n; i += (size_t)gridDim.x * 256) {
-        const float xv = a.x[base + i];
-        const float xh = a.norm ? (xv - mean) * rstd : xv;
-        const float z = a.norm ? fmaf(xh, g, be) : xv;
-        const float da = act_bwd(z, a.dy[base + i], a.act, slope, dsl);
-        dg = fmaf(da, xh, dg);
-        db += da;
-        s1 = fmaf(da, g, s1);
-        s2 = fmaf(da * g, xh, s2);
+    const float* __restrict__ x = a.x + (size_t)b * a.n;
+    const float* __restrict__ dy = a.dy + (size_t)b * a.n;
+    float s1 = 0.f, s2 = 0.f, dsl = 0.f, dg[V], db[V];
+#pragma unroll
+    for (int k = 0; k < V; k++) dg[k] = db[k] = 0.f;
+#pragma unroll 4
+    for (size_t i = i0; i < nv; i += (size_t)gridDim.x * 256) {
+        float xv[V], dv[V];
+        ldv<V>(x, i, xv);
+        ldv<V>(dy, i, dv);
+#pragma unroll
+        for (int k = 0; k < V; k++) {
+            const float xh = a.norm ? (xv[k] - p.mean[k]) * p.rstd[k] : xv[k];
+            const float z = a.norm ? fmaf(xh, p.g[k], p.be[k]) : xv[k];
+            const float da = act_bwd(z, dv[k], a.act, slope, dsl);
+            dg[k] = fmaf(da, xh, dg[k]);
+            db[k] += da;
+            s1 = fmaf(da, p.g[k], s1);
+            s2 = fmaf(da * p.g[k], xh, s2);
+        }
     }
     if (a.norm == 1) block_stats_atomic_pair(s1, s2, red, a.S + 2 * b);
-    part[0][tid] = dg;
-    part[1][tid] = db;
-    part[2][tid] = dsl;
+#pragma unroll
+    for (int k = 0; k < V; k++) {
+        part[2 * k][tid] = dg[k];
+        part[2 * k + 1][tid] = db[k];
+    }
+    part[2 * V][tid] = dsl;
     __syncthreads();
-    if (a.norm) {
-        if (a.C >= 256) {  // every thread of the workgroup has its own channel
-            unsafeAtomicAdd(a.dgamma + c, dg);
-            unsafeAtomicAdd(a.dbeta + c, db);
-        } else if (tid < a.C) {
+    const int CV = a.C / V;  // threads with distinct channels
+    if (a.norm && (CV >= 256 || tid < CV)) {
+#pragma unroll
+        for (int k = 0; k < V; k++) {
             float sg = 0.f, sb = 0.f;
-            for (int j = tid; j < 256; j += a.C) {
-                sg += part[0][j];
-                sb += part[1][j];
+            for (int j = tid; j < 256; j += CV) {
+                sg += part[2 * k][j];
+                sb += part[2 * k + 1][j];
             }
-            unsafeAtomicAdd(a.dgamma + tid, sg);
-            unsafeAtomicAdd(a.dbeta + tid, sb);
+            unsafeAtomicAdd(a.dgamma + c0 + k, sg);
+            unsafeAtomicAdd(a.dbeta + c0 + k, sb);
         }
     }
     if (a.act == 2 && tid < 64) {
-        float v = part[2][tid] + part[2][tid + 64] + part[2][tid + 128] + part[2][tid + 192];
+        float v = part[2 * V][tid] + part[2 * V][tid + 64] + part[2 * V][tid + 128] + part[2 * V][tid + 192];
         v = wave_sum(v);
         if (tid == 0) unsafeAtomicAdd(a.dslope, v);
     }
 }
 
+template <int V>
 __global__ __launch_bounds__(256) void cl_norm_act_bwd_apply_kernel(ClStageArgs a) {
     const int b = blockIdx.y;
-    float mean = 0.f, rstd = 1.f, m1 = 0.f, m2 = 0.f;
+    const size_t i0 = (size_t)blockIdx.x * 256 + threadIdx.x, nv = a.n / V;
+    const int c0 = (int)((i0 * V) & (size_t)(a.C - 1));
+    const ChanNorm<V> p(a, b, c0);
+    float m1 = 0.f, m2 = 0.f, cb[V], cg[V];
     if (a.norm == 1) {
-        stats_of(a.stats, b, 1.0 / (double)a.n, mean, rstd);
         m1 = (float)(a.S[2 * b] / (double)a.n);
         m2 = (float)(a.S[2 * b + 1] / (double)a.n);
     }
+#pragma unroll
+    for (int k = 0; k < V; k++) {
+        cb[k] = a.norm == 3 ? (float)a.inv_rows * a.dbeta[c0 + k] : 0.f;
+        cg[k] = a.norm == 3 ? (float)a.inv_rows * a.dgamma[c0 + k] : 0.f;
+    }
     const float slope = a.act == 2 ? a.slope[0] : 0.f;
-    const size_t base = (size_t)b * a.n;
+    const float* __restrict__ x = a.x + (size_t)b * a.n;
+    const float* __restrict__ dy = a.dy + (size_t)b * a.n;
+    float* __restrict__ dx = a.dx + (size_t)b * a.n;
     float dummy = 0.f;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (size_t)gridDim.x * 256) {
-        const int c = (int)(i & (a.C - 1));
-        const float xv = a.x[base + i];
-        norm_of(a, b, c, mean, rstd);
-        const float g = a.norm ? a.gamma[c] : 1.f;
-        const float xh = a.norm ? (xv - mean) * rstd : xv;
-        const float z = a.norm ? fmaf(xh, g, a.beta[c]) : xv;
-        const float da = act_bwd(z, a.dy[base + i], a.act, slope, dummy);
-        float out = da;
-        if (a.norm == 1) out = rstd * (da * g - m1 - xh * m2);
-        else if (a.norm == 2) out = da * g * rstd;
-        else if (a.norm == 3) out = g * rstd * (da - (float)a.inv_rows * (a.dbeta[c] + xh * a.dgamma[c]));
-        a.dx[base + i] = out;
+#pragma unroll 4
+    for (size_t i = i0; i < nv; i += (size_t)gridDim.x * 256) {
+        float xv[V], dv[V];
+        ldv<V>(x, i, xv);
+        ldv<V>(dy, i, dv);
+#pragma unroll
+        for (int k = 0; k < V; k++) {
+            const float xh = a.norm ? (xv[k] - p.mean[k]) * p.rstd[k] : xv[k];
+            const float z = a.norm ? fmaf(xh, p.g[k], p.be[k]) : xv[k];
+            const float da = act_bwd(z, dv[k], a.act, slope, dummy);
+            float out = da;
+            if (a.norm == 1) out = p.rstd[k] * (da * p.g[k] - m1 - xh * m2);
+            else if (a.norm == 2) out = da * p.g[k] * p.rstd[k];
+            else if (a.norm == 3) out = p.g[k] * p.rstd[k] * (da - (cb[k] + xh * cg[k]));
+            dv[k] = out;
+        }
+        stv<V>(dx, i, dv);
     }
 }
 
@@ -189,23 +258,28 @@ __global__ void bn_update_kernel(const double* __restrict__ st, float* __restric
     rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
 }
 
-// out[c] += sum over rows of d[row][c]   (bias gradients); grid stride a multiple of C
+// out[c] += sum over rows of d[row][c]   (bias gradients).  A thread owns four adjacent channels (16-byte loads; 4 | C, and the grid
+// stride in float4 columns is a multiple of C / 4), the workgroup folds its 256 partial quads onto C / 4 and ends in C atomics:
+// few, long workgroups - every one of them lands on the same C addresses.
 __global__ __launch_bounds__(256) void cl_colsum_kernel(const float* __restrict__ d, float* __restrict__ out, size_t n, int C) {
-    __shared__ float part[256];
-    const int tid = threadIdx.x;
-    float s = 0.f;
+    __shared__ float4 part[256];
+    const int tid = threadIdx.x, C4 = C >> 2;
+    const size_t n4 = n >> 2;
+    f32x4u_t s = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 8
-    for (size_t i = (size_t)blockIdx.x * 256 + tid; i < n; i += (size_t)gridDim.x * 256) s += d[i];
-    if (C >= 256) {
-        unsafeAtomicAdd(out + (((size_t)blockIdx.x * 256 + tid) & (C - 1)), s);
-        return;
-    }
-    part[tid] = s;
+    for (size_t i = (size_t)blockIdx.x * 256 + tid; i < n4; i += (size_t)gridDim.x * 256) s += reinterpret_cast<const f32x4u_t*>(d)[i];
+    part[tid] = make_float4(s[0], s[1], s[2], s[3]);
     __syncthreads();
-    if (tid < C) {
-        float v = 0.f;
-        for (int j = tid; j < 256; j += C) v += part[j];
-        unsafeAtomicAdd(out + tid, v);
+    if (tid < C4) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = tid; j < 256; j += C4) {
+            const float4 q = part[j];
+            v.x += q.x, v.y += q.y, v.z += q.z, v.w += q.w;
+        }
+        unsafeAtomicAdd(out + 4 * tid, v.x);
+        unsafeAtomicAdd(out + 4 * tid + 1, v.y);
+        unsafeAtomicAdd(out + 4 * tid + 2, v.z);
+        unsafeAtomicAdd(out + 4 * tid + 3, v.w);
     }
 }
 
@@ -383,8 +457,36 @@ __global__ __launch_bounds__(256) void cl_dw_wgrad_kernel(ClDwArgs a) {
         }
 }
 
+// Second stage of the depthwise weight gradient: nwg partial rows of taps*C floats -> dw (C, taps), accumulated.  A workgroup owns 64
+// float4 columns x 4 row lanes (independent 16-byte loads, LDS 4 -> 1), gridDim.y row slices meet in one atomic per element.
 __global__ __launch_bounds__(256) void cl_dw_wgrad_reduce_kernel(const float* __restrict__ scratch, float* __restrict__ dw, int nwg, int taps,
                                                                  int C) {
+    __shared__ float4 red[4][64];
+    const int n = taps * C, n4 = n >> 2, cl = threadIdx.x & 63, lane = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + cl;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (col < n4) {
+#pragma unroll 8
+        for (int w = blockIdx.y * 4 + lane; w < nwg; w += gridDim.y * 4) {
+            const float4 q = reinterpret_cast<const float4*>(scratch + (size_t)w * n)[col];
+            v.x += q.x, v.y += q.y, v.z += q.z, v.w += q.w;
+        }
+    }
+    red[lane][cl] = v;
+    __syncthreads();
+    if (lane == 0 && col < n4) {
+        const float4 a = red[1][cl], b = red[2][cl], c = red[3][cl];
+        const float s[4] = {v.x + a.x + b.x + c.x, v.y + a.y + b.y + c.y, v.z + a.z + b.z + c.z, v.w + a.w + b.w + c.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int i = col * 4 + k;  // (tap, c)
+            unsafeAtomicAdd(dw + (i % C) * taps + i / C, s[k]);
+        }
+    }
+}
+// taps * C not a multiple of 4 (1- or 2-channel tensors with odd tap counts): one float per thread
+__global__ __launch_bounds__(256) void cl_dw_wgrad_reduce1_kernel(const float* __restrict__ scratch, float* __restrict__ dw, int nwg, int taps,
+                                                                  int C) {
     const int i = blockIdx.x * 256 + threadIdx.x;  // (tap, c)
     if (i >= taps * C) return;
     float v = 0.f;
@@ -399,7 +501,8 @@ inline unsigned grid4(size_t n, unsigned cap) { return (grid_for(n, cap) + 3) / 
 }  // namespace
 int launch_cl_norm_act_fwd(const ClStageArgs& a, int B, hipStream_t st) {
     if (!cl_c_ok(a.C)) return RTFS_ERR_SHAPE;
-    hipLaunchKernelGGL(cl_norm_act_fwd_kernel, dim3(grid_for(a.n, 2048), B), dim3(256), 0, st, a);
+    if (a.C % 4 == 0) hipLaunchKernelGGL(cl_norm_act_fwd_kernel<4>, dim3(grid4(a.n / 4, 2048), B), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(cl_norm_act_fwd_kernel<1>, dim3(grid4(a.n, 2048), B), dim3(256), 0, st, a);
     return rtfs_launch_status();
 }
 // part 0: reduction + apply; 1: reduction only; 2: apply only (SyncBatchNorm all-reduces dgamma / dbeta in between)
@@ -407,9 +510,13 @@ int launch_cl_norm_act_bwd(const ClStageArgs& a, int B, hipStream_t st, int part
     if (!cl_c_ok(a.C)) return RTFS_ERR_SHAPE;
     if (part != 2 && (a.norm || a.act == 2)) {
         if (a.norm == 1 && hipMemsetAsync(a.S, 0, sizeof(double) * 2 * B, st) != hipSuccess) return RTFS_ERR_LAUNCH;
-        hipLaunchKernelGGL(cl_norm_act_bwd_reduce_kernel, dim3(grid4(a.n, 256), B), dim3(256), 0, st, a);
+        if (a.C % 4 == 0) hipLaunchKernelGGL(cl_norm_act_bwd_reduce_kernel<4>, dim3(grid4(a.n / 4 / 4, 256), B), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(cl_norm_act_bwd_reduce_kernel<1>, dim3(grid4(a.n, 256), B), dim3(256), 0, st, a);
     }
-    if (part != 1) hipLaunchKernelGGL(cl_norm_act_bwd_apply_kernel, dim3(grid_for(a.n, 2048), B), dim3(256), 0, st, a);
+    if (part != 1) {
+        if (a.C % 4 == 0) hipLaunchKernelGGL(cl_norm_act_bwd_apply_kernel<4>, dim3(grid4(a.n / 4, 2048), B), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(cl_norm_act_bwd_apply_kernel<1>, dim3(grid4(a.n, 2048), B), dim3(256), 0, st, a);
+    }
     return rtfs_launch_status();
 }
 int launch_cl_chan_stats(const float* x, double* stats, size_t n, int C, hipStream_t st) {
@@ -431,14 +538,14 @@ __global__ __launch_bounds__(256) void cl_colsum_any_kernel(const float* __restr
     }
 }
 int launch_cl_colsum(const float* d, float* out, size_t n, int C, hipStream_t st) {
-    if (C >= 1 && !cl_c_ok(C)) {
+    if (C >= 1 && (!cl_c_ok(C) || C < 4)) {
         const size_t rows = n / C;
         const int chunk = 64;
         hipLaunchKernelGGL(cl_colsum_any_kernel, dim3((unsigned)((rows + chunk - 1) / chunk)), dim3(256), 0, st, d, out, rows, C, chunk);
         return rtfs_launch_status();
     }
     if (!cl_c_ok(C)) return RTFS_ERR_SHAPE;
-    hipLaunchKernelGGL(cl_colsum_kernel, dim3(grid4(n, 1024)), dim3(256), 0, st, d, out, n, C);
+    hipLaunchKernelGGL(cl_colsum_kernel, dim3(grid_for(n / 4 / 8, 256)), dim3(256), 0, st, d, out, n, C);
     return rtfs_launch_status();
 }
 namespace {
@@ -455,8 +562,13 @@ int launch_cl_dw_chunk(const ClDwArgs& a, int what, hipStream_t st) {
         g = g < 1 ? 1 : (g > CL_DW_WGRAD_MAX_WG ? CL_DW_WGRAD_MAX_WG : g);
         if (!a.scratch) return RTFS_ERR_WORKSPACE;
         hipLaunchKernelGGL(cl_dw_wgrad_kernel, dim3((unsigned)g), dim3(256), 0, st, a);
-        hipLaunchKernelGGL(cl_dw_wgrad_reduce_kernel, dim3(cdiv(a.kh * a.kw * a.C, 256), g >= 64 ? 64 : (unsigned)g), dim3(256), 0, st,
-                           a.scratch, a.dw, (int)g, a.kh * a.kw, a.C);
+        const int n = a.kh * a.kw * a.C;
+        if (n % 4 == 0)
+            hipLaunchKernelGGL(cl_dw_wgrad_reduce_kernel, dim3(cdiv(n / 4, 64), g >= 128 ? 32 : (unsigned)cdiv((int)g, 4)), dim3(256), 0, st,
+                               a.scratch, a.dw, (int)g, a.kh * a.kw, a.C);
+        else
+            hipLaunchKernelGGL(cl_dw_wgrad_reduce1_kernel, dim3(cdiv(n, 256), g >= 64 ? 64 : (unsigned)g), dim3(256), 0, st, a.scratch, a.dw,
+                               (int)g, a.kh * a.kw, a.C);
     }
     return rtfs_launch_status();
 }

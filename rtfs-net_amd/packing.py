@@ -17,14 +17,26 @@ def _sub(sd, prefix):
     return {k[len(p):]: v for k, v in sd.items() if k.startswith(p)}
 
 
+_ZEROS = {}
+
+
+def zeros_view(n, device):
+    """n float32 zeros on ``device`` as a slice of one shared constant (read-only by contract: it only ever feeds torch.cat) - a fresh
+    torch.zeros per absent parameter / padding run cost ~400 one-workgroup fill kernels per training step."""
+    z = _ZEROS.get(device)
+    if z is None or z.numel() < n:
+        z = _ZEROS[device] = torch.zeros(max(n, 4096), device=device, dtype=torch.float32)
+    return z[:n]
+
+
 def _cat(tensors):
     out = []
     for t in tensors:
         t = t.detach().to(torch.float32).reshape(-1)
+        out.append(t)
         pad = (-t.numel()) % ALIGN
         if pad:
-            t = torch.cat([t, t.new_zeros(pad)])
-        out.append(t)
+            out.append(zeros_view(pad, t.device))
     return torch.cat(out).contiguous()
 
 
@@ -154,7 +166,7 @@ def pack_cna_train(cfg, pre_g, pre_b, pre_s, w, bias, g, b, s, rmean=None, rvar=
     cfg = (Cin, Cout, k, stride, depthwise, pre_norm, pre_act, norm, act, has_bias, is2d); absent parameters are zero-filled."""
     cin, cout, depthwise = cfg[0], cfg[1], cfg[4]
     dev = w.device
-    z = lambda n: torch.zeros(n, device=dev)
+    z = lambda n: zeros_view(n, dev)
     w2 = w.detach().to(torch.float32).reshape(cout, -1)
     parts = [pre_g if pre_g is not None else z(cin), pre_b if pre_b is not None else z(cin), pre_s if pre_s is not None else z(1), w2]
     if not depthwise:
