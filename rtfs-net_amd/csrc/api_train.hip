@@ -621,7 +621,8 @@ size_t rtfs_cna_saved_floats(const int* cfg, int B, int H, int W) {
 }
 size_t rtfs_cna_workspace_bytes(const int* cfg, int B, int H, int W) {
     CnaCfg c(cfg, B, H, W);
-    return (2 * c.rows_out * c.Cout + 2 * c.rows_in * c.Cin + 4 * (size_t)B + (size_t)CL_DW_WGRAD_MAX_WG * 20 * 256) * sizeof(float) + 8 * 256;
+    return (2 * c.rows_out * c.Cout + 2 * c.rows_in * c.Cin + 4 * (size_t)B + (size_t)CL_DW_WGRAD_MAX_WG * 20 * 256 +
+            cl_stage_partial_floats(B, c.Cin > c.Cout ? c.Cin : c.Cout)) * sizeof(float) + 9 * 256;
 }
 // float offset, inside `saved`, of the 2 * Cout doubles (sum, sum of squares per channel) a norm = 3 forward accumulates; the gradient
 // buffer's dgamma / dbeta float offsets for the matching exchange in the backward
@@ -726,6 +727,7 @@ int rtfs_cna_backward_f32(const float* x, const float* params, const float* save
     float* d0 = ar.take<float>(c.rows_in * c.Cin);
     double* Sb = ar.take<double>(2 * (size_t)B);
     float* wg_scratch = ar.take<float>(c.depthwise ? (size_t)CL_DW_WGRAD_MAX_WG * c.kh * c.kw * c.Cin : 0);
+    float* stage_partial = ar.take<float>(cl_stage_partial_floats(B, c.Cin > c.Cout ? c.Cin : c.Cout));
     RTFS_RETURN_IF(!ar.ok(), RTFS_ERR_WORKSPACE);
     hipStream_t st = S(stream);
     const size_t n_in = (size_t)H * W * c.Cin, n_out = (size_t)c.Ho * c.Wo * c.Cout;
@@ -743,14 +745,14 @@ int rtfs_cna_backward_f32(const float* x, const float* params, const float* save
         a.x = sv.r3; a.dy = d5; a.dx = d3b; a.n = n_out; a.C = c.Cout; a.norm = c.norm; a.act = c.act;
         a.gamma = params + c.o_g; a.beta = params + c.o_be; a.slope = params + c.o_s; a.stats = sv.st3; a.S = Sb;
         a.rmean = params + c.o_rm; a.rvar = params + c.o_rv; a.cstats = sv.cst; a.inv_rows = 1.0 / ((double)c.rows_out * c.world);
-        a.dgamma = dparams + c.g_g; a.dbeta = dparams + c.g_be; a.dslope = dparams + c.g_s;
+        a.dgamma = dparams + c.g_g; a.dbeta = dparams + c.g_be; a.dslope = dparams + c.g_s; a.partial = stage_partial;
         CHECK(launch_cl_norm_act_bwd(a, B, st, c.phase));
         if (c.phase == 1) return RTFS_OK;
         d3 = d3b;
     }
     const float* conv_in = c.pre() ? sv.r2 : r0;
     if (!c.pre() && c.in_rows) d2 = dx;  // the convolution's input gradient is the module's
-    if (c.has_bias) CHECK(launch_cl_colsum(d3, dparams + c.g_b, c.rows_out * c.Cout, c.Cout, st));
+    if (c.has_bias) CHECK(launch_cl_colsum(d3, dparams + c.g_b, c.rows_out * c.Cout, c.Cout, st, stage_partial));
     if (c.depthwise) {
         ClDwArgs d;
         d.x = conv_in; d.w = params + c.o_w; d.dy = d3; d.dx = d2; d.dw = dparams + c.g_w; d.scratch = wg_scratch;
@@ -767,7 +769,7 @@ int rtfs_cna_backward_f32(const float* x, const float* params, const float* save
         if (c.in_rows) d0 = dx;
         a.x = r0; a.dy = d2; a.dx = d0; a.n = n_in; a.C = c.Cin; a.norm = c.pre_norm; a.act = c.pre_act;
         a.gamma = params + c.o_pg; a.beta = params + c.o_pb; a.slope = params + c.o_ps; a.stats = sv.st0; a.S = Sb;
-        a.dgamma = dparams + c.g_pg; a.dbeta = dparams + c.g_pb; a.dslope = dparams + c.g_ps;
+        a.dgamma = dparams + c.g_pg; a.dbeta = dparams + c.g_pb; a.dslope = dparams + c.g_ps; a.partial = stage_partial;
         CHECK(launch_cl_norm_act_bwd(a, B, st));
         dfirst = d0;
     }

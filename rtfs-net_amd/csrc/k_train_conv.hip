@@ -1,6 +1,8 @@
 // Training-side kernels of the convolutional modules on channel-last rows: ConvNormAct stages (gLN / BatchNorm / activations),
 // depthwise convolutions, and the glue with adjoints (pooling, TFAR / CAF combine, encoder / decoder / S^3).
 #include "train_common.h"
+#define CL_STAGE_MAX_WG 256                      // workgroups per sample of the backward reduction pass
+#define CL_STAGE_PITCH(C) (2 * (C) + 6)          // floats per workgroup row: dgamma C | dbeta C | dslope, pad | S1, S2 as doubles
 
 // ------------------------------------------------------------------------------------------------ channel-last training kernels
 // ConvNormAct (conv_layers.py:65-129) in training: activations as rows (b, h, w) x C channels, C fastest.  A stage
@@ -147,7 +149,14 @@ __global__ __launch_bounds__(256) void cl_norm_act_bwd_reduce_kernel(ClStageArgs
             s2 = fmaf(da * p.g[k], xh, s2);
         }
     }
-    if (a.norm == 1) block_stats_atomic_pair(s1, s2, red, a.S + 2 * b);
+    // No atomics here: a thousand workgroups landing on the same 2C + 3 addresses serialise (~0.1 us each: 100 us for a 33 MB tensor
+    // whose streaming takes 15).  Every workgroup stores its sums as one row of `partial`; cl_stage_reduce2_kernel folds the rows.
+    const unsigned wg = blockIdx.y * gridDim.x + blockIdx.x;
+    float* __restrict__ row = a.partial + (size_t)wg * CL_STAGE_PITCH(a.C);
+    {
+        const double d1 = wave_sum_d((double)s1), d2 = wave_sum_d((double)s2);
+        if ((tid & 63) == 0) red[2 * (tid >> 6)] = d1, red[2 * (tid >> 6) + 1] = d2;
+    }
 #pragma unroll
     for (int k = 0; k < V; k++) {
         part[2 * k][tid] = dg[k];
@@ -155,8 +164,8 @@ __global__ __launch_bounds__(256) void cl_norm_act_bwd_reduce_kernel(ClStageArgs
     }
     part[2 * V][tid] = dsl;
     __syncthreads();
-    const int CV = a.C / V;  // threads with distinct channels
-    if (a.norm && (CV >= 256 || tid < CV)) {
+    const int CV = a.C / V;  // threads with distinct channels (<= 256: V = 1 serves C < 4 only)
+    if (tid < CV) {
 #pragma unroll
         for (int k = 0; k < V; k++) {
             float sg = 0.f, sb = 0.f;
@@ -164,14 +173,73 @@ __global__ __launch_bounds__(256) void cl_norm_act_bwd_reduce_kernel(ClStageArgs
                 sg += part[2 * k][j];
                 sb += part[2 * k + 1][j];
             }
-            unsafeAtomicAdd(a.dgamma + c0 + k, sg);
-            unsafeAtomicAdd(a.dbeta + c0 + k, sb);
+            row[c0 + k] = sg;
+            row[a.C + c0 + k] = sb;
         }
     }
-    if (a.act == 2 && tid < 64) {
+    if (tid < 64) {
         float v = part[2 * V][tid] + part[2 * V][tid + 64] + part[2 * V][tid + 128] + part[2 * V][tid + 192];
         v = wave_sum(v);
-        if (tid == 0) unsafeAtomicAdd(a.dslope, v);
+        if (tid == 0) {
+            row[2 * a.C] = v;
+            double* sd = reinterpret_cast<double*>(row + 2 * a.C + 2);  // 8-byte aligned: the pitch and 2C + 2 are even
+            sd[0] = (red[0] + red[2]) + (red[4] + red[6]);
+            sd[1] = (red[1] + red[3]) + (red[5] + red[7]);
+        }
+    }
+}
+
+// Second stage: rows of [dgamma C | dbeta C | dslope, -, S1 (f64), S2 (f64)] -> dgamma / dbeta / dslope (+=) and S (B, 2) (=).
+// grid (ceil(2C / 64) + 1, Y): 64 columns x 4 row lanes per workgroup, Y row slices meet in one atomic per column; the last column block
+// (y = 0 only) folds the PReLU slope and the per-sample pair.
+__global__ __launch_bounds__(256) void cl_stage_reduce2_kernel(const float* __restrict__ partial, int gx, int B, int C, float* __restrict__ dgamma,
+                                                               float* __restrict__ dbeta, float* __restrict__ dslope, double* __restrict__ S,
+                                                               int norm, int act) {
+    __shared__ float red[4][64];
+    __shared__ double dred[2][256];
+    const int tid = threadIdx.x, pitch = CL_STAGE_PITCH(C), nwg = gx * B;
+    if (blockIdx.x + 1 < gridDim.x) {
+        if (!norm) return;
+        const int cl = tid & 63, lane = tid >> 6, col = blockIdx.x * 64 + cl;
+        float v = 0.f;
+        if (col < 2 * C) {
+#pragma unroll 8
+            for (int w = blockIdx.y * 4 + lane; w < nwg; w += gridDim.y * 4) v += partial[(size_t)w * pitch + col];
+        }
+        red[lane][cl] = v;
+        __syncthreads();
+        if (lane == 0 && col < 2 * C) {
+            v = (v + red[1][cl]) + (red[2][cl] + red[3][cl]);
+            unsafeAtomicAdd(col < C ? dgamma + col : dbeta + (col - C), v);
+        }
+        return;
+    }
+    if (blockIdx.y) return;
+    if (act == 2) {
+        float v = 0.f;
+        for (int w = tid; w < nwg; w += 256) v += partial[(size_t)w * pitch + 2 * C];
+        v = wave_sum(v);
+        if ((tid & 63) == 0) red[0][tid >> 6] = v;
+        __syncthreads();
+        if (tid == 0) unsafeAtomicAdd(dslope, (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]));
+    }
+    if (norm == 1) {
+        for (int b = 0; b < B; ++b) {
+            double s1 = 0, s2 = 0;
+            for (int w = tid; w < gx; w += 256) {
+                const double* sd = reinterpret_cast<const double*>(partial + (size_t)(b * gx + w) * pitch + 2 * C + 2);
+                s1 += sd[0];
+                s2 += sd[1];
+            }
+            s1 = wave_sum_d(s1), s2 = wave_sum_d(s2);
+            __syncthreads();
+            if ((tid & 63) == 0) dred[0][tid >> 6] = s1, dred[1][tid >> 6] = s2;
+            __syncthreads();
+            if (tid == 0) {
+                S[2 * b] = (dred[0][0] + dred[0][1]) + (dred[0][2] + dred[0][3]);
+                S[2 * b + 1] = (dred[1][0] + dred[1][1]) + (dred[1][2] + dred[1][3]);
+            }
+        }
     }
 }
 
@@ -261,7 +329,8 @@ __global__ void bn_update_kernel(const double* __restrict__ st, float* __restric
 // out[c] += sum over rows of d[row][c]   (bias gradients).  A thread owns four adjacent channels (16-byte loads; 4 | C, and the grid
 // stride in float4 columns is a multiple of C / 4), the workgroup folds its 256 partial quads onto C / 4 and ends in C atomics:
 // few, long workgroups - every one of them lands on the same C addresses.
-__global__ __launch_bounds__(256) void cl_colsum_kernel(const float* __restrict__ d, float* __restrict__ out, size_t n, int C) {
+__global__ __launch_bounds__(256) void cl_colsum_kernel(const float* __restrict__ d, float* __restrict__ out, size_t n, int C,
+                                                        float* __restrict__ partial) {
     __shared__ float4 part[256];
     const int tid = threadIdx.x, C4 = C >> 2;
     const size_t n4 = n >> 2;
@@ -276,6 +345,10 @@ __global__ __launch_bounds__(256) void cl_colsum_kernel(const float* __restrict_
             const float4 q = part[j];
             v.x += q.x, v.y += q.y, v.z += q.z, v.w += q.w;
         }
+        if (partial) {  // two-stage: one row per workgroup, folded by cl_dw_wgrad_reduce_kernel (taps = 1)
+            *reinterpret_cast<float4*>(partial + (size_t)blockIdx.x * C + 4 * tid) = v;
+            return;
+        }
         unsafeAtomicAdd(out + 4 * tid, v.x);
         unsafeAtomicAdd(out + 4 * tid + 1, v.y);
         unsafeAtomicAdd(out + 4 * tid + 2, v.z);
@@ -287,7 +360,7 @@ __global__ __launch_bounds__(256) void cl_colsum_kernel(const float* __restrict_
 // top/left padding (pt, pl) and stride s (conv_layers.py:100-101: "same" k = 4 -> pt = pl = 1, stride 2 -> symmetric 1)
 __global__ __launch_bounds__(256) void cl_dw_fwd_kernel(ClDwArgs a) {
     const unsigned total = (unsigned)a.B * a.Ho * a.Wo * a.C;  // < 2^31 (launcher)
-    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    for (unsigned i = xcd_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
         const int c = (int)(i % (unsigned)a.C);
         unsigned r = i / (unsigned)a.C;
         const int wo = (int)(r % (unsigned)a.Wo);
@@ -326,7 +399,7 @@ __global__ __launch_bounds__(256) void cl_dw_s1_w4_kernel(ClDwArgs a) {
     const int W4 = (a.W + 3) >> 2;
     const unsigned total = (unsigned)a.B * a.H * W4 * a.C;
     const int pt = FLIP ? a.kh - 1 - a.pt : a.pt, pl = FLIP ? a.kw - 1 - a.pl : a.pl;
-    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    for (unsigned i = xcd_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
         const int c = (int)(i % (unsigned)a.C);
         unsigned r = i / (unsigned)a.C;
         const int w0 = (int)(r % (unsigned)W4) * 4;
@@ -375,12 +448,70 @@ __global__ __launch_bounds__(256) void cl_dw_s1_w4_kernel(ClDwArgs a) {
     }
 }
 
+// The same with four adjacent channels per thread (4 | C, taps up to 4 x 4): 16-byte loads / stores, a quarter of the memory
+// instructions per output - the dword version is bound by the texture addresser (one wave instruction per 16 cycles whatever the
+// width), not by HBM.  Weights of the thread's channel quad stay in registers across the grid-stride loop (the stride is a multiple of C / 4).
+template <bool FLIP>
+__global__ __launch_bounds__(256) void cl_dw_s1_w4c4_kernel(ClDwArgs a) {
+    const float* __restrict__ src = FLIP ? a.dy : a.x;
+    float* __restrict__ dst = FLIP ? a.dx : a.y;
+    const int W4 = (a.W + 3) >> 2, C4 = a.C >> 2;
+    const unsigned total = (unsigned)a.B * a.H * W4 * C4;
+    const int pt = FLIP ? a.kh - 1 - a.pt : a.pt, pl = FLIP ? a.kw - 1 - a.pl : a.pl;
+    const unsigned i0 = xcd_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
+    const int c = (int)(i0 % (unsigned)C4) * 4;
+    f32x4u_t wt[4][4];
+#pragma unroll
+    for (int ki = 0; ki < 4; ++ki)
+#pragma unroll
+        for (int kj = 0; kj < 4; ++kj) {
+            const int si = FLIP ? a.kh - 1 - ki : ki, sj = FLIP ? a.kw - 1 - kj : kj;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) wt[ki][kj][k] = (ki < a.kh && kj < a.kw) ? a.w[(c + k) * a.kh * a.kw + si * a.kw + sj] : 0.f;
+        }
+    f32x4u_t b4 = {0.f, 0.f, 0.f, 0.f};
+    if (!FLIP && a.bias) b4 = *reinterpret_cast<const f32x4u_t*>(a.bias + c);
+    for (unsigned i = i0; i < total; i += gridDim.x * 256) {
+        unsigned r = i / (unsigned)C4;
+        const int w0 = (int)(r % (unsigned)W4) * 4;
+        r /= (unsigned)W4;
+        const int h = (int)(r % (unsigned)a.H), b = (int)(r / (unsigned)a.H);
+        f32x4u_t acc[4] = {b4, b4, b4, b4};
+        const float* sb = src + ((size_t)b * a.H * a.W) * a.Cp + c;
+#pragma unroll
+        for (int ki = 0; ki < 4; ++ki) {
+            if (ki < a.kh) {  // uniform
+                const int hh = h - pt + ki;
+                const bool hok = hh >= 0 && hh < a.H;
+                const float* rowp = sb + (size_t)min(max(hh, 0), a.H - 1) * a.W * a.Cp;
+                f32x4u_t v[7];
+#pragma unroll
+                for (int j = 0; j < 7; ++j) v[j] = *reinterpret_cast<const f32x4u_t*>(rowp + (size_t)min(max(w0 - pl + j, 0), a.W - 1) * a.Cp);
+#pragma unroll
+                for (int j = 0; j < 7; ++j) {
+                    const int ww = w0 - pl + j;
+                    const float m = (hok && ww >= 0 && ww < a.W) ? 1.f : 0.f;
+                    const f32x4u_t x = v[j] * m;
+#pragma unroll
+                    for (int o = 0; o < 4; ++o) {
+                        const int kj = j - o;
+                        if (kj >= 0 && kj < 4) acc[o] += wt[ki][kj] * x;  // taps beyond kh x kw carry zero weights
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < 4; ++o)
+            if (w0 + o < a.W) *reinterpret_cast<f32x4u_t*>(dst + (((size_t)b * a.H + h) * a.W + w0 + o) * a.Cp + c) = acc[o];
+    }
+}
+
 // input gradient: dx[b,h,w,c] = sum over taps with (h + pt - ki) = ho*s, (w + pl - kj) = wo*s of w[c,ki,kj] * dy[b,ho,wo,c]
 // (conditional loads on purpose: this kernel serves the stride-2 case, where three taps in four fail the parity test - loading them
 // unconditionally costs 5x the traffic: 141 vs 50 us)
 __global__ __launch_bounds__(256) void cl_dw_bwd_data_kernel(ClDwArgs a) {
     const unsigned total = (unsigned)a.B * a.H * a.W * a.C;  // < 2^31 (launcher)
-    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    for (unsigned i = xcd_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
         const int c = (int)(i % (unsigned)a.C);
         unsigned r = i / (unsigned)a.C;
         const int w = (int)(r % (unsigned)a.W);
@@ -415,7 +546,7 @@ __global__ __launch_bounds__(256) void cl_dw_wgrad_kernel(ClDwArgs a) {
 #pragma unroll
         for (int j = 0; j < 5; ++j) acc[i][j] = 0.f;
     const unsigned rows = (unsigned)a.B * a.Ho * a.Wo, HoWo = (unsigned)a.Ho * a.Wo;
-    for (unsigned r = blockIdx.x * lanes + rl; r < rows; r += gridDim.x * lanes) {
+    for (unsigned r = xcd_block(blockIdx.x, gridDim.x) * lanes + rl; r < rows; r += gridDim.x * lanes) {
         const unsigned b = r / HoWo, q = r - b * HoWo;
         const int ho = (int)(q / (unsigned)a.Wo), wo = (int)(q - (unsigned)ho * a.Wo);
         const float d = a.dy[(size_t)r * a.Cp + c];
@@ -451,6 +582,61 @@ __global__ __launch_bounds__(256) void cl_dw_wgrad_kernel(ClDwArgs a) {
                     // per-workgroup partial; cl_dw_wgrad_reduce_kernel sums them (atomics onto kh*kw*C addresses from thousands
                     // of workgroups serialise: measured 515 us vs 110 us of work)
                     a.scratch[((size_t)blockIdx.x * a.kh * a.kw + ki * a.kw + kj) * a.C + tid] = v;
+                }
+                __syncthreads();
+            }
+        }
+}
+
+// The same with four adjacent channels per thread (4 | C, taps up to 4 x 4; see cl_dw_s1_w4c4_kernel): thread = (channel quad, one of
+// 1024 / C row lanes).
+__global__ __launch_bounds__(256) void cl_dw_wgrad_c4_kernel(ClDwArgs a) {
+    __shared__ float4 part[256];
+    const int tid = threadIdx.x, C4 = a.C >> 2, c = (tid % C4) * 4, lanes = 256 / C4, rl = tid / C4;
+    f32x4u_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4u_t{0.f, 0.f, 0.f, 0.f};
+    const unsigned rows = (unsigned)a.B * a.Ho * a.Wo, HoWo = (unsigned)a.Ho * a.Wo;
+    for (unsigned r = xcd_block(blockIdx.x, gridDim.x) * lanes + rl; r < rows; r += gridDim.x * lanes) {
+        const unsigned b = r / HoWo, q = r - b * HoWo;
+        const int ho = (int)(q / (unsigned)a.Wo), wo = (int)(q - (unsigned)ho * a.Wo);
+        const f32x4u_t d = *reinterpret_cast<const f32x4u_t*>(a.dy + (size_t)r * a.Cp + c);
+        const int hb = ho * a.s - a.pt, wb = wo * a.s - a.pl;
+        const float* xb = a.x + ((size_t)b * a.H * a.W) * a.Cp + c;
+#pragma unroll
+        for (int ki = 0; ki < 4; ++ki) {
+            if (ki < a.kh) {  // uniform
+                const int h = hb + ki;
+                const bool hok = h >= 0 && h < a.H;
+                const float* rowp = xb + (size_t)min(max(h, 0), a.H - 1) * a.W * a.Cp;
+                f32x4u_t v[4];
+#pragma unroll
+                for (int kj = 0; kj < 4; ++kj) v[kj] = *reinterpret_cast<const f32x4u_t*>(rowp + (size_t)min(max(wb + kj, 0), a.W - 1) * a.Cp);
+#pragma unroll
+                for (int kj = 0; kj < 4; ++kj) {
+                    const int w = wb + kj;
+                    const float m = (kj < a.kw && hok && w >= 0 && w < a.W) ? 1.f : 0.f;
+                    acc[ki][kj] += d * (v[kj] * m);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int ki = 0; ki < 4; ++ki)
+#pragma unroll
+        for (int kj = 0; kj < 4; ++kj) {
+            if (ki < a.kh && kj < a.kw) {  // uniform
+                part[tid] = make_float4(acc[ki][kj][0], acc[ki][kj][1], acc[ki][kj][2], acc[ki][kj][3]);
+                __syncthreads();
+                if (tid < C4) {
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    for (int j = tid; j < 256; j += C4) {
+                        const float4 q = part[j];
+                        v.x += q.x, v.y += q.y, v.z += q.z, v.w += q.w;
+                    }
+                    *reinterpret_cast<float4*>(a.scratch + ((size_t)blockIdx.x * a.kh * a.kw + ki * a.kw + kj) * a.C + 4 * tid) = v;
                 }
                 __syncthreads();
             }
@@ -499,6 +685,7 @@ namespace {
 inline bool cl_c_ok(int C) { return C >= 1 && C <= 1024 && !(C & (C - 1)); }
 inline unsigned grid4(size_t n, unsigned cap) { return (grid_for(n, cap) + 3) / 4 * 4; }  // stride (grid * 256) % C == 0 for C <= 1024
 }  // namespace
+size_t cl_stage_partial_floats(int B, int C) { return (size_t)B * CL_STAGE_MAX_WG * CL_STAGE_PITCH(C); }
 int launch_cl_norm_act_fwd(const ClStageArgs& a, int B, hipStream_t st) {
     if (!cl_c_ok(a.C)) return RTFS_ERR_SHAPE;
     if (a.C % 4 == 0) hipLaunchKernelGGL(cl_norm_act_fwd_kernel<4>, dim3(grid4(a.n / 4, 2048), B), dim3(256), 0, st, a);
@@ -509,9 +696,13 @@ int launch_cl_norm_act_fwd(const ClStageArgs& a, int B, hipStream_t st) {
 int launch_cl_norm_act_bwd(const ClStageArgs& a, int B, hipStream_t st, int part) {
     if (!cl_c_ok(a.C)) return RTFS_ERR_SHAPE;
     if (part != 2 && (a.norm || a.act == 2)) {
-        if (a.norm == 1 && hipMemsetAsync(a.S, 0, sizeof(double) * 2 * B, st) != hipSuccess) return RTFS_ERR_LAUNCH;
-        if (a.C % 4 == 0) hipLaunchKernelGGL(cl_norm_act_bwd_reduce_kernel<4>, dim3(grid4(a.n / 4 / 4, 256), B), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL(cl_norm_act_bwd_reduce_kernel<1>, dim3(grid4(a.n, 256), B), dim3(256), 0, st, a);
+        if (!a.partial) return RTFS_ERR_WORKSPACE;
+        const unsigned gx = a.C % 4 == 0 ? grid4(a.n / 4 / 4, CL_STAGE_MAX_WG) : grid4(a.n, CL_STAGE_MAX_WG);
+        if (a.C % 4 == 0) hipLaunchKernelGGL(cl_norm_act_bwd_reduce_kernel<4>, dim3(gx, B), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(cl_norm_act_bwd_reduce_kernel<1>, dim3(gx, B), dim3(256), 0, st, a);
+        const unsigned rows = gx * (unsigned)B;
+        hipLaunchKernelGGL(cl_stage_reduce2_kernel, dim3(cdiv(2 * a.C, 64) + 1, rows >= 128 ? 32 : cdiv((int)rows, 4)), dim3(256), 0, st,
+                           a.partial, (int)gx, B, a.C, a.dgamma, a.dbeta, a.dslope, a.S, a.norm, a.act);
     }
     if (part != 1) {
         if (a.C % 4 == 0) hipLaunchKernelGGL(cl_norm_act_bwd_apply_kernel<4>, dim3(grid4(a.n / 4, 2048), B), dim3(256), 0, st, a);
@@ -537,7 +728,9 @@ __global__ __launch_bounds__(256) void cl_colsum_any_kernel(const float* __restr
         unsafeAtomicAdd(out + c, s);
     }
 }
-int launch_cl_colsum(const float* d, float* out, size_t n, int C, hipStream_t st) {
+// `partial` (optional, >= 256 * C floats): per-workgroup rows + a second-stage fold instead of 256-way contended atomics (35 -> ~15 us
+// for a 33 MB tensor)
+int launch_cl_colsum(const float* d, float* out, size_t n, int C, hipStream_t st, float* partial) {
     if (C >= 1 && (!cl_c_ok(C) || C < 4)) {
         const size_t rows = n / C;
         const int chunk = 64;
@@ -545,23 +738,32 @@ int launch_cl_colsum(const float* d, float* out, size_t n, int C, hipStream_t st
         return rtfs_launch_status();
     }
     if (!cl_c_ok(C)) return RTFS_ERR_SHAPE;
-    hipLaunchKernelGGL(cl_colsum_kernel, dim3(grid_for(n / 4 / 8, 256)), dim3(256), 0, st, d, out, n, C);
+    const unsigned g = grid_for(n / 4 / 8, 256);
+    if (g < 16) partial = nullptr;  // few workgroups: the atomics are cheaper than a second launch
+    hipLaunchKernelGGL(cl_colsum_kernel, dim3(g), dim3(256), 0, st, d, out, n, C, partial);
+    if (partial)
+        hipLaunchKernelGGL(cl_dw_wgrad_reduce_kernel, dim3(cdiv(C / 4, 64), g >= 128 ? 32 : cdiv((int)g, 4)), dim3(256), 0, st, partial, out, (int)g,
+                           1, C);
     return rtfs_launch_status();
 }
 namespace {
 int launch_cl_dw_chunk(const ClDwArgs& a, int what, hipStream_t st) {
     const bool w4 = a.s == 1 && a.W >= 4 && a.Ho == a.H && a.Wo == a.W;
     const size_t n4 = (size_t)a.B * a.H * ((a.W + 3) / 4) * a.C;
-    if (what == 0 && w4) hipLaunchKernelGGL(cl_dw_s1_w4_kernel<false>, dim3(grid_for(n4)), dim3(256), 0, st, a);
-    else if (what == 1 && w4) hipLaunchKernelGGL(cl_dw_s1_w4_kernel<true>, dim3(grid_for(n4)), dim3(256), 0, st, a);
-    else if (what == 0) hipLaunchKernelGGL(cl_dw_fwd_kernel, dim3(grid_for((size_t)a.B * a.Ho * a.Wo * a.C)), dim3(256), 0, st, a);
-    else if (what == 1) hipLaunchKernelGGL(cl_dw_bwd_data_kernel, dim3(grid_for((size_t)a.B * a.H * a.W * a.C)), dim3(256), 0, st, a);
+    const bool c4 = a.C % 4 == 0 && a.Cp % 4 == 0 && a.kh <= 4 && a.kw <= 4;
+    if (what == 0 && w4 && c4) hipLaunchKernelGGL(cl_dw_s1_w4c4_kernel<false>, dim3(grid8(grid_for(n4 / 4))), dim3(256), 0, st, a);
+    else if (what == 1 && w4 && c4) hipLaunchKernelGGL(cl_dw_s1_w4c4_kernel<true>, dim3(grid8(grid_for(n4 / 4))), dim3(256), 0, st, a);
+    else if (what == 0 && w4) hipLaunchKernelGGL(cl_dw_s1_w4_kernel<false>, dim3(grid8(grid_for(n4))), dim3(256), 0, st, a);
+    else if (what == 1 && w4) hipLaunchKernelGGL(cl_dw_s1_w4_kernel<true>, dim3(grid8(grid_for(n4))), dim3(256), 0, st, a);
+    else if (what == 0) hipLaunchKernelGGL(cl_dw_fwd_kernel, dim3(grid8(grid_for((size_t)a.B * a.Ho * a.Wo * a.C))), dim3(256), 0, st, a);
+    else if (what == 1) hipLaunchKernelGGL(cl_dw_bwd_data_kernel, dim3(grid8(grid_for((size_t)a.B * a.H * a.W * a.C))), dim3(256), 0, st, a);
     else {
-        const size_t rows = (size_t)a.B * a.Ho * a.Wo, per_wg = (size_t)(256 / a.C) * 8;
+        const size_t rows = (size_t)a.B * a.Ho * a.Wo, per_wg = (size_t)(256 / (c4 ? a.C / 4 : a.C)) * 8;
         size_t g = (rows + per_wg - 1) / per_wg;
-        g = g < 1 ? 1 : (g > CL_DW_WGRAD_MAX_WG ? CL_DW_WGRAD_MAX_WG : g);
+        g = g > CL_DW_WGRAD_MAX_WG ? CL_DW_WGRAD_MAX_WG : grid8((unsigned)(g < 1 ? 1 : g));  // a multiple of 8 (xcd_block); idle workgroups store zeros
         if (!a.scratch) return RTFS_ERR_WORKSPACE;
-        hipLaunchKernelGGL(cl_dw_wgrad_kernel, dim3((unsigned)g), dim3(256), 0, st, a);
+        if (c4) hipLaunchKernelGGL(cl_dw_wgrad_c4_kernel, dim3((unsigned)g), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(cl_dw_wgrad_kernel, dim3((unsigned)g), dim3(256), 0, st, a);
         const int n = a.kh * a.kw * a.C;
         if (n % 4 == 0)
             hipLaunchKernelGGL(cl_dw_wgrad_reduce_kernel, dim3(cdiv(n / 4, 64), g >= 128 ? 32 : (unsigned)cdiv((int)g, 4)), dim3(256), 0, st,

@@ -277,6 +277,7 @@ struct ClStageArgs {  // y = act(gLN(x)) over rows x C, per-sample statistics
     const float* dy = nullptr;  // backward
     float* dx = nullptr;
     double* S = nullptr;        // backward scratch (B, 2)
+    float* partial = nullptr;   // backward: cl_stage_partial_floats(B, C) floats of per-workgroup sums (two-stage reduction)
     float *dgamma = nullptr, *dbeta = nullptr, *dslope = nullptr;
     size_t n = 0;               // elements per sample = rows per sample * C
     int C = 0, norm = 0, act = 0;
@@ -289,9 +290,10 @@ struct ClDwArgs {
     int B = 0, H = 0, W = 0, C = 0, Ho = 0, Wo = 0, kh = 0, kw = 0, s = 1, pt = 0, pl = 0;
     int Cp = 0;  // row pitch in channels (set by the launcher; C is the slice a launch covers)
 };
+size_t cl_stage_partial_floats(int B, int C);
 int launch_cl_norm_act_fwd(const ClStageArgs& a, int B, hipStream_t st);
 int launch_cl_norm_act_bwd(const ClStageArgs& a, int B, hipStream_t st, int part = 0);
-int launch_cl_colsum(const float* d, float* out, size_t n, int C, hipStream_t st);
+int launch_cl_colsum(const float* d, float* out, size_t n, int C, hipStream_t st, float* partial = nullptr);
 int launch_cl_chan_stats(const float* x, double* stats, size_t n, int C, hipStream_t st);
 int launch_bn_update(const double* stats, float* rmean, float* rvar, int C, double rows, float momentum, hipStream_t st);
 int launch_cl_dw(const ClDwArgs& a, int what /* 0 fwd, 1 bwd data, 2 wgrad */, hipStream_t st);

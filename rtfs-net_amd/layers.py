@@ -163,6 +163,62 @@ def _bn_all_reduce(t):
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
 
 
+class _GradBundleFn(torch.autograd.Function):
+    """Stands for "the parameters of one module" in the autograd graph.  forward: the parameters -> an uninitialised tensor the size of
+    the module kernels' flat gradient buffer (its values are never read); backward: that buffer -> per-parameter views.  The shared RTFS
+    block is applied R times per step: with the parameters as direct inputs autograd summed every parameter's gradient separately
+    (~370 one-workgroup add kernels per step); through the bundle it sums one flat buffer per module and application."""
+
+    @staticmethod
+    def forward(ctx, n, unpack, *params):
+        ctx.unpack = unpack
+        return params[0].new_empty(n, dtype=torch.float32)
+
+    @staticmethod
+    def backward(ctx, flat):
+        return (None, None) + tuple(ctx.unpack(flat.contiguous()))
+
+
+def _grad_bundle(kind, params, n, unpack):
+    """The bundle tensor of ``params`` (non-None tensors): cached on the first parameter like packing.cached_train_pack, so that the R
+    applications of a shared module inside one step feed ONE graph node; an optimizer step (version bump) starts a new one."""
+    cacheable = torch.is_grad_enabled() and all(isinstance(t, nn.Parameter) for t in params)
+    if not cacheable:
+        return _GradBundleFn.apply(n, unpack, *params)
+    store = params[0].__dict__.setdefault("_rtfs_grad_bundle", {})
+    key = (kind, n) + tuple((id(t), t._version, t.requires_grad) for t in params)
+    b = store.get(key)
+    if b is None:
+        store.clear()
+        b = store[key] = _GradBundleFn.apply(n, unpack, *params)
+    return b
+
+
+class _BundledFn(torch.autograd.Function):
+    """Runs one of the training Functions below (``fn``: inputs x, non-tensor ``head`` arguments, then parameters) with its parameters
+    hidden from autograd behind their bundle: the inner backward hands back its flat gradient buffer (``ctx.flat_grads``) as the
+    bundle's gradient."""
+
+    @staticmethod
+    def forward(ctx, fn, bundle, hidden, x, *head):
+        ctx.fn, ctx.nhead, ctx.flat_grads = fn, len(head), True
+        return fn.forward(ctx, x, *head, *hidden)
+
+    @staticmethod
+    def backward(ctx, dout):
+        dx, dpar = ctx.fn.backward(ctx, dout)
+        return (None, dpar, None, dx) + (None,) * ctx.nhead
+
+
+def _apply_bundled(fn, kind, x, head, params, n, unpack, tail=()):
+    """fn.apply(x, *head, *params, *tail) with the gradient of the (non-None) parameters routed through one bundle; ``unpack(flat)``
+    returns the gradients of exactly those parameters, in order.  ``tail``: trailing non-differentiable arguments."""
+    live = tuple(p for p in params if p is not None)
+    if not any(p.requires_grad for p in live):
+        return fn.apply(x, *head, *params, *tail)
+    return _BundledFn.apply(fn, _grad_bundle(kind, live, n, unpack), tuple(params) + tuple(tail), x, *head)
+
+
 class _CNATrainFn(torch.autograd.Function):
     """ConvNormAct forward/backward on the training kernels (csrc/k_train_conv.hip, channel-last rows inside).
     Inputs: x, cfg tuple (11 ints as in include/rtfs_amd.h + an optional 12th: synchronise the BatchNorm statistics across ranks), then
@@ -252,9 +308,24 @@ class _CNATrainFn(torch.autograd.Function):
             dpar[ob.value:ob.value + C] = local[1]
         else:
             run(carr)
+        if getattr(ctx, "flat_grads", False):
+            return dx, dpar
         grads = packing.unpack_cna_grads(ctx.cfg, dpar, ctx.pshapes[3])
         out = (dx, None) + tuple(None if shp is None else g.reshape(shp) for g, shp in zip(grads, ctx.pshapes))
         return out + (None,) * ctx.nrunning
+
+
+def _cna_apply(x, cfg, params, running=()):
+    """_CNATrainFn with the eight (optional) parameters behind a gradient bundle."""
+    import ctypes
+    shapes = [None if p is None else p.shape for p in params]
+
+    def unpack(flat):
+        grads = packing.unpack_cna_grads(cfg, flat, shapes[3])
+        return [g.reshape(shp) for g, shp in zip(grads, shapes) if shp is not None]
+    n = _lib.load().rtfs_cna_grad_floats((ctypes.c_int * 15)(*(tuple(cfg[:11]) + (0, 1, 0, 0))))
+    # the running statistics (buffers) and the momentum ride along as extra trailing arguments, as before
+    return _apply_bundled(_CNATrainFn, ("cna", tuple(cfg[:11])), x, (cfg,), tuple(params), n, unpack, tuple(running))
 
 
 class ConvNormAct(nn.Module):
@@ -329,8 +400,8 @@ class ConvNormAct(nn.Module):
         gn = lambda m, a: getattr(m.norm, a) if isinstance(m, GlobalLayerNorm) else (getattr(m, a) if bn and m is nrm else None)
         sl = lambda m: m.weight if isinstance(m, nn.PReLU) else None
         running = ((nrm.running_mean, nrm.running_var) + ((nrm.momentum,) if nrm.training else ())) if bn else ()
-        out = _CNATrainFn.apply(x, cfg, gn(pre_n, "weight"), gn(pre_n, "bias"), sl(pre_a), weight, conv.bias, gn(nrm, "weight"),
-                                gn(nrm, "bias"), sl(act), *running)
+        out = _cna_apply(x, cfg, (gn(pre_n, "weight"), gn(pre_n, "bias"), sl(pre_a), weight, conv.bias, gn(nrm, "weight"), gn(nrm, "bias"),
+                                  sl(act)), running)
         if bn and nrm.training:
             nrm.num_batches_tracked += 1
         return out
@@ -522,11 +593,26 @@ class _DualPathTrainFn(torch.autograd.Function):
         ws = _lib.workspace(lib.rtfs_dualpath_train_workspace_bytes(B, T, Fq, ctx.dim % 10), x.device)
         _lib.check(lib.rtfs_dualpath_backward_f32(_lib.ptr(x), _lib.ptr(tpack), _lib.ptr(saved), _lib.ptr(dout), _lib.ptr(dx), _lib.ptr(dpar),
                                                   B, T, Fq, ctx.dim, _lib.ptr(ws), ws.numel(), _lib.stream_of(x)), "rtfs_dualpath_backward_f32")
-        dg, db, dws, dwcs, dbs, dlw, dlb = packing.unpack_dualpath_grads(dpar)
-        out = [dx, None, dg.reshape(ctx.shapes[0]), db.reshape(ctx.shapes[1])]
+        if getattr(ctx, "flat_grads", False):
+            return dx, dpar
+        return (dx, None) + tuple(_dualpath_unpack(ctx.shapes)(dpar))
+
+
+def _dualpath_unpack(shapes):
+    def unpack(flat):
+        dg, db, dws, dwcs, dbs, dlw, dlb = packing.unpack_dualpath_grads(flat)
+        out = [dg.reshape(shapes[0]), db.reshape(shapes[1])]
         for i in range(4):
             out += [dws[i], dwcs[i], dbs[i]]
-        return tuple(out + [dlw, dlb])
+        return out + [dlw, dlb]
+    return unpack
+
+
+def dualpath_train(x, dim, gamma, beta, sru, lin_w, lin_b):
+    """_DualPathTrainFn (SRU cells) with the 16 parameters behind a gradient bundle."""
+    params = (gamma, beta) + tuple(sru) + (lin_w, lin_b)
+    return _apply_bundled(_DualPathTrainFn, "dualpath", x, (dim,), params, _lib.load().rtfs_dualpath_grad_floats(),
+                          _dualpath_unpack((gamma.shape, beta.shape)))
 
 
 class _DualPathLstmTrainFn(torch.autograd.Function):
@@ -608,7 +694,7 @@ class DualPathRNN(PackedModule):
                 return _DualPathLstmTrainFn.apply(x, self.dim, self.rnn_type.lower(), self.norm.gamma, self.norm.beta, *cell, self.linear.weight,
                                                   self.linear.bias)
             sru = [p for cell in self.rnn.rnn_lst for p in (cell.weight, cell.weight_c, cell.bias)]
-            return _DualPathTrainFn.apply(x, self.dim, self.norm.gamma, self.norm.beta, *sru, self.linear.weight, self.linear.bias)
+            return dualpath_train(x, self.dim, self.norm.gamma, self.norm.beta, sru, self.linear.weight, self.linear.bias)
         out = torch.empty_like(x)
         ws = _lib.workspace(lib.rtfs_dualpath_workspace_bytes(B, T, Fq), x.device)
         fn = lib.rtfs_dualpath_sru_f32 if self.rnn_type == "SRU" else lib.rtfs_dualpath_lstm_f32
@@ -648,8 +734,18 @@ class _AttentionTrainFn(torch.autograd.Function):
         _lib.check(lib.rtfs_tf_attention_backward_f32(_lib.ptr(xrows), _lib.ptr(tpack), _lib.ptr(saved), _lib.ptr(dout), _lib.ptr(dx), _lib.ptr(dpar),
                                                       B, T, int(ctx.rows), _lib.ptr(ws), ws.numel(), _lib.stream_of(dout)),
                    "rtfs_tf_attention_backward_f32")
+        if getattr(ctx, "flat_grads", False):
+            return dx, dpar
         g = packing.unpack_attention_grads(dpar)
         return (dx, None, None) + tuple(g[n] for n in ctx.names)
+
+
+def attention_train(x, names, rows, params):
+    """_AttentionTrainFn with the parameters behind a gradient bundle."""
+    def unpack(flat):
+        g = packing.unpack_attention_grads(flat)
+        return [g[n] for n in names]
+    return _apply_bundled(_AttentionTrainFn, "attention", x, (names, rows), tuple(params), _lib.load().rtfs_tf_attention_grad_floats(), unpack)
 
 
 class MultiHeadSelfAttention2D(PackedModule):
@@ -679,7 +775,7 @@ class MultiHeadSelfAttention2D(PackedModule):
             raise ValueError("expected (B, 64, T, 64)")
         if _recording(x, self):
             names, params = zip(*self.named_parameters())
-            return _AttentionTrainFn.apply(x, names, False, *params)
+            return attention_train(x, names, False, params)
         out = torch.empty_like(x)
         ws = _lib.workspace(lib.rtfs_tf_attention_workspace_bytes(B, T), x.device)
         _lib.check(lib.rtfs_tf_attention_f32(_lib.ptr(x), _lib.ptr(self.pack()), _lib.ptr(out), B, T, _lib.ptr(ws), ws.numel(),

@@ -297,10 +297,10 @@ class TDANetBlock(PackedModule):
         for m in self.globalatt:
             if isinstance(m, L.DualPathRNN):
                 sru = [p for cell in m.rnn.rnn_lst for p in (cell.weight, cell.weight_c, cell.bias)]
-                g = L._DualPathTrainFn.apply(g, m.dim + 10, m.norm.gamma, m.norm.beta, *sru, m.linear.weight, m.linear.bias)
+                g = L.dualpath_train(g, m.dim + 10, m.norm.gamma, m.norm.beta, sru, m.linear.weight, m.linear.bias)
             else:
                 names, params = zip(*m.named_parameters())
-                g = L._AttentionTrainFn.apply(g, names, True, *params)
+                g = L.attention_train(g, names, True, params)
         fused = [self.fusion_layers[i]._forward_train(down[i], g, True) for i in range(self.upsampling_depth)]
         expanded = self.concat_layers[-1]._forward_train(fused[-2], fused[-1], True) + down[-2]
         for i in range(self.upsampling_depth - 3, -1, -1):
