@@ -123,18 +123,20 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
 
 // ------------------------------------------------------------------------------------------------ C += A^T . B (split K)
 // A (K, M), B (K, N), both with K as the slow axis; C (M, N) must hold the running sum (zeroed by the caller).
-// M % 64 == 0, N % 64 == 0, any K.  One wave = one 64 x 64 tile of C over one K chunk; f32 atomics merge the chunks.
+// M % 64 == 0, N % 64 == 0, any K.  One wave = one 64 x 64 tile of C over one K chunk; the four waves of a workgroup take four
+// consecutive chunks of the same tile and fold their sums through LDS, then f32 atomics merge the workgroups (every atomic onto a
+// contended address costs ~0.1 us: with one atomic pass per wave the weight gradients of the 1x1 convolutions - 4 tiles, 500 to 2000
+// chunks - spent more time queueing at the L2 than streaming their operands).
 __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmArgs g) {
+    __shared__ float red[3][4096];
     g.A += (size_t)blockIdx.y * g.sA;
     g.B += (size_t)blockIdx.y * g.sB;
     g.C += (size_t)blockIdx.y * g.sC;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
     const int tiles_n = g.N >> 6, tiles = (g.M >> 6) * tiles_n;
-    const long gw = (long)blockIdx.x * 4 + wave;
-    const int tile = (int)(gw % tiles), kc = (int)(gw / tiles);
+    const int tile = (int)(blockIdx.x % (unsigned)tiles), kc = (int)(blockIdx.x / (unsigned)tiles) * 4 + wave;
     const int m0 = (tile / tiles_n) * 64, n0 = (tile % tiles_n) * 64;
-    const long kbeg = (long)kc * g.kchunk, kend = min((long)g.K, kbeg + g.kchunk);
-    if (kbeg >= kend) return;
+    const long kbeg = (long)kc * g.kchunk, kend = min((long)g.K, kbeg + g.kchunk);  // possibly empty (the last workgroup's spare waves)
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -169,14 +171,25 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmArgs g) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) mfma3(acc[i][j], fa[i], fb[j]);
     }
+    if (wave) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) red[wave - 1][((i * 2 + j) * 16 + q) * 64 + lane] = acc[i][j][q];
+    }
+    __syncthreads();
+    if (wave) return;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
+                const int e = ((i * 2 + j) * 16 + q) * 64 + lane;
                 const int row = m0 + 32 * i + (q & 3) + 8 * (q >> 2) + 4 * h;
-                unsafeAtomicAdd(g.C + (size_t)row * g.ldc + n0 + 32 * j + r, acc[i][j][q]);
+                unsafeAtomicAdd(g.C + (size_t)row * g.ldc + n0 + 32 * j + r, (acc[i][j][q] + red[0][e]) + (red[1][e] + red[2][e]));
             }
 }
 
@@ -209,8 +222,7 @@ int launch_gemm_tn(const float* A, int lda, const float* B, int ldb, float* C, i
     if (kchunk < 256) kchunk = 256;
     splits = (K + kchunk - 1) / kchunk;
     g.kchunk = (int)kchunk;
-    const long waves = splits * tiles;
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)((waves + 3) / 4), batch), dim3(256), 0, st, g);
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)((splits + 3) / 4 * tiles), batch), dim3(256), 0, st, g);
     return rtfs_launch_status();
 }
 
