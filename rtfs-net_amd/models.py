@@ -201,9 +201,9 @@ class AudioBottleneck(ConvNormAct, PackedModule):
 
     _pack_fn = staticmethod(packing.pack_audio_bn)
 
-    def forward(self, x, stats=None):
+    def forward(self, x, stats=None, rows_out=False):
         if x.is_cuda and L_recording(x, self):
-            return self._forward_train(x)  # ConvNormAct's training kernels
+            return self._forward_train(x, (False, rows_out))  # ConvNormAct's training kernels; rows_out: (B, T, F, C) for the RTFS blocks
         self._guard(x)
         if not (self.in_chan == 256 and self.out_chan == 256 and self.kernel_size == 1 and self.pre_norm_type == "gLN"
                 and self.pre_act_type == "ReLU" and not self.norm_type and not self.act_type and self.bias):
@@ -280,14 +280,15 @@ class TDANetBlock(PackedModule):
         _lib.check(lib.rtfs_vp_block_f32(_lib.ptr(x), _lib.ptr(pk), _lib.ptr(out), B, Tv, _lib.stream_of(x)), "rtfs_vp_block_f32")
         return out
 
-    def _forward_train_rows(self, x, x_res=None):
+    def _forward_train_rows(self, x, x_res=None, rows_in=False, rows_out=False):
         """The audio block inside a training step with rows (B, T, F, C) between its modules: the same composition as _forward_train,
-        but only the block's input and output change layout (every module converting at its own boundary costs 10 % of a step)."""
+        but only the block's input and output change layout (every module converting at its own boundary costs 10 % of a step) - and
+        not even those when the caller keeps rows between blocks (``rows_in`` / ``rows_out``; AVNet.forward_train)."""
         from . import layers as L
         if x_res is not None:
             x = x + x_res
         rr = (True, True)
-        residual = self.gateway._forward_train(x, (False, True))
+        residual = self.gateway._forward_train(x, (rows_in, True))
         x_enc = self.projection._forward_train(residual, rr)
         down = [self.downsample_layers[0]._forward_train(x_enc, rr)]
         for i in range(1, self.upsampling_depth):
@@ -306,7 +307,7 @@ class TDANetBlock(PackedModule):
         for i in range(self.upsampling_depth - 3, -1, -1):
             expanded = self.concat_layers[i]._forward_train(fused[i], expanded, True) + down[i]
         out = self.residual_conv._forward_train(expanded, rr) + residual
-        return L._LayoutFn.apply(out, False)
+        return out if rows_out else L._LayoutFn.apply(out, False)
 
     def _forward_train(self, x, x_res=None):
         """The block inside a training step (reference separators/tdanet.py:104-131, line by line): every module runs its HIP
@@ -496,14 +497,15 @@ class MaskGenerator(PackedModule):
         self.output_gate, self.dw_gate, self.RI_split, self.direct, self.is2d = output_gate, dw_gate, RI_split, direct, is2d
         self.mask_generator = nn.Sequential(nn.PReLU(), ConvNormAct(bottleneck_chan, n_src * audio_emb_dim, kernel_size, act_type=mask_act, is2d=is2d))
 
-    def forward(self, refined_features, audio_mixture_embedding):
+    def forward(self, refined_features, audio_mixture_embedding, rows_in=False):
         if refined_features.is_cuda and L_recording(refined_features, audio_mixture_embedding, self):
             from .layers import _CNATrainFn
             prelu, cna = self.mask_generator
             conv = cna.full_layer[2]
-            # PReLU -> 1x1 conv -> ReLU as one ConvNormAct whose pre-activation is the stand-alone nn.PReLU (mask_generator.py:52-58)
-            masks = _CNATrainFn.apply(refined_features, (256, 256, 1, 1, 0, 0, 2, 0, 1, 1, 1), None, None, prelu.weight, conv.weight, conv.bias,
-                                      None, None, None)
+            # PReLU -> 1x1 conv -> ReLU as one ConvNormAct whose pre-activation is the stand-alone nn.PReLU (mask_generator.py:52-58);
+            # rows_in: the refined features arrive as (B, T, F, C) rows from the last RTFS block
+            masks = _CNATrainFn.apply(refined_features, (256, 256, 1, 1, 0, 0, 2, 0, 1, 1, 1, 0, int(rows_in), 0), None, None, prelu.weight,
+                                      conv.weight, conv.bias, None, None, None)
             return _S3MulFn.apply(masks, audio_mixture_embedding).unsqueeze(1)
         self._guard(refined_features, audio_mixture_embedding)
         lib = _lib.load()
@@ -666,16 +668,31 @@ class AVNet(BaseAVModel):
                 with torch.no_grad():
                     video = vp_block(video)
         emb = self.encoder(audio_mixture)
-        audio = self.audio_bottleneck(emb)
-        a_res = audio
         blk = rm.audio_net.get_block(0)
-        audio = blk(audio)
+        # rows (B, T, F, C) from the bottleneck to the mask generator wherever the modules take them (the SRU block's rows pipeline); only
+        # the CAF block and the S^3 product work channel-first (each layout change of a 256-channel tensor is a 50 us transpose, twice
+        # per step with the backward)
+        rows = (isinstance(self.audio_bottleneck, AudioBottleneck) and isinstance(self.mask_generator, MaskGenerator)
+                and getattr(blk, "_hip", False) and blk.rnn_kind == 0 and not os.environ.get("RTFS_TRAIN_CF")
+                and L_recording(emb, self.audio_bottleneck) and blk.training and self.mask_generator.training)
+        if rows:
+            a_res = self.audio_bottleneck(emb, rows_out=True)
+            audio = blk._forward_train_rows(a_res, None, rows_in=True, rows_out=False)
+        else:
+            a_res = audio = self.audio_bottleneck(emb)
+            audio = blk(audio)
         main.wait_stream(side)
         video.record_stream(main)
         audio, _ = rm.crossmodal_fusion.get_fusion_block(0)(audio, video)
-        for _ in range(rm.audio_repeats):
-            audio = blk(audio, a_res)
-        sep = self.mask_generator(audio, emb)
+        if rows:
+            audio = layers._LayoutFn.apply(audio, True)
+            for _ in range(rm.audio_repeats):
+                audio = blk._forward_train_rows(audio, a_res, rows_in=True, rows_out=True)
+            sep = self.mask_generator(audio, emb, rows_in=True)
+        else:
+            for _ in range(rm.audio_repeats):
+                audio = blk(audio, a_res)
+            sep = self.mask_generator(audio, emb)
         return self.decoder(sep, STFTEncoder.unsqueeze_to_2D(audio_mixture).shape)
 
     def freeze_for_finetune(self):
