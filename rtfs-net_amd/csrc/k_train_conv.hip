@@ -452,7 +452,10 @@ __global__ __launch_bounds__(256) void cl_dw_s1_w4_kernel(ClDwArgs a) {
 // instructions per output - the dword version is bound by the texture addresser (one wave instruction per 16 cycles whatever the
 // width), not by HBM.  Weights of the thread's channel quad stay in registers across the grid-stride loop (the stride is a multiple of C / 4).
 template <bool FLIP>
-__global__ __launch_bounds__(256) void cl_dw_s1_w4c4_kernel(ClDwArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void cl_dw_s1_w4c4_kernel(ClDwArgs a) {
+    // the taps live in LDS as [ki][kj][channel] (one 16-byte read per tap and thread): in registers they cost 64 VGPRs and left two waves
+    // per SIMD for a kernel that is all load latency
+    __shared__ float wl[16 * 256];
     const float* __restrict__ src = FLIP ? a.dy : a.x;
     float* __restrict__ dst = FLIP ? a.dx : a.y;
     const int W4 = (a.W + 3) >> 2, C4 = a.C >> 2;
@@ -460,15 +463,13 @@ __global__ __launch_bounds__(256) void cl_dw_s1_w4c4_kernel(ClDwArgs a) {
     const int pt = FLIP ? a.kh - 1 - a.pt : a.pt, pl = FLIP ? a.kw - 1 - a.pl : a.pl;
     const unsigned i0 = xcd_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
     const int c = (int)(i0 % (unsigned)C4) * 4;
-    f32x4u_t wt[4][4];
-#pragma unroll
-    for (int ki = 0; ki < 4; ++ki)
-#pragma unroll
-        for (int kj = 0; kj < 4; ++kj) {
-            const int si = FLIP ? a.kh - 1 - ki : ki, sj = FLIP ? a.kw - 1 - kj : kj;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) wt[ki][kj][k] = (ki < a.kh && kj < a.kw) ? a.w[(c + k) * a.kh * a.kw + si * a.kw + sj] : 0.f;
-        }
+    for (int e = threadIdx.x; e < 16 * a.C; e += 256) {
+        const int t = e / a.C, ch = e - t * a.C, ki = t >> 2, kj = t & 3;
+        const int si = FLIP ? a.kh - 1 - ki : ki, sj = FLIP ? a.kw - 1 - kj : kj;
+        wl[e] = (ki < a.kh && kj < a.kw) ? a.w[ch * a.kh * a.kw + si * a.kw + sj] : 0.f;
+    }
+    __syncthreads();
+    const float4* __restrict__ wq = reinterpret_cast<const float4*>(wl) + (c >> 2);  // tap t: wq[t * C4]
     f32x4u_t b4 = {0.f, 0.f, 0.f, 0.f};
     if (!FLIP && a.bias) b4 = *reinterpret_cast<const f32x4u_t*>(a.bias + c);
     for (unsigned i = i0; i < total; i += gridDim.x * 256) {
@@ -495,7 +496,10 @@ __global__ __launch_bounds__(256) void cl_dw_s1_w4c4_kernel(ClDwArgs a) {
 #pragma unroll
                     for (int o = 0; o < 4; ++o) {
                         const int kj = j - o;
-                        if (kj >= 0 && kj < 4) acc[o] += wt[ki][kj] * x;  // taps beyond kh x kw carry zero weights
+                        if (kj >= 0 && kj < 4) {  // taps beyond kh x kw carry zero weights
+                            const float4 w4 = wq[(ki * 4 + kj) * C4];
+                            acc[o] += f32x4u_t{w4.x, w4.y, w4.z, w4.w} * x;
+                        }
                     }
                 }
             }
