@@ -101,24 +101,45 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
                 rb[i][x] = nb[i][x];
             }
     }
+    if (MODE == 2) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int row = m0 + 32 * i + (q & 3) + 8 * (q >> 2) + 4 * h;
-            if (row < g.M) {
+            for (int q = 0; q < 16; ++q) {
+                const int row = m0 + 32 * i + (q & 3) + 8 * (q >> 2) + 4 * h;
+                if (row < g.M) {
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    if (MODE == 2) {
-                        unsafeAtomicAdd(g.C + (size_t)(row + colblk) * g.ldc + 32 * j + r, acc[i][j][q]);
-                    } else {
-                        float* p = g.C + (size_t)row * g.ldc + n0 + 32 * j + r;
-                        const float v = acc[i][j][q] + (g.bias ? g.bias[n0 + 32 * j + r] : 0.f);
-                        *p = MODE == 1 ? *p + v : v;
-                    }
+                    for (int j = 0; j < 2; ++j) unsafeAtomicAdd(g.C + (size_t)(row + colblk) * g.ldc + 32 * j + r, acc[i][j][q]);
                 }
             }
+        return;
+    }
+    // Epilogue through LDS: the accumulator layout puts a lane's registers in different ROWS, so direct stores are dwords in 128-byte
+    // runs (64 store instructions per tile, ~3 TB/s).  Each wave turns its tile, 32 rows at a time, into rows of 16 lanes x 16 bytes:
+    // 8 fully coalesced 16-byte stores per half instead of 32 dword ones.
+    __shared__ float tile[4][32][68];
+    float (*t)[68] = tile[wave];
+    const int cq = (lane & 15) * 4, r4 = lane >> 4;
+    f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+    if (g.bias) b4 = *(const f32x4*)(g.bias + n0 + cq);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) t[(q & 3) + 8 * (q >> 2) + 4 * h][32 * j + r] = acc[i][j][q];
+        // a wave only reads what it wrote itself: no workgroup barrier (LDS operations of a wave complete in order)
+#pragma unroll
+        for (int p8 = 0; p8 < 8; ++p8) {
+            const int lr = r4 + 4 * p8, row = m0 + 32 * i + lr;
+            if (row < g.M) {
+                f32x4 v = *(const f32x4*)&t[lr][cq] + b4;
+                f32x4* p = (f32x4*)(g.C + (size_t)row * g.ldc + n0 + cq);
+                if (MODE == 1) v += *p;
+                *p = v;
+            }
         }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ C += A^T . B (split K)
@@ -196,6 +217,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmArgs g) {
 int launch_gemm_nt(const float* A, int lda, const float* Bt, int ldb, float* C, int ldc, int M, int N, int K, int mode,
                    hipStream_t st, const float* bias, int batch, size_t sA, size_t sB, size_t sC) {
     if (M < 1 || N < 64 || (N & 63) || K < 16 || (K & 15) || (lda & 3) || (ldb & 3)) return RTFS_ERR_SHAPE;
+    if (mode != 2 && ((ldc & 3) || ((size_t)C & 15) || (bias && ((size_t)bias & 15)))) return RTFS_ERR_SHAPE;  // 16-byte row stores
     GemmArgs g;
     g.A = A; g.B = Bt; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.bias = bias;
     g.sA = sA; g.sB = sB; g.sC = sC;
