@@ -327,3 +327,50 @@ def test_gradient_oracle_matches_numpy_oracle_and_finite_differences():
         lm[li][pi][idx] -= eps
         fd = (loss(x, lp) - loss(x, lm)) / (2 * eps)
         assert abs(fd - gl[li][pi][idx]) <= 1e-6 * max(1.0, abs(fd)), (li, pi, idx, fd, gl[li][pi][idx])
+
+
+def test_gradient_bundle_accumulates_over_applications():
+    """layers._GradBundleFn / _apply_bundled (host logic, CPU tensors): a module applied three times through one bundle gets the same
+    parameter gradients as plain autograd; the bundle is shared by the applications of one step and renewed after the parameters change;
+    the shared zero constant used while packing is never written."""
+    import rtfs_net_amd as R
+    from rtfs_net_amd import layers as L, packing
+
+    class Affine(torch.autograd.Function):  # y = x * w + b, flat gradient buffer [dw | db] like the C ABI's dparams
+        @staticmethod
+        def forward(ctx, x, w, b):
+            ctx.save_for_backward(x, w)
+            return x * w + b
+
+        @staticmethod
+        def backward(ctx, dy):
+            x, w = ctx.saved_tensors
+            flat = torch.stack([(dy * x).sum(), dy.sum()])
+            if getattr(ctx, "flat_grads", False):
+                return dy * w, flat
+            return dy * w, flat[0], flat[1]
+
+    w, b = torch.nn.Parameter(torch.tensor(1.5)), torch.nn.Parameter(torch.tensor(-0.25))
+    x = torch.linspace(-1, 2, 7, requires_grad=True)
+    unpack = lambda flat: [flat[0], flat[1]]
+    run = lambda t: L._apply_bundled(Affine, "affine", t, (), (w, b), 2, unpack)
+    y = run(run(run(x)))
+    assert L._grad_bundle("affine", (w, b), 2, unpack) is L._grad_bundle("affine", (w, b), 2, unpack)  # one node per step
+    y.square().sum().backward()
+    got = (x.grad.clone(), w.grad.clone(), b.grad.clone())
+    x.grad = w.grad = b.grad = None
+    f = lambda t: t * w + b
+    f(f(f(x))).square().sum().backward()
+    for g, r in zip(got, (x.grad, w.grad, b.grad)):
+        assert torch.allclose(g, r, rtol=1e-6, atol=1e-6), (g, r)
+    before = L._grad_bundle("affine", (w, b), 2, unpack)
+    with torch.no_grad():
+        w.add_(1.0)  # what an optimizer step does: the version counter moves, the next step gets a fresh node
+    assert L._grad_bundle("affine", (w, b), 2, unpack) is not before
+    # frozen parameters: no bundle, plain call
+    w.requires_grad_(False), b.requires_grad_(False)
+    assert torch.allclose(run(x), x * w + b)
+    z = packing.zeros_view(5, torch.device("cpu"))
+    packed = packing._cat([torch.ones(3), torch.ones(70)])
+    assert packed.numel() == 64 + 128 and float(packed.sum()) == 73.0 and float(z.abs().sum()) == 0.0
+    assert R is not None
