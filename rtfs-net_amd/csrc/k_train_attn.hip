@@ -3,7 +3,6 @@
 #include "train_common.h"
 
 // ------------------------------------------------------------------------------------------------ TF attention, training side
-#define LNG_BT 1  // (b,t) slices per workgroup of the LNG backward
 // MultiHeadSelfAttention2D (attention.py:149-189) on channel-last rows (b, t, f) x CZ.  "LNG" = the tail of a ConvActNorm
 // (conv_layers.py:201-205): PReLU, then LayerNormalization4D((C_out, F)) = statistics over (channels of the module, F) per (b, t)
 // with a (C_out, F) affine (normalizations.py:26,33-37).  The twelve Q/K/V modules are evaluated side by side: their channels are
@@ -48,103 +47,85 @@ __global__ __launch_bounds__(256) void att_lng_fwd_kernel(LngArgs a) {
     }
 }
 
+// One workgroup per (b, t) slice.  256 % CZ == 0, so a thread keeps its channel c (hence its group, slope and statistics) over its
+// 64 * CZ / 256 elements and only f moves.  The (C, F) affine's gradient contributions leave as one coalesced row of per-workgroup
+// partials in slice order [f][c] (att_lng_reduce_kernel folds and transposes them: atomics from every workgroup onto the 2 x 8192
+// addresses serialise, 346 -> 60 us); the PReLU slope gradient is summed in a register and merged once per thread (an LDS atomic per
+// negative element - ~4000 onto 16 addresses per slice - was a quarter of this kernel).
 __global__ __launch_bounds__(256) void att_lng_bwd_kernel(LngArgs a) {
-    extern __shared__ float lds[];  // A [64][CZ+1] (activated input, later xhat), D [64][CZ+1] (gamma * dY)
+    extern __shared__ float lds[];  // A [64][CZ+1] (xhat), D [64][CZ+1] (gamma * dY)
     __shared__ float g1[16], g2[16], gsl[16];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, CZ = a.CZ, P = CZ + 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, CZ = a.CZ, P = CZ + 1, bt = blockIdx.x;
     float* A = lds;
     float* D = lds + 64 * P;
-    // a workgroup walks LNG_BT consecutive (b,t) slices; each thread owns the same (f, c) elements in every slice, so the
-    // (C, F) affine's gradients stay in registers and reach HBM as one atomic per element per workgroup
-    float acc_g[32], acc_b[32];
-#pragma unroll
-    for (int k = 0; k < 32; ++k) acc_g[k] = acc_b[k] = 0.f;
+    const int c = tid & (CZ - 1), f0 = tid / CZ, fstep = 256 / CZ, per = 64 * CZ / 256;
+    const int g = a.gof[c];
+    const bool on = g < 16;
+    const float slope = a.slope[c];
+    const float mean = on ? a.stats[((size_t)bt * 16 + g) * 2] : 0.f, rstd = on ? a.stats[((size_t)bt * 16 + g) * 2 + 1] : 0.f;
     if (tid < 16) gsl[tid] = 0.f;
-    const int per = 64 * CZ / 256;  // 16 (CZ 64) or 32 (CZ 128) elements per thread
-    for (int bt = blockIdx.x * LNG_BT; bt < min(a.nbt, (blockIdx.x + 1) * LNG_BT); ++bt) {
-        const float* z = a.Z + (size_t)bt * 64 * CZ;
-        const float* dy = a.dY + (size_t)bt * 64 * CZ;
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < 32; ++k) {
-            if (k < per) {
-                const int idx = tid + 256 * k;
-                const int f = idx / CZ, c = idx - f * CZ, g = a.gof[c];
-                const float v = z[idx];
-                const float act = v >= 0.f ? v : a.slope[c] * v;
-                float xh = 0.f, gd = 0.f;
-                if (g < 16) {
-                    xh = (act - a.stats[((size_t)bt * 16 + g) * 2]) * a.stats[((size_t)bt * 16 + g) * 2 + 1];
-                    const float d = dy[idx];
-                    gd = a.gamma[c * 64 + f] * d;
-                    acc_g[k] = fmaf(d, xh, acc_g[k]);
-                    acc_b[k] += d;
-                }
-                A[f * P + c] = xh;
-                D[f * P + c] = gd;
-            }
+    const float* __restrict__ z = a.Z + (size_t)bt * 64 * CZ;
+    const float* __restrict__ dy = a.dY + (size_t)bt * 64 * CZ;
+    float* __restrict__ sc = a.scratch + (size_t)bt * 2 * CZ * 64;
+    const int n = 64 * CZ;
+#pragma unroll 8
+    for (int k = 0; k < per; ++k) {
+        const int idx = tid + 256 * k, f = f0 + fstep * k;
+        const float v = z[idx], d = dy[idx];
+        const float act = v >= 0.f ? v : slope * v;
+        const float xh = on ? (act - mean) * rstd : 0.f;
+        A[f * P + c] = xh;
+        D[f * P + c] = on ? a.gamma[c * 64 + f] * d : 0.f;
+        sc[idx] = on ? d * xh : 0.f;
+        sc[n + idx] = on ? d : 0.f;
+    }
+    __syncthreads();
+    for (int q = wave; q < a.ngroups; q += 4) {
+        const int c0 = a.gstart[q], gs = a.gstart[q + 1] - c0, m = 64 * gs;
+        float s1 = 0.f, s2 = 0.f;
+        for (int i = lane; i < m; i += 64) {
+            const int o = (i / gs) * P + c0 + i % gs;
+            s1 += D[o];
+            s2 = fmaf(D[o], A[o], s2);
         }
-        __syncthreads();
-        for (int g = wave; g < a.ngroups; g += 4) {
-            const int c0 = a.gstart[g], gs = a.gstart[g + 1] - c0, n = 64 * gs;
-            float s1 = 0.f, s2 = 0.f;
-            for (int i = lane; i < n; i += 64) {
-                const int o = (i / gs) * P + c0 + i % gs;
-                s1 += D[o];
-                s2 = fmaf(D[o], A[o], s2);
-            }
-            s1 = wave_sum(s1) / n;
-            s2 = wave_sum(s2) / n;
-            if (lane == 0) {
-                g1[g] = s1;
-                g2[g] = s2;
-            }
-        }
-        __syncthreads();
-        float* dz = a.dZ + (size_t)bt * 64 * CZ;
-        for (int idx = tid; idx < 64 * CZ; idx += 256) {
-            const int f = idx / CZ, c = idx - f * CZ, g = a.gof[c];
-            float out = 0.f;
-            if (g < 16) {
-                const float rstd = a.stats[((size_t)bt * 16 + g) * 2 + 1];
-                const float dA = rstd * (D[f * P + c] - g1[g] - A[f * P + c] * g2[g]);
-                const float v = z[idx];
-                if (v >= 0.f) out = dA;
-                else {
-                    out = dA * a.slope[c];
-                    atomicAdd(&gsl[g], dA * v);
-                }
-            }
-            dz[idx] = out;
+        s1 = wave_sum(s1) / m;
+        s2 = wave_sum(s2) / m;
+        if (lane == 0) {
+            g1[q] = s1;
+            g2[q] = s2;
         }
     }
     __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 32; ++k) {
-        if (k < per) {
-            const int idx = tid + 256 * k;
-            const int f = idx / CZ, c = idx - f * CZ;
-            // per-workgroup partial sums; att_lng_reduce_kernel adds them up (atomics from every workgroup onto the (C, F) affine's
-            // 2 x 8192 addresses serialise: 346 -> 60 us)
-            float* sc = a.scratch + (size_t)blockIdx.x * 2 * CZ * 64;
-            sc[c * 64 + f] = a.gof[c] < 16 ? acc_g[k] : 0.f;
-            sc[CZ * 64 + c * 64 + f] = a.gof[c] < 16 ? acc_b[k] : 0.f;
-        }
+    float* __restrict__ dz = a.dZ + (size_t)bt * 64 * CZ;
+    const float m1 = on ? g1[g] : 0.f, m2 = on ? g2[g] : 0.f;
+    float dsl = 0.f;
+#pragma unroll 8
+    for (int k = 0; k < per; ++k) {
+        const int idx = tid + 256 * k, f = f0 + fstep * k;
+        const float dA = rstd * (D[f * P + c] - m1 - A[f * P + c] * m2);  // rstd = 0 for padding channels
+        const float v = z[idx];
+        dz[idx] = v >= 0.f ? dA : dA * slope;
+        dsl += v >= 0.f ? 0.f : dA * v;
     }
+    if (on && dsl != 0.f) atomicAdd(&gsl[g], dsl);
+    __syncthreads();
     if (tid < a.ngroups && gsl[tid] != 0.f) unsafeAtomicAdd(a.dslope + tid, gsl[tid]);
 }
 
+// nwg rows of [d*xhat | d] in slice order (f, c) -> dgamma, dbeta (c, f) (+=)
 __global__ __launch_bounds__(256) void att_lng_reduce_kernel(const float* __restrict__ scratch, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                             int nwg, int n) {
-    const int i = blockIdx.x * 256 + threadIdx.x;  // element of the (CZ, 64) affine
+                                                             int nwg, int n, int CZ) {
+    const int i = blockIdx.x * 256 + threadIdx.x;  // f * CZ + c
     if (i >= n) return;
     float g = 0.f, b = 0.f;
+#pragma unroll 4
     for (int w = blockIdx.y; w < nwg; w += gridDim.y) {
         g += scratch[(size_t)w * 2 * n + i];
         b += scratch[(size_t)w * 2 * n + n + i];
     }
-    unsafeAtomicAdd(dgamma + i, g);
-    unsafeAtomicAdd(dbeta + i, b);
+    const int o = (i % CZ) * 64 + i / CZ;
+    unsafeAtomicAdd(dgamma + o, g);
+    unsafeAtomicAdd(dbeta + o, b);
 }
 
 // Y rows (b,t,f) x 128 <-> Qp, Kp (4B, Tp, 256 = f*4 + e), Vp (4B, Tp, 1024 = f*16 + c); head-major batch index h*B + b
@@ -226,7 +207,7 @@ __global__ __launch_bounds__(256) void att_softmax_kernel(float* __restrict__ S,
     }
 }
 
-size_t att_lng_scratch_floats(int nbt) { return (size_t)cdiv(nbt, LNG_BT) * 2 * 128 * 64; }
+size_t att_lng_scratch_floats(int nbt) { return (size_t)nbt * 2 * 128 * 64; }
 int launch_att_lng(const LngArgs& a, int nbt, bool bwd, hipStream_t st) {
     if (a.CZ != 64 && a.CZ != 128) return RTFS_ERR_SHAPE;
     const size_t lds = (size_t)(bwd ? 2 : 1) * 64 * (a.CZ + 1) * sizeof(float);
@@ -236,10 +217,10 @@ int launch_att_lng(const LngArgs& a, int nbt, bool bwd, hipStream_t st) {
         LngArgs b = a;
         b.nbt = nbt;
         if (!b.scratch) return RTFS_ERR_WORKSPACE;
-        const int nwg = cdiv(nbt, LNG_BT);
+        const int nwg = nbt;
         hipLaunchKernelGGL(att_lng_bwd_kernel, dim3(nwg), dim3(256), lds, st, b);
         hipLaunchKernelGGL(att_lng_reduce_kernel, dim3(cdiv(a.CZ * 64, 256), nwg >= 16 ? 16 : nwg), dim3(256), 0, st, b.scratch, a.dgamma, a.dbeta, nwg,
-                           a.CZ * 64);
+                           a.CZ * 64, a.CZ);
     }
     else hipLaunchKernelGGL(att_lng_fwd_kernel, dim3(nbt), dim3(256), lds, st, a);
     return rtfs_launch_status();
