@@ -67,6 +67,54 @@ def cpu_baseline(repeats, workers=None):
                       f"(forwards alone {min(per) / per_worker:.1f}-{max(per) / per_worker:.1f} s per mixture)"}
 
 
+def train_cpu_baseline(repeats, threads=None):
+    """One training step (forward, PIT neg-SNR loss, backward) of the torch-autograd restatement (oracle/grad_oracle.py, float32 like the
+    reference's training) on this box's host cores: 2 mixtures x 2 s (train-mode BatchNorm needs two), one process with `threads` intra-op
+    threads.  Child process: must start BEFORE this process touches the GPU."""
+    import subprocess
+    threads = threads or min(16, os.cpu_count() or 1)
+    t0 = time.perf_counter()
+    pr = subprocess.run([sys.executable, "-m", "oracle.cpu_train_worker", str(repeats), "2", str(threads), "3", "f32"], cwd=ROOT,
+                        stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=1200)
+    if pr.returncode != 0 or not pr.stdout.strip():
+        return {"value": None, "unit": "mixtures/s", "cores": threads, "kind": "port", "sample": "CPU training worker failed"}
+    rec = json.loads(pr.stdout.strip().splitlines()[-1])
+    return {"value": round(rec["n"] / rec["seconds"], 4), "unit": "mixtures/s", "cores": int(threads), "kind": "port",
+            "sample": f"3 training steps of 2 mixtures each (2 s @16 kHz, RTFS-Net-{repeats}) through the float32 torch-autograd port "
+                      f"(oracle/grad_oracle.py; python time loop for the SRU cells), {threads} intra-op threads: {rec['seconds']:.1f} s "
+                      f"(wall incl. start-up {time.perf_counter() - t0:.1f} s)"}
+
+
+def train_roofline(dev, B, L):
+    """The training step's dominant kernel by time, gemm_nt_kernel<0> (1x1 convolutions on channel-last rows), timed alone with events on
+    torch's current stream at its most expensive shape: the 64 -> 256 residual convolution (and the input gradient of the 256 -> 64
+    projection) over all B*T*F rows.  Algorithmic bytes: A (M, K) + W (N, K) + C (M, N) floats, once each.  (Back-to-back launches on the
+    same operands: the 33 MB A stays in the memory-side cache, so this is the kernel's best case - inside a step, rocprofv3 shows the
+    same launch at ~78 us, see profiles/r01_train_step_kernel_stats.csv.)"""
+    from rtfs_net_amd import _lib
+    lib = _lib.load()
+    M, N, K = B * lib.rtfs_num_frames(L) * 129, 256, 64
+    A = torch.randn(M, K, device=dev)
+    W = torch.randn(N, K, device=dev)
+    C = torch.empty(M, N, device=dev)
+    st = _lib.stream_of(A)
+    run = lambda: _lib.check(lib.rtfs_debug_gemm_f32(0, _lib.ptr(A), _lib.ptr(W), _lib.ptr(C), M, N, K, 0, st), "rtfs_debug_gemm_f32")
+    for _ in range(3):
+        run()
+    n = 20
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / n
+    nbytes = 4.0 * (M * K + N * K + M * N)
+    return {"kernel": f"gemm_nt_kernel<0> (bf16x3 MFMA, C = A.W^T) at M={M}, N={N}, K={K}: the 64->256 1x1 convolution of an RTFS block on rows",
+            "bound": "hbm", "achieved": round(nbytes / ms / 1e6, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(nbytes / ms / 1e6 / 8000.0, 4),
+            "traffic": None, "launches_timed": n, "avg_launch_ms": round(ms, 4), "algorithmic_bytes_per_launch": int(nbytes)}
+
+
 def rank_inputs(rank, B, L, Tv):
     """Per-rank synthetic batch: s1, s2 ~ N(0, 0.05^2), mixture = s1 + s2, lip embedding ~ N(0, 1)."""
     g = torch.Generator().manual_seed(1234 + rank)
@@ -101,6 +149,7 @@ def train_main(args):
         os.environ.setdefault("MASTER_PORT", "29511")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    cpu_res = train_cpu_baseline(args.repeats) if (world == 1 and not args.no_cpu_baseline) else None  # before the GPU is initialised
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     import rtfs_net_amd as R
@@ -132,6 +181,10 @@ def train_main(args):
     dt = max_over_ranks(time.perf_counter() - t0, dist, dev)
     assert bool(torch.isfinite(last))
     if rank == 0:
+        peak_gib = round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)
+        extra = {"roofline": train_roofline(dev, B, L)}
+        if cpu_res is not None:
+            extra["cpu_baseline"] = cpu_res
         print(json.dumps({
             "metric": f"mixtures/sec trained ({args.seconds:g} s@16 kHz) RTFS-Net-{args.repeats} training step", "value": round(throughput(world, B, args.steps, dt), 3),
             "unit": "mixtures/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
@@ -141,7 +194,7 @@ def train_main(args):
                                    + (", SyncBatchNorm" if world > 1 else ""),
                        "per_gpu_batch": B, "global_batch": B * world, "samples": L,
                        "parallelism": f"dp{world} (one flattened gradient all-reduce of {sum(p.numel() for p in model.parameters())} floats per step)"},
-            "peak_memory_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}), flush=True)
+            "peak_memory_gib": peak_gib, **extra}), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
