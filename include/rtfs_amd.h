@@ -277,6 +277,16 @@ int rtfs_caf_combine_f32(const float* key, const float* value, const float* resi
                          int Tv, void* stream);
 int rtfs_caf_combine_backward_f32(const float* dout, const float* key, const float* value, const float* resized, const float* att,
                                   float* dkey, float* dvalue, float* dresized, float* datt, int N, int T, int F, int Tv, void* stream);
+/* The RTFS block's gateway on rows (B, T, F, C), C fastest (reference separators/tdanet.py:30-38 `gateway = ConvNormAct(in_chan, in_chan, 1,
+ * groups=in_chan, act_type)` applied at :106-108 to `x + x_res`): out = PReLU(w_c * (x + x_res) + b_c) in one pass (x_res may be NULL);
+ * backward in one pass: dx (the gradient of x and of x_res alike) and dparams = [dw C | db C | dslope 1] (each slot rounded up to 64
+ * floats; rtfs_gateway_grad_floats).  w, b: the depthwise Conv2d's weight (C,1,1,1) and bias; slope: nn.PReLU's single weight. */
+size_t rtfs_gateway_grad_floats(int C);
+size_t rtfs_gateway_workspace_bytes(int C);
+int rtfs_gateway_forward_train_f32(const float* x, const float* x_res, const float* w, const float* b, const float* slope, float* out,
+                                   size_t rows, int C, void* stream);
+int rtfs_gateway_backward_f32(const float* x, const float* x_res, const float* w, const float* b, const float* slope, const float* dout,
+                              float* dx, float* dparams, size_t rows, int C, void* ws, size_t ws_bytes, void* stream);
 /* Gradient of PITLossWrapper(PairwiseNegSDR) (src/losses/pit_wrapper.py:84-110 around matrix.py:22-53) with respect to the estimates,
  * for the permutation the forward chose: dmin_loss (B) = upstream gradient of min_loss, perm (B, n_src) as returned by
  * rtfs_pit_pairwise_sdr_f32 -> dests (B, n_src, L).  (The targets are data.) */

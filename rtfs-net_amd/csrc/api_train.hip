@@ -777,6 +777,32 @@ int rtfs_cna_backward_f32(const float* x, const float* params, const float* save
     return launch_transpose(dfirst, dx, B, H * W, c.Cin, st);
 }
 
+// ------------------------------------------------------------ RTFS block gateway (depthwise 1x1 + PReLU on x + x_res), training side
+// gradient buffer: [dw C | db C | dslope 1], C and 2C + 1 rounded up to 64
+size_t rtfs_gateway_grad_floats(int C) { return 2 * (size_t)align_up((size_t)C, 64) + 64; }
+size_t rtfs_gateway_workspace_bytes(int C) { return cl_stage_partial_floats(1, C) * sizeof(float) + 256; }
+int rtfs_gateway_forward_train_f32(const float* x, const float* x_res, const float* w, const float* b, const float* slope, float* out,
+                                   size_t rows, int C, void* stream) {
+    RTFS_RETURN_IF(!x || !w || !b || !slope || !out || rows < 1, RTFS_ERR_ARG);
+    GatewayArgs a;
+    a.x = x; a.xr = x_res; a.w = w; a.b = b; a.slope = slope; a.y = out; a.n4 = rows * (size_t)C / 4; a.C = C;
+    return launch_gateway(a, false, nullptr, nullptr, nullptr, S(stream));
+}
+int rtfs_gateway_backward_f32(const float* x, const float* x_res, const float* w, const float* b, const float* slope, const float* dout,
+                              float* dx, float* dparams, size_t rows, int C, void* ws, size_t ws_bytes, void* stream) {
+    RTFS_RETURN_IF(!x || !w || !b || !slope || !dout || !dx || !dparams || rows < 1, RTFS_ERR_ARG);
+    RTFS_RETURN_IF(!ws || ws_bytes < rtfs_gateway_workspace_bytes(C), RTFS_ERR_WORKSPACE);
+    Arena ar(ws, ws_bytes);
+    GatewayArgs a;
+    a.partial = ar.take<float>(cl_stage_partial_floats(1, C));
+    RTFS_RETURN_IF(!ar.ok(), RTFS_ERR_WORKSPACE);
+    hipStream_t st = S(stream);
+    if (hipMemsetAsync(dparams, 0, rtfs_gateway_grad_floats(C) * sizeof(float), st) != hipSuccess) return RTFS_ERR_LAUNCH;
+    a.x = x; a.xr = x_res; a.w = w; a.b = b; a.slope = slope; a.dy = dout; a.dx = dx; a.n4 = rows * (size_t)C / 4; a.C = C;
+    const size_t Cp = align_up((size_t)C, 64);
+    return launch_gateway(a, true, dparams, dparams + Cp, dparams + 2 * Cp, st);
+}
+
 // ------------------------------------------------------------ MultiHeadSelfAttention2D, training side
 namespace {
 // parameter slots (floats)

@@ -284,6 +284,73 @@ __global__ __launch_bounds__(256) void cl_norm_act_bwd_apply_kernel(ClStageArgs 
     }
 }
 
+// ------------------------------------------------------------------------------------------------ RTFS block gateway, one pass each way
+// tdanet.py:30-38,106-108: gateway = ConvNormAct(C, C, 1, groups = C, act PReLU) applied to x (+ x_res) - on rows that is
+// y = PReLU(w_c * (x + x_res) + b_c).  As separate modules it cost an add, a depthwise pass and an activation pass forward and five
+// passes backward over the block's largest tensor (133 MB at batch 4); here each direction is one pass: the backward recomputes z from
+// x (+ x_res), writes dx (the gradient of both addends) and leaves per-workgroup rows [dw C | db C | dslope] for cl_stage_reduce2_kernel.
+template <bool BWD>
+__global__ __launch_bounds__(256) void gateway_kernel(GatewayArgs a) {
+    __shared__ float part[9][256];
+    const int tid = threadIdx.x;
+    const size_t i0 = (size_t)blockIdx.x * 256 + tid;
+    const int c0 = (int)((i0 * 4) & (size_t)(a.C - 1));
+    const f32x4u_t w4 = *reinterpret_cast<const f32x4u_t*>(a.w + c0), b4 = *reinterpret_cast<const f32x4u_t*>(a.b + c0);
+    const float slope = a.slope[0];
+    f32x4u_t dw = {0.f, 0.f, 0.f, 0.f}, db = {0.f, 0.f, 0.f, 0.f};
+    float dsl = 0.f;
+#pragma unroll 4
+    for (size_t i = i0; i < a.n4; i += (size_t)gridDim.x * 256) {
+        f32x4u_t v = reinterpret_cast<const f32x4u_t*>(a.x)[i];
+        if (a.xr) v += reinterpret_cast<const f32x4u_t*>(a.xr)[i];
+        const f32x4u_t z = w4 * v + b4;
+        if (!BWD) {
+            f32x4u_t y;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) y[k] = z[k] >= 0.f ? z[k] : slope * z[k];
+            reinterpret_cast<f32x4u_t*>(a.y)[i] = y;
+        } else {
+            const f32x4u_t d = reinterpret_cast<const f32x4u_t*>(a.dy)[i];
+            f32x4u_t da;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                da[k] = z[k] >= 0.f ? d[k] : slope * d[k];
+                dsl += z[k] >= 0.f ? 0.f : d[k] * z[k];
+            }
+            dw += da * v;
+            db += da;
+            reinterpret_cast<f32x4u_t*>(a.dx)[i] = da * w4;
+        }
+    }
+    if (!BWD) return;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        part[2 * k][tid] = dw[k];
+        part[2 * k + 1][tid] = db[k];
+    }
+    part[8][tid] = dsl;
+    __syncthreads();
+    float* __restrict__ row = a.partial + (size_t)blockIdx.x * CL_STAGE_PITCH(a.C);
+    const int CV = a.C >> 2;
+    if (tid < CV) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float sw = 0.f, sb = 0.f;
+            for (int j = tid; j < 256; j += CV) {
+                sw += part[2 * k][j];
+                sb += part[2 * k + 1][j];
+            }
+            row[c0 + k] = sw;
+            row[a.C + c0 + k] = sb;
+        }
+    }
+    if (tid < 64) {
+        float v = part[8][tid] + part[8][tid + 64] + part[8][tid + 128] + part[8][tid + 192];
+        v = wave_sum(v);
+        if (tid == 0) row[2 * a.C] = v;
+    }
+}
+
 // per-channel sum and sum of squares over all rows (BatchNorm batch statistics), f64 atomics; grid stride a multiple of C
 __global__ __launch_bounds__(256) void cl_chan_stats_kernel(const float* __restrict__ x, double* __restrict__ st, size_t n, int C) {
     __shared__ double part[2][256];
@@ -712,6 +779,20 @@ int launch_cl_norm_act_bwd(const ClStageArgs& a, int B, hipStream_t st, int part
         if (a.C % 4 == 0) hipLaunchKernelGGL(cl_norm_act_bwd_apply_kernel<4>, dim3(grid4(a.n / 4, 2048), B), dim3(256), 0, st, a);
         else hipLaunchKernelGGL(cl_norm_act_bwd_apply_kernel<1>, dim3(grid4(a.n, 2048), B), dim3(256), 0, st, a);
     }
+    return rtfs_launch_status();
+}
+// bwd: a.dx, a.dy, a.partial (cl_stage_partial_floats(1, C) floats), dw / db / dslope accumulate into zeroed buffers
+int launch_gateway(const GatewayArgs& a, bool bwd, float* dw, float* db, float* dslope, hipStream_t st) {
+    if (a.C < 4 || a.C > 1024 || (a.C & (a.C - 1))) return RTFS_ERR_SHAPE;
+    if (!bwd) {
+        hipLaunchKernelGGL(gateway_kernel<false>, dim3(grid4(a.n4, 2048)), dim3(256), 0, st, a);
+        return rtfs_launch_status();
+    }
+    if (!a.partial) return RTFS_ERR_WORKSPACE;
+    const unsigned gx = grid4(a.n4 / 4, CL_STAGE_MAX_WG);
+    hipLaunchKernelGGL(gateway_kernel<true>, dim3(gx), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(cl_stage_reduce2_kernel, dim3(cdiv(2 * a.C, 64) + 1, gx >= 128 ? 32 : cdiv((int)gx, 4)), dim3(256), 0, st, a.partial, (int)gx, 1,
+                       a.C, dw, db, dslope, (double*)nullptr, 2, 2);
     return rtfs_launch_status();
 }
 int launch_cl_chan_stats(const float* x, double* stats, size_t n, int C, hipStream_t st) {

@@ -290,6 +290,13 @@ struct ClDwArgs {
     int B = 0, H = 0, W = 0, C = 0, Ho = 0, Wo = 0, kh = 0, kw = 0, s = 1, pt = 0, pl = 0;
     int Cp = 0;  // row pitch in channels (set by the launcher; C is the slice a launch covers)
 };
+struct GatewayArgs {  // y = PReLU(w_c * (x + xr) + b_c) over n4 float4 of rows x C (C fastest)
+    const float *x = nullptr, *xr = nullptr, *w = nullptr, *b = nullptr, *slope = nullptr, *dy = nullptr;
+    float *y = nullptr, *dx = nullptr, *partial = nullptr;
+    size_t n4 = 0;
+    int C = 0;
+};
+int launch_gateway(const GatewayArgs& a, bool bwd, float* dw, float* db, float* dslope, hipStream_t st);
 size_t cl_stage_partial_floats(int B, int C);
 int launch_cl_norm_act_fwd(const ClStageArgs& a, int B, hipStream_t st);
 int launch_cl_norm_act_bwd(const ClStageArgs& a, int B, hipStream_t st, int part = 0);

@@ -315,6 +315,57 @@ class _CNATrainFn(torch.autograd.Function):
         return out + (None,) * ctx.nrunning
 
 
+class _GatewayFn(torch.autograd.Function):
+    """The RTFS block's gateway on rows (tdanet.py:30-38 applied at :106-108): PReLU(depthwise 1x1 conv(x + x_res)) in one pass each way
+    (csrc/k_train_conv.hip gateway_kernel).  Inputs: x, x_res (or None) as (B, T, F, C) rows, the gradient bundle of (conv.weight, conv.bias,
+    prelu.weight), and those three parameters hidden in a tuple."""
+
+    @staticmethod
+    def forward(ctx, x, x_res, bundle, params):
+        lib = _lib.load()
+        w, b, slope = (p.detach().contiguous() for p in params)
+        x = x.contiguous()
+        x_res = None if x_res is None else x_res.contiguous()
+        C = x.shape[-1]
+        out = torch.empty_like(x)
+        _lib.check(lib.rtfs_gateway_forward_train_f32(_lib.ptr(x), _lib.ptr(x_res), _lib.ptr(w), _lib.ptr(b), _lib.ptr(slope), _lib.ptr(out),
+                                                      x.numel() // C, C, _lib.stream_of(x)), "rtfs_gateway_forward_train_f32")
+        ctx.save_for_backward(x, x_res, w, b, slope)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        x, x_res, w, b, slope = ctx.saved_tensors
+        C = x.shape[-1]
+        dout = dout.contiguous()
+        dx = torch.empty_like(x)
+        dpar = torch.empty(lib.rtfs_gateway_grad_floats(C), device=x.device, dtype=torch.float32)
+        ws = _lib.workspace(lib.rtfs_gateway_workspace_bytes(C), x.device)
+        _lib.check(lib.rtfs_gateway_backward_f32(_lib.ptr(x), _lib.ptr(x_res), _lib.ptr(w), _lib.ptr(b), _lib.ptr(slope), _lib.ptr(dout), _lib.ptr(dx),
+                                                 _lib.ptr(dpar), x.numel() // C, C, _lib.ptr(ws), ws.numel(), _lib.stream_of(x)),
+                   "rtfs_gateway_backward_f32")
+        return dx, (dx if x_res is not None else None), dpar, None
+
+
+def gateway_train(cna, x, x_res):
+    """``cna`` = the block's gateway ConvNormAct (depthwise 1x1 with bias, no norm, PReLU); x, x_res rows.  None when the module is
+    configured differently (the caller then composes add + ConvNormAct)."""
+    pre_n, pre_a, conv, nrm, act = cna.full_layer
+    C = x.shape[-1]
+    if not (isinstance(pre_n, nn.Identity) and isinstance(pre_a, nn.Identity) and isinstance(nrm, nn.Identity) and isinstance(act, nn.PReLU)
+            and act.weight.numel() == 1 and isinstance(conv, (nn.Conv1d, nn.Conv2d)) and cna.kernel_size == 1 and cna.stride == 1
+            and conv.groups == C and conv.in_channels == C and conv.out_channels == C and conv.bias is not None
+            and C % 4 == 0 and C <= 1024 and not (C & (C - 1))):
+        return None
+    params = (conv.weight, conv.bias, act.weight)
+    Cp = (C + 63) // 64 * 64
+    unpack = lambda flat: [flat[:C].reshape(conv.weight.shape), flat[Cp:Cp + C], flat[2 * Cp:2 * Cp + 1]]
+    n = _lib.load().rtfs_gateway_grad_floats(C)
+    bundle = _grad_bundle(("gateway", C), params, n, unpack) if any(p.requires_grad for p in params) else None
+    return _GatewayFn.apply(x, x_res, bundle, params)
+
+
 def _cna_apply(x, cfg, params, running=()):
     """_CNATrainFn with the eight (optional) parameters behind a gradient bundle."""
     import ctypes

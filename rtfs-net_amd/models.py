@@ -285,10 +285,16 @@ class TDANetBlock(PackedModule):
         but only the block's input and output change layout (every module converting at its own boundary costs 10 % of a step) - and
         not even those when the caller keeps rows between blocks (``rows_in`` / ``rows_out``; AVNet.forward_train)."""
         from . import layers as L
-        if x_res is not None:
-            x = x + x_res
         rr = (True, True)
-        residual = self.gateway._forward_train(x, (rows_in, True))
+        residual = None
+        if x.is_cuda:  # gateway fused with the residual input: one pass each way over the block's largest tensor
+            xr = x if rows_in else L._LayoutFn.apply(x, True)
+            rr_res = x_res if (rows_in or x_res is None) else L._LayoutFn.apply(x_res, True)
+            residual = L.gateway_train(self.gateway, xr, rr_res)
+        if residual is None:
+            if x_res is not None:
+                x = x + x_res
+            residual = self.gateway._forward_train(x, (rows_in, True))
         x_enc = self.projection._forward_train(residual, rr)
         down = [self.downsample_layers[0]._forward_train(x_enc, rr)]
         for i in range(1, self.upsampling_depth):

@@ -850,3 +850,45 @@ def test_two_process_training_step_matches_single_process(tmp_path):
     worst = sorted(errs.items(), key=lambda kv: -kv[1])[:3]
     print(f"[parity] 2-process vs 1-process gradients over {len(errs)} tensors: median l2-rel {np.median(list(errs.values())):.3e}, worst {worst}")
     assert np.median(list(errs.values())) <= 1e-4 and worst[0][1] <= 2e-2, worst
+
+
+@pytest.mark.parametrize("shape,with_res,seed", [((2, 5, 7, 256), True, 151), ((1, 33, 129, 256), False, 152), ((3, 1, 3, 64), True, 153)])
+def test_gateway_one_pass_forward_backward(shape, with_res, seed):
+    """rtfs_gateway_forward_train_f32 / rtfs_gateway_backward_f32 (PReLU(depthwise 1x1(x + x_res)) on rows, tdanet.py:30-38,106-108) against
+    torch autograd in float64 on the same values; the kink is kept out of reach (|z| > 1e-3) so the bound can be tight (1e-5)."""
+    import rtfs_net_amd as R
+    from rtfs_net_amd import layers as L
+    C = shape[-1]
+    cna = R.layers.ConvNormAct(C, C, 1, groups=C, act_type="PReLU", is2d=True).cuda().train()
+    rng = np.random.default_rng(seed)
+    with torch.no_grad():
+        cna.full_layer[2].weight.copy_(torch.from_numpy(rng.uniform(0.5, 1.5, (C, 1, 1, 1)).astype(np.float32)))
+        cna.full_layer[2].bias.copy_(torch.from_numpy(rng.uniform(-0.2, 0.2, C).astype(np.float32)))
+        cna.full_layer[4].weight.fill_(0.3)
+    x = rand(shape, seed)
+    res = rand(shape, seed + 1) if with_res else None
+    w64 = cna.full_layer[2].weight.detach().double().cpu().reshape(C)
+    b64 = cna.full_layer[2].bias.detach().double().cpu()
+    z0 = w64 * (torch.from_numpy(x).double() + (torch.from_numpy(res).double() if with_res else 0)) + b64
+    x = np.where(np.abs(z0.numpy()) < 1e-3, x + 0.01, x).astype(np.float32)  # move the few pre-activations near 0 away from the kink
+    dout = rand(shape, seed + 2)
+    xt = dev(x).requires_grad_(True)
+    rt = dev(res).requires_grad_(True) if with_res else None
+    out = L.gateway_train(cna, xt, rt)
+    assert out is not None
+    out.backward(dev(dout))
+    x64 = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    r64 = torch.tensor(res, dtype=torch.float64, requires_grad=True) if with_res else None
+    w = w64.clone().requires_grad_(True)
+    b = b64.clone().requires_grad_(True)
+    sl = torch.tensor([0.3], dtype=torch.float64, requires_grad=True)
+    z = w * (x64 + r64 if with_res else x64) + b
+    ref = torch.where(z >= 0, z, sl * z)
+    ref.backward(torch.tensor(dout, dtype=torch.float64))
+    close("gateway forward", host(out), ref.detach().numpy(), 1e-6)
+    close("gateway dx", host(xt.grad), x64.grad.numpy(), 1e-5)
+    if with_res:
+        close("gateway dx_res", host(rt.grad), r64.grad.numpy(), 1e-5)
+    close("gateway dweight", host(cna.full_layer[2].weight.grad).reshape(C), w.grad.numpy(), 1e-5)
+    close("gateway dbias", host(cna.full_layer[2].bias.grad), b.grad.numpy(), 1e-5)
+    close("gateway dslope", host(cna.full_layer[4].weight.grad), sl.grad.numpy(), 1e-5)
