@@ -277,6 +277,13 @@ int rtfs_caf_combine_f32(const float* key, const float* value, const float* resi
                          int Tv, void* stream);
 int rtfs_caf_combine_backward_f32(const float* dout, const float* key, const float* value, const float* resized, const float* att,
                                   float* dkey, float* dvalue, float* dresized, float* datt, int N, int T, int F, int Tv, void* stream);
+/* rtfs_caf_combine[_backward]_f32 on rows: key, value, out and their gradients (B, T, F, C) with C fastest; resized, att and their
+ * gradients stay (B, C, Tv). */
+int rtfs_caf_combine_rows_f32(const float* key, const float* value, const float* resized, const float* att, float* out, int B, int T, int F,
+                              int C, int Tv, void* stream);
+int rtfs_caf_combine_rows_backward_f32(const float* dout, const float* key, const float* value, const float* resized, const float* att,
+                                       float* dkey, float* dvalue, float* dresized, float* datt, int B, int T, int F, int C, int Tv,
+                                       void* stream);
 /* The RTFS block's gateway on rows (B, T, F, C), C fastest (reference separators/tdanet.py:30-38 `gateway = ConvNormAct(in_chan, in_chan, 1,
  * groups=in_chan, act_type)` applied at :106-108 to `x + x_res`): out = PReLU(w_c * (x + x_res) + b_c) in one pass (x_res may be NULL);
  * backward in one pass: dx (the gradient of x and of x_res alike) and dparams = [dw C | db C | dslope 1] (each slot rounded up to 64

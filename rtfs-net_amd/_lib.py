@@ -101,6 +101,8 @@ SIGNATURES = {
     "rtfs_caf_attention_backward_f32": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "rtfs_caf_combine_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "rtfs_caf_combine_backward_f32": (_i, [_p] * 9 + [_i, _i, _i, _i, _p]),
+    "rtfs_caf_combine_rows_f32": (_i, [_p] * 5 + [_i] * 5 + [_p]),
+    "rtfs_caf_combine_rows_backward_f32": (_i, [_p] * 9 + [_i] * 5 + [_p]),
     "rtfs_gateway_grad_floats": (_z, [_i]),
     "rtfs_gateway_workspace_bytes": (_z, [_i]),
     "rtfs_gateway_forward_train_f32": (_i, [_p] * 6 + [_z, _i, _p]),

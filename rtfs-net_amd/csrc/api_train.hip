@@ -777,10 +777,23 @@ int rtfs_cna_backward_f32(const float* x, const float* params, const float* save
     return launch_transpose(dfirst, dx, B, H * W, c.Cin, st);
 }
 
+// CAF combine on rows: key, value, out (B, T, F, C); resized, att (B, C, Tv)
+int rtfs_caf_combine_rows_f32(const float* key, const float* value, const float* resized, const float* att, float* out, int B, int T, int F,
+                              int C, int Tv, void* stream) {
+    RTFS_RETURN_IF(!key || !value || !resized || !att || !out || B < 1, RTFS_ERR_ARG);
+    return launch_caf_combine_rows(key, value, resized, att, out, B, T, F, C, Tv, S(stream));
+}
+int rtfs_caf_combine_rows_backward_f32(const float* dout, const float* key, const float* value, const float* resized, const float* att,
+                                       float* dkey, float* dvalue, float* dresized, float* datt, int B, int T, int F, int C, int Tv,
+                                       void* stream) {
+    RTFS_RETURN_IF(!dout || !key || !value || !resized || !att || !dkey || !dvalue || !dresized || !datt || B < 1, RTFS_ERR_ARG);
+    return launch_caf_combine_rows_bwd(dout, key, value, resized, att, dkey, dvalue, dresized, datt, B, T, F, C, Tv, S(stream));
+}
+
 // ------------------------------------------------------------ RTFS block gateway (depthwise 1x1 + PReLU on x + x_res), training side
 // gradient buffer: [dw C | db C | dslope 1], C and 2C + 1 rounded up to 64
 size_t rtfs_gateway_grad_floats(int C) { return 2 * (size_t)align_up((size_t)C, 64) + 64; }
-size_t rtfs_gateway_workspace_bytes(int C) { return cl_stage_partial_floats(1, C) * sizeof(float) + 256; }
+size_t rtfs_gateway_workspace_bytes(int C) { return cl_stage_partial_floats(2, C) * sizeof(float) + 256; }
 int rtfs_gateway_forward_train_f32(const float* x, const float* x_res, const float* w, const float* b, const float* slope, float* out,
                                    size_t rows, int C, void* stream) {
     RTFS_RETURN_IF(!x || !w || !b || !slope || !out || rows < 1, RTFS_ERR_ARG);
@@ -794,7 +807,7 @@ int rtfs_gateway_backward_f32(const float* x, const float* x_res, const float* w
     RTFS_RETURN_IF(!ws || ws_bytes < rtfs_gateway_workspace_bytes(C), RTFS_ERR_WORKSPACE);
     Arena ar(ws, ws_bytes);
     GatewayArgs a;
-    a.partial = ar.take<float>(cl_stage_partial_floats(1, C));
+    a.partial = ar.take<float>(cl_stage_partial_floats(2, C));
     RTFS_RETURN_IF(!ar.ok(), RTFS_ERR_WORKSPACE);
     hipStream_t st = S(stream);
     if (hipMemsetAsync(dparams, 0, rtfs_gateway_grad_floats(C) * sizeof(float), st) != hipSuccess) return RTFS_ERR_LAUNCH;

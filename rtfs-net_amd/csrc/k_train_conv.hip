@@ -781,7 +781,7 @@ int launch_cl_norm_act_bwd(const ClStageArgs& a, int B, hipStream_t st, int part
     }
     return rtfs_launch_status();
 }
-// bwd: a.dx, a.dy, a.partial (cl_stage_partial_floats(1, C) floats), dw / db / dslope accumulate into zeroed buffers
+// bwd: a.dx, a.dy, a.partial (cl_stage_partial_floats(2, C) floats), dw / db / dslope accumulate into zeroed buffers
 int launch_gateway(const GatewayArgs& a, bool bwd, float* dw, float* db, float* dslope, hipStream_t st) {
     if (a.C < 4 || a.C > 1024 || (a.C & (a.C - 1))) return RTFS_ERR_SHAPE;
     if (!bwd) {
@@ -789,7 +789,7 @@ int launch_gateway(const GatewayArgs& a, bool bwd, float* dw, float* db, float* 
         return rtfs_launch_status();
     }
     if (!a.partial) return RTFS_ERR_WORKSPACE;
-    const unsigned gx = grid4(a.n4 / 4, CL_STAGE_MAX_WG);
+    const unsigned gx = grid4(a.n4 / 4, 2 * CL_STAGE_MAX_WG);  // four streams of the block's largest tensor: two workgroups per CU
     hipLaunchKernelGGL(gateway_kernel<true>, dim3(gx), dim3(256), 0, st, a);
     hipLaunchKernelGGL(cl_stage_reduce2_kernel, dim3(cdiv(2 * a.C, 64) + 1, gx >= 128 ? 32 : cdiv((int)gx, 4)), dim3(256), 0, st, a.partial, (int)gx, 1,
                        a.C, dw, db, dslope, (double*)nullptr, 2, 2);
@@ -1172,6 +1172,79 @@ __global__ __launch_bounds__(256) void caf_combine_bwd_kernel(const float* __res
 int launch_caf_att(const float* in, float* out, const float* dout, float* din, int nbc, int Tv, bool bwd, hipStream_t st) {
     if (Tv < 1 || Tv > 256) return RTFS_ERR_SHAPE;
     hipLaunchKernelGGL(caf_att_kernel, dim3(cdiv(nbc, 4)), dim3(256), 0, st, in, out, dout, din, nbc, Tv, bwd ? 1 : 0);
+    return rtfs_launch_status();
+}
+// The same on rows: key, value, out (B, T, F, C) with C fastest; r, att stay (B, C, Tv) (they come from the video side).
+// One workgroup per (b, t) slab of F x C floats; C divides 1024, so a thread keeps its channel quad (c4 = tid % (C / 4)) and its
+// r / att values (gathered once, stride Tv) while f moves.  BWD: dkey = dout * r, dvalue = dout * att, and the slab's share of
+// dr = sum dout * key, datt = sum dout * value, folded over the threads of a channel quad in LDS and added to the (zeroed) outputs -
+// a handful of frames t share a video frame tv.
+template <bool BWD>
+__global__ __launch_bounds__(256) void caf_combine_rows_kernel(const float* __restrict__ dout, const float* __restrict__ key,
+                                                               const float* __restrict__ value, const float* __restrict__ r,
+                                                               const float* __restrict__ att, float* __restrict__ o1, float* __restrict__ o2,
+                                                               float* __restrict__ dr, float* __restrict__ datt, int T, int F, int C, int Tv) {
+    __shared__ float4 part[2][256];
+    const int b = blockIdx.x / T, t = blockIdx.x - b * T, tid = threadIdx.x;
+    const int C4 = C >> 2, c = (tid % C4) * 4, n4 = F * C4;
+    const size_t j = ((size_t)b * C + c) * Tv + nearest_src(t, Tv, T);
+    f32x4u_t r4, a4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        r4[q] = r[j + (size_t)q * Tv];
+        a4[q] = att[j + (size_t)q * Tv];
+    }
+    const size_t base = (size_t)blockIdx.x * n4;
+    f32x4u_t sr = {0.f, 0.f, 0.f, 0.f}, sa = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int i = tid; i < n4; i += 256) {
+        const f32x4u_t k4 = reinterpret_cast<const f32x4u_t*>(key)[base + i], v4 = reinterpret_cast<const f32x4u_t*>(value)[base + i];
+        if (!BWD) {
+            reinterpret_cast<f32x4u_t*>(o1)[base + i] = k4 * r4 + a4 * v4;
+        } else {
+            const f32x4u_t d = reinterpret_cast<const f32x4u_t*>(dout)[base + i];
+            reinterpret_cast<f32x4u_t*>(o1)[base + i] = d * r4;
+            reinterpret_cast<f32x4u_t*>(o2)[base + i] = d * a4;
+            sr += d * k4;
+            sa += d * v4;
+        }
+    }
+    if (!BWD) return;
+    part[0][tid] = make_float4(sr[0], sr[1], sr[2], sr[3]);
+    part[1][tid] = make_float4(sa[0], sa[1], sa[2], sa[3]);
+    __syncthreads();
+    if (tid < C4) {
+        float4 x = make_float4(0.f, 0.f, 0.f, 0.f), y = x;
+        for (int k = tid; k < 256; k += C4) {
+            const float4 p = part[0][k], q = part[1][k];
+            x.x += p.x, x.y += p.y, x.z += p.z, x.w += p.w;
+            y.x += q.x, y.y += q.y, y.z += q.z, y.w += q.w;
+        }
+        const float xs[4] = {x.x, x.y, x.z, x.w}, ys[4] = {y.x, y.y, y.z, y.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            unsafeAtomicAdd(dr + j + (size_t)q * Tv, xs[q]);
+            unsafeAtomicAdd(datt + j + (size_t)q * Tv, ys[q]);
+        }
+    }
+}
+namespace {
+inline bool caf_rows_ok(int T, int C, int Tv) { return Tv >= 1 && Tv <= T && C >= 4 && C <= 1024 && !(1024 % C); }
+}  // namespace
+int launch_caf_combine_rows(const float* key, const float* value, const float* r, const float* att, float* out, int B, int T, int F, int C, int Tv,
+                            hipStream_t st) {
+    if (!caf_rows_ok(T, C, Tv)) return RTFS_ERR_SHAPE;
+    hipLaunchKernelGGL(caf_combine_rows_kernel<false>, dim3((unsigned)(B * T)), dim3(256), 0, st, (const float*)nullptr, key, value, r, att, out,
+                       (float*)nullptr, (float*)nullptr, (float*)nullptr, T, F, C, Tv);
+    return rtfs_launch_status();
+}
+int launch_caf_combine_rows_bwd(const float* dout, const float* key, const float* value, const float* r, const float* att, float* dkey,
+                                float* dvalue, float* dr, float* datt, int B, int T, int F, int C, int Tv, hipStream_t st) {
+    if (!caf_rows_ok(T, C, Tv)) return RTFS_ERR_SHAPE;
+    if (hipMemsetAsync(dr, 0, sizeof(float) * B * C * Tv, st) != hipSuccess || hipMemsetAsync(datt, 0, sizeof(float) * B * C * Tv, st) != hipSuccess)
+        return RTFS_ERR_LAUNCH;
+    hipLaunchKernelGGL(caf_combine_rows_kernel<true>, dim3((unsigned)(B * T)), dim3(256), 0, st, dout, key, value, r, att, dkey, dvalue, dr, datt, T, F,
+                       C, Tv);
     return rtfs_launch_status();
 }
 int launch_caf_combine(const float* key, const float* value, const float* r, const float* att, float* out, size_t N, int T, int F, int Tv,

@@ -334,6 +334,10 @@ int launch_cmul(const float* a, const float* b, float* out, int B, size_t half, 
 int launch_caf_att(const float* in, float* out, const float* dout, float* din, int nbc, int Tv, bool bwd, hipStream_t st);
 int launch_caf_combine(const float* key, const float* value, const float* r, const float* att, float* out, size_t N, int T, int F, int Tv,
                        hipStream_t st);
+int launch_caf_combine_rows(const float* key, const float* value, const float* r, const float* att, float* out, int B, int T, int F, int C, int Tv,
+                            hipStream_t st);
+int launch_caf_combine_rows_bwd(const float* dout, const float* key, const float* value, const float* r, const float* att, float* dkey,
+                                float* dvalue, float* dr, float* datt, int B, int T, int F, int C, int Tv, hipStream_t st);
 int launch_caf_combine_bwd(const float* dout, const float* key, const float* value, const float* r, const float* att, float* dkey,
                            float* dvalue, float* dr, float* datt, size_t N, int T, int F, int Tv, hipStream_t st);
 int launch_pit_sdr_bwd(const float* est, const float* tgt, const int* perm, const float* dmin, float* dest, int B, int n, int L, int kind,

@@ -1017,29 +1017,41 @@ class _CafCombineFn(torch.autograd.Function):
     """key * up(resized) + up(att) * value (fusion.py:255-272), with the four adjoints."""
 
     @staticmethod
-    def forward(ctx, key, value, resized, att):
+    def forward(ctx, key, value, resized, att, rows=False):
         lib = _lib.load()
         key, value, resized, att = key.contiguous(), value.contiguous(), resized.contiguous(), att.contiguous()
-        B, C, T, Fq = key.shape
         Tv = resized.shape[-1]
         out = torch.empty_like(key)
-        _lib.check(lib.rtfs_caf_combine_f32(_lib.ptr(key), _lib.ptr(value), _lib.ptr(resized), _lib.ptr(att), _lib.ptr(out), B * C, T, Fq, Tv,
-                                            _lib.stream_of(key)), "rtfs_caf_combine_f32")
+        if rows:  # key, value (B, T, F, C)
+            B, T, Fq, C = key.shape
+            _lib.check(lib.rtfs_caf_combine_rows_f32(_lib.ptr(key), _lib.ptr(value), _lib.ptr(resized), _lib.ptr(att), _lib.ptr(out), B, T, Fq, C, Tv,
+                                                     _lib.stream_of(key)), "rtfs_caf_combine_rows_f32")
+        else:
+            B, C, T, Fq = key.shape
+            _lib.check(lib.rtfs_caf_combine_f32(_lib.ptr(key), _lib.ptr(value), _lib.ptr(resized), _lib.ptr(att), _lib.ptr(out), B * C, T, Fq, Tv,
+                                                _lib.stream_of(key)), "rtfs_caf_combine_f32")
         ctx.save_for_backward(key, value, resized, att)
+        ctx.rows = bool(rows)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         lib = _lib.load()
         key, value, resized, att = ctx.saved_tensors
-        B, C, T, Fq = key.shape
         Tv = resized.shape[-1]
         dout = dout.contiguous()
         dk, dv, dr, da = torch.empty_like(key), torch.empty_like(value), torch.empty_like(resized), torch.empty_like(att)
-        _lib.check(lib.rtfs_caf_combine_backward_f32(_lib.ptr(dout), _lib.ptr(key), _lib.ptr(value), _lib.ptr(resized), _lib.ptr(att), _lib.ptr(dk),
-                                                     _lib.ptr(dv), _lib.ptr(dr), _lib.ptr(da), B * C, T, Fq, Tv, _lib.stream_of(dout)),
-                   "rtfs_caf_combine_backward_f32")
-        return dk, dv, dr, da
+        if ctx.rows:
+            B, T, Fq, C = key.shape
+            _lib.check(lib.rtfs_caf_combine_rows_backward_f32(_lib.ptr(dout), _lib.ptr(key), _lib.ptr(value), _lib.ptr(resized), _lib.ptr(att),
+                                                              _lib.ptr(dk), _lib.ptr(dv), _lib.ptr(dr), _lib.ptr(da), B, T, Fq, C, Tv,
+                                                              _lib.stream_of(dout)), "rtfs_caf_combine_rows_backward_f32")
+        else:
+            B, C, T, Fq = key.shape
+            _lib.check(lib.rtfs_caf_combine_backward_f32(_lib.ptr(dout), _lib.ptr(key), _lib.ptr(value), _lib.ptr(resized), _lib.ptr(att), _lib.ptr(dk),
+                                                         _lib.ptr(dv), _lib.ptr(dr), _lib.ptr(da), B * C, T, Fq, Tv, _lib.stream_of(dout)),
+                       "rtfs_caf_combine_backward_f32")
+        return dk, dv, dr, da, None
 
 
 class ATTNFusionCell(PackedModule):
@@ -1056,13 +1068,17 @@ class ATTNFusionCell(PackedModule):
         self.attention_embed = ConvNormAct(in_chan_b, kernel_size * in_chan_a, 1, groups=in_chan_a, norm_type="gLN")
         self.resize = ConvNormAct(in_chan_b, in_chan_a, 1, groups=in_chan_a, norm_type="gLN")
 
-    def _forward_train(self, a, v):
+    def _forward_train(self, a, v, rows=False):
         """Inside a training step (BatchNorm layers in eval mode = frozen statistics): the four ConvNormActs on their training kernels
-        plus the attention / combine kernels; reference layers/fusion.py:252-274 line by line."""
+        plus the attention / combine kernels; reference layers/fusion.py:252-274 line by line.  ``rows``: the audio tensor arrives and
+        leaves as (B, T, F, C) rows (the video side stays (B, C, Tv))."""
         if self.kernel_size != 4:
             raise RuntimeError("CAF training kernels: kernel_size 4 (yaml fusion_params)")
         resized = self.resize(v)
         att = _CafAttentionFn.apply(self.attention_embed(v), self.in_chan_a)
+        if rows:
+            rr = (True, True)
+            return _CafCombineFn.apply(self.key_embed._forward_train(a, rr), self.value_embed._forward_train(a, rr), resized, att, True)
         return _CafCombineFn.apply(self.key_embed(a), self.value_embed(a), resized, att)
 
     def forward(self, tensor_a, tensor_b):

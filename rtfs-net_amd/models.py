@@ -681,17 +681,24 @@ class AVNet(BaseAVModel):
         rows = (isinstance(self.audio_bottleneck, AudioBottleneck) and isinstance(self.mask_generator, MaskGenerator)
                 and getattr(blk, "_hip", False) and blk.rnn_kind == 0 and not os.environ.get("RTFS_TRAIN_CF")
                 and L_recording(emb, self.audio_bottleneck) and blk.training and self.mask_generator.training)
+        fb = rm.crossmodal_fusion.get_fusion_block(0)
+        caf_rows = (rows and isinstance(fb, ATTNFusion) and fb.audio_lstm.kernel_size == 4 and fb.audio_lstm.is2d
+                    and fb.audio_lstm.in_chan_a in (64, 128, 256, 512, 1024) and L_recording(emb, fb.audio_lstm))
         if rows:
             a_res = self.audio_bottleneck(emb, rows_out=True)
-            audio = blk._forward_train_rows(a_res, None, rows_in=True, rows_out=False)
+            audio = blk._forward_train_rows(a_res, None, rows_in=True, rows_out=caf_rows)
         else:
             a_res = audio = self.audio_bottleneck(emb)
             audio = blk(audio)
         main.wait_stream(side)
         video.record_stream(main)
-        audio, _ = rm.crossmodal_fusion.get_fusion_block(0)(audio, video)
+        if caf_rows:
+            audio = fb.audio_lstm._forward_train(audio, video, rows=True)
+        else:
+            audio, _ = fb(audio, video)
         if rows:
-            audio = layers._LayoutFn.apply(audio, True)
+            if not caf_rows:
+                audio = layers._LayoutFn.apply(audio, True)
             for _ in range(rm.audio_repeats):
                 audio = blk._forward_train_rows(audio, a_res, rows_in=True, rows_out=True)
             sep = self.mask_generator(audio, emb, rows_in=True)
