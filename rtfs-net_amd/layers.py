@@ -224,11 +224,34 @@ class _CNATrainFn(torch.autograd.Function):
     Inputs: x, cfg tuple (11 ints as in include/rtfs_amd.h + an optional 12th: synchronise the BatchNorm statistics across ranks), then
     pre_gamma, pre_beta, pre_slope, weight, bias, gamma, beta, slope (None where the stage is absent) [, running mean, var, momentum]."""
 
+    _CARR, _GEOM = {}, {}
+
     @staticmethod
     def _carr(cfg, phase, world):
+        """The HOST int[15] configuration of the C ABI (cached: a step makes ~200 of these calls and every ctypes object costs microseconds
+        the GPU then waits for)."""
         import ctypes
         lay = tuple(int(v) for v in cfg[12:14]) if len(cfg) >= 14 else (0, 0)  # (in_rows, out_rows)
-        return (ctypes.c_int * 15)(*(tuple(cfg[:11]) + (phase, world) + lay))
+        key = tuple(cfg[:11]) + (phase, world) + lay
+        arr = _CNATrainFn._CARR.get(key)
+        if arr is None:
+            arr = _CNATrainFn._CARR[key] = (ctypes.c_int * 15)(*key)
+        return arr
+
+    @staticmethod
+    def _geom(cfg, world, B, H, W):
+        """(carr, Ho, Wo, saved floats, workspace bytes, gradient floats) of one configuration and input geometry, cached."""
+        import ctypes
+        carr = _CNATrainFn._carr(cfg, 0, world)
+        key = (tuple(carr), B, H, W)
+        g = _CNATrainFn._GEOM.get(key)
+        if g is None:
+            lib = _lib.load()
+            ho, wo = ctypes.c_int(), ctypes.c_int()
+            lib.rtfs_cna_out_shape(carr, H, W, ctypes.byref(ho), ctypes.byref(wo))
+            g = _CNATrainFn._GEOM[key] = (carr, ho.value, wo.value, lib.rtfs_cna_saved_floats(carr, B, H, W),
+                                          lib.rtfs_cna_workspace_bytes(carr, B, H, W), lib.rtfs_cna_grad_floats(carr))
+        return g
 
     @staticmethod
     def forward(ctx, x, cfg, *params):
@@ -241,20 +264,18 @@ class _CNATrainFn(torch.autograd.Function):
         else:
             B, H, W = x.shape[0], (x.shape[2] if x.dim() == 4 else 1), x.shape[-1]
         world = _bn_world() if (len(cfg) > 11 and cfg[11] and cfg[7] == 3) else 1
-        carr = _CNATrainFn._carr(cfg, 0, world)
+        carr, ho_v, wo_v, n_saved, ws_bytes, _ = _CNATrainFn._geom(cfg, world, B, H, W)
         params, running = params[:8], params[8:]  # optional: BatchNorm running mean / var (+ momentum in train mode)
         build = lambda: packing.pack_cna_train(cfg, *params, *running[:2])
         # BatchNorm's running statistics are buffers that change without a version bump the cache could see: pack those afresh
         pk = packing.cached_train_pack(("cna", tuple(cfg[:11])), tuple(params), build) if cfg[7] < 2 else build()
-        ho, wo = ctypes.c_int(), ctypes.c_int()
-        lib.rtfs_cna_out_shape(carr, H, W, ctypes.byref(ho), ctypes.byref(wo))
         if out_rows:
-            oshape = (B, ho.value, wo.value, cfg[1]) if x.dim() == 4 else (B, wo.value, cfg[1])
+            oshape = (B, ho_v, wo_v, cfg[1]) if x.dim() == 4 else (B, wo_v, cfg[1])
         else:
-            oshape = (B, cfg[1], ho.value, wo.value) if x.dim() == 4 else (B, cfg[1], wo.value)
+            oshape = (B, cfg[1], ho_v, wo_v) if x.dim() == 4 else (B, cfg[1], wo_v)
         out = torch.empty(oshape, device=x.device, dtype=torch.float32)
-        saved = torch.empty(lib.rtfs_cna_saved_floats(carr, B, H, W), device=x.device, dtype=torch.float32)
-        ws = _lib.workspace(lib.rtfs_cna_workspace_bytes(carr, B, H, W), x.device)
+        saved = torch.empty(n_saved, device=x.device, dtype=torch.float32)
+        ws = _lib.workspace(ws_bytes, x.device)
 
         def run(c):
             _lib.check(lib.rtfs_cna_forward_train_f32(_lib.ptr(x), _lib.ptr(pk), _lib.ptr(out), _lib.ptr(saved), c, B, H, W, _lib.ptr(ws), ws.numel(),
@@ -283,11 +304,11 @@ class _CNATrainFn(torch.autograd.Function):
         pk, saved, xrows = ctx.saved_tensors
         B, H, W = ctx.geom
         world = ctx.world
-        carr = _CNATrainFn._carr(ctx.cfg, 0, world)
+        carr, _, _, _, ws_bytes, n_grad = _CNATrainFn._geom(ctx.cfg, world, B, H, W)
         dout = dout.contiguous().to(torch.float32)
         dx = torch.empty(ctx.xshape, device=dout.device, dtype=torch.float32)
-        dpar = torch.empty(lib.rtfs_cna_grad_floats(carr), device=dout.device, dtype=torch.float32)
-        ws = _lib.workspace(lib.rtfs_cna_workspace_bytes(carr, B, H, W), dout.device)
+        dpar = torch.empty(n_grad, device=dout.device, dtype=torch.float32)
+        ws = _lib.workspace(ws_bytes, dout.device)
 
         def run(c):
             _lib.check(lib.rtfs_cna_backward_f32(_lib.ptr(xrows), _lib.ptr(pk), _lib.ptr(saved), _lib.ptr(dout), _lib.ptr(dx), _lib.ptr(dpar), c,
@@ -374,7 +395,7 @@ def _cna_apply(x, cfg, params, running=()):
     def unpack(flat):
         grads = packing.unpack_cna_grads(cfg, flat, shapes[3])
         return [g.reshape(shp) for g, shp in zip(grads, shapes) if shp is not None]
-    n = _lib.load().rtfs_cna_grad_floats((ctypes.c_int * 15)(*(tuple(cfg[:11]) + (0, 1, 0, 0))))
+    n = _CNATrainFn._geom(tuple(cfg[:11]), 1, 1, 8, 8)[5]  # the gradient layout does not depend on the geometry
     # the running statistics (buffers) and the momentum ride along as extra trailing arguments, as before
     return _apply_bundled(_CNATrainFn, ("cna", tuple(cfg[:11])), x, (cfg,), tuple(params), n, unpack, tuple(running))
 
