@@ -139,10 +139,15 @@ def load():
             "the RTFS-Net MI355X path has no non-HIP fallback"
         )
     lib = C.CDLL(LIB_PATH)
+    import functools
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
+        # size queries are pure functions of a few integers and a training step asks ~1000 of them: memoise (an instance attribute
+        # shadows the CDLL's own lookup)
+        if res is _z and args and all(a in (_i, _z) for a in args):
+            setattr(lib, name, functools.lru_cache(maxsize=None)(fn))
     _lib = lib
     return lib
 
@@ -156,7 +161,15 @@ def ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream_of(t: torch.Tensor):
+    """torch's current stream on the tensor's device as the void* the C ABI takes (the raw-handle query when this torch has it: building a
+    torch.cuda.Stream object per call costs microseconds, ~800 times a step)."""
+    if _raw_stream is not None:
+        idx = t.device.index
+        return C.c_void_p(_raw_stream(torch.cuda.current_device() if idx is None else idx))
     return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
 
