@@ -910,27 +910,36 @@ __global__ __launch_bounds__(256) void pool2d_fwd_kernel(const float* __restrict
         y[i] = s / (float)((h1 - h0) * (w1 - w0));
     }
 }
+// V adjacent channels per thread (V = 4 on rows: the window arithmetic - a dozen integer divisions - is paid once per 16-byte store)
+template <int V>
 __global__ __launch_bounds__(256) void pool2d_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, size_t N, int H, int W, int Ho,
                                                          int Wo, int C) {
-    const size_t total = N * H * W * C;
+    const int CV = C / V;
+    const size_t total = N * H * W * CV;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int c = (int)(i % C);
-        const size_t p = i / C;
+        const int c = (int)(i % CV) * V;
+        const size_t p = i / CV;
         const int w = (int)(p % W), h = (int)((p / W) % H);
         const size_t n = p / ((size_t)W * H);
         // candidate windows around floor(h * out / in): window starts are non-decreasing and each is at most in/out + 1 long
         const int hc = (int)(((long)h * Ho) / H), wc = (int)(((long)w * Wo) / W);
-        float s = 0.f;
+        float s[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) s[k] = 0.f;
         for (int ho = max(hc - 1, 0); ho <= min(hc + 1, Ho - 1); ++ho) {
             const int h0 = win_lo(ho, H, Ho), h1 = win_hi(ho, H, Ho);
             if (h < h0 || h >= h1) continue;
             for (int wo = max(wc - 1, 0); wo <= min(wc + 1, Wo - 1); ++wo) {
                 const int w0 = win_lo(wo, W, Wo), w1 = win_hi(wo, W, Wo);
                 if (w < w0 || w >= w1) continue;
-                s += dy[((n * Ho + ho) * Wo + wo) * C + c] / (float)((h1 - h0) * (w1 - w0));
+                const float inv = 1.0f / (float)((h1 - h0) * (w1 - w0));
+                float d[V];
+                ldv<V>(dy + ((n * Ho + ho) * Wo + wo) * C + c, 0, d);
+#pragma unroll
+                for (int k = 0; k < V; ++k) s[k] += d[k] * inv;
             }
         }
-        dx[i] = s;
+        stv<V>(dx + p * C + c, 0, s);
     }
 }
 // InjectionMultiSum's last line (fusion.py:54-69): out = local * up(gate) + up(global), up = F.interpolate(mode="nearest")
@@ -977,7 +986,8 @@ __global__ __launch_bounds__(256) void tfar_combine_bwd_kernel(const float* __re
 }
 int launch_pool2d(const float* x, float* y, size_t N, int H, int W, int Ho, int Wo, bool bwd, hipStream_t st, int C) {
     if (H < 1 || W < 1 || Ho < 1 || Wo < 1 || Ho > H || Wo > W || C < 1) return RTFS_ERR_SHAPE;
-    if (bwd) hipLaunchKernelGGL(pool2d_bwd_kernel, dim3(grid_for(N * H * W * C)), dim3(256), 0, st, x, y, N, H, W, Ho, Wo, C);
+    if (bwd && C % 4 == 0) hipLaunchKernelGGL(pool2d_bwd_kernel<4>, dim3(grid_for(N * H * W * C / 4)), dim3(256), 0, st, x, y, N, H, W, Ho, Wo, C);
+    else if (bwd) hipLaunchKernelGGL(pool2d_bwd_kernel<1>, dim3(grid_for(N * H * W * C)), dim3(256), 0, st, x, y, N, H, W, Ho, Wo, C);
     else hipLaunchKernelGGL(pool2d_fwd_kernel, dim3(grid_for(N * Ho * Wo * C)), dim3(256), 0, st, x, y, N, H, W, Ho, Wo, C);
     return rtfs_launch_status();
 }
