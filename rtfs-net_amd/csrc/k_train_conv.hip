@@ -943,45 +943,63 @@ __global__ __launch_bounds__(256) void pool2d_bwd_kernel(const float* __restrict
     }
 }
 // InjectionMultiSum's last line (fusion.py:54-69): out = local * up(gate) + up(global), up = F.interpolate(mode="nearest")
+template <int V>
 __global__ __launch_bounds__(256) void tfar_combine_fwd_kernel(const float* __restrict__ le, const float* __restrict__ gate,
                                                                const float* __restrict__ ge, float* __restrict__ out, size_t N, int H, int W,
                                                                int Hg, int Wg, int C) {
-    const size_t total = N * H * W * C;
+    const int CV = C / V;
+    const size_t total = N * H * W * CV;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int c = (int)(i % C);
-        const size_t p = i / C;
+        const int c = (int)(i % CV) * V;
+        const size_t p = i / CV;
         const int w = (int)(p % W), h = (int)((p / W) % H);
         const size_t n = p / ((size_t)W * H);
         const size_t j = ((n * Hg + nearest_src(h, Hg, H)) * Wg + nearest_src(w, Wg, W)) * C + c;
-        out[i] = fmaf(le[i], gate[j], ge[j]);
+        float l[V], g[V], e[V];
+        ldv<V>(le + p * C + c, 0, l);
+        ldv<V>(gate + j, 0, g);
+        ldv<V>(ge + j, 0, e);
+#pragma unroll
+        for (int k = 0; k < V; ++k) l[k] = fmaf(l[k], g[k], e[k]);
+        stv<V>(out + p * C + c, 0, l);
     }
 }
+template <int V>
 __global__ __launch_bounds__(256) void tfar_combine_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ le,
                                                                const float* __restrict__ gate, float* __restrict__ dle,
                                                                float* __restrict__ dgate, float* __restrict__ dge, size_t N, int H, int W, int Hg,
                                                                int Wg, int C) {
-    // one thread per GLOBAL element: it owns the local pixels that read it (a contiguous block of rows x columns)
-    const size_t total = N * Hg * Wg * C;
+    // one thread per GLOBAL element (V adjacent channels): it owns the local pixels that read it (a contiguous block of rows x columns)
+    const int CV = C / V;
+    const size_t total = N * Hg * Wg * CV;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int c = (int)(i % C);
-        const size_t p = i / C;
+        const int c = (int)(i % CV) * V;
+        const size_t p = i / CV;
         const int wg = (int)(p % Wg), hg = (int)((p / Wg) % Hg);
         const size_t n = p / ((size_t)Wg * Hg);
         // local h reads global floor(h * Hg / H) == hg  <=>  h in [ceil(hg*H/Hg), ceil((hg+1)*H/Hg))
         const int h0 = (int)(((long)hg * H + Hg - 1) / Hg), h1 = min(H, (int)(((long)(hg + 1) * H + Hg - 1) / Hg));
         const int w0 = (int)(((long)wg * W + Wg - 1) / Wg), w1 = min(W, (int)(((long)(wg + 1) * W + Wg - 1) / Wg));
-        const float g = gate[i];
-        float sg = 0.f, se = 0.f;
+        float g[V], sg[V], se[V];
+        ldv<V>(gate + p * C + c, 0, g);
+#pragma unroll
+        for (int k = 0; k < V; ++k) sg[k] = se[k] = 0.f;
         for (int h = h0; h < h1; ++h)
             for (int w = w0; w < w1; ++w) {
-                const size_t k = ((n * H + h) * W + w) * C + c;
-                const float d = dout[k];
-                dle[k] = d * g;
-                sg = fmaf(d, le[k], sg);
-                se += d;
+                const size_t q = ((n * H + h) * W + w) * C + c;
+                float d[V], l[V], o[V];
+                ldv<V>(dout + q, 0, d);
+                ldv<V>(le + q, 0, l);
+#pragma unroll
+                for (int k = 0; k < V; ++k) {
+                    o[k] = d[k] * g[k];
+                    sg[k] = fmaf(d[k], l[k], sg[k]);
+                    se[k] += d[k];
+                }
+                stv<V>(dle + q, 0, o);
             }
-        dgate[i] = sg;
-        dge[i] = se;
+        stv<V>(dgate + p * C + c, 0, sg);
+        stv<V>(dge + p * C + c, 0, se);
     }
 }
 int launch_pool2d(const float* x, float* y, size_t N, int H, int W, int Ho, int Wo, bool bwd, hipStream_t st, int C) {
@@ -994,13 +1012,18 @@ int launch_pool2d(const float* x, float* y, size_t N, int H, int W, int Ho, int 
 int launch_tfar_combine(const float* le, const float* gate, const float* ge, float* out, size_t N, int H, int W, int Hg, int Wg, hipStream_t st,
                         int C) {
     if (Hg < 1 || Wg < 1 || Hg > H || Wg > W || C < 1) return RTFS_ERR_SHAPE;
-    hipLaunchKernelGGL(tfar_combine_fwd_kernel, dim3(grid_for(N * H * W * C)), dim3(256), 0, st, le, gate, ge, out, N, H, W, Hg, Wg, C);
+    if (C % 4 == 0) hipLaunchKernelGGL(tfar_combine_fwd_kernel<4>, dim3(grid_for(N * H * W * C / 4)), dim3(256), 0, st, le, gate, ge, out, N, H, W, Hg, Wg, C);
+    else hipLaunchKernelGGL(tfar_combine_fwd_kernel<1>, dim3(grid_for(N * H * W * C)), dim3(256), 0, st, le, gate, ge, out, N, H, W, Hg, Wg, C);
     return rtfs_launch_status();
 }
 int launch_tfar_combine_bwd(const float* dout, const float* le, const float* gate, float* dle, float* dgate, float* dge, size_t N, int H, int W,
                             int Hg, int Wg, hipStream_t st, int C) {
     if (Hg < 1 || Wg < 1 || Hg > H || Wg > W || C < 1) return RTFS_ERR_SHAPE;
-    hipLaunchKernelGGL(tfar_combine_bwd_kernel, dim3(grid_for(N * Hg * Wg * C)), dim3(256), 0, st, dout, le, gate, dle, dgate, dge, N, H, W, Hg, Wg, C);
+    if (C % 4 == 0)
+        hipLaunchKernelGGL(tfar_combine_bwd_kernel<4>, dim3(grid_for(N * Hg * Wg * C / 4)), dim3(256), 0, st, dout, le, gate, dle, dgate, dge, N, H, W, Hg, Wg,
+                           C);
+    else
+        hipLaunchKernelGGL(tfar_combine_bwd_kernel<1>, dim3(grid_for(N * Hg * Wg * C)), dim3(256), 0, st, dout, le, gate, dle, dgate, dge, N, H, W, Hg, Wg, C);
     return rtfs_launch_status();
 }
 
