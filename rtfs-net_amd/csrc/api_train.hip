@@ -622,7 +622,7 @@ size_t rtfs_cna_saved_floats(const int* cfg, int B, int H, int W) {
 size_t rtfs_cna_workspace_bytes(const int* cfg, int B, int H, int W) {
     CnaCfg c(cfg, B, H, W);
     return (2 * c.rows_out * c.Cout + 2 * c.rows_in * c.Cin + 4 * (size_t)B + (size_t)CL_DW_WGRAD_MAX_WG * 20 * 256 +
-            cl_stage_partial_floats(B, c.Cin > c.Cout ? c.Cin : c.Cout)) * sizeof(float) + 9 * 256;
+            cl_stage_partial_floats(B, c.Cin > c.Cout ? c.Cin : c.Cout) + 1024 * (size_t)B) * sizeof(float) + 10 * 256;
 }
 // float offset, inside `saved`, of the 2 * Cout doubles (sum, sum of squares per channel) a norm = 3 forward accumulates; the gradient
 // buffer's dgamma / dbeta float offsets for the matching exchange in the backward
@@ -651,6 +651,8 @@ int rtfs_cna_forward_train_f32(const float* x, const float* params, float* out, 
     CnaSaved sv((float*)align_up((size_t)saved, 16), c);
     Arena ar(ws, ws_bytes);
     float* r5 = ar.take<float>(c.rows_out * c.Cout);
+    double* stat_part = ar.take<double>(512 * (size_t)B);
+    RTFS_RETURN_IF(!ar.ok(), RTFS_ERR_WORKSPACE);
     hipStream_t st = S(stream);
     const size_t n_in = (size_t)H * W * c.Cin, n_out = (size_t)c.Ho * c.Wo * c.Cout;
     // phase 1 stops once the BatchNorm batch statistics are in `saved`; phase 2 resumes there (the caller all-reduced them in between)
@@ -664,8 +666,7 @@ int rtfs_cna_forward_train_f32(const float* x, const float* params, float* out, 
         a.x = r0; a.y = sv.r2; a.n = n_in; a.C = c.Cin; a.norm = c.pre_norm; a.act = c.pre_act;
         a.gamma = params + c.o_pg; a.beta = params + c.o_pb; a.slope = params + c.o_ps; a.stats = sv.st0;
         if (c.pre_norm) {
-            if (hipMemsetAsync(sv.st0, 0, sizeof(double) * 2 * B, st) != hipSuccess) return RTFS_ERR_LAUNCH;
-            CHECK(launch_stats(r0, sv.st0, B, n_in, st));
+            CHECK(launch_stats2(r0, sv.st0, B, n_in, stat_part, st));
         }
         CHECK(launch_cl_norm_act_fwd(a, B, st));
         conv_in = sv.r2;
@@ -692,8 +693,7 @@ int rtfs_cna_forward_train_f32(const float* x, const float* params, float* out, 
         a.gamma = params + c.o_g; a.beta = params + c.o_be; a.slope = params + c.o_s; a.stats = sv.st3;
         a.rmean = params + c.o_rm; a.rvar = params + c.o_rv; a.cstats = sv.cst; a.inv_rows = 1.0 / ((double)c.rows_out * c.world);
         if (c.norm == 1) {
-            if (hipMemsetAsync(sv.st3, 0, sizeof(double) * 2 * B, st) != hipSuccess) return RTFS_ERR_LAUNCH;
-            CHECK(launch_stats(sv.r3, sv.st3, B, n_out, st));
+            CHECK(launch_stats2(sv.r3, sv.st3, B, n_out, stat_part, st));
         }
         CHECK(launch_cl_norm_act_fwd(a, B, st));
     }

@@ -837,6 +837,61 @@ int launch_transpose(const float* x, float* y, int N, int H, int W, hipStream_t 
     return rtfs_launch_status();
 }
 
+// Two-stage form for the training path (no memset, no contended f64 atomics: 256 workgroups per sample queue ~10 us at their sample's
+// pair): every workgroup stores its (sum, sum of squares), a second kernel with one workgroup per sample folds and STORES stats[2b..].
+__global__ __launch_bounds__(256) void stats_partial_kernel(const float* __restrict__ x, double* __restrict__ part, size_t N) {
+    __shared__ double red[8];
+    const int b = blockIdx.y;
+    const float* xb = x + (size_t)b * N;
+    const size_t n4 = N >> 2;
+    f32x4u s4 = {0.f, 0.f, 0.f, 0.f}, q4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const f32x4u v = reinterpret_cast<const f32x4u*>(xb)[i];
+        s4 += v;
+        q4 += v * v;
+    }
+    float s = (s4[0] + s4[1]) + (s4[2] + s4[3]), ss = (q4[0] + q4[1]) + (q4[2] + q4[3]);
+    if (blockIdx.x == 0 && threadIdx.x < (N & 3)) {
+        const float v = xb[(n4 << 2) + threadIdx.x];
+        s += v;
+        ss = fmaf(v, v, ss);
+    }
+    const double ds = wave_sum_d((double)s), dss = wave_sum_d((double)ss);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) red[2 * w] = ds, red[2 * w + 1] = dss;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double* p = part + ((size_t)b * gridDim.x + blockIdx.x) * 2;
+        p[0] = (red[0] + red[2]) + (red[4] + red[6]);
+        p[1] = (red[1] + red[3]) + (red[5] + red[7]);
+    }
+}
+__global__ __launch_bounds__(256) void stats_fold_kernel(const double* __restrict__ part, double* __restrict__ stats, int gx) {
+    __shared__ double red[8];
+    const int b = blockIdx.x, t = threadIdx.x;
+    double s = 0, ss = 0;
+    for (int i = t; i < gx; i += 256) {
+        s += part[((size_t)b * gx + i) * 2];
+        ss += part[((size_t)b * gx + i) * 2 + 1];
+    }
+    s = wave_sum_d(s), ss = wave_sum_d(ss);
+    if ((t & 63) == 0) red[2 * (t >> 6)] = s, red[2 * (t >> 6) + 1] = ss;
+    __syncthreads();
+    if (t == 0) {
+        stats[2 * b] = (red[0] + red[2]) + (red[4] + red[6]);
+        stats[2 * b + 1] = (red[1] + red[3]) + (red[5] + red[7]);
+    }
+}
+// part: 2 * 256 * B doubles
+int launch_stats2(const float* x, double* stats, int B, size_t N, double* part, hipStream_t st) {
+    int gx = (int)((N / 4 + 256 * 8 - 1) / (256 * 8));
+    gx = gx < 1 ? 1 : (gx > 256 ? 256 : gx);
+    hipLaunchKernelGGL(stats_partial_kernel, dim3(gx, B), dim3(256), 0, st, x, part, N);
+    hipLaunchKernelGGL(stats_fold_kernel, dim3(B), dim3(256), 0, st, part, stats, gx);
+    return rtfs_launch_status();
+}
+
 int launch_stats(const float* x, double* stats, int B, size_t N, hipStream_t st) {
     // every workgroup ends in two f64 atomics on its sample's pair: a few hundred long workgroups per sample beat thousands of short ones
     int gx = (int)((N / 4 + 256 * 8 - 1) / (256 * 8));

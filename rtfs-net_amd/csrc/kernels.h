@@ -120,6 +120,7 @@ int launch_g_form(const float* p0, const float* c1, const double* st1, double in
 int launch_g_combine(const GCombineArgs& a, int B, hipStream_t st);
 int launch_transpose(const float* x, float* y, int N, int H, int W, hipStream_t st);
 int launch_stats(const float* x, double* stats, int B, size_t N, hipStream_t st);
+int launch_stats2(const float* x, double* stats, int B, size_t N, double* part, hipStream_t st);  // part: 512 * B doubles
 
 // Fused dual-path SRU sweep.  Sequence n = (b, row): element (c, s) at
 //   x[(n / R) * bstride + (n % R) * rstride + c * cstride + s],  s = 0..Ls-1 contiguous.
