@@ -185,12 +185,17 @@ def _grad_bundle(kind, params, n, unpack):
     cacheable = torch.is_grad_enabled() and all(isinstance(t, nn.Parameter) for t in params)
     if not cacheable:
         return _GradBundleFn.apply(n, unpack, *params)
-    store = params[0].__dict__.setdefault("_rtfs_grad_bundle", {})
+    import weakref
+    store = packing.param_store(params[0], "grad_bundle")
     key = (kind, n) + tuple((id(t), t._version, t.requires_grad) for t in params)
-    b = store.get(key)
+    ref = store.get(key)
+    b = ref() if ref is not None else None
     if b is None:
         store.clear()
-        b = store[key] = _GradBundleFn.apply(n, unpack, *params)
+        b = _GradBundleFn.apply(n, unpack, *params)
+        # a WEAK reference: the bundle's graph node holds the parameters, so a strong one in the module-level table would keep every model
+        # alive for ever; within a step the graph of the block outputs keeps the bundle alive, which is exactly as long as it must be shared
+        store[key] = weakref.ref(b)
     return b
 
 
@@ -202,6 +207,7 @@ class _BundledFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, fn, bundle, hidden, x, *head):
         ctx.fn, ctx.nhead, ctx.flat_grads = fn, len(head), True
+        ctx.bundle = bundle  # keeps the shared tensor (not just its graph node) alive as long as this application's node: see _grad_bundle
         return fn.forward(ctx, x, *head, *hidden)
 
     @staticmethod
@@ -352,6 +358,7 @@ class _GatewayFn(torch.autograd.Function):
         _lib.check(lib.rtfs_gateway_forward_train_f32(_lib.ptr(x), _lib.ptr(x_res), _lib.ptr(w), _lib.ptr(b), _lib.ptr(slope), _lib.ptr(out),
                                                       x.numel() // C, C, _lib.stream_of(x)), "rtfs_gateway_forward_train_f32")
         ctx.save_for_backward(x, x_res, w, b, slope)
+        ctx.bundle = bundle  # see _BundledFn
         return out
 
     @staticmethod

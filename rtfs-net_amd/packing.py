@@ -95,17 +95,33 @@ def _dualpath_parts(sd):
     return parts
 
 
+_PARAM_STORES = {}
+
+
+def param_store(anchor, name):
+    """A private dict tied to the lifetime of the tensor ``anchor`` (normally a module's first nn.Parameter) without touching the tensor:
+    entries live in a module-level table keyed by id(anchor) and a weakref finalizer drops them when the tensor dies, so a new tensor that
+    reuses the address never sees them - and nothing rides along when a module is pickled or deep-copied."""
+    import weakref
+    key = (id(anchor), name)
+    st = _PARAM_STORES.get(key)
+    if st is None:
+        st = _PARAM_STORES[key] = {}
+        weakref.finalize(anchor, _PARAM_STORES.pop, key, None)
+    return st
+
+
 def cached_train_pack(kind, tensors, build):
     """The training kernels take re-ordered copies of the live parameters.  Within one step the shared RTFS block is applied R times
-    with unchanged parameters, so the copy is cached - ON the first parameter object (it dies with the module, so a new module that
-    happens to reuse the addresses cannot see it), keyed by (storage address, version counter) of every parameter: an optimizer step
+    with unchanged parameters, so the copy is cached - in a store tied to the first parameter object (param_store: it dies with the
+    module, so a new module that happens to reuse the addresses cannot see it), keyed by (storage address, version counter) of every parameter: an optimizer step
     bumps the versions.  Only genuine nn.Parameters are cached (a temporary may reuse an address with different contents)."""
     if not all(t is None or isinstance(t, torch.nn.Parameter) for t in tensors):
         return build()
     anchor = next((t for t in tensors if t is not None), None)
     if anchor is None:
         return build()
-    store = anchor.__dict__.setdefault("_rtfs_train_pack", {})
+    store = param_store(anchor, "train_pack")
     key = (kind,) + tuple(None if t is None else (id(t), t.data_ptr(), t._version) for t in tensors)
     pk = store.get(key)
     if pk is None:

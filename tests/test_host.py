@@ -356,6 +356,14 @@ def test_gradient_bundle_accumulates_over_applications():
     run = lambda t: L._apply_bundled(Affine, "affine", t, (), (w, b), 2, unpack)
     y = run(run(run(x)))
     assert L._grad_bundle("affine", (w, b), 2, unpack) is L._grad_bundle("affine", (w, b), 2, unpack)  # one node per step
+    seen, todo = set(), [y.grad_fn]
+    while todo:  # the three applications share ONE bundle node although nobody kept the bundle tensor
+        node = todo.pop()
+        if node is None or node in seen:
+            continue
+        seen.add(node)
+        todo.extend(f for f, _ in node.next_functions)
+    assert sum(type(nd).__name__.startswith("_GradBundleFn") for nd in seen) == 1, [type(nd).__name__ for nd in seen]
     y.square().sum().backward()
     got = (x.grad.clone(), w.grad.clone(), b.grad.clone())
     x.grad = w.grad = b.grad = None
