@@ -714,6 +714,69 @@ __global__ __launch_bounds__(256) void cl_dw_wgrad_c4_kernel(ClDwArgs a) {
         }
 }
 
+// Stride 1, four adjacent channels AND four adjacent output columns per thread: the 7 input columns of a kernel row serve the four
+// outputs (7 + 1 16-byte loads per output row of the window instead of 16 + 4: the per-pixel version is bound by its load instructions).
+__global__ __launch_bounds__(256) void cl_dw_wgrad_w4c4_kernel(ClDwArgs a) {
+    __shared__ float4 part[256];
+    const int tid = threadIdx.x, C4 = a.C >> 2, c = (tid % C4) * 4, lanes = 256 / C4, rl = tid / C4;
+    f32x4u_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4u_t{0.f, 0.f, 0.f, 0.f};
+    const unsigned W4 = (unsigned)(a.Wo + 3) >> 2, HoW4 = (unsigned)a.Ho * W4, rows4 = (unsigned)a.B * HoW4;
+    for (unsigned r = xcd_block(blockIdx.x, gridDim.x) * lanes + rl; r < rows4; r += gridDim.x * lanes) {
+        const unsigned b = r / HoW4, q = r - b * HoW4;
+        const int ho = (int)(q / W4), wo0 = (int)(q - (unsigned)ho * W4) * 4;
+        const float* dyb = a.dy + (((size_t)b * a.Ho + ho) * a.Wo) * a.Cp + c;
+        f32x4u_t d[4];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            const f32x4u_t t = *reinterpret_cast<const f32x4u_t*>(dyb + (size_t)min(wo0 + o, a.Wo - 1) * a.Cp);
+            d[o] = t * (wo0 + o < a.Wo ? 1.f : 0.f);
+        }
+        const float* xb = a.x + ((size_t)b * a.H * a.W) * a.Cp + c;
+#pragma unroll
+        for (int ki = 0; ki < 4; ++ki) {
+            if (ki < a.kh) {  // uniform
+                const int h = ho - a.pt + ki;
+                const bool hok = h >= 0 && h < a.H;
+                const float* rowp = xb + (size_t)min(max(h, 0), a.H - 1) * a.W * a.Cp;
+                f32x4u_t v[7];
+#pragma unroll
+                for (int j = 0; j < 7; ++j) v[j] = *reinterpret_cast<const f32x4u_t*>(rowp + (size_t)min(max(wo0 - a.pl + j, 0), a.W - 1) * a.Cp);
+#pragma unroll
+                for (int j = 0; j < 7; ++j) {
+                    const int w = wo0 - a.pl + j;
+                    v[j] = v[j] * ((hok && w >= 0 && w < a.W) ? 1.f : 0.f);
+                }
+#pragma unroll
+                for (int kj = 0; kj < 4; ++kj)
+#pragma unroll
+                    for (int o = 0; o < 4; ++o) acc[ki][kj] += d[o] * v[o + kj];  // taps beyond kw are never stored
+            }
+        }
+    }
+#pragma unroll
+    for (int ki = 0; ki < 4; ++ki)
+#pragma unroll
+        for (int kj = 0; kj < 4; ++kj) {
+            if (ki < a.kh && kj < a.kw) {  // uniform
+                part[tid] = make_float4(acc[ki][kj][0], acc[ki][kj][1], acc[ki][kj][2], acc[ki][kj][3]);
+                __syncthreads();
+                if (tid < C4) {
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    for (int j = tid; j < 256; j += C4) {
+                        const float4 q = part[j];
+                        v.x += q.x, v.y += q.y, v.z += q.z, v.w += q.w;
+                    }
+                    *reinterpret_cast<float4*>(a.scratch + ((size_t)blockIdx.x * a.kh * a.kw + ki * a.kw + kj) * a.C + 4 * tid) = v;
+                }
+                __syncthreads();
+            }
+        }
+}
+
 // Second stage of the depthwise weight gradient: nwg partial rows of taps*C floats -> dw (C, taps), accumulated.  A workgroup owns 64
 // float4 columns x 4 row lanes (independent 16-byte loads, LDS 4 -> 1), gridDim.y row slices meet in one atomic per element.
 __global__ __launch_bounds__(256) void cl_dw_wgrad_reduce_kernel(const float* __restrict__ scratch, float* __restrict__ dw, int nwg, int taps,
@@ -843,11 +906,14 @@ int launch_cl_dw_chunk(const ClDwArgs& a, int what, hipStream_t st) {
     else if (what == 0) hipLaunchKernelGGL(cl_dw_fwd_kernel, dim3(grid8(grid_for((size_t)a.B * a.Ho * a.Wo * a.C))), dim3(256), 0, st, a);
     else if (what == 1) hipLaunchKernelGGL(cl_dw_bwd_data_kernel, dim3(grid8(grid_for((size_t)a.B * a.H * a.W * a.C))), dim3(256), 0, st, a);
     else {
-        const size_t rows = (size_t)a.B * a.Ho * a.Wo, per_wg = (size_t)(256 / (c4 ? a.C / 4 : a.C)) * 8;
+        const bool w4c4 = c4 && a.s == 1 && a.Wo >= 4;
+        const size_t rows = w4c4 ? (size_t)a.B * a.Ho * ((a.Wo + 3) / 4) : (size_t)a.B * a.Ho * a.Wo,
+                     per_wg = (size_t)(256 / (c4 ? a.C / 4 : a.C)) * (w4c4 ? 2 : 8);
         size_t g = (rows + per_wg - 1) / per_wg;
         g = g > CL_DW_WGRAD_MAX_WG ? CL_DW_WGRAD_MAX_WG : grid8((unsigned)(g < 1 ? 1 : g));  // a multiple of 8 (xcd_block); idle workgroups store zeros
         if (!a.scratch) return RTFS_ERR_WORKSPACE;
-        if (c4) hipLaunchKernelGGL(cl_dw_wgrad_c4_kernel, dim3((unsigned)g), dim3(256), 0, st, a);
+        if (w4c4) hipLaunchKernelGGL(cl_dw_wgrad_w4c4_kernel, dim3((unsigned)g), dim3(256), 0, st, a);
+        else if (c4) hipLaunchKernelGGL(cl_dw_wgrad_c4_kernel, dim3((unsigned)g), dim3(256), 0, st, a);
         else hipLaunchKernelGGL(cl_dw_wgrad_kernel, dim3((unsigned)g), dim3(256), 0, st, a);
         const int n = a.kh * a.kw * a.C;
         if (n % 4 == 0)
