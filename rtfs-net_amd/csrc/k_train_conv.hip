@@ -910,6 +910,10 @@ int launch_cl_dw_chunk(const ClDwArgs& a, int what, hipStream_t st) {
         const size_t rows = w4c4 ? (size_t)a.B * a.Ho * ((a.Wo + 3) / 4) : (size_t)a.B * a.Ho * a.Wo,
                      per_wg = (size_t)(256 / (c4 ? a.C / 4 : a.C)) * (w4c4 ? 2 : 8);
         size_t g = (rows + per_wg - 1) / per_wg;
+        if (w4c4) {  // 148 VGPRs: three workgroups per CU = 768 resident; one balanced round instead of 1.35 or 2.7 ragged ones
+            const size_t lanes = 256 / (a.C / 4), n = (rows + lanes - 1) / lanes, iters = (n + 767) / 768;
+            g = (n + iters - 1) / iters;
+        }
         g = g > CL_DW_WGRAD_MAX_WG ? CL_DW_WGRAD_MAX_WG : grid8((unsigned)(g < 1 ? 1 : g));  // a multiple of 8 (xcd_block); idle workgroups store zeros
         if (!a.scratch) return RTFS_ERR_WORKSPACE;
         if (w4c4) hipLaunchKernelGGL(cl_dw_wgrad_w4c4_kernel, dim3((unsigned)g), dim3(256), 0, st, a);
