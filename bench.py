@@ -1,7 +1,12 @@
 #!/usr/bin/env python3
 """Throughput benchmark of the MI355X-native RTFS-Net separator forward.
 
-  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W
+
+N > 1: either launched by `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` (RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_* in the environment, one rank per GPU over RCCL), or started plainly as `python bench.py --gpus N ...`:
+the parent then spawns the N ranks itself as fresh child processes BEFORE anything in it touches the GPU (`spawn_ranks`),
+relays rank 0's JSON line and exits non-zero if any rank failed.
 
 Metric (BASELINE.json): mixtures/s of the RTFS-Net-4 forward on synthetic 2 s @16 kHz 2-speaker mixtures with
 dummy lip embeddings, batch 32 per GPU (configs[1]); inputs and weights are resident in HBM before the timed
@@ -28,12 +33,12 @@ import torch  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md); ~6300 GB/s achievable
 
 
+DTYPE = "f32 (f16x3 split-precision MFMA products, f32 accumulate; every tensor in HBM is f32)"
+
+
 def audionet_config(repeats):
-    import copy
-    from tests.test_host import RTFS4_AUDIONET
-    c = copy.deepcopy(RTFS4_AUDIONET)
-    c["audio_params"]["repeats"] = repeats
-    return c
+    from rtfs_net_amd.configs import audionet_config as cfg
+    return cfg(repeats)
 
 
 def sweep_bytes(seq_len, n_seq):
@@ -41,7 +46,7 @@ def sweep_bytes(seq_len, n_seq):
     return 20.0 * (seq_len - 7) * n_seq * 64 * 4
 
 
-def cpu_baseline(repeats, workers=None):
+def cpu_baseline(repeats, workers=None, leg_seconds=12.0):
     """The CPU oracle (oracle/rtfs_oracle.py, numpy) on this box's host cores: one single-threaded worker process per core
     of the CPU share (16 per GPU), four 2 s mixtures each -> aggregate mixtures/s.  Must run BEFORE this process touches the
     GPU (the workers are child processes)."""
@@ -61,10 +66,25 @@ def cpu_baseline(repeats, workers=None):
     dt = time.perf_counter() - t0
     if done == 0:
         return {"value": None, "unit": "mixtures/s", "cores": workers, "kind": "port", "sample": "CPU oracle workers failed"}
-    return {"value": round(done / dt, 4), "unit": "mixtures/s", "cores": int(workers), "kind": "port",
-            "sample": f"{done} x (1 mixture, 2 s @16 kHz, RTFS-Net-{repeats}) through the numpy CPU oracle, one single-threaded "
-                      f"process per core on {workers} of {os.cpu_count()} host cpus, wall {dt:.1f} s incl. start-up "
-                      f"(forwards alone {min(per) / per_worker:.1f}-{max(per) / per_worker:.1f} s per mixture)"}
+    res = {"value": round(done / dt, 4), "unit": "mixtures/s", "cores": int(workers), "kind": "port",
+           "sample": f"{done} x (1 mixture, 2 s @16 kHz, RTFS-Net-{repeats}) through the numpy CPU oracle, one single-threaded "
+                     f"process per core on {workers} of {os.cpu_count()} host cpus, wall {dt:.1f} s incl. start-up "
+                     f"(forwards alone {min(per) / per_worker:.1f}-{max(per) / per_worker:.1f} s per mixture)"}
+    # SURVEY 8(d)'s protocol beside it: the numpy restatement AND the stock-torch-ops composition, batch 1 and 4, all `workers` cores in
+    # one process (torch.set_num_threads), 3 warm-up + 5 timed forwards per leg, each leg bounded to `leg_seconds` of wall time
+    try:
+        pr = subprocess.run([sys.executable, "-m", "oracle.cpu_bench", str(repeats), str(workers), str(leg_seconds)], cwd=ROOT,
+                            stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=600)
+        rec = json.loads(pr.stdout.strip().splitlines()[-1])
+        res["threaded"] = rec
+        best = max(rec["legs"], key=lambda l: l["mixtures_per_s"])
+        res["sample"] += (f"; one process on {rec['threads']} threads (3 warm-up + 5 timed forwards, <= {leg_seconds:g} s per leg): best "
+                          f"{best['mixtures_per_s']} mixtures/s ({best['impl']}, batch {best['batch']}), all legs under 'threaded'")
+        if best["mixtures_per_s"] > res["value"]:
+            res["value"] = best["mixtures_per_s"]
+    except Exception as e:  # the single-threaded-workers figure above stands on its own
+        res["threaded"] = {"error": repr(e)[:200]}
+    return res
 
 
 def train_cpu_baseline(repeats, threads=None):
@@ -136,19 +156,111 @@ def throughput(world, B, steps, dt):
     return world * B * steps / dt
 
 
-def train_main(args):
-    """Training-step throughput, same timing protocol as the forward bench (W warm-up steps, K steps between barrier + synchronize on both
-    sides, MAX over ranks, whole-job aggregate).  Per-GPU batch defaults to the reference's training batch_size 4 unless --batch is given."""
+def spawn_ranks(n, argv, timeout=3000):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes of THIS process, which has not
+    touched the GPU (no HIP call, no torch.cuda.is_available()) and never will: it only waits, relays rank 0's JSON line (its stdout)
+    and returns non-zero if any rank failed (the others are then terminated by PID so nobody waits at a barrier for ever).
+    Rendezvous on 127.0.0.1 and a free port; ranks see exactly what torch.distributed.run would give them."""
+    import socket
+    import subprocess
+    import tempfile
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    procs, outs = [], []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on these hosts (RCCL needs it)
+        out = tempfile.TemporaryFile(mode="w+")
+        outs.append(out)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env, cwd=ROOT, stdout=out))
+    t0, failed = time.time(), None
+    while failed is None and any(p.poll() is None for p in procs):
+        for r, p in enumerate(procs):
+            if p.poll() not in (None, 0):
+                failed = r
+        if time.time() - t0 > timeout:
+            failed = -1
+        time.sleep(0.05)
+    if failed is None:
+        failed = next((r for r, p in enumerate(procs) if p.returncode != 0), None)
+    if failed is not None:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except Exception:
+                p.kill()
+        print(f"bench.py: rank {failed} failed (rc {procs[failed].returncode if failed >= 0 else 'timeout'}); job aborted", file=sys.stderr)
+        return 1
+    outs[0].seek(0)
+    sys.stdout.write(outs[0].read())
+    sys.stdout.flush()
+    return 0
+
+
+def init_ranks(args, backend="nccl"):
+    """(rank, local_rank, world, dist-or-None) from the launcher's environment; the process group is RCCL (`nccl`) on the GPU box."""
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, local_rank, world, dist
+
+
+def dry_run_main(args):
+    """`--dist-dry-run`: the whole multi-rank protocol of the bench (spawned or launched ranks, gloo rendezvous, per-rank shards, W warm-up
+    + K timed steps between barriers, MAX over ranks, rank 0's one JSON line) on the CPU with a stand-in step (a small matmul in place of
+    the forward) -- what tests/test_bench_dist.py runs end to end where there is no GPU.  Never a measurement."""
+    rank, _, world, dist = init_ranks(args, backend="gloo")
+    if os.environ.get("RTFS_BENCH_FAIL_RANK") == str(rank):  # fault injection for the launcher test
+        raise SystemExit(3)
+    B = args.batch if args.batch is not None else 32
+    wav, emb = rank_inputs(rank, B, 4096, 7)
+    w = torch.randn(4096, 64, generator=torch.Generator().manual_seed(0))
+
+    def step():
+        return (wav @ w).sum() + emb.sum()
+    for _ in range(args.warmup):
+        step()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        chk = step()
+    if dist is not None:
+        dist.barrier()
+    dt = max_over_ranks(time.perf_counter() - t0 + 0.01 * rank, dist, torch.device("cpu"))
+    assert bool(torch.isfinite(chk))
+    if rank == 0:
+        print(json.dumps({"metric": "dry run (launcher + rendezvous + timing protocol only; NOT a measurement)", "value": round(throughput(world, B, args.steps, dt), 3),
+                          "unit": "mixtures/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                          "config": {"workload": "stand-in step on CPU over gloo", "per_gpu_batch": B, "global_batch": B * world}}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def train_main(args):
+    """Training-step throughput, same timing protocol as the forward bench (W warm-up steps, K steps between barrier + synchronize on both
+    sides, MAX over ranks, whole-job aggregate).  Per-GPU batch defaults to the reference's training batch_size 4 unless --batch is given."""
+    rank, local_rank, world, dist = init_ranks(args)
     cpu_res = train_cpu_baseline(args.repeats) if (world == 1 and not args.no_cpu_baseline) else None  # before the GPU is initialised
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
@@ -160,7 +272,7 @@ def train_main(args):
     system = R.System(audio_model=model, loss_func={"train": loss, "val": loss}, optimizer=opt)
     if world > 1:
         system.convert_sync_batchnorm()
-    B = args.batch if "--batch" in sys.argv else 4
+    B = args.batch if args.batch is not None else 4  # the reference's training batch_size
     L, Tv = int(args.seconds * 16000), int(args.seconds * 25)
     wav, emb = rank_inputs(rank, B, L, Tv)
     g = torch.Generator().manual_seed(4321 + rank)
@@ -205,30 +317,23 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=32, help="mixtures per GPU per step")
+    ap.add_argument("--batch", type=int, default=None, help="mixtures per GPU per step (default: 32 forward, 4 training)")
     ap.add_argument("--repeats", type=int, default=4, help="RTFS-Net-R")
     ap.add_argument("--seconds", type=float, default=2.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--train", action="store_true",
                     help="measure the training step instead (forward_train + PIT loss + HIP backward + one flattened gradient all-reduce "
                          "over RCCL + clip + AdamW; SyncBatchNorm at N > 1); not the contract metric, a separate JSON line")
+    ap.add_argument("--dist-dry-run", action="store_true", help="CPU/gloo rehearsal of the multi-rank protocol with a stand-in step (tests)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args.gpus, sys.argv[1:])  # this process never touches the GPU
+    if args.dist_dry_run:
+        return dry_run_main(args)
     if args.train:
         return train_main(args)
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with `python -m torch.distributed.run --nproc-per-node N bench.py ...`")
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    rank, local_rank, world, dist = init_ranks(args)
     cpu_res = None
     if world == 1 and not args.no_cpu_baseline:
         cpu_res = cpu_baseline(args.repeats)  # child processes: started before this process initialises the GPU
@@ -241,7 +346,7 @@ def main():
 
     torch.manual_seed(0)  # random-init weights of the named architecture (no checkpoints offline)
     model = R.AVNet(print_macs=False, **audionet_config(args.repeats)).to(dev).eval()
-    B, L = args.batch, int(args.seconds * 16000)
+    B, L = (args.batch if args.batch is not None else 32), int(args.seconds * 16000)
     Tv = int(args.seconds * 25)
     wav, emb = (t.to(dev) for t in rank_inputs(rank, B, L, Tv))
 
@@ -296,7 +401,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": DTYPE,
             "data": "synthetic",
             "config": {"workload": f"RTFS-Net-{args.repeats} forward, batch {B}/GPU, {args.seconds:g} s @16 kHz 2-speaker mixtures "
                                    f"+ dummy lip embeddings (B,512,{Tv}), random-init weights, eval",
@@ -323,4 +428,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

@@ -4,7 +4,8 @@ Mirrors the reference's ``src/models`` surface for the RTFS-Net path (``AVNet`` 
 plus the north_star names ``RTFSNet``, ``RTFSBlock``, ``CAFBlock``, ``S3Block``); all arithmetic on the audio
 path runs in ``librtfs_amd.so`` (hand-written gfx950 HIP kernels behind the C ABI of ``include/rtfs_amd.h``).
 """
-from . import _lib, layers, losses, packing, system, videomodels  # noqa: F401
+from . import _lib, configs, layers, losses, packing, system, torch_utils, videomodels  # noqa: F401
+from .packing import invalidate_packs  # noqa: F401
 from .system import System  # noqa: F401
 from .videomodels import FRCNNVideoModel  # noqa: F401
 from .models import (AVNet, ATTNFusion, BaseAVModel, CAFBlock, MaskGenerator, MultiModalFusion, RefinementModule, RTFSBlock, RTFSNet,  # noqa: F401

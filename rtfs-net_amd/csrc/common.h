@@ -20,6 +20,11 @@ static inline int rtfs_launch_status() {
     return e == hipSuccess ? RTFS_OK : RTFS_ERR_LAUNCH;
 }
 
+// Raise a kernel's dynamic-LDS limit to `bytes` on the CURRENT device if it is not already that high.  The attribute is per device
+// (and the library may be driven from several host threads / devices in one process): the cache is keyed by (device, kernel) and
+// guarded by a mutex (runtime.hip).
+int rtfs_set_max_lds(const void* kernel, size_t bytes);
+
 #define RTFS_RETURN_IF(cond, code) \
     do {                           \
         if (cond) return (code);   \

@@ -323,12 +323,7 @@ int launch_row_can_proj(const RowCanArgs& a, int B, hipStream_t st) {
 int launch_attn_core(const AttnArgs& a, int B, hipStream_t st) {
     if (a.T < 1 || a.T > 256) return RTFS_ERR_SHAPE;
     const size_t lds = attn_core_lds_bytes(a.T);
-    static size_t configured = 0;
-    if (lds > configured) {
-        if (hipFuncSetAttribute((const void*)attn_core_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return RTFS_ERR_LAUNCH;
-        configured = lds;
-    }
+    if (rtfs_set_max_lds((const void*)attn_core_kernel, lds) != RTFS_OK) return RTFS_ERR_LAUNCH;
     AttnArgs a2 = a;
     a2.npairs = B * 4;
     hipLaunchKernelGGL(attn_core_kernel, dim3(cdiv(a2.npairs, 8) * 8 * cdiv(a.T, 32)), dim3(256), lds, st, a2);

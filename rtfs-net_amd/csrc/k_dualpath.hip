@@ -14,6 +14,7 @@
 //   (lanes 0-31 forward j, lanes 32-63 backward j).
 #include "common.h"
 #include "kernels.h"
+#include <mutex>
 
 #define DP_C 64     // channels of the sequence
 #define DP_K 8      // unfold / conv-transpose kernel
@@ -202,18 +203,22 @@ struct TimingSlot {
     hipEvent_t beg, end;
     int Ls, nseq;
 };
+// a process-wide DIAGNOSTIC log (bench.py's roofline object): off by default, guarded by a mutex so concurrent launchers cannot corrupt it
 TimingSlot g_slots[TIMING_CAP];
 int g_nslots = 0, g_nalloc = 0;
 bool g_timing = false;
+std::mutex g_timing_mu;
 }  // namespace
 
 int dualpath_timing_enable(int on) {
+    std::lock_guard<std::mutex> lock(g_timing_mu);
     g_timing = on != 0;
     g_nslots = 0;
     return RTFS_OK;
 }
 
 int dualpath_timing_collect(float* ms, int* ls, int* nseq, int cap) {
+    std::lock_guard<std::mutex> lock(g_timing_mu);
     int n = 0;
     for (int i = 0; i < g_nslots && n < cap; ++i) {
         if (hipEventSynchronize(g_slots[i].end) != hipSuccess) return RTFS_ERR_LAUNCH;
@@ -229,7 +234,9 @@ int dualpath_timing_collect(float* ms, int* ls, int* nseq, int cap) {
 }
 
 static TimingSlot* timing_begin(int Ls, int nseq, hipStream_t st) {
-    if (!g_timing || g_nslots >= TIMING_CAP) return nullptr;
+    if (!g_timing) return nullptr;  // the product path: one relaxed read, no lock
+    std::lock_guard<std::mutex> lock(g_timing_mu);
+    if (g_nslots >= TIMING_CAP) return nullptr;
     if (g_nslots >= g_nalloc) {
         if (hipEventCreate(&g_slots[g_nalloc].beg) != hipSuccess || hipEventCreate(&g_slots[g_nalloc].end) != hipSuccess) return nullptr;
         ++g_nalloc;
@@ -255,20 +262,10 @@ size_t dualpath_lds_bytes(int Ls) {
 int launch_dualpath(const DpArgs& a, int nseq, hipStream_t st) {
     if (a.Ls < DP_K || a.Ls > 250) return RTFS_ERR_SHAPE;
     const size_t lds = dualpath_lds_bytes(a.Ls);
-    static size_t configured = 0;
-    if (lds > configured) {
-        if (hipFuncSetAttribute((const void*)dualpath_sru_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return RTFS_ERR_LAUNCH;
-        configured = lds;
-    }
+    if (rtfs_set_max_lds((const void*)dualpath_sru_kernel<false, false>, lds) != RTFS_OK) return RTFS_ERR_LAUNCH;
     TimingSlot* slot = timing_begin(a.Ls, nseq, st);
     if (a.whh) {
-        static size_t configured_l = 0;
-        if (lds > configured_l) {
-            if (hipFuncSetAttribute((const void*)dualpath_sru_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-                return RTFS_ERR_LAUNCH;
-            configured_l = lds;
-        }
+        if (rtfs_set_max_lds((const void*)dualpath_sru_kernel<false, true>, lds) != RTFS_OK) return RTFS_ERR_LAUNCH;
         hipLaunchKernelGGL((dualpath_sru_kernel<false, true>), dim3(nseq), dim3(256), lds, st, a);
     } else {
         hipLaunchKernelGGL((dualpath_sru_kernel<false, false>), dim3(nseq), dim3(256), lds, st, a);
@@ -290,12 +287,7 @@ int launch_sru_standalone(const float* x, float* h, int L, int N, const float* W
     a.wc = wc;
     a.bias = bias;
     const size_t lds = dualpath_lds_bytes(a.Ls);
-    static size_t configured = 0;
-    if (lds > configured) {
-        if (hipFuncSetAttribute((const void*)dualpath_sru_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return RTFS_ERR_LAUNCH;
-        configured = lds;
-    }
+    if (rtfs_set_max_lds((const void*)dualpath_sru_kernel<true>, lds) != RTFS_OK) return RTFS_ERR_LAUNCH;
     hipLaunchKernelGGL(dualpath_sru_kernel<true>, dim3(N), dim3(256), lds, st, a);
     return rtfs_launch_status();
 }

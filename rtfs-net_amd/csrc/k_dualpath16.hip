@@ -428,12 +428,7 @@ static int launch_dp16_stamp_t(const Dp16Args& a, hipStream_t st) {
 template <int NSEQ, int NHALF, bool PAIRED>
 static int launch_dp16_t(const Dp16Args& a, hipStream_t st) {
     const size_t lds = dp16_lds_bytes(a.Ls, NSEQ);
-    static size_t configured = 0;
-    if (lds > configured) {
-        if (hipFuncSetAttribute((const void*)dp16_kernel<NSEQ, NHALF, PAIRED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return RTFS_ERR_LAUNCH;
-        configured = lds;
-    }
+    if (rtfs_set_max_lds((const void*)dp16_kernel<NSEQ, NHALF, PAIRED>, lds) != RTFS_OK) return RTFS_ERR_LAUNCH;
     void* slot = dualpath_timing_begin(a.Ls, a.nseq, st);
     hipLaunchKernelGGL((dp16_kernel<NSEQ, NHALF, PAIRED>), dim3(cdiv(a.nseq, NSEQ)), dim3(512), lds, st, a);
     dualpath_timing_end(slot, st);

@@ -230,12 +230,7 @@ __global__ __launch_bounds__(256, 2) void pwr_kernel(PwArgs a, int ntiles, int t
 
 template <int MODE>
 int launch_pwr_t(const PwArgs& a, int B, hipStream_t st) {
-    static bool configured = false;
-    if (!configured) {
-        if (hipFuncSetAttribute((const void*)pwr_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PWR_LDS) != hipSuccess)
-            return RTFS_ERR_LAUNCH;
-        configured = true;
-    }
+    if (rtfs_set_max_lds((const void*)pwr_kernel<MODE>, PWR_LDS) != RTFS_OK) return RTFS_ERR_LAUNCH;
     const int tps = cdiv(a.P, PWR_PT), ntiles = tps * B;
     const int grid = ntiles < 512 ? ntiles : 512;  // persistent: 2 workgroups per CU
     hipLaunchKernelGGL((pwr_kernel<MODE>), dim3(grid), dim3(256), PWR_LDS, st, a, ntiles, tps);

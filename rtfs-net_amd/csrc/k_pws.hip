@@ -198,12 +198,7 @@ static int launch_pws_t(const PwArgs& a, int B, hipStream_t st) {
     constexpr int S = COUT <= 64 ? 2 : 1;  // two pixels per lane where the accumulators allow it (COUT 64: 64 registers)
     if (a.P < 2) return RTFS_ERR_SHAPE;
     const size_t lds = (size_t)2 * COUT * (CIN + 8) * 2 + (size_t)(CAF ? 6 : 2) * CIN * 4;
-    static bool configured = false;
-    if (!configured) {
-        if (hipFuncSetAttribute((const void*)pws_kernel<CIN, COUT, PRO, EPI, HAS_X2, CAF, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return RTFS_ERR_LAUNCH;
-        configured = true;
-    }
+    if (rtfs_set_max_lds((const void*)pws_kernel<CIN, COUT, PRO, EPI, HAS_X2, CAF, S>, lds) != RTFS_OK) return RTFS_ERR_LAUNCH;
     constexpr int PTB = 32 * S * (4 / (COUT / 32 > 4 ? COUT / 32 / 4 : 1));
     const int tps = cdiv(a.P, PTB), ntiles = tps * B;
     const int grid = ntiles < 512 ? ntiles : 512;  // 2 resident workgroups per CU
@@ -308,11 +303,7 @@ __global__ __launch_bounds__(256, 2) void pws_res2_kernel(PwArgs a, int ntiles, 
 static int launch_pws_res2(const PwArgs& a, int B, hipStream_t st) {
     if (a.P < 2) return RTFS_ERR_SHAPE;
     const size_t lds = (size_t)2 * 256 * 72 * 2 + 256 * 4;
-    static bool configured = false;
-    if (!configured) {
-        if (hipFuncSetAttribute((const void*)pws_res2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return RTFS_ERR_LAUNCH;
-        configured = true;
-    }
+    if (rtfs_set_max_lds((const void*)pws_res2_kernel, lds) != RTFS_OK) return RTFS_ERR_LAUNCH;
     const int tps = cdiv(a.P, 256), ntiles = tps * B;
     const int grid = ntiles < 512 ? ntiles : 512;  // 2 resident workgroups per CU
     hipLaunchKernelGGL(pws_res2_kernel, dim3(grid), dim3(256), lds, st, a, ntiles, tps);
@@ -514,11 +505,7 @@ __global__ __launch_bounds__(B2B_NT) void pws_b2b_kernel(B2bArgs a, int ntiles, 
 template <bool CAF>
 static int launch_b2b_t(const B2bArgs& a, int B, hipStream_t st) {
     const size_t lds = (size_t)2 * 256 * 72 * 2 + (size_t)2 * 64 * 264 * 2 + (size_t)(CAF ? 7 : 3) * 256 * 4;
-    static bool configured = false;
-    if (!configured) {
-        if (hipFuncSetAttribute((const void*)pws_b2b_kernel<CAF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return RTFS_ERR_LAUNCH;
-        configured = true;
-    }
+    if (rtfs_set_max_lds((const void*)pws_b2b_kernel<CAF>, lds) != RTFS_OK) return RTFS_ERR_LAUNCH;
     if (a.P < 2) return RTFS_ERR_SHAPE;
     const int tps = cdiv(a.P, B2B_NT / 64 * 64), ntiles = tps * B;
     const int grid = ntiles < 256 ? ntiles : 256;  // one resident 8-wave workgroup per CU

@@ -394,11 +394,7 @@ int conv3l_launch(const VidConvArgs& a, hipStream_t st) {
     }
     const size_t lds = (size_t)2 * 2 * (32 * MT) * V_LDW * 2 + (size_t)G * (RH + 2) * (a.Wo + 2) * VL_PIXLD * 4;
     if (lds > 160 * 1024) return RTFS_ERR_SHAPE;
-    static size_t configured = 0;
-    if (lds > configured) {
-        if (hipFuncSetAttribute((const void*)vid_conv3l_kernel<MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return RTFS_ERR_LAUNCH;
-        configured = lds;
-    }
+    if (rtfs_set_max_lds((const void*)vid_conv3l_kernel<MT>, lds) != RTFS_OK) return RTFS_ERR_LAUNCH;
     hipLaunchKernelGGL((vid_conv3l_kernel<MT>), dim3(cdiv(a.N, G) * bands, a.Cout / (32 * MT)), dim3(256), lds, st, a, G, RH, bands);
     return rtfs_launch_status();
 }

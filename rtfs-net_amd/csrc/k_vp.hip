@@ -310,11 +310,7 @@ int launch_vp_block(const float* video, const float* pack, float* out, int B, in
     for (int i = 1; i < VDEPTH; ++i) Lg = (Lg - 1) / 2 + 1;
     if (Tv < 1 || Lg > 16 || Tv > 120) return RTFS_ERR_SHAPE;
     const size_t lds = vp_lds_bytes(Tv);
-    static size_t configured = 0;
-    if (lds > configured) {
-        if (hipFuncSetAttribute((const void*)vp_block_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return RTFS_ERR_LAUNCH;
-        configured = lds;
-    }
+    if (rtfs_set_max_lds((const void*)vp_block_kernel, lds) != RTFS_OK) return RTFS_ERR_LAUNCH;
     hipLaunchKernelGGL(vp_block_kernel, dim3(B), dim3(256), lds, st, video, pack, out, Tv);
     return rtfs_launch_status();
 }

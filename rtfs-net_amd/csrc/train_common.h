@@ -8,9 +8,7 @@ namespace {
 template <typename K>
 int set_lds(K kernel, size_t bytes) {
     if (bytes > 160 * 1024) return RTFS_ERR_SHAPE;
-    if (bytes > 48 * 1024 && hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess)
-        return RTFS_ERR_LAUNCH;
-    return RTFS_OK;
+    return bytes > 48 * 1024 ? rtfs_set_max_lds((const void*)kernel, bytes) : RTFS_OK;
 }
 // grid of 256-thread workgroups for a grid-stride loop over n elements
 inline unsigned grid_for(size_t n, unsigned cap = 8192) {

@@ -33,7 +33,7 @@ class PackedModule(nn.Module):
 
     def pack(self) -> torch.Tensor:
         sd = self._state_tensors()
-        key = tuple((v.data_ptr(), v._version) for v in sd.values())
+        key = (packing.pack_epoch(),) + tuple((v.data_ptr(), v._version) for v in sd.values())
         if getattr(self, "_pack_key", None) != key:
             with torch.no_grad():
                 pk = type(self)._pack_fn(sd)
@@ -187,7 +187,7 @@ def _grad_bundle(kind, params, n, unpack):
         return _GradBundleFn.apply(n, unpack, *params)
     import weakref
     store = packing.param_store(params[0], "grad_bundle")
-    key = (kind, n) + tuple((id(t), t._version, t.requires_grad) for t in params)
+    key = (kind, n, packing.pack_epoch()) + tuple((id(t), t._version, t.requires_grad) for t in params)
     ref = store.get(key)
     b = ref() if ref is not None else None
     if b is None:

@@ -260,7 +260,7 @@ class TDANetBlock(PackedModule):
 
     def pack_vp(self):
         sd = self._state_tensors()
-        key = tuple((v.data_ptr(), v._version) for v in sd.values())
+        key = (packing.pack_epoch(),) + tuple((v.data_ptr(), v._version) for v in sd.values())
         if getattr(self, "_vp_key", None) != key:
             with torch.no_grad():
                 pk = packing.pack_vp(sd)

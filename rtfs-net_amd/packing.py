@@ -111,6 +111,23 @@ def param_store(anchor, name):
     return st
 
 
+_PACK_EPOCH = [0]
+
+
+def invalidate_packs():
+    """Drop every cached parameter pack (inference packs, training packs, gradient bundles) at its next use.
+
+    The caches are keyed on (data_ptr, Tensor._version) of the live parameters, which every in-place update THROUGH THE PARAMETER bumps
+    (optimizer steps, load_state_dict, p.copy_ under no_grad).  An update through ``p.data`` (``p.data.copy_(ema)``, ``p.data.clamp_()``
+    - EMA swaps, weight clipping in older code) runs on a detached alias with its OWN version counter and is invisible to that key:
+    call this after such an update."""
+    _PACK_EPOCH[0] += 1
+
+
+def pack_epoch():
+    return _PACK_EPOCH[0]
+
+
 def cached_train_pack(kind, tensors, build):
     """The training kernels take re-ordered copies of the live parameters.  Within one step the shared RTFS block is applied R times
     with unchanged parameters, so the copy is cached - in a store tied to the first parameter object (param_store: it dies with the
@@ -122,7 +139,7 @@ def cached_train_pack(kind, tensors, build):
     if anchor is None:
         return build()
     store = param_store(anchor, "train_pack")
-    key = (kind,) + tuple(None if t is None else (id(t), t.data_ptr(), t._version) for t in tensors)
+    key = (kind, _PACK_EPOCH[0]) + tuple(None if t is None else (id(t), t.data_ptr(), t._version) for t in tensors)
     pk = store.get(key)
     if pk is None:
         store.clear()  # one live entry per (anchor): older versions are dead weight

@@ -88,10 +88,39 @@ class System(nn.Module):
             off += n
         return flat.numel()
 
+    def broadcast_parameters(self, src=0):
+        """What DistributedDataParallel does at construction (train.py:135-146 runs under Lightning's DDP strategy): every rank starts
+        from rank `src`'s parameters AND buffers (BatchNorm running statistics), so ranks that were seeded differently cannot drift apart
+        silently.  One broadcast of one flattened float buffer (+ one for the integer buffers).  No-op without a process group."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return 0
+        tensors = [t for t in list(self.audio_model.parameters()) + list(self.audio_model.buffers())]
+        done = 0
+        for is_float in (True, False):
+            group = [t for t in tensors if t.is_floating_point() == is_float]
+            if not group:
+                continue
+            flat = torch.cat([t.detach().reshape(-1).to(torch.float32 if is_float else torch.int64) for t in group])
+            dist.broadcast(flat, src=src)
+            off = 0
+            with torch.no_grad():
+                for t in group:
+                    n = t.numel()
+                    t.copy_(flat[off:off + n].view_as(t).to(t.dtype))  # in place through the tensor itself: bumps _version (pack caches)
+                    off += n
+            done += flat.numel()
+        self._params_broadcast = True
+        return done
+
     def optimization_step(self, batch, batch_nb=0, gradient_clip_val=5.0):
-        """zero_grad -> training_step -> backward -> gradient all-reduce -> clip (train.py:142 gradient_clip_val 5.0) -> optimizer step."""
+        """zero_grad -> training_step -> backward -> gradient all-reduce -> clip (train.py:142 gradient_clip_val 5.0) -> optimizer step.
+        The first step of a multi-rank job broadcasts rank 0's parameters and buffers first (DDP's construction-time broadcast)."""
         if self.optimizer is None:
             raise RuntimeError("System.optimization_step needs an optimizer")
+        if not getattr(self, "_params_broadcast", False):
+            self.broadcast_parameters()
+            self._params_broadcast = True
         self.optimizer.zero_grad(set_to_none=True)
         loss = self.training_step(batch, batch_nb)["loss"]
         loss.backward()

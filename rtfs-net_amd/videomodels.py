@@ -95,7 +95,7 @@ class FRCNNVideoModel(nn.Module):
 
     def pack(self) -> torch.Tensor:
         sd = {k: v for k, v in self.state_dict().items() if v.is_floating_point()}
-        key = tuple((v.data_ptr(), v._version) for v in sd.values())
+        key = (packing.pack_epoch(),) + tuple((v.data_ptr(), v._version) for v in sd.values())
         if getattr(self, "_pack_key", None) != key:
             with torch.no_grad():
                 object.__setattr__(self, "_pack_buf", packing.pack_video(sd))

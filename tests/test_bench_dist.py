@@ -71,7 +71,17 @@ for i, p in enumerate(system.trainable_parameters()):
 system.trainable_parameters()[1].grad = None                                                # a parameter that got no gradient on this rank
 n = system.allreduce_gradients()
 g = [float(p.grad.reshape(-1)[0]) for p in system.trainable_parameters()]
-print("RESULT " + json.dumps({"rank": rank, "n": n, "g": g, "frozen": net[2].bias.grad is None}), flush=True)
+# DDP's construction-time broadcast: ranks that start from different values end on rank 0's, parameters and buffers alike
+bn = torch.nn.BatchNorm1d(3)
+net2 = torch.nn.Sequential(torch.nn.Linear(5, 3), bn)
+with torch.no_grad():
+    for t in list(net2.parameters()) + [bn.running_mean, bn.running_var]:
+        t.fill_(float(rank + 2))
+    bn.num_batches_tracked.fill_(rank + 7)
+sys2 = R.System(audio_model=net2)
+nb = sys2.broadcast_parameters()
+after = sorted({float(t.reshape(-1)[0]) for t in list(net2.parameters()) + list(net2.buffers())})
+print("RESULT " + json.dumps({"rank": rank, "n": n, "g": g, "frozen": net[2].bias.grad is None, "nb": nb, "after": after}), flush=True)
 dist.destroy_process_group()
 """
 
@@ -93,3 +103,46 @@ def test_gradient_allreduce_two_ranks_gloo():
     # parameter i carried (rank + 1) * (i + 1): mean over ranks 1.5 * (i + 1); parameter 1 had no gradient anywhere -> 0
     assert res[0]["g"] == res[1]["g"] == [1.5, 0.0, 4.5, 6.0]
     assert res[0]["frozen"] and res[1]["frozen"]
+    # broadcast: 5*3 + 3 + 3 + 3 + 3 + 3 floats and one integer buffer, every value now rank 0's (2.0; num_batches_tracked 7)
+    assert res[0]["nb"] == res[1]["nb"] == 15 + 3 + 3 + 3 + 3 + 3 + 1
+    assert res[0]["after"] == res[1]["after"] == [2.0, 7.0]
+
+
+def _bench(*argv, env=None):
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                          text=True, timeout=300)
+
+
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus 2 ...` exactly as the driver types it (no torch.distributed.run, no WORLD_SIZE): the parent spawns the ranks,
+    relays rank 0's ONE JSON line and exits 0.  --dist-dry-run swaps the forward for a stand-in step over gloo so the launcher, the
+    rendezvous and the timing protocol run end to end where there is no GPU."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    pr = _bench("--gpus", "2", "--steps", "3", "--warmup", "1", "--dist-dry-run", env=env)
+    assert pr.returncode == 0, pr.stderr[-2000:]
+    lines = [l for l in pr.stdout.splitlines() if l.startswith("{")]  # (gloo itself prints a "[Gloo] Rank 0 is connected ..." line)
+    assert len(lines) == 1, pr.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["warmup"] == 1 and rec["config"]["global_batch"] == 64
+    assert rec["value"] == round(2 * 32 * 3 / (rec["ms_per_step"] * 3e-3), 3) or abs(rec["value"] * rec["ms_per_step"] * 1e-3 - 64) < 0.05
+    # the same through torch.distributed.run (the driver's other launch form)
+    port = _free_port()
+    pr = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                         "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--dist-dry-run"],
+                        cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert pr.returncode == 0, pr.stderr[-2000:]
+    recs = [json.loads(l) for l in pr.stdout.splitlines() if l.startswith("{")]
+    assert len(recs) == 1 and recs[0]["n_gpus"] == 2
+
+
+def test_bench_launcher_reports_a_failed_rank():
+    """A rank that dies must fail the whole job (non-zero exit, no JSON line), not leave the others at a barrier: here --gpus disagrees
+    with a pre-set WORLD_SIZE inside the children (the mismatch check), and the training leg is covered by the same launcher."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["WORLD_SIZE"] = "3"
+    pr = _bench("--gpus", "2", "--steps", "1", "--warmup", "0", "--dist-dry-run", env=env)
+    assert pr.returncode != 0 and "{" not in pr.stdout
+    env.pop("WORLD_SIZE")
+    env["RTFS_BENCH_FAIL_RANK"] = "1"
+    pr = _bench("--gpus", "2", "--steps", "1", "--warmup", "0", "--dist-dry-run", env=env)
+    assert pr.returncode != 0 and "{" not in pr.stdout and "rank 1 failed" in pr.stderr

@@ -21,7 +21,7 @@ CELL = O._sub(SD, "refinement_module.crossmodal_fusion.fusion_module.audio_lstm"
 
 def _conf(repeats=4):
     import copy
-    from tests.test_host import RTFS4_AUDIONET
+    from rtfs_net_amd.configs import RTFS4_AUDIONET
     c = copy.deepcopy(RTFS4_AUDIONET)
     c["audio_params"]["repeats"] = repeats
     return c
@@ -48,11 +48,15 @@ def host(t):
     return t.detach().cpu().numpy()
 
 
-def close(name, got, ref, tol=TOL):
+def close(name, got, ref, tol=TOL, tol_l2=None):
+    """Two readings of the north_star's "1e-4 rel", both asserted: max|d| / max|ref| <= tol, and the stricter aggregate
+    ||d||_2 / ||ref||_2 <= tol / 10 (measured 1e-7 ... 1e-6 on every case)."""
     e, l2 = rel_err(got, ref), l2_rel(got, ref)
+    tol_l2 = tol / 10 if tol_l2 is None else tol_l2
     print(f"[parity] {name}: max-rel {e:.3e}  l2-rel {l2:.3e}  shape {tuple(np.shape(ref))}")
     assert np.isfinite(np.asarray(got)).all(), f"{name}: non-finite output"
     assert e <= tol, f"{name}: rel err {e:.3e} > {tol:.1e}"
+    assert l2 <= tol_l2, f"{name}: l2-rel err {l2:.3e} > {tol_l2:.1e}"
 
 
 def test_library_loaded_is_hip():
@@ -243,8 +247,7 @@ def test_end_to_end_vs_golden(name, R, B, L, Tv, seed, fused):
         out = host(m(dev(wav), dev(emb)))
     finally:
         m.fused = True
-    tol = TOL if R <= 6 else 5e-4  # 12 un-trained repeats amplify rounding ~45x (oracle vs reference: 2e-4 bound)
-    close(f"{name} fused={fused}", out, g["out"], tol)
+    close(f"{name} fused={fused}", out, g["out"])
 
 
 def test_end_to_end_4s_vs_oracle():
@@ -253,7 +256,7 @@ def test_end_to_end_4s_vs_oracle():
     (the oracle is the checker), R = 2 keeps the CPU side short."""
     m = model(4)
     import copy, rtfs_net_amd as R
-    from tests.test_host import RTFS4_AUDIONET
+    from rtfs_net_amd.configs import RTFS4_AUDIONET
     c = copy.deepcopy(RTFS4_AUDIONET); c["audio_params"]["repeats"] = 2
     m2 = R.AVNet(print_macs=False, **c)
     m2.load_state_dict(m.state_dict())
@@ -271,7 +274,7 @@ _LSTM = {}
 def lstm_model():
     import copy, json, os
     import rtfs_net_amd as R
-    from tests.test_host import RTFS4_AUDIONET
+    from rtfs_net_amd.configs import RTFS4_AUDIONET
     from tests.util import GOLDEN
     if "m" not in _LSTM:
         c = copy.deepcopy(RTFS4_AUDIONET)
@@ -331,6 +334,32 @@ def test_batch_independence_property():
     for i in (0, 3):
         one = host(m(dev(wav[i:i + 1]), dev(emb[i:i + 1])))
         assert rel_err(full[i:i + 1], one) <= 2e-6
+
+
+def test_relocated_package_runs_the_forward(tmp_path):
+    """train.py:95 copies the models package into the experiment directory, test.py:33-36 imports the copy as `<exp>.models` and calls
+    AVNet.from_pretrain(...)(mix, mouth_emb): the copied package (with its librtfs_amd.so) must produce the reference's output."""
+    import importlib
+    import shutil
+    import sys
+    from tests.util import ROOT
+    exp = tmp_path / "exp_gpu"
+    shutil.copytree(os.path.join(ROOT, "rtfs-net_amd"), exp / "models", ignore=shutil.ignore_patterns("csrc", "__pycache__"))
+    (exp / "__init__.py").write_text("")
+    sys.path.append(str(tmp_path))
+    try:
+        models = importlib.import_module("exp_gpu.models")
+        ck = tmp_path / "best_model.pth"
+        torch.save(model().serialize(), ck)
+        m = models.AVNet.from_pretrain(str(ck), **_conf(4)).cuda().eval()
+        wav, emb = make_inputs(2, 4096, 7, 1)
+        with torch.no_grad():
+            out = host(m(dev(wav), dev(emb)))
+        close("relocated package e2e_R4_L4096_B2", out, load_golden("e2e_R4_L4096_B2")["out"])
+    finally:
+        sys.path.remove(str(tmp_path))
+        for k in [k for k in sys.modules if k.startswith("exp_gpu")]:
+            del sys.modules[k]
 
 
 def test_cpu_tensor_rejected():
@@ -396,7 +425,7 @@ def test_system_forward_and_validation_step():
     the HIP path; checked against the composition of the three oracles."""
     import copy
     from oracle import loss_oracle as LO, video_oracle as V
-    from tests.test_host import RTFS4_AUDIONET
+    from rtfs_net_amd.configs import RTFS4_AUDIONET
     import rtfs_net_amd as R
     B, L, Tv = 1, 4096, 3
     sd = make_state_dict(spec_R4(), 0)

@@ -788,7 +788,7 @@ import numpy as np, torch
 import torch.distributed as dist
 sys.path.insert(0, os.environ["RTFS_ROOT"])
 import rtfs_net_amd as R
-from tests.test_host import RTFS4_AUDIONET
+from rtfs_net_amd.configs import RTFS4_AUDIONET
 from oracle.params import make_inputs
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 if world > 1:

@@ -11,30 +11,7 @@ import torch
 
 from tests.util import ROOT, spec_R4
 
-# config/lrs2_RTFSNet_4_layer.yaml `audionet` section, restated as data so the tests do not read /root/reference
-RTFS4_AUDIONET = {
-    "n_src": 1,
-    "pretrained_vout_chan": 512,
-    "video_bn_params": {"kernel_size": -1},
-    "audio_bn_params": {"pre_norm_type": "gLN", "pre_act_type": "ReLU", "out_chan": 256, "kernel_size": 1, "is2d": True},
-    "enc_dec_params": {"encoder_type": "STFTEncoder", "decoder_type": "STFTDecoder", "win": 256, "hop_length": 128, "out_chan": 256,
-                       "kernel_size": 3, "stride": 1, "bias": False, "act_type": None, "norm_type": None},
-    "audio_params": {"audio_net": "TDANet", "hid_chan": 64, "kernel_size": 4, "stride": 2, "norm_type": "gLN", "act_type": "PReLU",
-                     "upsampling_depth": 2, "repeats": 4, "shared": True, "is2d": True,
-                     "layers": {
-                         "layer_1": {"layer_type": "DualPathRNN", "hid_chan": 32, "dim": 4, "kernel_size": 8, "stride": 1, "rnn_type": "SRU",
-                                     "num_layers": 4, "bidirectional": True},
-                         "layer_2": {"layer_type": "DualPathRNN", "hid_chan": 32, "dim": 3, "kernel_size": 8, "stride": 1, "rnn_type": "SRU",
-                                     "num_layers": 4, "bidirectional": True},
-                         "layer_3": {"layer_type": "MultiHeadSelfAttention2D", "dim": 3, "n_freqs": 64, "n_head": 4, "hid_chan": 4,
-                                     "act_type": "PReLU", "norm_type": "LayerNormalization4D"}}},
-    "video_params": {"video_net": "TDANet", "hid_chan": 64, "kernel_size": 3, "stride": 2, "norm_type": "BatchNorm1d", "act_type": "PReLU",
-                     "upsampling_depth": 4, "repeats": 1, "shared": True, "is2d": False,
-                     "layers": {"layer_1": {"layer_type": "GlobalAttention", "ffn_name": "FeedForwardNetwork", "kernel_size": 3, "n_head": 8,
-                                            "dropout": 0.1}}},
-    "fusion_params": {"fusion_type": "ATTNFusion", "fusion_shared": True, "kernel_size": 4, "is2d": True},
-    "mask_generation_params": {"mask_generator_type": "MaskGenerator", "mask_act": "ReLU", "RI_split": True, "is2d": True},
-}
+from rtfs_net_amd.configs import RTFS4_AUDIONET  # noqa: E402  (package data; checked against the reference yaml below)
 
 
 def build(repeats=4):
@@ -382,3 +359,57 @@ def test_gradient_bundle_accumulates_over_applications():
     packed = packing._cat([torch.ones(3), torch.ones(70)])
     assert packed.numel() == 64 + 128 and float(packed.sum()) == 73.0 and float(z.abs().sum()) == 0.0
     assert R is not None
+
+
+def test_free_gpu_polling_on_amd_smi_output():
+    """get_free_gpu_indices (reference src/utils/torch_utils.py:58-75 shells out to nvidia-smi; here amd-smi): canned output of
+    `amd-smi process --json` in both document shapes, idle GPUs carry the "No running processes detected" placeholder."""
+    from rtfs_net_amd import torch_utils as TU
+    idle = {"process_info": "No running processes detected"}
+    proc = {"process_info": {"name": "python3", "pid": 4242, "memory_usage": {"vram_mem": {"value": 1024, "unit": "B"}}}}
+    doc = [{"gpu": 0, "process_list": [idle]}, {"gpu": 1, "process_list": [proc]}, {"gpu": 2, "process_list": [proc, proc]}, {"gpu": 3, "process_list": [idle]}]
+    assert TU.parse_amd_smi_process(json.dumps(doc)) == ([0, 1, 2, 3], [1, 2])
+    assert TU.get_free_gpu_indices(run=lambda cmd: json.dumps(doc)) == [0, 3]
+    wrapped = "WARNING: something on the first line\n" + json.dumps({"gpu_data": doc})
+    assert TU.get_free_gpu_indices(run=lambda cmd: wrapped) == [0, 3]
+    assert TU.get_free_gpu_indices(run=lambda cmd: json.dumps([{"gpu": i, "process_list": [idle]} for i in range(8)])) == list(range(8))
+    with pytest.raises(ValueError):
+        TU.parse_amd_smi_process("ERROR:root:Unable to get devices")
+
+
+def test_package_survives_relocation(tmp_path):
+    """train.py:95 copies src/models into the experiment directory and test.py:33-36 / inference.py:31-34 import THAT copy as
+    `<exp_name>.models`: the package (relative imports only, librtfs_amd.so found next to its own files) must work from there."""
+    import importlib
+    import shutil
+    import sys
+    exp = tmp_path / "exp_rtfs4"
+    shutil.copytree(os.path.join(ROOT, "rtfs-net_amd"), exp / "models", ignore=shutil.ignore_patterns("csrc", "__pycache__"))
+    (exp / "__init__.py").write_text("")
+    sys.path.append(str(tmp_path))
+    try:
+        models = importlib.import_module("exp_rtfs4.models")
+        assert os.path.dirname(models._lib.LIB_PATH) == str(exp / "models") and b"gfx950" in models._lib.load().rtfs_version()
+        m = models.get("AVNet")(print_macs=False, **RTFS4_AUDIONET)
+        assert sum(p.numel() for p in m.parameters()) == 739952
+        assert type(m).__module__.startswith("exp_rtfs4.models")
+    finally:
+        sys.path.remove(str(tmp_path))
+        for k in [k for k in sys.modules if k.startswith("exp_rtfs4")]:
+            del sys.modules[k]
+
+
+def test_pack_cache_survives_dot_data_updates_after_invalidate():
+    """An in-place update through `.data` (EMA swap, weight clipping) has its own version counter and is invisible to the
+    (data_ptr, _version) pack key; `rtfs_net_amd.invalidate_packs()` is the documented way to make the kernels see it."""
+    import rtfs_net_amd as R
+    m = build()
+    dp = m.refinement_module.audio_net.blocks.globalatt[0]
+    p0 = dp.pack()
+    dp.linear.bias.data.add_(1.0)
+    assert dp.pack() is p0  # the blind spot
+    R.invalidate_packs()
+    p1 = dp.pack()
+    assert p1 is not p0
+    off = 64 + 64 + 512 * 256 + 3 * 64 * 256 + 2 * 4 * 128 + 512 * 64
+    assert torch.equal(p1[off:off + 64], dp.linear.bias.detach())

@@ -214,3 +214,14 @@ def test_gradient_oracle_against_reference_autograd(case):
         worst = max(worst, err)
         assert err <= 1e-6, (k, err)
     print(f"gradient oracle vs reference autograd ({case}): worst relative error {worst:.2e} over {len(names)} tensors")
+
+
+@pytest.mark.slow
+def test_end_to_end_lstm_ragged_5s():
+    """Past BASELINE config 5's length, 100 % reference arithmetic (stock nn.LSTM): L = 85000 (ragged), T' = 332, Tv = 133
+    (oracle/make_golden_sizes.py)."""
+    g = load_golden("e2e_lstm_R4_L85000_B1")
+    wav, emb = make_inputs(1, 85000, 133, 35)
+    out = O.avnet_forward(wav, emb, _lstm_sd(), repeats=4)
+    e = rel_err(out, g["out"])
+    assert e <= 1e-4, f"5.3 s LSTM end-to-end rel err {e:.3e}"

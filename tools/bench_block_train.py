@@ -16,7 +16,7 @@ def main():
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--iters", type=int, default=5)
     a = ap.parse_args()
-    from tests.test_host import RTFS4_AUDIONET
+    from rtfs_net_amd.configs import RTFS4_AUDIONET
     torch.manual_seed(0)
     m = R.AVNet(print_macs=False, **RTFS4_AUDIONET).cuda()
     blk = m.refinement_module.audio_net.get_block(0)

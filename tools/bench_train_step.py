@@ -20,7 +20,7 @@ def main():
     ap.add_argument("--full", action="store_true", help="train everything (VP block with dropout, BatchNorm on batch statistics) instead of "
                     "the fine-tuning configuration (frozen BatchNorm statistics and VP block)")
     a = ap.parse_args()
-    from tests.test_host import RTFS4_AUDIONET
+    from rtfs_net_amd.configs import RTFS4_AUDIONET
     conf = copy.deepcopy(RTFS4_AUDIONET)
     conf["audio_params"]["repeats"] = a.repeats
     torch.manual_seed(0)

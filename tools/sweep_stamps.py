@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import rtfs_net_amd as R
 from rtfs_net_amd import _lib
-from tests.test_host import RTFS4_AUDIONET
+from rtfs_net_amd.configs import RTFS4_AUDIONET
 import copy
 lib = _lib.load()
 torch.manual_seed(0)

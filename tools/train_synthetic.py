@@ -31,7 +31,7 @@ def main():
     torch.cuda.set_device(local)
     if world > 1:
         dist.init_process_group("nccl", rank=rank, world_size=world)  # RCCL
-    from tests.test_host import RTFS4_AUDIONET
+    from rtfs_net_amd.configs import RTFS4_AUDIONET
     conf = copy.deepcopy(RTFS4_AUDIONET)
     conf["audio_params"]["repeats"] = a.repeats
     torch.manual_seed(0)  # identical initial weights on every rank
