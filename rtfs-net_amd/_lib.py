@@ -183,5 +183,13 @@ def need_gpu(*tensors):
             raise RuntimeError(f"rtfs_net_amd kernels are float32; got {t.dtype}")
 
 
+_POISON = bool(os.environ.get("RTFS_POISON_WS"))
+
+
 def workspace(nbytes: int, device):
-    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+    """Caller-owned scratch for one C call.  The kernels must never read a workspace byte they have not written in the same call;
+    RTFS_POISON_WS=1 (tests) fills every workspace with 0xFF bytes (NaN as f32 / f64) so such a read shows up in the output."""
+    ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+    if _POISON:
+        ws.fill_(0xFF)
+    return ws

@@ -413,3 +413,17 @@ def test_pack_cache_survives_dot_data_updates_after_invalidate():
     assert p1 is not p0
     off = 64 + 64 + 512 * 256 + 3 * 64 * 256 + 2 * 4 * 128 + 512 * 64
     assert torch.equal(p1[off:off + 64], dp.linear.bias.detach())
+
+
+def test_no_hazardous_packed_f32_instructions_in_the_code_object():
+    """tools/isa_check.py: no `v_pk_{fma,mul,add}_f32` with an op_sel that feeds a HIGH source dword to the LOW lane (the instruction form
+    that was caught producing wrong results on MI355X under load in round 2; the library is built with -fno-slp-vectorize)."""
+    import importlib.util
+    from rtfs_net_amd import _lib
+    spec = importlib.util.spec_from_file_location("isa_check", os.path.join(ROOT, "tools", "isa_check.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    bad = mod.hazardous(_lib.LIB_PATH)
+    assert not bad, bad[:5]
+    assert mod.PAT.search("v_pk_fma_f32 v[72:73], v[168:169], v[76:77], v[72:73] op_sel:[0,1,1]")
+    assert not mod.PAT.search("v_pk_fma_f32 v[154:155], v[154:155], v[76:77], v[72:73] op_sel_hi:[1,0,0]")

@@ -1,0 +1,50 @@
+"""Static check of the shipped code object: no packed-f32 VALU instruction may select a HIGH source dword for its LOW lane (`op_sel`
+with a 1).  Found in round 2 on MI355X: `v_pk_fma_f32 vD, vA, vS, vT op_sel:[0,1,1]` (emitted by the SLP vectoriser for two adjacent
+pixels sharing one scale / shift) intermittently computed its low result with a zero product in lanes 48-63 when it followed the VALU
+write of vA.lo - about once per 10^6 executions, only under full-chip load (tools/diag_batch4.py; DESIGN.md "A hardware / toolchain
+hazard").  The library is built with -fno-slp-vectorize; this check keeps the pattern from coming back.
+
+    python tools/isa_check.py [path/to/librtfs_amd.so]      exit status 1 and a listing when the pattern is present
+"""
+import os
+import re
+import shutil
+import subprocess
+import sys
+import tempfile
+
+LLVM = "/opt/rocm/lib/llvm/bin"
+PAT = re.compile(r"\bv_pk_(fma|mul|add)_f32\b.*\bop_sel:\[[01,]*1[01,]*\]")
+
+
+def device_disassembly(so_path):
+    """Yield (kernel, instruction) for every instruction of every gfx950 code object bundled in `so_path`."""
+    with tempfile.TemporaryDirectory() as td:
+        local = os.path.join(td, "lib.so")
+        shutil.copy(so_path, local)
+        subprocess.run([f"{LLVM}/llvm-objdump", "--offloading", local], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        cos = sorted(f for f in os.listdir(td) if "amdgcn" in f)
+        if not cos:
+            raise RuntimeError(f"no gfx950 code object found in {so_path}")
+        for co in cos:
+            out = subprocess.run([f"{LLVM}/llvm-objdump", "-d", "--no-show-raw-insn", os.path.join(td, co)], check=True, stdout=subprocess.PIPE, text=True).stdout
+            kernel = "?"
+            for line in out.splitlines():
+                m = re.match(r"^[0-9a-f]+ <(.+)>:", line)
+                if m:
+                    kernel = m.group(1)
+                elif line.startswith("\t") or line.startswith(" "):
+                    yield kernel, line.strip()
+
+
+def hazardous(so_path):
+    return [(k, ins) for k, ins in device_disassembly(so_path) if PAT.search(ins)]
+
+
+if __name__ == "__main__":
+    so = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rtfs-net_amd", "librtfs_amd.so")
+    bad = hazardous(so)
+    for k, ins in bad:
+        print(f"{k}: {ins}")
+    print(f"{len(bad)} hazardous packed-f32 instruction(s) in {so}")
+    sys.exit(1 if bad else 0)
