@@ -35,6 +35,7 @@ struct BnPack {
 struct DpPack {
     const float *ln_g, *ln_b, *W0, *Wl, *wc = nullptr, *bias, *Wt, *bt;
     const float *w16_l0 = nullptr, *w16_l = nullptr, *w16_ct = nullptr, *wc16 = nullptr, *bias16 = nullptr;  // f16x3 images (k_dualpath16.hip)
+    const float *wf_l0 = nullptr, *wf_l = nullptr, *wf_ct = nullptr;  // the same images in fragment order (k_dualpath16s.hip)
     const float* whh = nullptr;  // LSTM cell only
     explicit DpPack(Cursor& c, int rnn_kind = 0) {
         ln_g = c.take(CH);
@@ -59,6 +60,9 @@ struct DpPack {
         w16_ct = c.take(512 * 64);
         wc16 = c.take(4 * 128);
         bias16 = c.take(4 * 128);
+        wf_l0 = c.take(512 * 256);
+        wf_l = c.take(3 * 64 * 256);
+        wf_ct = c.take(512 * 64);
     }
 };
 struct AttnPack {
@@ -203,6 +207,9 @@ Dp16Args dp16_args(const DpPack& p, const float* x, float* out, int nseq, int R,
     a.w16_l0 = reinterpret_cast<const half8*>(p.w16_l0);
     a.w16_l = reinterpret_cast<const half8*>(p.w16_l);
     a.w16_ct = reinterpret_cast<const half8*>(p.w16_ct);
+    a.wf_l0 = reinterpret_cast<const half8*>(p.wf_l0);
+    a.wf_l = reinterpret_cast<const half8*>(p.wf_l);
+    a.wf_ct = reinterpret_cast<const half8*>(p.wf_ct);
     a.wc16 = p.wc16;
     a.bias16 = p.bias16;
     a.bt = p.bt;

@@ -18,6 +18,7 @@
 //     folded into the gate weights; hidden outputs are written back to the LDS planes in place.
 #include "common.h"
 #include "kernels.h"
+#include <stdlib.h>
 #include <type_traits>
 
 
@@ -438,6 +439,9 @@ static int launch_dp16_t(const Dp16Args& a, hipStream_t st) {
 int launch_dualpath16(const Dp16Args& a, hipStream_t st) {
     const int L = a.Ls - 7;
     if (L < 1 || L > 256) return RTFS_ERR_SHAPE;
+    // 2 s inputs (L <= 128): the two-workgroups-per-CU generation (k_dualpath16s.hip); RTFS_SWEEP_GEN2=1 keeps this file's kernels for A/B
+    static const bool gen2 = getenv("RTFS_SWEEP_GEN2") != nullptr;
+    if (L <= 128 && !gen2) return launch_dualpath16s(a, st);
     if (a.stamps) {
         if (L <= 64) return launch_dp16_stamp_t<4, 2, true>(a, st);
         if (L <= 128) return launch_dp16_stamp_t<2, 4, true>(a, st);

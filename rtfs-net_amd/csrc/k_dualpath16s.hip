@@ -1,0 +1,420 @@
+// Fused dual-path SRU sweep, generation 3: the generation-2 dataflow (k_dualpath16.hip) cut for TWO co-resident workgroups per CU.
+// DualPathRNN.forward, reference src/models/layers/rnn_layers.py:136-162, with the third-party sru.SRU cell (call site
+// rnn_layers.py:99-105,150): LayerNorm over channels, Unfold(8) as an addressing mode, four bidirectional SRU layers (f16x3
+// split-precision MFMA GEMM + in-register recurrence), ConvTranspose1d, bias, residual - one launch per sweep.
+//
+// Why a third generation: the generation-2 workgroup (512 threads, 155 KB of LDS, 219 VGPRs) is alone on its CU, so nothing runs
+// under its serial phases - the recurrences (24 % / 35 % of the F / T sweep), the load + LayerNorm phase, the epilogue, the
+// barrier waits of the weight stream (profiles/r01_sweep_stamps.txt).  Here a workgroup is 256 threads (one wave per SIMD) that
+// owns HALF as many sequences and needs < 80 KB of LDS, so two independent workgroups share every CU and every SIMD: while one
+// wave walks its recurrence (latency-bound on two dependent transcendentals per step, ~25 % of the VALU issue slots) its
+// neighbour from the other workgroup has the matrix pipe.  What had to change for the 80 KB:
+//   * the weight stream is double-buffered in K = 16 steps of 16 KB (was K = 32, 2 x 40 KB of padded rows).  The pack carries a
+//     second copy of the f16 hi / lo images in FRAGMENT ORDER ([K step][direction][gate tile][hi|lo][lane] x 16 bytes,
+//     packing.frag_image_gate / frag_image_ct): staging a step is a straight 16 KB copy (four coalesced 16-byte loads per thread,
+//     one step ahead in registers, then four ds_write_b128) and every fragment read is 64 consecutive 16-byte pieces - conflict
+//     free without padding or swizzling.  (Tried and measured on the way, tools/sweep_stamps.py, cycles per K step of a workgroup
+//     alone on its CU against 768 of MFMA issue: the same steps written by LDS-DMA 1420 - a DMA piece costs the issuing wave
+//     60+ cycles and the barrier drains it; B fragments straight from L2 to registers with no LDS at all 1063 alone but 1750
+//     with the second workgroup present - the L1 delivers ~35 B/clk/CU of 16-byte fragment loads, four waves x 8 KB per step
+//     saturate it.)
+//   * F sweep (L <= 64): 2 sequences per workgroup as one PAIR - accumulator register q of lane half h is time step q of
+//     sequence h, wave = (time part of 32 steps, direction);
+//   * T sweep (L <= 128): 1 sequence per workgroup, wave = (time part of 64 steps, direction): the A-operand rows of a tile are
+//     ordered so that lane half h holds 16 CONSECUTIVE steps (16 h + q); the halves take turns 16 steps at a time (one
+//     v_permlane32_swap per hand-off) - the chain is latency-bound, so the idle half costs nothing.
+// Both variants keep the generation-2 tricks: only the cell-state chain c_t = u0 + (c_{t-1} - u0) sigmoid(u1 + v_f c_{t-1}) is
+// serial, the reset gate / highway output are evaluated after the hand-off; sigmoid = rcp(1 + exp2(z)) with -log2(e) folded into
+// the gate weights; the highway input of layers 1-3 comes out of the same MFMAs through an identity block in the weight image.
+#include "common.h"
+#include "kernels.h"
+#include <stdlib.h>
+
+#define HLD 72          // activation row stride (halfs): 144-byte rows -> conflict-free b128 fragment reads
+#define WBUF 16384      // one staged K step of the weight stream (bytes)
+#define WINV (1.0f / 256.0f)
+
+namespace {
+
+__device__ __forceinline__ void split8(const float (&v)[8], half8& hi, half8& lo) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const _Float16 hh = (_Float16)v[i];
+        hi[i] = hh;
+        lo[i] = (_Float16)(v[i] - (float)hh);
+    }
+}
+
+// sigmoid with the -log2(e) factor already folded into z
+__device__ __forceinline__ float sig2(float z) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z)); }
+
+// value held by lane half `ph` (0 = lanes 0-31, 1 = lanes 32-63), in both halves
+__device__ __forceinline__ float take_half(float v, int ph) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(ph == 0 ? r[0] : r[1]);
+}
+__device__ __forceinline__ float sum_halves(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+}  // namespace
+
+template <int NSEQ, bool PAIRED, bool STAMP = false>
+__global__ __launch_bounds__(256, 2) void dp16s_kernel(Dp16Args a) {
+    static_assert((NSEQ == 2 && PAIRED) || (NSEQ == 1 && !PAIRED), "F sweep: one sequence pair; T sweep: one sequence");
+    constexpr int STEPS = PAIRED ? 32 : 64;  // time steps covered by one wave; 2 parts per workgroup
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    const int Ls = a.Ls, L = Ls - 7, rowsH = Ls + 1;  // one extra all-zero row for the conv-transpose borders
+    half8* Wst = reinterpret_cast<half8*>(smem);                          // [2 buffers][1024 pieces of 16 B], fragment order
+    _Float16* Hh = reinterpret_cast<_Float16*>(smem + 2 * WBUF);          // [NSEQ][rowsH][HLD]
+    _Float16* Hl = Hh + NSEQ * rowsH * HLD;
+    float* chand = reinterpret_cast<float*>(Hl + NSEQ * rowsH * HLD);     // [NSEQ][2 dirs][32]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int part = wave >> 1, dir = wave & 1;           // time part MAJOR (the two waves of a part run their chains together)
+    const int seq = PAIRED ? h : 0;                       // the sequence this LANE's accumulator registers belong to
+    constexpr int CPART = 2 / NSEQ;                       // conv-transpose roles: (sequence, co tile, 64-position part)
+    const int cseq = wave / (2 * CPART), ccot = (wave / CPART) & 1, cpart = wave % CPART;
+    const int n0 = blockIdx.x * NSEQ;
+
+    int nstamp = 0;
+    auto stamp = [&]() {
+        if (STAMP) {
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            if (tid == 0 && nstamp < 16) a.stamps[(size_t)blockIdx.x * 16 + nstamp] = t;
+            ++nstamp;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    stamp();  // 0: start
+    // Two workgroups share a CU.  Dispatched together and running the same program they would stay in lockstep - both in their GEMM
+    // phases (fighting for the matrix pipe), then both in their recurrences (matrix pipe idle) - which is the one arrangement that gains
+    // nothing from sharing.  The workgroup that got the CU's second LDS allocation in the first resident round starts `a.stagger`
+    // x 4096 cycles late; every later workgroup inherits the offset of the slot it is dispatched into.
+    if (a.stagger > 0 && blockIdx.x < 512) {
+        const unsigned lds_base = __builtin_amdgcn_s_getreg(6 | (0 << 6) | (11 << 11)) & 0xFFF;  // HW_REG_LDS_ALLOC.LDS_BASE
+        if (lds_base != 0)
+            for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(64);  // 64 x 64 cycles
+    }
+    auto seq_base = [&](int s) {
+        int n = n0 + s;
+        n = n < a.nseq ? n : a.nseq - 1;
+        return (size_t)(n / a.R) * a.bstride + (size_t)(n % a.R) * a.rstride;
+    };
+
+    // ---------------- weight stream.  Global images in fragment order, 1024 pieces (16 KB) per K step:
+    //   gate step:  piece ((dir * 4 + m) * 2 + part) * 64 + lane      conv-transpose tap: piece ((co tile * 4 + ks) * 2 + part) * 64 + lane
+    // Staging copies the step linearly: thread tid moves pieces tid + 256 j.  `pre` holds the step after the one in LDS.
+    half8 pre[4];
+    auto stage_load = [&](const half8* __restrict__ step) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pre[j] = step[tid + 256 * j];
+    };
+    auto stage_write = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Wst[buf * 1024 + tid + 256 * j] = pre[j];
+    };
+    stage_load(a.wf_l0);  // step 0 of layer 0: in flight under the load + LayerNorm phase
+
+    // ---------------- phase 0: load rows, LayerNorm over channels, split to f16 planes (normalizations.py:33-37).
+    // lane = (position, channel half): 32 consecutive positions x 2 halves per wave, the halves meet in one permlane swap
+    {
+        const int task = wave * 32 + r, ntask = NSEQ * Ls;  // <= 128
+        const bool live = task < ntask;
+        const int tk = live ? task : ntask - 1;
+        const int s = (NSEQ == 2 && tk >= Ls) ? 1 : 0, pos = tk - s * Ls;
+        const float* xp = a.x + seq_base(s) + pos + (size_t)(32 * h) * a.cstride;
+        float v[32];
+#pragma unroll
+        for (int c = 0; c < 32; ++c) v[c] = xp[(size_t)c * a.cstride];
+        float sum = 0.f;
+#pragma unroll
+        for (int c = 0; c < 32; ++c) sum += v[c];
+        const float mean = sum_halves(sum) * (1.0f / 64);
+        float var = 0.f;
+#pragma unroll
+        for (int c = 0; c < 32; ++c) {
+            const float d = v[c] - mean;
+            var = fmaf(d, d, var);
+        }
+        const float rstd = 1.0f / sqrtf(sum_halves(var) * (1.0f / 64) + RTFS_EPS);
+        _Float16* dh = Hh + (s * rowsH + pos) * HLD + 32 * h;
+        _Float16* dl = Hl + (s * rowsH + pos) * HLD + 32 * h;
+        if (live) {
+#pragma unroll
+            for (int c8 = 0; c8 < 4; ++c8) {
+                float y[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) y[i] = fmaf((v[c8 * 8 + i] - mean) * rstd, a.ln_gamma[32 * h + c8 * 8 + i], a.ln_beta[32 * h + c8 * 8 + i]);
+                half8 hi, lo;
+                split8(y, hi, lo);
+                *reinterpret_cast<half8*>(dh + c8 * 8) = hi;
+                *reinterpret_cast<half8*>(dl + c8 * 8) = lo;
+            }
+        }
+        if (tid < NSEQ * 9) {  // the zero rows (72 halfs = 9 x 16 B each)
+            half8 z;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) z[i] = (_Float16)0.f;
+            const int zs = tid / 9, pc = tid % 9;
+            *reinterpret_cast<half8*>(Hh + (zs * rowsH + Ls) * HLD + pc * 8) = z;
+            *reinterpret_cast<half8*>(Hl + (zs * rowsH + Ls) * HLD + pc * 8) = z;
+        }
+    }
+
+    // activation rows of this wave's two row tiles (virtual time tau; the backward direction reads position L-1-tau).
+    // A-operand row r of tile t: PAIRED   -> sequence (r >> 2) & 1, step 16 t + (r & 3) + 4 (r >> 3)
+    //                            unpaired -> step 32 t + 16 ((r >> 2) & 1) + (r & 3) + 4 (r >> 3)
+    // either way accumulator register q of lane half h (row (q & 3) + 8 (q >> 2) + 4 h) is step q of that half's 16-step run
+    int rowbase[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int rs = PAIRED ? (r >> 2) & 1 : 0;
+        int tau = STEPS * part + (r & 3) + 4 * (r >> 3) + (PAIRED ? 16 * t : 32 * t + 16 * ((r >> 2) & 1));
+        tau = tau < L ? tau : L - 1;
+        rowbase[t] = (rs * rowsH + (dir ? L - 1 - tau : tau)) * HLD + 8 * h;
+    }
+    stamp();  // 1: after load + LN issue (before first barrier)
+    stage_write(0);
+    stage_load(a.wf_l0 + 1024);
+    __syncthreads();  // activation planes filled, step 0 staged; step 1 on its way to `pre`
+
+    int g = 0;  // steps consumed so far: step g sits in buffer g & 1, step g + 1 in `pre`
+    // ---------------- four SRU layers
+    for (int layer = 0; layer < 4; ++layer) {
+        const int nchunk = layer == 0 ? 32 : 4;
+        const float vf = a.wc16[layer * 128 + dir * 32 + r], vr = a.wc16[layer * 128 + 64 + dir * 32 + r];
+        const float bf = a.bias16[layer * 128 + dir * 32 + r] * 256.f, br = a.bias16[layer * 128 + 64 + dir * 32 + r] * 256.f;
+        f32x16 acc[2][4];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                acc[t][0][q] = 0.f;
+                acc[t][1][q] = bf;
+                acc[t][2][q] = br;
+                acc[t][3][q] = 0.f;
+            }
+        const half8* const gsrc = layer == 0 ? a.wf_l0 : a.wf_l + (size_t)(layer - 1) * 4 * 1024;
+        // what follows this layer in the stream: the next layer's steps, then the conv-transpose's taps
+        const half8* const gnext = layer < 3 ? a.wf_l + (size_t)layer * 4 * 1024 : a.wf_ct;
+        // One barrier per K step.  (Issue-time stamps of this loop, a workgroup alone on its CU: 1390 cycles per step against 768 of MFMA
+        // issue - ~220 waiting for the first fragments after the barrier, ~85 in the barrier, the rest around the staging point.  Deferring
+        // gate tile 3 of step g - 1 across the barrier to cover the read latency, with all 12 fragment reads pinned in front of the staging
+        // writes, measured SLOWER (1650 per step: 24 register moves per step to hand the operands on, and a worse schedule); with the CU's
+        // second workgroup present both lose ~25 % and together they keep the matrix pipe ~86 % busy through the GEMM phases.)
+        for (int q = 0; q < nchunk; ++q, ++g) {
+            const int aoff = layer == 0 ? (q >> 2) * HLD + (q & 3) * 16 : q * 16;
+            half8 ah[2], al[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                ah[t] = *reinterpret_cast<const half8*>(Hh + rowbase[t] + aoff);
+                al[t] = *reinterpret_cast<const half8*>(Hl + rowbase[t] + aoff);
+            }
+            const half8* wb = Wst + (g & 1) * 1024 + dir * 512 + lane;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const half8 bh = wb[m * 128], bl = wb[m * 128 + 64];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], bh, acc[t][m], 0, 0, 0);
+                    acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], bl, acc[t][m], 0, 0, 0);
+                    acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[t], bh, acc[t][m], 0, 0, 0);
+                }
+                if (m == 1) {
+                    // step g + 1 (in `pre` since the last step) goes to the other buffer, which every wave left at the barrier that ended
+                    // step g - 1; then step g + 2 is requested: a whole step of MFMAs covers its latency
+                    stage_write((g + 1) & 1);
+                    const int q2 = q + 2;
+                    stage_load(q2 < nchunk ? gsrc + (size_t)q2 * 1024 : gnext + (size_t)(q2 - nchunk) * 1024);
+                }
+            }
+            __syncthreads();  // step g consumed by every wave, step g + 1 visible
+        }
+        // (that barrier also means: every wave has finished reading the activation planes - the scan may overwrite them in place)
+        stamp();  // 2,4,6,8: GEMM of layer done
+        // undo the 2^8 weight prescale on all 128 accumulators now, on every wave at once, so the serialised per-part recurrence
+        // below is the bare dependency chain
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[t][m][q] *= WINV;
+        __builtin_amdgcn_sched_barrier(0);
+        float cin[2] = {0.f, 0.f};  // c_{t-1} of register 0 of tile t (this lane's run)
+        for (int hp = 0; hp < 2; ++hp) {
+            if (part == hp) {
+                float c = hp > 0 ? chand[(seq * 2 + dir) * 32 + r] : 0.f;
+                if (PAIRED) {
+                    // register q of tile t = time step 16 t + q of this lane's own sequence.  Only the cell-state chain is serial; it
+                    // overwrites u0 in place.  The reset gate and the hidden output depend on c_{t-1}, c_t but nothing depends on
+                    // them: they are evaluated after the hand-off below, concurrently with the next time part's chain.
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        cin[t] = c;
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) {
+                            const float u0 = acc[t][0][q];
+                            const float f = sig2(fmaf(vf, c, acc[t][1][q]));
+                            c = fmaf(c - u0, f, u0);
+                            acc[t][0][q] = c;
+                        }
+                    }
+                    chand[(seq * 2 + dir) * 32 + r] = c;
+                } else {
+                    // the two lane halves hold steps 16 h + q of a tile: they take turns, 16 steps each; the idle half runs the same
+                    // instructions on its own (not yet / no longer needed) registers and keeps them unchanged
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+                        for (int ph = 0; ph < 2; ++ph) {
+                            if (h == ph) cin[t] = c;
+                            float cr = c;
+#pragma unroll
+                            for (int q = 0; q < 16; ++q) {
+                                const float u0 = acc[t][0][q];
+                                const float f = sig2(fmaf(vf, cr, acc[t][1][q]));
+                                cr = fmaf(cr - u0, f, u0);
+                                acc[t][0][q] = h == ph ? cr : u0;
+                            }
+                            c = take_half(cr, ph);
+                        }
+                    }
+                    if (h == 0) chand[dir * 32 + r] = c;
+                }
+            }
+            __syncthreads();  // cell state published: the next time part starts while this one writes back
+            if (part == hp) {
+                // deferred reset gate + highway: h = x' + (c_t - x') r(c_{t-1}); hidden outputs (this wave's direction half of the
+                // channels) go back into the planes in place
+                const int tau0 = STEPS * part;
+                int o0 = (seq * rowsH + (dir ? L - 1 - tau0 : tau0)) * HLD + dir * 32 + r;
+                asm volatile("" : "+v"(o0));  // opaque per layer: keeps 32 derived addresses from being hoisted + spilled
+                const int ostep = dir ? -HLD : HLD;
+                const int nvalid = L - tau0;
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    float cprev = cin[t];
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const int idx = PAIRED ? 16 * t + q : 32 * t + 16 * h + q;
+                        const float ct = acc[t][0][q];
+                        const float gte = sig2(fmaf(vr, cprev, acc[t][2][q])), xp = acc[t][3][q];
+                        cprev = ct;
+                        const float hv = fmaf(ct - xp, gte, xp);
+                        if (idx < nvalid) {
+                            const _Float16 hh = (_Float16)hv;
+                            const int o = o0 + idx * ostep;
+                            Hh[o] = hh;
+                            Hl[o] = (_Float16)(hv - (float)hh);
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();  // all hidden outputs of this layer are in the planes
+        stamp();  // 3,5,7,9: scan of layer done
+    }
+
+    // ---------------- ConvTranspose1d(64->64, k=8) + bias + residual (rnn_layers.py:153-156), transposed:
+    //   y[co][t] = bt[co] + sum_{kk,ci} Wt[co][kk*64+ci] * H[t-kk][ci];  wave = (sequence, co tile, position part)
+    {
+        f32x16 acc[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
+        // the residual rows of the epilogue are requested now and arrive under the GEMM (clamped addresses: dead
+        // sequences / positions read a valid element that is never stored)
+        float res[2][16];
+        const size_t rbase = seq_base(cseq);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int p = min(64 * cpart + 32 * t + r, Ls - 1);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int co = ccot * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+                res[t][q] = a.x[rbase + (size_t)co * a.cstride + p] + a.bt[co];  // residual + conv-transpose bias, both fetched under the GEMM
+            }
+        }
+        // tap 0 is staged in buffer g & 1, tap 1 in `pre`; 8 taps of 64 k' each
+        for (int q = 0; q < 8; ++q, ++g) {
+            int hrow[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int p = 64 * cpart + 32 * t + r - q;
+                hrow[t] = (cseq * rowsH + ((p >= 0 && p < L) ? p : Ls)) * HLD + 8 * h;
+            }
+            const half8* wb = Wst + (g & 1) * 1024 + ccot * 512 + lane;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const half8 wh = wb[ks * 128], wl = wb[ks * 128 + 64];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const half8 xh = *reinterpret_cast<const half8*>(Hh + hrow[t] + ks * 16);
+                    const half8 xl = *reinterpret_cast<const half8*>(Hl + hrow[t] + ks * 16);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, acc[t], 0, 0, 0);
+                }
+                if (ks == 1 && q + 1 < 8) {
+                    stage_write((g + 1) & 1);
+                    stage_load(a.wf_ct + (size_t)(q + 2 < 8 ? q + 2 : 7) * 1024);  // unconditional (clamped; the last ones are not used)
+                }
+            }
+            __syncthreads();
+        }
+        stamp();  // 10: conv-transpose GEMM done
+        if (n0 + cseq < a.nseq) {
+            const size_t base = seq_base(cseq);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int p = 64 * cpart + 32 * t + r;
+                if (p < Ls) {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const int co = ccot * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+                        a.out[base + (size_t)co * a.cstride + p] = fmaf(acc[t][q], WINV, res[t][q]);
+                    }
+                }
+            }
+        }
+        stamp();  // 11: end
+    }
+}
+
+size_t dp16s_lds_bytes(int Ls, int nseq_per_wg) {
+    return (size_t)2 * WBUF + (size_t)2 * nseq_per_wg * (Ls + 1) * HLD * 2 + (size_t)nseq_per_wg * 2 * 32 * 4;
+}
+
+template <int NSEQ, bool PAIRED>
+static int launch_dp16s_t(const Dp16Args& a, hipStream_t st) {
+    const size_t lds = dp16s_lds_bytes(a.Ls, NSEQ);
+    if (lds > 80 * 1024) return RTFS_ERR_SHAPE;  // two workgroups per CU
+    if (a.stamps) {
+        if (rtfs_set_max_lds((const void*)dp16s_kernel<NSEQ, PAIRED, true>, lds) != RTFS_OK) return RTFS_ERR_LAUNCH;
+        hipLaunchKernelGGL((dp16s_kernel<NSEQ, PAIRED, true>), dim3(cdiv(a.nseq, NSEQ)), dim3(256), lds, st, a);
+        return rtfs_launch_status();
+    }
+    if (rtfs_set_max_lds((const void*)dp16s_kernel<NSEQ, PAIRED>, lds) != RTFS_OK) return RTFS_ERR_LAUNCH;
+    void* slot = dualpath_timing_begin(a.Ls, a.nseq, st);
+    hipLaunchKernelGGL((dp16s_kernel<NSEQ, PAIRED>), dim3(cdiv(a.nseq, NSEQ)), dim3(256), lds, st, a);
+    dualpath_timing_end(slot, st);
+    return rtfs_launch_status();
+}
+
+// L <= 64 (the F sweep: L = 57): one sequence pair per workgroup; L <= 128 (the 2 s T sweep: L = 118): one sequence per workgroup
+int launch_dualpath16s(const Dp16Args& a0, hipStream_t st) {
+    const int L = a0.Ls - 7;
+    if (L < 1 || L > 128) return RTFS_ERR_SHAPE;
+    static const int stagger = getenv("RTFS_SWEEP_STAGGER") ? atoi(getenv("RTFS_SWEEP_STAGGER")) : 14;
+    Dp16Args a = a0;
+    a.stagger = cdiv(a.nseq, L <= 64 ? 2 : 1) > 512 ? stagger : 0;  // only when a CU's two slots run several workgroups each
+    return L <= 64 ? launch_dp16s_t<2, true>(a, st) : launch_dp16s_t<1, false>(a, st);
+}

@@ -202,13 +202,20 @@ struct Dp16Args {
     const half8* w16_l0 = nullptr;  // [16 chunks][hi|lo][256 cols = dir*128 + gate*32 + j][32 k'], k' = kk*64 + c
     const half8* w16_l = nullptr;   // 3 x [2 chunks][hi|lo][256][32]; gate 3 = identity block (highway input)
     const half8* w16_ct = nullptr;  // [8 chunks][hi|lo][64 co][64 k'], k' = kk*64 + ci
+    // the same three images in MFMA fragment order (generation 3, k_dualpath16s.hip): [K step 16][dir][gate tile m][hi|lo][lane] x half8 with
+    // lane (h, r) = W[k = 16 step + 8 h + j][col = dir*128 + m*32 + r]; conv-transpose: [tap][co tile][ks][hi|lo][lane], W[co = 32 tile + r][k = 16 ks + 8 h + j]
+    const half8 *wf_l0 = nullptr, *wf_l = nullptr, *wf_ct = nullptr;
     const float* wc16 = nullptr;    // 4 x (128): v_f, v_r scaled by -log2(e)
     const float* bias16 = nullptr;  // 4 x (128): b_f, b_r scaled by -log2(e)
     const float* bt = nullptr;      // (64)
     unsigned long long* stamps = nullptr;  // diagnostic build only: [workgroups][16] s_memtime stamps
+    int stagger = 0;                       // generation 3: start delay of a CU's second workgroup, units of 4096 cycles
 };
 size_t dp16_lds_bytes(int Ls, int nseq_per_wg);
 int launch_dualpath16(const Dp16Args& a, hipStream_t st);
+// generation 3 (k_dualpath16s.hip): 256-thread workgroups, two per CU, L <= 128; launch_dualpath16 routes to it
+size_t dp16s_lds_bytes(int Ls, int nseq_per_wg);
+int launch_dualpath16s(const Dp16Args& a, hipStream_t st);
 void* dualpath_timing_begin(int Ls, int nseq, hipStream_t st);
 void dualpath_timing_end(void* slot, hipStream_t st);
 

@@ -55,6 +55,21 @@ def split16_image(w, kc=32):
     return img.contiguous().view(torch.float32).reshape(-1)
 
 
+def frag_image_gate(img):
+    """split16_image of a (256 cols, K) gate weight ([K/32][hi|lo][256][32] halfs, as float32) -> the same halfs in MFMA fragment order for
+    k_dualpath16s.hip: [K step 16][dir 2][gate tile m 4][hi|lo][lane = h*32 + r][8] with element j of lane (h, r) =
+    W[k = 16 step + 8 h + j][col = dir*128 + m*32 + r]: a wave's B fragments of one K step are eight contiguous 1 KiB pieces."""
+    h16 = img.view(torch.float16).reshape(-1, 2, 2, 4, 32, 2, 2, 8)  # chunk32, part, dir, m, r, half-chunk, h, j
+    return h16.permute(0, 5, 2, 3, 1, 6, 4, 7).contiguous().view(torch.float32).reshape(-1)
+
+
+def frag_image_ct(img):
+    """split16_image(., 64) of the (64 co, 512 k') conv-transpose weight ([8 taps][hi|lo][64 co][64] halfs) -> A fragments in order
+    [tap 8][co tile 2][ks 4][hi|lo][lane = h*32 + r][8]: element j of lane (h, r) = W[co = 32 tile + r][k' = 64 tap + 16 ks + 8 h + j]."""
+    h16 = img.view(torch.float16).reshape(8, 2, 2, 32, 4, 2, 8)  # tap, part, co tile, r, ks, h, j
+    return h16.permute(0, 2, 4, 1, 5, 3, 6).contiguous().view(torch.float32).reshape(-1)
+
+
 def pack_encoder(sd):
     """STFTEncoder: conv.full_layer.2.weight (256,2,3,3) -> (256,18)."""
     return _cat([sd["conv.full_layer.2.weight"].reshape(256, 18)])
@@ -81,7 +96,8 @@ def _dualpath_parts(sd):
     gate_scale = torch.tensor([1.0, -LOG2E, -LOG2E, 1.0], dtype=torch.float32, device=sd["norm.gamma"].device)
     w0 = sd["rnn.rnn_lst.0.weight"].detach().to(torch.float32).reshape(64, 8, 2, 32, 4) * gate_scale  # (c, kk, dir, j, m)
     w0 = w0.permute(1, 0, 2, 4, 3).reshape(512, 256)  # rows k' = kk*64 + c, cols dir*128 + m*32 + j
-    parts.append(split16_image(w0.t()))
+    img0 = split16_image(w0.t())
+    parts.append(img0)
     imgs = []
     eye = torch.eye(64, dtype=torch.float32, device=w0.device).reshape(64, 2, 32, 1)  # highway input via an identity gate
     for i in (1, 2, 3):
@@ -89,9 +105,14 @@ def _dualpath_parts(sd):
         w = torch.cat([w, eye], 3) * gate_scale  # (k, dir, j, m)
         imgs.append(split16_image(w.permute(0, 1, 3, 2).reshape(64, 256).t()))
     parts.append(torch.stack(imgs))
-    parts.append(split16_image(sd["linear.weight"].detach().to(torch.float32).permute(1, 2, 0).reshape(64, 512), 64))  # rows co, k' = kk*64+ci
+    imgct = split16_image(sd["linear.weight"].detach().to(torch.float32).permute(1, 2, 0).reshape(64, 512), 64)  # rows co, k' = kk*64+ci
+    parts.append(imgct)
     parts.append(torch.stack([sd[f"rnn.rnn_lst.{i}.weight_c"] for i in range(4)]) * (-LOG2E))
     parts.append(torch.stack([sd[f"rnn.rnn_lst.{i}.bias"] for i in range(4)]) * (-LOG2E))
+    # the same three images in fragment order (generation-3 sweep kernel: B fragments straight from L2, no LDS staging)
+    parts.append(frag_image_gate(img0))
+    parts.append(torch.stack([frag_image_gate(i) for i in imgs]))
+    parts.append(frag_image_ct(imgct))
     return parts
 
 

@@ -12,8 +12,9 @@ torch.manual_seed(0)
 m = R.AVNet(print_macs=False, **copy.deepcopy(RTFS4_AUDIONET)).cuda().eval()
 blk = m.refinement_module.audio_net.blocks
 names = ["start", "load+LN", "L0 gemm", "L0 scan", "L1 gemm", "L1 scan", "L2 gemm", "L2 scan", "L3 gemm", "L3 scan", "convT gemm", "epilogue"]
-for label, dp, Rr, Ls, per in [("F-path", blk.globalatt[0], 125, 64, 4), ("T-path", blk.globalatt[1], 64, 125, 2)]:
-    B = 32
+GEN2 = bool(os.environ.get("RTFS_SWEEP_GEN2"))  # generation 2: 4 / 2 sequences per 512-thread workgroup; generation 3: 2 / 1 per 256-thread workgroup
+for label, dp, Rr, Ls, per in [("F-path", blk.globalatt[0], 125, 64, 4 if GEN2 else 2), ("T-path", blk.globalatt[1], 64, 125, 2 if GEN2 else 1)]:
+    B = int(os.environ.get('STAMP_B', '32'))
     x = torch.randn(B, 64, Rr, Ls, device="cuda")
     out = torch.empty_like(x)
     nwg = (B * Rr + per - 1) // per
@@ -26,5 +27,8 @@ for label, dp, Rr, Ls, per in [("F-path", blk.globalatt[0], 125, 64, 4), ("T-pat
     print(f"== {label}: {nwg} workgroups; cycles per phase (median / mean), total median {np.median(s[:,11]-s[:,0]):.0f}")
     for i in range(11):
         print(f"   {names[i+1]:12s} {np.median(d[:, i]):9.0f} {d[:, i].mean():9.0f}")
+    inner = st.cpu().numpy()[:, 12:16].astype(np.float64)
+    print("   inside K step 8 of layer 0, wave 0 (issue-time deltas, median): reads+first tile issued %.0f | to staging point %.0f | rest of MFMAs issued %.0f | barrier %.0f"
+          % tuple(np.median(inner, axis=0)))
     t0 = s[:, 0].min(); t1 = s[:, 11].max()
     print(f"   kernel span {t1 - t0:.0f} ticks (s_memtime 100MHz?)")
