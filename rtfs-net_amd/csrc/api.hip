@@ -890,6 +890,7 @@ int rtfs_separator_forward_f32(const float* wav, const float* video_vp, const fl
     if (!gemm_f32() && !getenv("RTFS_NO_S3T")) {  // S3 + decoder taps in one kernel: the separated spectrum never goes to HBM
         PwArgs a;
         a.x = cur; a.bias = ps.bias; a.aux = w.a0; a.out = w.z; a.slope = ps.slope; a.P = P; a.w16 = ps.w16; a.w16b = pd.w16p; a.cout_live = 18;
+        a.stats = w.st0; a.inv_count = 1.0 / ((double)CA * P);  // rms(a0) per mixture: the amplitude the taps GEMM's operand is normalised by
         CHECK(launch_pwr_s3_taps(a, B, st));
         return launch_dec_istft(w.z, out, B, T, NF, L, (size_t)T * NF, (size_t)18 * T * NF, st);
     }

@@ -110,9 +110,21 @@ __device__ __forceinline__ void pwr_body(const PwArgs& a, const float* __restric
         // ---- 8 output tiles of 32 rows
         f32x16 keep;  // S3: the mask's real-part tile waits for its imaginary partner
         f32x16 acc2;  // S3T: decoder taps (32 rows, 18 live) x this wave's 32 pixels
+        // S3T range safety: the separated spectrum (the taps GEMM's B operand) scales with the waveform's amplitude, and an f16 hi / lo
+        // split keeps its low part only while |x| >= 2^-3 or so (f16 subnormals are flushed).  The encoder's statistics give the
+        // mixture's rms(a0): the encoder rows are multiplied by the power of two that brings it to [1, 2) before the complex product and
+        // the accumulator is scaled back - exact, and a quiet (x 1e-4) or hot (x 1e4) recording keeps the full split precision.
+        float esc = 1.0f, eisc = WINV;
         if (MODE == PWR_S3T) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc2[q] = 0.f;
+            if (a.stats) {
+                const float ms = (float)(a.stats[2 * b + 1] * a.inv_count);  // mean square of a0 over the mixture
+                int e = ms > 0.f ? -(int)rintf(0.5f * log2f(ms)) : 0;
+                e = e < -40 ? -40 : (e > 40 ? 40 : e);
+                esc = exp2f((float)e);
+                eisc = exp2f((float)(-e - 8));
+            }
         }
         float er[16], ei[16];
 #pragma unroll 1
@@ -166,8 +178,8 @@ __device__ __forceinline__ void pwr_body(const PwArgs& a, const float* __restric
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         const unsigned ro = (unsigned)((j & 3) + 8 * (2 * s2 + (j >> 2))) * (unsigned)P;
-                        er[j] = Ab[ro];
-                        ei[j] = Ab[ro + (unsigned)(128 * P)];
+                        er[j] = Ab[ro] * esc;
+                        ei[j] = Ab[ro + (unsigned)(128 * P)] * esc;
                     }
                     half8 rh, rl, ih, il;
 #pragma unroll
@@ -217,7 +229,7 @@ __device__ __forceinline__ void pwr_body(const PwArgs& a, const float* __restric
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const int tap = (q & 3) + 8 * (q >> 2) + 4 * h;
-                if (tap < a.cout_live) Zb[(unsigned)tap * (unsigned)P] = acc2[q] * (WINV);
+                if (tap < a.cout_live) Zb[(unsigned)tap * (unsigned)P] = acc2[q] * eisc;
             }
         }
     }

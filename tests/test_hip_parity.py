@@ -447,3 +447,39 @@ def test_system_forward_and_validation_step():
     assert rel_err(est.cpu().numpy(), ref) < 1e-4
     ref_loss = LO.pit_from_pw_mtx(LO.pairwise_neg_sdr(ref, tgt, "snr"))[0]
     assert abs(float(out["val_loss"]) - float(ref_loss)) < 1e-3
+
+
+@pytest.mark.parametrize("scale", [1e-5, 1e-3, 30.0, 1e4])
+def test_input_amplitude_range(scale):
+    """Range safety of the f16x3 split-precision GEMMs: the same mixture at very quiet (x 1e-5, x 1e-3) and very hot (x 30, x 1e4)
+    amplitudes.  Everything behind the first gLN is amplitude-free, but the encoder output a0 (and with it the S3 product and the
+    decoder's taps GEMM, whose B operand is the separated spectrum) scales with the waveform: un-scaled, its f16 low parts are flushed below
+    ~1e-3 (measured 8e-6 at x 1e-3, fp16-grade below) and the products overflow f16 above ~1e5; the fused S3 + taps kernel therefore
+    normalises the encoder rows by the power of two nearest 1 / rms(a0) of the mixture.  Oracle on the scaled input, same 1e-4 / 1e-5 bar."""
+    m = model()
+    wav, emb = make_inputs(2, 4096, 7, 1)
+    wav = (wav * scale).astype(np.float32)
+    out = host(m(dev(wav), dev(emb)))
+    ref = O.avnet_forward(wav, emb, SD, repeats=4)
+    close(f"input x {scale:g}", out, ref)
+
+
+@pytest.mark.parametrize("log2_scale", [-10, 10])
+def test_block_with_rescaled_intermediate(log2_scale):
+    """Range safety inside the RTFS block: the gateway's depthwise weight and bias scaled by 2^-10 / 2^+10 put the block's residual stream and
+    the projection GEMM's operand at ~1e-3 / ~1e3 instead of the O(1) of every other fixture (what a trained checkpoint may do); the
+    projection output is re-normalised by the gLN behind it, so a precision loss there is amplified back to O(1).  Oracle with the same
+    parameters, same 1e-4 / 1e-5 bar."""
+    import copy
+    import rtfs_net_amd as R
+    sc = 2.0 ** log2_scale
+    pre = "refinement_module.audio_net.blocks.gateway.full_layer.2."
+    sd = dict(SD)
+    sd[pre + "weight"] = SD[pre + "weight"] * np.float32(sc)
+    sd[pre + "bias"] = SD[pre + "bias"] * np.float32(sc)
+    m = R.AVNet(print_macs=False, **_conf(4))
+    m.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()})
+    m = m.cuda().eval()
+    x = rand((2, 256, 17, 129), 215)
+    y = host(m.refinement_module.audio_net.blocks(dev(x)))
+    close(f"rtfs block, gateway x 2^{log2_scale}", y, O.rtfs_block(x, O._sub(sd, "refinement_module.audio_net.blocks")))
