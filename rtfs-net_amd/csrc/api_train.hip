@@ -103,7 +103,10 @@ struct DpGeom {
         rows = (size_t)nseq * Ls;
         elems = (size_t)B * CH * T * F;
     }
-    bool ok() const { return Ls >= 8 && Ls <= 256 && rows * 512 < 0x7fffffffu; }
+    // the forward takes any sweep length (layout kernels walk 256-position chunks, the scans are loops); the BACKWARD's layout kernels
+    // (dp_dy, dp_ln_bwd) still hold a whole sequence in LDS: training segments are limited to Ls <= 256 (4 s), inference is not
+    bool ok() const { return Ls >= 8 && rows * 512 < 0x7fffffffu; }
+    bool ok_backward() const { return ok() && Ls <= 256; }
 };
 }  // namespace
 
@@ -178,7 +181,7 @@ int rtfs_dualpath_backward_f32(const float* x, const float* tpack, const float* 
     dim = rows ? dim - 10 : dim;
     RTFS_RETURN_IF(!x || !tpack || !saved || !dout || !dx || !dparams || B < 1 || (dim != 3 && dim != 4), RTFS_ERR_ARG);
     DpGeom g(B, T, F, dim);
-    RTFS_RETURN_IF(!g.ok(), RTFS_ERR_SHAPE);
+    RTFS_RETURN_IF(!g.ok_backward(), RTFS_ERR_SHAPE);
     RTFS_RETURN_IF(!ws || ws_bytes < rtfs_dualpath_train_workspace_bytes(B, T, F, dim), RTFS_ERR_WORKSPACE);
     Arena ar(ws, ws_bytes);
     float* xt = ar.take<float>(g.elems);
@@ -343,7 +346,7 @@ int rtfs_dualpath_lstm_backward_f32(const float* x, const float* tpack, const fl
                                     int B, int T, int F, int dim, void* ws, size_t ws_bytes, void* stream) {
     RTFS_RETURN_IF(!x || !tpack || !saved || !dout || !dx || !dparams || B < 1 || (dim != 3 && dim != 4), RTFS_ERR_ARG);
     DpGeom g(B, T, F, dim);
-    RTFS_RETURN_IF(!g.ok(), RTFS_ERR_SHAPE);
+    RTFS_RETURN_IF(!g.ok_backward(), RTFS_ERR_SHAPE);
     RTFS_RETURN_IF(!ws || ws_bytes < rtfs_dualpath_lstm_train_workspace_bytes(B, T, F, dim), RTFS_ERR_WORKSPACE);
     Arena ar(ws, ws_bytes);
     float* xt = ar.take<float>(g.elems);
@@ -496,7 +499,7 @@ int rtfs_dualpath_gru_backward_f32(const float* x, const float* tpack, const flo
                                    int B, int T, int F, int dim, void* ws, size_t ws_bytes, void* stream) {
     RTFS_RETURN_IF(!x || !tpack || !saved || !dout || !dx || !dparams || B < 1 || (dim != 3 && dim != 4), RTFS_ERR_ARG);
     DpGeom g(B, T, F, dim);
-    RTFS_RETURN_IF(!g.ok(), RTFS_ERR_SHAPE);
+    RTFS_RETURN_IF(!g.ok_backward(), RTFS_ERR_SHAPE);
     RTFS_RETURN_IF(!ws || ws_bytes < rtfs_dualpath_gru_train_workspace_bytes(B, T, F, dim), RTFS_ERR_WORKSPACE);
     Arena ar(ws, ws_bytes);
     float* xt = ar.take<float>(g.elems);
@@ -881,7 +884,7 @@ size_t rtfs_tf_attention_train_workspace_bytes(int B, int T) {
 int rtfs_tf_attention_forward_train_f32(const float* x, const float* tpack, float* out, float* saved, int B, int T, int rows, void* ws,
                                         size_t ws_bytes, void* stream) {
     RTFS_RETURN_IF(!x || !tpack || !out || !saved || B < 1 || T < 1, RTFS_ERR_ARG);
-    RTFS_RETURN_IF(T > 256 || (size_t)B * T * 64 * 128 >= 0x7fffffffu, RTFS_ERR_SHAPE);
+    RTFS_RETURN_IF(T > 4096 || (size_t)B * T * 64 * 128 >= 0x7fffffffu, RTFS_ERR_SHAPE);  // scores are (4B, Tp, Tp) floats in `saved`
     RTFS_RETURN_IF(!ws || ws_bytes < rtfs_tf_attention_train_workspace_bytes(B, T), RTFS_ERR_WORKSPACE);
     AttGeom g(B, T);
     AttSaved sv(saved, g);

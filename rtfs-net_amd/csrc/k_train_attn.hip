@@ -176,6 +176,24 @@ __global__ __launch_bounds__(256) void att_softmax_kernel(float* __restrict__ S,
     // rows are stored (batch, Tp rows, Tp columns) but only the first T rows of a batch are scores
     const size_t batch = rid / T, row = rid % T;
     float* s = S + (batch * Tp + row) * Tp;
+    if (Tp > 256) {  // long rows (inputs past 4 s): three passes over the row instead of four register-resident values per lane
+        if (!bwd) {
+            float m = -INFINITY;
+            for (int k = lane; k < T; k += 64) m = fmaxf(m, scale * s[k]);
+            m = wave_max(m);
+            float sum = 0.f;
+            for (int k = lane; k < T; k += 64) sum += __expf(scale * s[k] - m);
+            const float inv = 1.0f / wave_sum(sum);
+            for (int k = lane; k < Tp; k += 64) s[k] = k < T ? __expf(scale * s[k] - m) * inv : 0.f;
+        } else {
+            const float* pm = Pm + (batch * Tp + row) * Tp;
+            float dot = 0.f;
+            for (int k = lane; k < T; k += 64) dot = fmaf(pm[k], s[k], dot);
+            dot = wave_sum(dot);
+            for (int k = lane; k < Tp; k += 64) s[k] = k < T ? scale * pm[k] * (s[k] - dot) : 0.f;
+        }
+        return;
+    }
     if (!bwd) {
         float v[4], m = -INFINITY;
         for (int i = 0; i < 4; ++i) {
@@ -234,7 +252,7 @@ int launch_att_pack_o(float* rows, float* Op, int B, int T, int Tp, int dir, hip
     return rtfs_launch_status();
 }
 int launch_att_softmax(float* S, const float* P, int nbatch, int T, int Tp, float scale, bool bwd, hipStream_t st) {
-    if (T < 1 || Tp > 256) return RTFS_ERR_SHAPE;
+    if (T < 1) return RTFS_ERR_SHAPE;
     const size_t rows = (size_t)nbatch * T;
     hipLaunchKernelGGL(att_softmax_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, S, P, rows, T, Tp, scale, bwd ? 1 : 0);
     return rtfs_launch_status();

@@ -149,19 +149,21 @@ namespace {
 __device__ __forceinline__ size_t seq_base(int n, int R, int Ls) { return ((size_t)(n / R) * 64 * R + (n % R)) * Ls; }
 }
 
-// LayerNorm over channels per position + layout change: x -> xn[n*Ls + s][c]
+// LayerNorm over channels per position + layout change: x -> xn[n*Ls + s][c].  blockIdx.y = chunk of 256 positions (any Ls).
 __global__ __launch_bounds__(256) void dp_ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float* __restrict__ xn, int R, int Ls) {
-    extern __shared__ float tile[];  // [64][Ls + 1]
+    extern __shared__ float tile[];  // [64][len + 1]
     __shared__ float mu[256], rs[256];
-    const int n = blockIdx.x, tid = threadIdx.x, P = Ls + 1;
-    const size_t base = seq_base(n, R, Ls), cs = (size_t)R * Ls;
-    for (int idx = tid; idx < 64 * Ls; idx += 256) {
-        const int c = idx / Ls, s = idx - c * Ls;
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const int s0 = blockIdx.y * 256, len = min(256, Ls - s0), P = len + 1;
+    const size_t base = seq_base(n, R, Ls) + s0, cs = (size_t)R * Ls;
+    for (int idx = tid; idx < 64 * len; idx += 256) {
+        const int c = idx / len, s = idx - c * len;
         tile[c * P + s] = x[base + c * cs + s];
     }
     __syncthreads();
-    for (int s = tid; s < Ls; s += 256) {
+    if (tid < len) {
+        const int s = tid;
         float m = 0.f;
         for (int c = 0; c < 64; ++c) m += tile[c * P + s];
         m *= (1.f / 64);
@@ -170,26 +172,26 @@ __global__ __launch_bounds__(256) void dp_ln_fwd_kernel(const float* __restrict_
             const float d = tile[c * P + s] - m;
             v = fmaf(d, d, v);
         }
-        mu[s & 255] = m;
-        rs[s & 255] = 1.0f / sqrtf(v * (1.f / 64) + RTFS_EPS);
-        // Ls <= 256 is guaranteed by the launcher, so one round of this loop
+        mu[s] = m;
+        rs[s] = 1.0f / sqrtf(v * (1.f / 64) + RTFS_EPS);
     }
     __syncthreads();
     const int c = tid & 63;
     const float g = gamma[c], b = beta[c];
-    for (int s = tid >> 6; s < Ls; s += 4) xn[((size_t)n * Ls + s) * 64 + c] = fmaf((tile[c * P + s] - mu[s]) * rs[s], g, b);
+    for (int s = tid >> 6; s < len; s += 4) xn[((size_t)n * Ls + s0 + s) * 64 + c] = fmaf((tile[c * P + s] - mu[s]) * rs[s], g, b);
 }
 
-// out = y[n*Ls + s][c] + bias[c] + x  (back to the (B, 64, R, Ls) layout)
+// out = y[n*Ls + s][c] + bias[c] + x  (back to the (B, 64, R, Ls) layout).  blockIdx.y = chunk of 256 positions.
 __global__ __launch_bounds__(256) void dp_out_kernel(const float* __restrict__ y, const float* __restrict__ bias,
                                                      const float* __restrict__ x, float* __restrict__ out, int R, int Ls) {
-    extern __shared__ float tile[];  // [Ls][65]
+    extern __shared__ float tile[];  // [len][65]
     const int n = blockIdx.x, tid = threadIdx.x;
-    const size_t base = seq_base(n, R, Ls), cs = (size_t)R * Ls;
-    for (int idx = tid; idx < 64 * Ls; idx += 256) tile[(idx >> 6) * 65 + (idx & 63)] = y[(size_t)n * Ls * 64 + idx] + bias[idx & 63];
+    const int s0 = blockIdx.y * 256, len = min(256, Ls - s0);
+    const size_t base = seq_base(n, R, Ls) + s0, cs = (size_t)R * Ls;
+    for (int idx = tid; idx < 64 * len; idx += 256) tile[(idx >> 6) * 65 + (idx & 63)] = y[((size_t)n * Ls + s0) * 64 + idx] + bias[idx & 63];
     __syncthreads();
-    for (int idx = tid; idx < 64 * Ls; idx += 256) {
-        const int c = idx / Ls, s = idx - c * Ls;
+    for (int idx = tid; idx < 64 * len; idx += 256) {
+        const int c = idx / len, s = idx - c * len;
         out[base + c * cs + s] = tile[s * 65 + c] + x[base + c * cs + s];
     }
 }
@@ -284,19 +286,19 @@ __global__ __launch_bounds__(256) void dp_ln_bwd_kernel(const float* __restrict_
 
 
 int launch_dp_ln_fwd(const float* x, const float* gamma, const float* beta, float* xn, int nseq, int R, int Ls, hipStream_t st) {
-    if (Ls < 8 || Ls > 256) return RTFS_ERR_SHAPE;
-    const size_t lds = (size_t)64 * (Ls + 1) * sizeof(float);
+    if (Ls < 8) return RTFS_ERR_SHAPE;
+    const size_t lds = (size_t)64 * ((Ls < 256 ? Ls : 256) + 1) * sizeof(float);
     int rc = set_lds(dp_ln_fwd_kernel, lds);
     if (rc) return rc;
-    hipLaunchKernelGGL(dp_ln_fwd_kernel, dim3(nseq), dim3(256), lds, st, x, gamma, beta, xn, R, Ls);
+    hipLaunchKernelGGL(dp_ln_fwd_kernel, dim3(nseq, cdiv(Ls, 256)), dim3(256), lds, st, x, gamma, beta, xn, R, Ls);
     return rtfs_launch_status();
 }
 int launch_dp_out(const float* y, const float* bias, const float* x, float* out, int nseq, int R, int Ls, hipStream_t st) {
-    if (Ls < 8 || Ls > 256) return RTFS_ERR_SHAPE;
-    const size_t lds = (size_t)Ls * 65 * sizeof(float);
+    if (Ls < 8) return RTFS_ERR_SHAPE;
+    const size_t lds = (size_t)(Ls < 256 ? Ls : 256) * 65 * sizeof(float);
     int rc = set_lds(dp_out_kernel, lds);
     if (rc) return rc;
-    hipLaunchKernelGGL(dp_out_kernel, dim3(nseq), dim3(256), lds, st, y, bias, x, out, R, Ls);
+    hipLaunchKernelGGL(dp_out_kernel, dim3(nseq, cdiv(Ls, 256)), dim3(256), lds, st, y, bias, x, out, R, Ls);
     return rtfs_launch_status();
 }
 int launch_dp_dy(const float* dout, float* dy, float* dbias, int nseq, int R, int Ls, hipStream_t st) {

@@ -52,6 +52,14 @@ class PackedModule(nn.Module):
 
 _FORCE_TRAIN_KERNELS = [False]
 
+# Fused inference kernels keep a whole sweep / score row / video pyramid on chip: a sweep axis of 250 positions (4 s of audio, BASELINE
+# config 5), 256 attention keys, 120 video frames.  The reference's forward has no length limit (rnn_layers.py:136-162, attention.py:149-189;
+# infer_any_video.py:86 feeds whole files): longer inputs run on the UNFUSED HIP kernels (GEMM + scan + GEMM, batched-GEMM attention,
+# per-layer video block) that also serve training - same arithmetic, tensors through HBM between the steps, any length.
+FUSED_MAX_SWEEP = 250
+FUSED_MAX_KEYS = 256
+FUSED_MAX_VIDEO_FRAMES = 120
+
 
 class force_train_kernels:
     """Context manager: route every module through its unfused HIP kernels whatever the mode.  Used for configurations that have
@@ -767,7 +775,8 @@ class DualPathRNN(PackedModule):
         B, C, T, Fq = x.shape
         if (T if self.dim == 3 else Fq) < self.kernel_size:
             raise ValueError(f"sweep axis shorter than kernel_size {self.kernel_size}")  # nn.Unfold raises in the reference
-        if _recording(x, self) or self.rnn_type == "GRU":  # GRU: no fused inference kernel, the GEMM + scan kernels serve both
+        long_axis = (T if self.dim == 3 else Fq) > FUSED_MAX_SWEEP  # past the fused kernel's on-chip sweep: the unfused kernels, any length
+        if _recording(x, self) or self.rnn_type == "GRU" or long_axis:  # GRU: no fused inference kernel, the GEMM + scan kernels serve both
             if self.rnn_type in ("LSTM", "GRU"):
                 cell = [getattr(self.rnn, n) for n in packing.lstm_param_names()]
                 return _DualPathLstmTrainFn.apply(x, self.dim, self.rnn_type.lower(), self.norm.gamma, self.norm.beta, *cell, self.linear.weight,
@@ -852,7 +861,7 @@ class MultiHeadSelfAttention2D(PackedModule):
         B, C, T, Fq = x.shape
         if C != 64 or Fq != 64:
             raise ValueError("expected (B, 64, T, 64)")
-        if _recording(x, self):
+        if _recording(x, self) or T > FUSED_MAX_KEYS:  # more keys than the fused kernel's LDS score tile: batched-GEMM attention, any length
             names, params = zip(*self.named_parameters())
             return attention_train(x, names, False, params)
         out = torch.empty_like(x)

@@ -340,14 +340,20 @@ class TDANetBlock(PackedModule):
     def forward(self, x, x_res=None):
         if x.is_cuda and L_recording(x, x_res, self):  # audio (2-D) and video (1-D) blocks alike
             return self._forward_train(x, x_res)
-        if self._hip and self.rnn_kind == 2:
+        if self._hip and (self.rnn_kind == 2 or x.shape[2] // 2 > layers.FUSED_MAX_SWEEP):
+            # GRU cells, or a time axis past the fused kernels' on-chip sweep (> 4 s): the block composed from the unfused HIP kernels
             _lib.need_gpu(x, x_res)
-            with layers.force_train_kernels():
+            if self.training:
+                raise RuntimeError("TDANetBlock: call .eval() for inference")
+            with torch.no_grad(), layers.force_train_kernels():
                 return self._forward_train(x, x_res)
         if not self._hip:
             x = x if x_res is None else x + x_res
-            if x.is_cuda and not self.training and self._vp_supported() and x.shape[-1] <= 120:
+            if x.is_cuda and not self.training and self._vp_supported() and x.shape[-1] <= layers.FUSED_MAX_VIDEO_FRAMES:
                 return self.forward_vp(x)
+            if x.is_cuda and not self.training:  # more frames than the one-workgroup-per-clip kernel holds in LDS: the per-layer HIP kernels
+                with torch.no_grad(), layers.force_train_kernels():
+                    return self._forward_train(x, None)
             return self._forward_1d(x)
         self._guard(x, x_res)
         lib = _lib.load()
@@ -606,10 +612,14 @@ class AVNet(BaseAVModel):
         _lib.need_gpu(wav, mouth_embedding)
         if L_recording(self):
             return self.forward_train(audio_mixture, mouth_embedding)
-        if self.refinement_module.audio_net.get_block(0).rnn_kind == 2:  # GRU cells: the separator composed from the unfused HIP kernels
+        frames = int(_lib.load().rtfs_num_frames(int(wav.shape[-1])))
+        too_long = frames // 2 > layers.FUSED_MAX_SWEEP or (mouth_embedding is not None and mouth_embedding.shape[-1] > layers.FUSED_MAX_VIDEO_FRAMES)
+        if self.refinement_module.audio_net.get_block(0).rnn_kind == 2 or too_long:
+            # GRU cells, or an utterance past the fused kernels' on-chip limits (> 4 s of audio / > 120 video frames): the separator
+            # composed from the unfused HIP kernels - any length, like the reference (infer_any_video.py:86 feeds whole files)
             if self.training:
                 raise RuntimeError("AVNet: call .eval() for inference")
-            with layers.force_train_kernels():
+            with torch.no_grad(), layers.force_train_kernels():
                 return self.forward_train(audio_mixture, mouth_embedding)
         if self.training:
             raise RuntimeError("AVNet: in .train() mode only the gradient-recording forward exists (see forward_train); "

@@ -52,7 +52,8 @@ def close(name, got, ref, tol=TOL, tol_l2=None):
     """Two readings of the north_star's "1e-4 rel", both asserted: max|d| / max|ref| <= tol, and the stricter aggregate
     ||d||_2 / ||ref||_2 <= tol / 10 (measured 1e-7 ... 1e-6 on every case)."""
     e, l2 = rel_err(got, ref), l2_rel(got, ref)
-    tol_l2 = tol / 10 if tol_l2 is None else tol_l2
+    if tol_l2 is None:  # the inference path's bar; tests that pass their own (training-side, bf16x3) tolerance get it for both readings
+        tol_l2 = tol / 10 if tol == TOL else tol
     print(f"[parity] {name}: max-rel {e:.3e}  l2-rel {l2:.3e}  shape {tuple(np.shape(ref))}")
     assert np.isfinite(np.asarray(got)).all(), f"{name}: non-finite output"
     assert e <= tol, f"{name}: rel err {e:.3e} > {tol:.1e}"
@@ -132,9 +133,11 @@ def test_dualpath(name, idx, dim, shape, seed):
     check_probe(load_golden(name), "out", y, TOL)
 
 
-@pytest.mark.parametrize("dim,shape", [(4, (1, 64, 125, 64)), (3, (1, 64, 125, 64)), (3, (1, 64, 250, 64)), (4, (2, 64, 9, 64)), (3, (3, 64, 37, 64))])
+@pytest.mark.parametrize("dim,shape", [(4, (1, 64, 125, 64)), (3, (1, 64, 125, 64)), (3, (1, 64, 250, 64)), (4, (2, 64, 9, 64)), (3, (3, 64, 37, 64)),
+                                       (3, (1, 64, 251, 64)), (3, (2, 64, 400, 64)), (3, (1, 64, 700, 64))])
 def test_dualpath_full_size_rows(dim, shape):
-    """2 s (T'=125) and 4 s (T'=250) sweep lengths, odd tile remainders."""
+    """2 s (T'=125) and 4 s (T'=250) sweep lengths, odd tile remainders; 250 = the longest sweep of the fused kernel, 251 / 400 / 700 = past it
+    (6.4 s, 11 s: the unfused GEMM + scan + GEMM kernels; the reference has no length limit, rnn_layers.py:136-162)."""
     m = model()
     x = rand(shape, 11 + dim)
     idx = 0 if dim == 4 else 1
@@ -158,7 +161,8 @@ def test_sru_operator():
     close("sru operator", host(h), O.sru_forward(x, O._sru_layers(p)))
 
 
-@pytest.mark.parametrize("shape,seed", [((2, 64, 12, 64), 103), ((1, 64, 125, 64), 5), ((1, 64, 250, 64), 6), ((2, 64, 33, 64), 8)])
+@pytest.mark.parametrize("shape,seed", [((2, 64, 12, 64), 103), ((1, 64, 125, 64), 5), ((1, 64, 250, 64), 6), ((2, 64, 33, 64), 8),
+                                        ((1, 64, 256, 64), 9), ((1, 64, 257, 64), 10), ((2, 64, 400, 64), 11)])
 def test_mhsa2d(shape, seed):
     m = model()
     x = rand(shape, seed)

@@ -435,7 +435,7 @@ def test_avnet_training_step_end_to_end(smooth, full):
     o_ref = G.avnet_torch(torch.tensor(wav, dtype=torch.float64), torch.tensor(vp, dtype=torch.float64), pt, 2, vp_trainable=full, bn_train=full)
     l_ref = G.pit_loss_torch(o_ref, torch.tensor(tgt, dtype=torch.float64), "snr")
     l_ref.backward()
-    close("avnet train forward", host(out), o_ref.detach().numpy())
+    close("avnet train forward", host(out), o_ref.detach().numpy(), tol_l2=3e-5)  # bf16x3 GEMMs (2^-17 per product): measured 1.1e-5
     close("avnet loss", np.array([float(loss)]), np.array([float(l_ref)]), tol=1e-5)
     got = {k: v.grad for k, v in m.named_parameters() if v.requires_grad}
     assert set(got) == {k for k, v in pt.items() if v.requires_grad}
@@ -730,7 +730,7 @@ def test_training_gradients_vs_reference_golden(case):
     out = m(dev(wav), dev(emb))
     loss = R.losses.PITLossWrapper(R.losses.PairwiseNegSDR("snr"), pit_from="pw_mtx")(out, dev(tgt))
     loss.backward()
-    close(f"hip vs reference ({case}) separated waveform", host(out), gold[f"{case}/est"])
+    close(f"hip vs reference ({case}) separated waveform", host(out), gold[f"{case}/est"], tol_l2=3e-5)  # training-side bf16x3 GEMMs
     assert abs(float(loss) - float(gold[f"{case}/loss"])) <= 1e-5 * abs(float(gold[f"{case}/loss"]))
     errs = {}
     gscale = max(np.abs(gold[f"{case}/{k}"]).max() for k, _ in m.named_parameters())
