@@ -29,6 +29,7 @@
 #include "common.h"
 #include "kernels.h"
 #include <stdlib.h>
+#include <type_traits>
 
 #define HLD 72          // activation row stride (halfs): 144-byte rows -> conflict-free b128 fragment reads
 #define WBUF 16384      // one staged K step of the weight stream (bytes)
@@ -110,16 +111,23 @@ __global__ __launch_bounds__(256, 2) void dp16s_kernel(Dp16Args a) {
     // ---------------- weight stream.  Global images in fragment order, 1024 pieces (16 KB) per K step:
     //   gate step:  piece ((dir * 4 + m) * 2 + part) * 64 + lane      conv-transpose tap: piece ((co tile * 4 + ks) * 2 + part) * 64 + lane
     // Staging copies the step linearly: thread tid moves pieces tid + 256 j.  `pre` holds the step after the one in LDS.
-    half8 pre[4];
-    auto stage_load = [&](const half8* __restrict__ step) {
+    // Two register sets: `pre[s]` holds stream step g + 1 + s while step g is multiplied.  Under full load an L2 round trip of this stream
+    // takes longer than one K step (the issue-time stamps showed ~760 ticks of a 1400-tick step waiting for `pre` with one set), two steps
+    // cover it.  All phases have an even number of steps, so set = step parity and the sets alternate without moves.
+    half8 pre[2][4];
+    auto stage_load = [&](auto set_c, const half8* __restrict__ step) {
+        constexpr int S = decltype(set_c)::value;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) pre[j] = step[tid + 256 * j];
+        for (int j = 0; j < 4; ++j) pre[S][j] = step[tid + 256 * j];
     };
-    auto stage_write = [&](int buf) {
+    auto stage_write = [&](auto set_c, int buf) {
+        constexpr int S = decltype(set_c)::value;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) Wst[buf * 1024 + tid + 256 * j] = pre[j];
+        for (int j = 0; j < 4; ++j) Wst[buf * 1024 + tid + 256 * j] = pre[S][j];
     };
-    stage_load(a.wf_l0);  // step 0 of layer 0: in flight under the load + LayerNorm phase
+    const std::integral_constant<int, 0> S0;
+    const std::integral_constant<int, 1> S1;
+    stage_load(S0, a.wf_l0);  // step 0 of layer 0: in flight under the load + LayerNorm phase
 
     // ---------------- phase 0: load rows, LayerNorm over channels, split to f16 planes (normalizations.py:33-37).
     // lane = (position, channel half): 32 consecutive positions x 2 halves per wave, the halves meet in one permlane swap
@@ -180,11 +188,12 @@ __global__ __launch_bounds__(256, 2) void dp16s_kernel(Dp16Args a) {
         rowbase[t] = (rs * rowsH + (dir ? L - 1 - tau : tau)) * HLD + 8 * h;
     }
     stamp();  // 1: after load + LN issue (before first barrier)
-    stage_write(0);
-    stage_load(a.wf_l0 + 1024);
-    __syncthreads();  // activation planes filled, step 0 staged; step 1 on its way to `pre`
+    stage_write(S0, 0);
+    stage_load(S0, a.wf_l0 + 1024);      // step 1 -> set 0 (written to LDS during step 0)
+    stage_load(S1, a.wf_l0 + 2 * 1024);  // step 2 -> set 1 (written during step 1)
+    __syncthreads();  // activation planes filled, step 0 staged
 
-    int g = 0;  // steps consumed so far: step g sits in buffer g & 1, step g + 1 in `pre`
+    int g = 0;  // steps consumed so far: step g sits in buffer g & 1, steps g + 1 and g + 2 in the register sets (g + 1) in set g & 1
     // ---------------- four SRU layers
     for (int layer = 0; layer < 4; ++layer) {
         const int nchunk = layer == 0 ? 32 : 4;
@@ -203,12 +212,29 @@ __global__ __launch_bounds__(256, 2) void dp16s_kernel(Dp16Args a) {
         const half8* const gsrc = layer == 0 ? a.wf_l0 : a.wf_l + (size_t)(layer - 1) * 4 * 1024;
         // what follows this layer in the stream: the next layer's steps, then the conv-transpose's taps
         const half8* const gnext = layer < 3 ? a.wf_l + (size_t)layer * 4 * 1024 : a.wf_ct;
-        // One barrier per K step.  (Issue-time stamps of this loop, a workgroup alone on its CU: 1390 cycles per step against 768 of MFMA
-        // issue - ~220 waiting for the first fragments after the barrier, ~85 in the barrier, the rest around the staging point.  Deferring
-        // gate tile 3 of step g - 1 across the barrier to cover the read latency, with all 12 fragment reads pinned in front of the staging
-        // writes, measured SLOWER (1650 per step: 24 register moves per step to hand the operands on, and a worse schedule); with the CU's
-        // second workgroup present both lose ~25 % and together they keep the matrix pipe ~86 % busy through the GEMM phases.)
-        for (int q = 0; q < nchunk; ++q, ++g) {
+        // MFMA issue order: the three split-precision terms of one accumulator must not follow each other (a dependent MFMA issues 48 ticks
+        // after its predecessor, independent ones every 16-32): a gate-tile pair is issued term-major over its four accumulators.
+        auto gate_pair = [&](int m0, const half8 (&ah)[2], const half8 (&al)[2], const half8& b0h, const half8& b0l, const half8& b1h, const half8& b1l) {
+#pragma unroll
+            for (int term = 0; term < 3; ++term) {
+#pragma unroll
+                for (int mm = 0; mm < 2; ++mm) {
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const half8& av = term == 2 ? al[t] : ah[t];
+                        const half8& bv = term == 1 ? (mm ? b1l : b0l) : (mm ? b1h : b0h);
+                        acc[t][m0 + mm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, acc[t][m0 + mm], 0, 0, 0);
+                    }
+                }
+            }
+        };
+        // One K step: fragments of step g from buffer g & 1, 24 MFMAs; between the gate-tile pairs step g + 1 leaves its register set for the
+        // other buffer (every wave left it at the barrier that ended step g - 1) and step g + 3 is requested into the freed set; one barrier.
+        // (Cycles per step of a workgroup alone on its CU, 768 of them MFMA issue: ~1390; variants measured on the way, none better alone:
+        // LDS-DMA staging 1420; all fragment reads pinned to the top of the step 1350; a mid-step barrier with the next step's first
+        // fragments requested behind it 1360-1490 (+36 registers); gate tile 3 deferred across the barrier 1650.  Under full load the
+        // second workgroup of the CU fills most of the gaps: ~1780 per step each, the matrix pipe ~86 % busy through the GEMM phases.)
+        auto kstep = [&](int q, auto set_c) {
             const int aoff = layer == 0 ? (q >> 2) * HLD + (q & 3) * 16 : q * 16;
             half8 ah[2], al[2];
 #pragma unroll
@@ -217,24 +243,16 @@ __global__ __launch_bounds__(256, 2) void dp16s_kernel(Dp16Args a) {
                 al[t] = *reinterpret_cast<const half8*>(Hl + rowbase[t] + aoff);
             }
             const half8* wb = Wst + (g & 1) * 1024 + dir * 512 + lane;
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const half8 bh = wb[m * 128], bl = wb[m * 128 + 64];
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], bh, acc[t][m], 0, 0, 0);
-                    acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], bl, acc[t][m], 0, 0, 0);
-                    acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[t], bh, acc[t][m], 0, 0, 0);
-                }
-                if (m == 1) {
-                    // step g + 1 (in `pre` since the last step) goes to the other buffer, which every wave left at the barrier that ended
-                    // step g - 1; then step g + 2 is requested: a whole step of MFMAs covers its latency
-                    stage_write((g + 1) & 1);
-                    const int q2 = q + 2;
-                    stage_load(q2 < nchunk ? gsrc + (size_t)q2 * 1024 : gnext + (size_t)(q2 - nchunk) * 1024);
-                }
-            }
+            gate_pair(0, ah, al, wb[0], wb[64], wb[128], wb[192]);
+            stage_write(set_c, (g + 1) & 1);
+            stage_load(set_c, q + 3 < nchunk ? gsrc + (size_t)(q + 3) * 1024 : gnext + (size_t)(q + 3 - nchunk) * 1024);
+            gate_pair(2, ah, al, wb[256], wb[320], wb[384], wb[448]);
             __syncthreads();  // step g consumed by every wave, step g + 1 visible
+            ++g;
+        };
+        for (int q = 0; q < nchunk; q += 2) {
+            kstep(q, S0);
+            kstep(q + 1, S1);
         }
         // (that barrier also means: every wave has finished reading the activation planes - the scan may overwrite them in place)
         stamp();  // 2,4,6,8: GEMM of layer done
@@ -325,11 +343,12 @@ __global__ __launch_bounds__(256, 2) void dp16s_kernel(Dp16Args a) {
     // ---------------- ConvTranspose1d(64->64, k=8) + bias + residual (rnn_layers.py:153-156), transposed:
     //   y[co][t] = bt[co] + sum_{kk,ci} Wt[co][kk*64+ci] * H[t-kk][ci];  wave = (sequence, co tile, position part)
     {
-        f32x16 acc[2];
+        // four accumulators: the sum over k is split by ks parity, so no MFMA follows a dependent one (see the issue-order note above)
+        f32x16 acc[2], accB[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
+            for (int q = 0; q < 16; ++q) acc[t][q] = accB[t][q] = 0.f;
         // the residual rows of the epilogue are requested now and arrive under the GEMM (clamped addresses: dead
         // sequences / positions read a valid element that is never stored)
         float res[2][16];
@@ -343,8 +362,8 @@ __global__ __launch_bounds__(256, 2) void dp16s_kernel(Dp16Args a) {
                 res[t][q] = a.x[rbase + (size_t)co * a.cstride + p] + a.bt[co];  // residual + conv-transpose bias, both fetched under the GEMM
             }
         }
-        // tap 0 is staged in buffer g & 1, tap 1 in `pre`; 8 taps of 64 k' each
-        for (int q = 0; q < 8; ++q, ++g) {
+        // tap 0 is staged in buffer g & 1, taps 1 and 2 in the register sets; 8 taps of 64 k' each
+        auto tap = [&](int q, auto set_c) {
             int hrow[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
@@ -353,22 +372,35 @@ __global__ __launch_bounds__(256, 2) void dp16s_kernel(Dp16Args a) {
             }
             const half8* wb = Wst + (g & 1) * 1024 + ccot * 512 + lane;
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const half8 wh = wb[ks * 128], wl = wb[ks * 128 + 64];
+            for (int k2 = 0; k2 < 4; k2 += 2) {  // two k steps x two position tiles = four accumulators, issued term-major
+                half8 xh[2][2], xl[2][2];
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const half8 xh = *reinterpret_cast<const half8*>(Hh + hrow[t] + ks * 16);
-                    const half8 xl = *reinterpret_cast<const half8*>(Hl + hrow[t] + ks * 16);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, acc[t], 0, 0, 0);
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        xh[kk][t] = *reinterpret_cast<const half8*>(Hh + hrow[t] + (k2 + kk) * 16);
+                        xl[kk][t] = *reinterpret_cast<const half8*>(Hl + hrow[t] + (k2 + kk) * 16);
+                    }
+                const half8 w0h = wb[k2 * 128], w0l = wb[k2 * 128 + 64], w1h = wb[(k2 + 1) * 128], w1l = wb[(k2 + 1) * 128 + 64];
+#pragma unroll
+                for (int term = 0; term < 3; ++term) {
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(term == 2 ? w0l : w0h, term == 1 ? xl[0][t] : xh[0][t], acc[t], 0, 0, 0);
+                        accB[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(term == 2 ? w1l : w1h, term == 1 ? xl[1][t] : xh[1][t], accB[t], 0, 0, 0);
+                    }
                 }
-                if (ks == 1 && q + 1 < 8) {
-                    stage_write((g + 1) & 1);
-                    stage_load(a.wf_ct + (size_t)(q + 2 < 8 ? q + 2 : 7) * 1024);  // unconditional (clamped; the last ones are not used)
+                if (k2 == 0) {
+                    stage_write(set_c, (g + 1) & 1);  // (the last tap rewrites tap 7's neighbour with a clamped copy: never read)
+                    stage_load(set_c, a.wf_ct + (size_t)(q + 3 < 8 ? q + 3 : 7) * 1024);  // unconditional, clamped
                 }
             }
             __syncthreads();
+            ++g;
+        };
+        for (int q = 0; q < 8; q += 2) {
+            tap(q, S0);
+            tap(q + 1, S1);
         }
         stamp();  // 10: conv-transpose GEMM done
         if (n0 + cseq < a.nseq) {
@@ -380,7 +412,7 @@ __global__ __launch_bounds__(256, 2) void dp16s_kernel(Dp16Args a) {
 #pragma unroll
                     for (int q = 0; q < 16; ++q) {
                         const int co = ccot * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
-                        a.out[base + (size_t)co * a.cstride + p] = fmaf(acc[t][q], WINV, res[t][q]);
+                        a.out[base + (size_t)co * a.cstride + p] = fmaf(acc[t][q] + accB[t][q], WINV, res[t][q]);
                     }
                 }
             }

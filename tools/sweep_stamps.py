@@ -27,8 +27,10 @@ for label, dp, Rr, Ls, per in [("F-path", blk.globalatt[0], 125, 64, 4 if GEN2 e
     print(f"== {label}: {nwg} workgroups; cycles per phase (median / mean), total median {np.median(s[:,11]-s[:,0]):.0f}")
     for i in range(11):
         print(f"   {names[i+1]:12s} {np.median(d[:, i]):9.0f} {d[:, i].mean():9.0f}")
-    inner = st.cpu().numpy()[:, 12:16].astype(np.float64)
-    print("   inside K step 8 of layer 0, wave 0 (issue-time deltas, median): reads+first tile issued %.0f | to staging point %.0f | rest of MFMAs issued %.0f | barrier %.0f"
-          % tuple(np.median(inner, axis=0)))
+    raw = st.cpu().numpy()[:, 12:15].astype(np.uint64)
+    dl = np.stack([raw & np.uint64(0xFFFFFFFF), raw >> np.uint64(32)], -1).reshape(len(raw), 6).astype(np.float64)
+    if dl.any():
+        print("   inside K step 9 of layer 0, wave 0, issue-time deltas (median): B tiles 2-3 read issue %.0f | tiles 0-1 (12 MFMA) %.0f | staging %.0f | "
+              "barrier %.0f | next-step reads issue %.0f | tiles 2-3 (12 MFMA) %.0f" % tuple(np.median(dl, axis=0)))
     t0 = s[:, 0].min(); t1 = s[:, 11].max()
     print(f"   kernel span {t1 - t0:.0f} ticks (s_memtime 100MHz?)")
