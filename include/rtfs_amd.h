@@ -16,7 +16,16 @@
  *     kernels are enqueued on `stream` (a hipStream_t passed as void*), never synchronise, never
  *     allocate, never call back; workspace contents are scratch
  *   - return 0 on success; <0 on error: -1 bad shape, -2 workspace too small, -3 launch failure, -4 bad argument
- *   - eval-mode semantics (BatchNorm running statistics, no dropout); re-entrant, stateless.
+ *   - eval-mode semantics (BatchNorm running statistics, no dropout); re-entrant: the only host-side state is a mutex-guarded cache
+ *     of per-(device, kernel) launch attributes and the diagnostic sweep-timing log (off by default), so the library may be driven from
+ *     several host threads / devices in one process.
+ *   - length limits of the FUSED entry points (they keep a whole sweep / score row / video pyramid on chip and return -1 beyond):
+ *       sweep axis of rtfs_dualpath_* / rtfs_block_f32 / rtfs_separator_forward_f32   <= 250 positions (T/2 <= 250: 4 s of audio)
+ *       keys of rtfs_tf_attention_f32                                                 <= 256
+ *       video frames of rtfs_vp_block_f32                                             <= 120
+ *     The reference has no length limit (rnn_layers.py:136-162, attention.py:149-189; infer_any_video.py:86 feeds whole files): longer
+ *     inputs go through the UNFUSED entry points below (rtfs_*_forward_train_f32 and friends: GEMM + scan + GEMM sweeps, batched-GEMM
+ *     attention, per-layer video block), which take any length; rtfs-net_amd/{models,layers}.py route by length (FUSED_MAX_*).
  * F must satisfy F/2 == 64 wherever a block / attention is involved (the reference's n_freqs: 64 ties
  * LayerNormalization4D's parameters to 64 compressed frequency bins, config/lrs2_RTFSNet_4_layer.yaml:68).
  */
@@ -97,7 +106,7 @@ int rtfs_caf_f32(const float* audio, const float* video, const float* pack, floa
                  void* ws, size_t ws_bytes, void* stream);
 
 /* VP block = the video-side 1-D TDANetBlock.forward (upsampling_depth 4, kernel 3, BatchNorm1d, GlobalAttention;
- * src/models/separators/tdanet.py:104-131 with yaml video_params): video (B,512,Tv) -> (B,512,Tv), Tv <= 120.
+ * src/models/separators/tdanet.py:104-131 with yaml video_params): video (B,512,Tv) -> (B,512,Tv), Tv <= 120 (see the conventions).
  * pack = rtfs-net_amd/packing.py:pack_vp (eval BatchNorm folded); rtfs_vp_pack_floats() returns its length. */
 size_t rtfs_vp_pack_floats(void);
 int rtfs_vp_block_f32(const float* video, const float* pack, float* out, int B, int Tv, void* stream);
