@@ -283,10 +283,28 @@ struct BlockWs {
     float *c1, *p0, *g, *gF, *tA, *tB, *gT, *gA, *q, *k, *v, *o;         // compressed resolution
     float *E0, *G0, *E1, *G1, *L1, *xf1, *E2, *G2;
     double* stats;  // 11 slots x (B,2)
+    int Bfull = 0, b0 = 0;  // batch size the statistic slots are laid out for, first mixture of this view
+    size_t P_ = 0, Pg_ = 0;
     static constexpr int NSTAT = 11;
     enum { S_C0, S_C1, S_E0, S_G0, S_E1, S_G1, S_L1, S_E2, S_G2, S_L0, S_L2 };
+    // the same buffers seen from mixture `first` on (a sub-batch of the block's inner part, see separator_forward)
+    BlockWs sub(int first) const {
+        BlockWs v = *this;
+        v.b0 = b0 + first;
+        v.residual += (size_t)first * CA * P_;
+        float** full[] = {&v.x_enc, &v.c0, &v.xf0, &v.expanded};
+        for (float** q_ : full) *q_ += (size_t)first * CH * P_;
+        float** gs[] = {&v.c1, &v.p0, &v.g, &v.gF, &v.tA, &v.tB, &v.gT, &v.gA, &v.v, &v.o, &v.E0, &v.G0, &v.E1, &v.G1, &v.L1, &v.xf1, &v.E2, &v.G2};
+        for (float** q_ : gs) *q_ += (size_t)first * CH * Pg_;
+        v.q += (size_t)first * CH * Pg_ / 4;
+        v.k += (size_t)first * CH * Pg_ / 4;
+        return v;
+    }
     BlockWs(Arena& a, int B, int T, int F) {
         const size_t P = (size_t)T * F, Pg = (size_t)(T / 2) * (F / 2);
+        Bfull = B;
+        P_ = P;
+        Pg_ = Pg;
         residual = a.take<float>(B * CA * P);
         x_enc = a.take<float>(B * CH * P);
         c0 = a.take<float>(B * CH * P);
@@ -298,7 +316,7 @@ struct BlockWs {
         k = a.take<float>(B * CH * Pg / 4);
         stats = a.take<double>((size_t)NSTAT * B * 2);
     }
-    double* st(int slot, int B) const { return stats ? stats + (size_t)slot * B * 2 : nullptr; }
+    double* st(int slot, int /*B of the view*/) const { return stats ? stats + ((size_t)slot * Bfull + b0) * 2 : nullptr; }
 };
 
 int block_head(const BlockPack& p, const float* x, const float* x_res, int B, int T, int F, BlockWs& w, hipStream_t st, const CafArgs* caf) {
@@ -327,12 +345,12 @@ int block_head(const BlockPack& p, const float* x, const float* x_res, int B, in
 }
 
 // steps 2-17: everything between the projection (x_enc, residual in the workspace) and `expanded`
-int block_body(const BlockPack& p, int B, int T, int F, BlockWs& w, hipStream_t st) {
+int block_body(const BlockPack& p, int B, int T, int F, const BlockWs& w, hipStream_t st, bool zero_stats = true) {
     const int Tp = T / 2, Fp = F / 2;
     const int P = T * F, Pg = Tp * Fp;
     const double icF = 1.0 / ((double)CH * P), icG = 1.0 / ((double)CH * Pg);
     typedef BlockWs W;
-    if (hipMemsetAsync(w.stats, 0, sizeof(double) * W::NSTAT * B * 2, st) != hipSuccess) return RTFS_ERR_LAUNCH;
+    if (zero_stats && hipMemsetAsync(w.stats, 0, sizeof(double) * W::NSTAT * w.Bfull * 2, st) != hipSuccess) return RTFS_ERR_LAUNCH;
     {  // 2. downsample[0]: dw 4x4 s1 + bias -> c0 (pre-gLN) + stats                         tdanet.py:110
         DwArgs a;
         a.x = w.x_enc;
@@ -877,8 +895,19 @@ int rtfs_separator_forward_f32(const float* wav, const float* video_vp, const fl
         // block outputs between applications never reach HBM: the residual conv of block i, the CAF (after block 0),
         // the "+ a1" and the gateway + projection of block i+1 run back to back in one kernel (block_boundary).
         CHECK(block_head(pk, w.a1, nullptr, B, T, NF, w.blk, st, nullptr));
+        // Experiment knob (default off): RTFS_SUBBATCH=n runs the inner part of a block (the 21 launches between the projection and
+        // `expanded`) per sub-batch of n mixtures.  Idea: at batch 32 a 64-channel full-resolution tensor is 265 MB, just past the 256 MB
+        // Infinity Cache, and is read by two to four consecutive kernels; at 16 it is 133 MB.  Measured (bench, one box): whole batch
+        // 15.5 ms, n = 16 16.8, n = 8 19.0, n = 4 26.6 - the smaller launches cost more than the on-die re-reads save.
+        static const int sb_env = getenv("RTFS_SUBBATCH") ? atoi(getenv("RTFS_SUBBATCH")) : 0;
+        const int sb = sb_env > 0 && sb_env < B ? sb_env : B;
         for (int i = 0; i < repeats; ++i) {
-            CHECK(block_body(pk, B, T, NF, w.blk, st));
+            if (hipMemsetAsync(w.blk.stats, 0, sizeof(double) * BlockWs::NSTAT * B * 2, st) != hipSuccess) return RTFS_ERR_LAUNCH;
+            for (int first = 0; first < B; first += sb) {
+                const int nb = B - first < sb ? B - first : sb;
+                const BlockWs view = w.blk.sub(first);
+                CHECK(block_body(pk, nb, T, NF, view, st, false));
+            }
             if (i == 0) {
                 if (video_ready && hipStreamWaitEvent(st, (hipEvent_t)video_ready, 0) != hipSuccess) return RTFS_ERR_LAUNCH;
                 CHECK(launch_caf_video(ca, B, st));
