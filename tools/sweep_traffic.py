@@ -29,8 +29,8 @@ def main():
     fpath, wpath = sys.argv[1], sys.argv[2]
     B, repeats, seconds = (int(sys.argv[3]) if len(sys.argv) > 3 else 32), 4, 2.0
     fetch, write = per_kernel(fpath, "FETCH_SIZE"), per_kernel(wpath, "WRITE_SIZE")
-    sweeps = sorted(k for k in fetch if k[0].startswith("void dp16_kernel") or k[0].startswith("dp16_kernel"))
-    out = {"what": "HBM bytes per launch of the fused dual-path sweep kernel (dp16_kernel), RTFS-Net-4, batch %d, 2 s: "
+    sweeps = sorted(k for k in fetch if "dp16s_kernel" in k[0] or "dp16_kernel" in k[0])
+    out = {"what": "HBM bytes per launch of the fused dual-path sweep kernel (dp16s_kernel), RTFS-Net-4, batch %d, 2 s: "
                    "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, corrected as MI355X_MICROARCH.md "
                    "prescribes: bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024" % B,
            "batch": B, "repeats": repeats, "seconds": seconds, "paths": []}
