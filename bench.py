@@ -167,6 +167,8 @@ def max_over_ranks(dt, dist, device):
     """Whole-job time = the slowest rank's time."""
     if dist is None:
         return dt
+    if dist.get_backend() == "gloo":
+        device = torch.device("cpu")
     tt = torch.tensor([dt], device=device, dtype=torch.float64)
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     return float(tt.item())
@@ -235,11 +237,15 @@ def init_ranks(args, backend="nccl"):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        if backend == "nccl":
+        if backend == "nccl" and not os.environ.get("RTFS_BENCH_SHARE_GPU"):
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group("gloo" if backend == "nccl" else backend, rank=rank, world_size=world)
+    if os.environ.get("RTFS_BENCH_SHARE_GPU"):
+        # rehearsal of the N-rank protocol on a ONE-GPU box: every rank uses cuda:0 (time-sliced) and the process group is gloo (RCCL needs a
+        # device per rank).  Exercises the real launcher + forward + timing + JSON path; the number it prints is NOT a scaling measurement.
+        local_rank = 0
     return rank, local_rank, world, dist
 
 

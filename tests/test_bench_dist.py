@@ -146,3 +146,22 @@ def test_bench_launcher_reports_a_failed_rank():
     env["RTFS_BENCH_FAIL_RANK"] = "1"
     pr = _bench("--gpus", "2", "--steps", "1", "--warmup", "0", "--dist-dry-run", env=env)
     assert pr.returncode != 0 and "{" not in pr.stdout and "rank 1 failed" in pr.stderr
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_bench_self_launch_with_the_real_forward_on_one_gpu():
+    """The N-rank protocol with the REAL forward: `python bench.py --gpus 2` spawns its two ranks; RTFS_BENCH_SHARE_GPU=1 lets both use cuda:0
+    (time-sliced) with a gloo process group, because a test box has one GPU and RCCL wants a device per rank.  Checks the launcher, the
+    per-rank forward, the max-over-ranks timing and rank 0's single JSON line (roofline object included) - not a scaling number."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["RTFS_BENCH_SHARE_GPU"] = "1"
+    pr = _bench("--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2", env=env)
+    assert pr.returncode == 0, pr.stderr[-2000:]
+    recs = [json.loads(l) for l in pr.stdout.splitlines() if l.startswith("{")]
+    assert len(recs) == 1
+    r = recs[0]
+    assert r["n_gpus"] == 2 and r["config"]["global_batch"] == 4 and r["value"] > 0 and "cpu_baseline" not in r
+    assert r["roofline"]["launches_timed"] == 2 * 8 and 0 < r["roofline"]["frac"] < 2
