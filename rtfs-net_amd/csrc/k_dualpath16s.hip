@@ -61,10 +61,17 @@ __device__ __forceinline__ float sum_halves(float v) {
 
 }  // namespace
 
-template <int NSEQ, bool PAIRED, bool STAMP = false>
-__global__ __launch_bounds__(256, 2) void dp16s_kernel(Dp16Args a) {
+// NT = row tiles per wave.  NT = 2: 4 waves (2 time parts x 2 directions), 128 accumulators per wave, <= 256 registers: one wave of the
+// workgroup per SIMD.  NT = 1: 8 waves (4 time parts x 2 directions), 64 accumulators, <= 128 registers: two waves of the workgroup per SIMD
+// and, with the CU's second workgroup, four per SIMD.
+template <int NSEQ, bool PAIRED, int NT, bool STAMP = false>
+__global__ __launch_bounds__(NT == 2 ? 256 : 512, NT == 2 ? 2 : 4) void dp16s_kernel(Dp16Args a) {
     static_assert((NSEQ == 2 && PAIRED) || (NSEQ == 1 && !PAIRED), "F sweep: one sequence pair; T sweep: one sequence");
-    constexpr int STEPS = PAIRED ? 32 : 64;  // time steps covered by one wave; 2 parts per workgroup
+    static_assert(NT == 1 || NT == 2, "row tiles per wave");
+    constexpr int STEPS = (PAIRED ? 16 : 32) * NT;  // time steps covered by one wave
+    constexpr int NPART = 4 / NT;                   // time parts per workgroup
+    constexpr int NTHR = 128 * NPART;               // 2 directions x NPART waves
+    constexpr int NPIECE = 1024 / NTHR;             // 16-byte pieces of a staged K step per thread
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     const int Ls = a.Ls, L = Ls - 7, rowsH = Ls + 1;  // one extra all-zero row for the conv-transpose borders
     half8* Wst = reinterpret_cast<half8*>(smem);                          // [2 buffers][1024 pieces of 16 B], fragment order
@@ -77,7 +84,7 @@ __global__ __launch_bounds__(256, 2) void dp16s_kernel(Dp16Args a) {
     const int r = lane & 31, h = lane >> 5;
     const int part = wave >> 1, dir = wave & 1;           // time part MAJOR (the two waves of a part run their chains together)
     const int seq = PAIRED ? h : 0;                       // the sequence this LANE's accumulator registers belong to
-    constexpr int CPART = 2 / NSEQ;                       // conv-transpose roles: (sequence, co tile, 64-position part)
+    constexpr int CPART = (NSEQ == 2 ? 64 : 128) / (32 * NT);  // conv-transpose roles: (sequence, co tile, part of 32 NT positions)
     const int cseq = wave / (2 * CPART), ccot = (wave / CPART) & 1, cpart = wave % CPART;
     const int n0 = blockIdx.x * NSEQ;
 
@@ -114,16 +121,16 @@ __global__ __launch_bounds__(256, 2) void dp16s_kernel(Dp16Args a) {
     // Two register sets: `pre[s]` holds stream step g + 1 + s while step g is multiplied.  Under full load an L2 round trip of this stream
     // takes longer than one K step (the issue-time stamps showed ~760 ticks of a 1400-tick step waiting for `pre` with one set), two steps
     // cover it.  All phases have an even number of steps, so set = step parity and the sets alternate without moves.
-    half8 pre[2][4];
+    half8 pre[2][NPIECE];
     auto stage_load = [&](auto set_c, const half8* __restrict__ step) {
         constexpr int S = decltype(set_c)::value;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) pre[S][j] = step[tid + 256 * j];
+        for (int j = 0; j < NPIECE; ++j) pre[S][j] = step[tid + NTHR * j];
     };
     auto stage_write = [&](auto set_c, int buf) {
         constexpr int S = decltype(set_c)::value;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) Wst[buf * 1024 + tid + 256 * j] = pre[S][j];
+        for (int j = 0; j < NPIECE; ++j) Wst[buf * 1024 + tid + NTHR * j] = pre[S][j];
     };
     const std::integral_constant<int, 0> S0;
     const std::integral_constant<int, 1> S1;
@@ -131,7 +138,7 @@ __global__ __launch_bounds__(256, 2) void dp16s_kernel(Dp16Args a) {
 
     // ---------------- phase 0: load rows, LayerNorm over channels, split to f16 planes (normalizations.py:33-37).
     // lane = (position, channel half): 32 consecutive positions x 2 halves per wave, the halves meet in one permlane swap
-    {
+    if (wave < 4) {  // (NT = 1: waves 4-7 have nothing to load; the phase is latency-bound)
         const int task = wave * 32 + r, ntask = NSEQ * Ls;  // <= 128
         const bool live = task < ntask;
         const int tk = live ? task : ntask - 1;
@@ -179,9 +186,9 @@ __global__ __launch_bounds__(256, 2) void dp16s_kernel(Dp16Args a) {
     // A-operand row r of tile t: PAIRED   -> sequence (r >> 2) & 1, step 16 t + (r & 3) + 4 (r >> 3)
     //                            unpaired -> step 32 t + 16 ((r >> 2) & 1) + (r & 3) + 4 (r >> 3)
     // either way accumulator register q of lane half h (row (q & 3) + 8 (q >> 2) + 4 h) is step q of that half's 16-step run
-    int rowbase[2];
+    int rowbase[NT];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < NT; ++t) {
         const int rs = PAIRED ? (r >> 2) & 1 : 0;
         int tau = STEPS * part + (r & 3) + 4 * (r >> 3) + (PAIRED ? 16 * t : 32 * t + 16 * ((r >> 2) & 1));
         tau = tau < L ? tau : L - 1;
@@ -199,9 +206,9 @@ __global__ __launch_bounds__(256, 2) void dp16s_kernel(Dp16Args a) {
         const int nchunk = layer == 0 ? 32 : 4;
         const float vf = a.wc16[layer * 128 + dir * 32 + r], vr = a.wc16[layer * 128 + 64 + dir * 32 + r];
         const float bf = a.bias16[layer * 128 + dir * 32 + r] * 256.f, br = a.bias16[layer * 128 + 64 + dir * 32 + r] * 256.f;
-        f32x16 acc[2][4];
+        f32x16 acc[NT][4];
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 acc[t][0][q] = 0.f;
@@ -214,39 +221,49 @@ __global__ __launch_bounds__(256, 2) void dp16s_kernel(Dp16Args a) {
         const half8* const gnext = layer < 3 ? a.wf_l + (size_t)layer * 4 * 1024 : a.wf_ct;
         // MFMA issue order: the three split-precision terms of one accumulator must not follow each other (a dependent MFMA issues 48 ticks
         // after its predecessor, independent ones every 16-32): a gate-tile pair is issued term-major over its four accumulators.
-        auto gate_pair = [&](int m0, const half8 (&ah)[2], const half8 (&al)[2], const half8& b0h, const half8& b0l, const half8& b1h, const half8& b1l) {
+        // `tiles` consecutive gate tiles from m0, term-major: NT = 2 issues pairs (4 accumulators), NT = 1 all four gate tiles at once
+        auto gate_tiles = [&](int m0, auto ntile_c, const half8 (&ah)[NT], const half8 (&al)[NT], const half8* __restrict__ wb) {
+            constexpr int NM = decltype(ntile_c)::value;
+            half8 bh[NM], bl[NM];
+#pragma unroll
+            for (int mm = 0; mm < NM; ++mm) {
+                bh[mm] = wb[(m0 + mm) * 128];
+                bl[mm] = wb[(m0 + mm) * 128 + 64];
+            }
 #pragma unroll
             for (int term = 0; term < 3; ++term) {
 #pragma unroll
-                for (int mm = 0; mm < 2; ++mm) {
+                for (int mm = 0; mm < NM; ++mm) {
 #pragma unroll
-                    for (int t = 0; t < 2; ++t) {
-                        const half8& av = term == 2 ? al[t] : ah[t];
-                        const half8& bv = term == 1 ? (mm ? b1l : b0l) : (mm ? b1h : b0h);
-                        acc[t][m0 + mm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, acc[t][m0 + mm], 0, 0, 0);
-                    }
+                    for (int t = 0; t < NT; ++t)
+                        acc[t][m0 + mm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(term == 2 ? al[t] : ah[t], term == 1 ? bl[mm] : bh[mm], acc[t][m0 + mm], 0, 0, 0);
                 }
             }
         };
-        // One K step: fragments of step g from buffer g & 1, 24 MFMAs; between the gate-tile pairs step g + 1 leaves its register set for the
-        // other buffer (every wave left it at the barrier that ended step g - 1) and step g + 3 is requested into the freed set; one barrier.
-        // (Cycles per step of a workgroup alone on its CU, 768 of them MFMA issue: ~1390; variants measured on the way, none better alone:
-        // LDS-DMA staging 1420; all fragment reads pinned to the top of the step 1350; a mid-step barrier with the next step's first
-        // fragments requested behind it 1360-1490 (+36 registers); gate tile 3 deferred across the barrier 1650.  Under full load the
-        // second workgroup of the CU fills most of the gaps: ~1780 per step each, the matrix pipe ~86 % busy through the GEMM phases.)
+        // One K step: fragments of step g from buffer g & 1, 12 NT MFMAs; in the middle step g + 1 leaves its register set for the other buffer
+        // (every wave left it at the barrier that ended step g - 1) and step g + 3 is requested into the freed set; one barrier.
+        // (Cycles per step of a 4-wave workgroup alone on its CU, 768 of them MFMA issue: ~1350; variants measured on the way, none better
+        // alone: LDS-DMA staging 1420; all fragment reads pinned to the top of the step 1350; a mid-step barrier with the next step's first
+        // fragments requested behind it 1360-1490 (+36 registers); gate tile 3 deferred across the barrier 1650.)
         auto kstep = [&](int q, auto set_c) {
             const int aoff = layer == 0 ? (q >> 2) * HLD + (q & 3) * 16 : q * 16;
-            half8 ah[2], al[2];
+            half8 ah[NT], al[NT];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
+            for (int t = 0; t < NT; ++t) {
                 ah[t] = *reinterpret_cast<const half8*>(Hh + rowbase[t] + aoff);
                 al[t] = *reinterpret_cast<const half8*>(Hl + rowbase[t] + aoff);
             }
             const half8* wb = Wst + (g & 1) * 1024 + dir * 512 + lane;
-            gate_pair(0, ah, al, wb[0], wb[64], wb[128], wb[192]);
-            stage_write(set_c, (g + 1) & 1);
-            stage_load(set_c, q + 3 < nchunk ? gsrc + (size_t)(q + 3) * 1024 : gnext + (size_t)(q + 3 - nchunk) * 1024);
-            gate_pair(2, ah, al, wb[256], wb[320], wb[384], wb[448]);
+            if (NT == 2) {
+                gate_tiles(0, std::integral_constant<int, 2>(), ah, al, wb);
+                stage_write(set_c, (g + 1) & 1);
+                stage_load(set_c, q + 3 < nchunk ? gsrc + (size_t)(q + 3) * 1024 : gnext + (size_t)(q + 3 - nchunk) * 1024);
+                gate_tiles(2, std::integral_constant<int, 2>(), ah, al, wb);
+            } else {
+                stage_write(set_c, (g + 1) & 1);
+                stage_load(set_c, q + 3 < nchunk ? gsrc + (size_t)(q + 3) * 1024 : gnext + (size_t)(q + 3 - nchunk) * 1024);
+                gate_tiles(0, std::integral_constant<int, 4>(), ah, al, wb);
+            }
             __syncthreads();  // step g consumed by every wave, step g + 1 visible
             ++g;
         };
@@ -259,14 +276,16 @@ __global__ __launch_bounds__(256, 2) void dp16s_kernel(Dp16Args a) {
         // undo the 2^8 weight prescale on all 128 accumulators now, on every wave at once, so the serialised per-part recurrence
         // below is the bare dependency chain
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
                 for (int q = 0; q < 16; ++q) acc[t][m][q] *= WINV;
         __builtin_amdgcn_sched_barrier(0);
-        float cin[2] = {0.f, 0.f};  // c_{t-1} of register 0 of tile t (this lane's run)
-        for (int hp = 0; hp < 2; ++hp) {
+        float cin[NT];  // c_{t-1} of register 0 of tile t (this lane's run)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) cin[t] = 0.f;
+        for (int hp = 0; hp < NPART; ++hp) {
             if (part == hp) {
                 float c = hp > 0 ? chand[(seq * 2 + dir) * 32 + r] : 0.f;
                 if (PAIRED) {
@@ -274,7 +293,7 @@ __global__ __launch_bounds__(256, 2) void dp16s_kernel(Dp16Args a) {
                     // overwrites u0 in place.  The reset gate and the hidden output depend on c_{t-1}, c_t but nothing depends on
                     // them: they are evaluated after the hand-off below, concurrently with the next time part's chain.
 #pragma unroll
-                    for (int t = 0; t < 2; ++t) {
+                    for (int t = 0; t < NT; ++t) {
                         cin[t] = c;
 #pragma unroll
                         for (int q = 0; q < 16; ++q) {
@@ -289,7 +308,7 @@ __global__ __launch_bounds__(256, 2) void dp16s_kernel(Dp16Args a) {
                     // the two lane halves hold steps 16 h + q of a tile: they take turns, 16 steps each; the idle half runs the same
                     // instructions on its own (not yet / no longer needed) registers and keeps them unchanged
 #pragma unroll
-                    for (int t = 0; t < 2; ++t) {
+                    for (int t = 0; t < NT; ++t) {
 #pragma unroll
                         for (int ph = 0; ph < 2; ++ph) {
                             if (h == ph) cin[t] = c;
@@ -317,7 +336,7 @@ __global__ __launch_bounds__(256, 2) void dp16s_kernel(Dp16Args a) {
                 const int ostep = dir ? -HLD : HLD;
                 const int nvalid = L - tau0;
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
+                for (int t = 0; t < NT; ++t) {
                     float cprev = cin[t];
 #pragma unroll
                     for (int q = 0; q < 16; ++q) {
@@ -344,18 +363,18 @@ __global__ __launch_bounds__(256, 2) void dp16s_kernel(Dp16Args a) {
     //   y[co][t] = bt[co] + sum_{kk,ci} Wt[co][kk*64+ci] * H[t-kk][ci];  wave = (sequence, co tile, position part)
     {
         // four accumulators: the sum over k is split by ks parity, so no MFMA follows a dependent one (see the issue-order note above)
-        f32x16 acc[2], accB[2];
+        f32x16 acc[NT], accB[NT];
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[t][q] = accB[t][q] = 0.f;
         // the residual rows of the epilogue are requested now and arrive under the GEMM (clamped addresses: dead
         // sequences / positions read a valid element that is never stored)
-        float res[2][16];
+        float res[NT][16];
         const size_t rbase = seq_base(cseq);
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int p = min(64 * cpart + 32 * t + r, Ls - 1);
+        for (int t = 0; t < NT; ++t) {
+            const int p = min(32 * NT * cpart + 32 * t + r, Ls - 1);
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const int co = ccot * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
@@ -364,20 +383,20 @@ __global__ __launch_bounds__(256, 2) void dp16s_kernel(Dp16Args a) {
         }
         // tap 0 is staged in buffer g & 1, taps 1 and 2 in the register sets; 8 taps of 64 k' each
         auto tap = [&](int q, auto set_c) {
-            int hrow[2];
+            int hrow[NT];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int p = 64 * cpart + 32 * t + r - q;
+            for (int t = 0; t < NT; ++t) {
+                const int p = 32 * NT * cpart + 32 * t + r - q;
                 hrow[t] = (cseq * rowsH + ((p >= 0 && p < L) ? p : Ls)) * HLD + 8 * h;
             }
             const half8* wb = Wst + (g & 1) * 1024 + ccot * 512 + lane;
 #pragma unroll
             for (int k2 = 0; k2 < 4; k2 += 2) {  // two k steps x two position tiles = four accumulators, issued term-major
-                half8 xh[2][2], xl[2][2];
+                half8 xh[2][NT], xl[2][NT];
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-                    for (int t = 0; t < 2; ++t) {
+                    for (int t = 0; t < NT; ++t) {
                         xh[kk][t] = *reinterpret_cast<const half8*>(Hh + hrow[t] + (k2 + kk) * 16);
                         xl[kk][t] = *reinterpret_cast<const half8*>(Hl + hrow[t] + (k2 + kk) * 16);
                     }
@@ -385,7 +404,7 @@ __global__ __launch_bounds__(256, 2) void dp16s_kernel(Dp16Args a) {
 #pragma unroll
                 for (int term = 0; term < 3; ++term) {
 #pragma unroll
-                    for (int t = 0; t < 2; ++t) {
+                    for (int t = 0; t < NT; ++t) {
                         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(term == 2 ? w0l : w0h, term == 1 ? xl[0][t] : xh[0][t], acc[t], 0, 0, 0);
                         accB[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(term == 2 ? w1l : w1h, term == 1 ? xl[1][t] : xh[1][t], accB[t], 0, 0, 0);
                     }
@@ -406,8 +425,8 @@ __global__ __launch_bounds__(256, 2) void dp16s_kernel(Dp16Args a) {
         if (n0 + cseq < a.nseq) {
             const size_t base = seq_base(cseq);
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int p = 64 * cpart + 32 * t + r;
+            for (int t = 0; t < NT; ++t) {
+                const int p = 32 * NT * cpart + 32 * t + r;
                 if (p < Ls) {
 #pragma unroll
                     for (int q = 0; q < 16; ++q) {
@@ -425,18 +444,19 @@ size_t dp16s_lds_bytes(int Ls, int nseq_per_wg) {
     return (size_t)2 * WBUF + (size_t)2 * nseq_per_wg * (Ls + 1) * HLD * 2 + (size_t)nseq_per_wg * 2 * 32 * 4;
 }
 
-template <int NSEQ, bool PAIRED>
+template <int NSEQ, bool PAIRED, int NT>
 static int launch_dp16s_t(const Dp16Args& a, hipStream_t st) {
     const size_t lds = dp16s_lds_bytes(a.Ls, NSEQ);
     if (lds > 80 * 1024) return RTFS_ERR_SHAPE;  // two workgroups per CU
+    constexpr int NTHR = NT == 2 ? 256 : 512;
     if (a.stamps) {
-        if (rtfs_set_max_lds((const void*)dp16s_kernel<NSEQ, PAIRED, true>, lds) != RTFS_OK) return RTFS_ERR_LAUNCH;
-        hipLaunchKernelGGL((dp16s_kernel<NSEQ, PAIRED, true>), dim3(cdiv(a.nseq, NSEQ)), dim3(256), lds, st, a);
+        if (rtfs_set_max_lds((const void*)dp16s_kernel<NSEQ, PAIRED, NT, true>, lds) != RTFS_OK) return RTFS_ERR_LAUNCH;
+        hipLaunchKernelGGL((dp16s_kernel<NSEQ, PAIRED, NT, true>), dim3(cdiv(a.nseq, NSEQ)), dim3(NTHR), lds, st, a);
         return rtfs_launch_status();
     }
-    if (rtfs_set_max_lds((const void*)dp16s_kernel<NSEQ, PAIRED>, lds) != RTFS_OK) return RTFS_ERR_LAUNCH;
+    if (rtfs_set_max_lds((const void*)dp16s_kernel<NSEQ, PAIRED, NT>, lds) != RTFS_OK) return RTFS_ERR_LAUNCH;
     void* slot = dualpath_timing_begin(a.Ls, a.nseq, st);
-    hipLaunchKernelGGL((dp16s_kernel<NSEQ, PAIRED>), dim3(cdiv(a.nseq, NSEQ)), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((dp16s_kernel<NSEQ, PAIRED, NT>), dim3(cdiv(a.nseq, NSEQ)), dim3(NTHR), lds, st, a);
     dualpath_timing_end(slot, st);
     return rtfs_launch_status();
 }
@@ -445,8 +465,10 @@ static int launch_dp16s_t(const Dp16Args& a, hipStream_t st) {
 int launch_dualpath16s(const Dp16Args& a0, hipStream_t st) {
     const int L = a0.Ls - 7;
     if (L < 1 || L > 128) return RTFS_ERR_SHAPE;
-    static const int stagger = getenv("RTFS_SWEEP_STAGGER") ? atoi(getenv("RTFS_SWEEP_STAGGER")) : 14;
+    static const int stagger = getenv("RTFS_SWEEP_STAGGER") ? atoi(getenv("RTFS_SWEEP_STAGGER")) : 0;
+    static const int nt = getenv("RTFS_SWEEP_NT") ? atoi(getenv("RTFS_SWEEP_NT")) : 2;  // row tiles per wave: 2 = 4-wave, 1 = 8-wave workgroups
     Dp16Args a = a0;
     a.stagger = cdiv(a.nseq, L <= 64 ? 2 : 1) > 512 ? stagger : 0;  // only when a CU's two slots run several workgroups each
-    return L <= 64 ? launch_dp16s_t<2, true>(a, st) : launch_dp16s_t<1, false>(a, st);
+    if (nt == 1) return L <= 64 ? launch_dp16s_t<2, true, 1>(a, st) : launch_dp16s_t<1, false, 1>(a, st);
+    return L <= 64 ? launch_dp16s_t<2, true, 2>(a, st) : launch_dp16s_t<1, false, 2>(a, st);
 }
