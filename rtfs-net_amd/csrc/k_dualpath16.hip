@@ -364,7 +364,10 @@ __global__ __launch_bounds__(512) void dp16_kernel(Dp16Args a) {
         for (int t = 0; t < 2; ++t) {
             const int p = min(64 * cpart + 32 * t + r, Ls - 1);
 #pragma unroll
-            for (int q = 0; q < 16; ++q) res[t][q] = a.x[rbase + (size_t)(ccot * 32 + (q & 3) + 8 * (q >> 2) + 4 * h) * a.cstride + p];
+            for (int q = 0; q < 16; ++q) {  // residual + conv-transpose bias, both fetched under the GEMM (the bias loads in the epilogue cost 5 %)
+                const int co = ccot * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+                res[t][q] = a.x[rbase + (size_t)co * a.cstride + p] + a.bt[co];
+            }
         }
         // chunk 0 is already staged; the barrier that ended the layer-3 scan ordered the hidden outputs.
         // 8 chunks of 64 k' (one tap kk each): staged image [hi|lo][64 co][64 + 8 pad]
@@ -404,7 +407,7 @@ __global__ __launch_bounds__(512) void dp16_kernel(Dp16Args a) {
 #pragma unroll
                     for (int q = 0; q < 16; ++q) {
                         const int co = cot * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
-                        a.out[base + (size_t)co * a.cstride + p] = fmaf(acc[t][q], WINV, a.bt[co]) + res[t][q];
+                        a.out[base + (size_t)co * a.cstride + p] = fmaf(acc[t][q], WINV, res[t][q]);
                     }
                 }
             }
