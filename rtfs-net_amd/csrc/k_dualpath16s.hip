@@ -267,10 +267,13 @@ __global__ __launch_bounds__(NT == 2 ? 256 : 512, NT == 2 ? 2 : 4) void dp16s_ke
             __syncthreads();  // step g consumed by every wave, step g + 1 visible
             ++g;
         };
+        if (a.prio == 1) __builtin_amdgcn_s_setprio(1);  // GEMM phases over the co-resident workgroup's (latency-bound) recurrence
+        if (a.prio == 2) __builtin_amdgcn_s_setprio(3);
         for (int q = 0; q < nchunk; q += 2) {
             kstep(q, S0);
             kstep(q + 1, S1);
         }
+        if (a.prio) __builtin_amdgcn_s_setprio(0);
         // (that barrier also means: every wave has finished reading the activation planes - the scan may overwrite them in place)
         stamp();  // 2,4,6,8: GEMM of layer done
         // undo the 2^8 weight prescale on all 128 accumulators now, on every wave at once, so the serialised per-part recurrence
@@ -466,8 +469,10 @@ int launch_dualpath16s(const Dp16Args& a0, hipStream_t st) {
     const int L = a0.Ls - 7;
     if (L < 1 || L > 128) return RTFS_ERR_SHAPE;
     static const int stagger = getenv("RTFS_SWEEP_STAGGER") ? atoi(getenv("RTFS_SWEEP_STAGGER")) : 0;
+    static const int prio = getenv("RTFS_SWEEP_PRIO") ? atoi(getenv("RTFS_SWEEP_PRIO")) : 0;
     static const int nt = getenv("RTFS_SWEEP_NT") ? atoi(getenv("RTFS_SWEEP_NT")) : 2;  // row tiles per wave: 2 = 4-wave, 1 = 8-wave workgroups
     Dp16Args a = a0;
+    a.prio = prio;
     a.stagger = cdiv(a.nseq, L <= 64 ? 2 : 1) > 512 ? stagger : 0;  // only when a CU's two slots run several workgroups each
     if (nt == 1) return L <= 64 ? launch_dp16s_t<2, true, 1>(a, st) : launch_dp16s_t<1, false, 1>(a, st);
     return L <= 64 ? launch_dp16s_t<2, true, 2>(a, st) : launch_dp16s_t<1, false, 2>(a, st);

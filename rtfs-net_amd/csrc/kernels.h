@@ -210,6 +210,7 @@ struct Dp16Args {
     const float* bt = nullptr;      // (64)
     unsigned long long* stamps = nullptr;  // diagnostic build only: [workgroups][16] s_memtime stamps
     int stagger = 0;                       // generation 3: start delay of a CU's second workgroup, units of 4096 cycles
+    int prio = 0;                          // generation 3: s_setprio level of the GEMM phases (experiment knob)
 };
 size_t dp16_lds_bytes(int Ls, int nseq_per_wg);
 int launch_dualpath16(const Dp16Args& a, hipStream_t st);
