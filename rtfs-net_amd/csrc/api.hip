@@ -36,6 +36,7 @@ struct DpPack {
     const float *ln_g, *ln_b, *W0, *Wl, *wc = nullptr, *bias, *Wt, *bt;
     const float *w16_l0 = nullptr, *w16_l = nullptr, *w16_ct = nullptr, *wc16 = nullptr, *bias16 = nullptr;  // f16x3 images (k_dualpath16.hip)
     const float *wf_l0 = nullptr, *wf_l = nullptr, *wf_ct = nullptr;  // the same images in fragment order (k_dualpath16s.hip)
+    const float *wg_l0 = nullptr, *wg_l = nullptr, *wg_ct = nullptr;  // ... split by GEMM pass (k_dualpath16t.hip)
     const float* whh = nullptr;  // LSTM cell only
     explicit DpPack(Cursor& c, int rnn_kind = 0) {
         ln_g = c.take(CH);
@@ -63,6 +64,9 @@ struct DpPack {
         wf_l0 = c.take(512 * 256);
         wf_l = c.take(3 * 64 * 256);
         wf_ct = c.take(512 * 64);
+        wg_l0 = c.take(512 * 256);
+        wg_l = c.take(3 * 64 * 256);
+        wg_ct = c.take(512 * 64);
     }
 };
 struct AttnPack {
@@ -210,6 +214,9 @@ Dp16Args dp16_args(const DpPack& p, const float* x, float* out, int nseq, int R,
     a.wf_l0 = reinterpret_cast<const half8*>(p.wf_l0);
     a.wf_l = reinterpret_cast<const half8*>(p.wf_l);
     a.wf_ct = reinterpret_cast<const half8*>(p.wf_ct);
+    a.wg_l0 = reinterpret_cast<const half8*>(p.wg_l0);
+    a.wg_l = reinterpret_cast<const half8*>(p.wg_l);
+    a.wg_ct = reinterpret_cast<const half8*>(p.wg_ct);
     a.wc16 = p.wc16;
     a.bias16 = p.bias16;
     a.bt = p.bt;

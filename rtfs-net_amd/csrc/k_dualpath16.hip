@@ -444,6 +444,8 @@ int launch_dualpath16(const Dp16Args& a, hipStream_t st) {
     if (L < 1 || L > 256) return RTFS_ERR_SHAPE;
     // 2 s inputs (L <= 128): the two-workgroups-per-CU generation (k_dualpath16s.hip); RTFS_SWEEP_GEN2=1 keeps this file's kernels for A/B
     static const bool gen2 = getenv("RTFS_SWEEP_GEN2") != nullptr;
+    static const bool gen4 = getenv("RTFS_SWEEP_GEN4") != nullptr;  // experiment: two-pass GEMM, three workgroups per CU
+    if (L <= 128 && gen4) return launch_dualpath16t(a, st);
     if (L <= 128 && !gen2) return launch_dualpath16s(a, st);
     if (a.stamps) {
         if (L <= 64) return launch_dp16_stamp_t<4, 2, true>(a, st);

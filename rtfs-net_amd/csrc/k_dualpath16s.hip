@@ -34,6 +34,9 @@
 #define HLD 72          // activation row stride (halfs): 144-byte rows -> conflict-free b128 fragment reads
 #define WBUF 16384      // one staged K step of the weight stream (bytes)
 #define WINV (1.0f / 256.0f)
+#ifndef DP16S_SGB
+#define DP16S_SGB 1
+#endif
 
 namespace {
 
@@ -219,8 +222,8 @@ __global__ __launch_bounds__(NT == 2 ? 256 : 512, NT == 2 ? 2 : 4) void dp16s_ke
         const half8* const gsrc = layer == 0 ? a.wf_l0 : a.wf_l + (size_t)(layer - 1) * 4 * 1024;
         // what follows this layer in the stream: the next layer's steps, then the conv-transpose's taps
         const half8* const gnext = layer < 3 ? a.wf_l + (size_t)layer * 4 * 1024 : a.wf_ct;
-        // MFMA issue order: the three split-precision terms of one accumulator must not follow each other (a dependent MFMA issues 48 ticks
-        // after its predecessor, independent ones every 16-32): a gate-tile pair is issued term-major over its four accumulators.
+        // (MFMA order: tools/mfma_rate.hip measures 32.5 ticks per v_mfma_f32_32x32x16_f16 whether 1, 2, 4 or 8 accumulators rotate - a
+        // dependent chain costs nothing, so the order of the three split-precision terms is free; term-major is kept, it is harmless.)
         // `tiles` consecutive gate tiles from m0, term-major: NT = 2 issues pairs (4 accumulators), NT = 1 all four gate tiles at once
         auto gate_tiles = [&](int m0, auto ntile_c, const half8 (&ah)[NT], const half8 (&al)[NT], const half8* __restrict__ wb) {
             constexpr int NM = decltype(ntile_c)::value;
@@ -254,7 +257,58 @@ __global__ __launch_bounds__(NT == 2 ? 256 : 512, NT == 2 ? 2 : 4) void dp16s_ke
                 al[t] = *reinterpret_cast<const half8*>(Hl + rowbase[t] + aoff);
             }
             const half8* wb = Wst + (g & 1) * 1024 + dir * 512 + lane;
-            if (NT == 2) {
+            if (NT == 2 && DP16S_SGB) {
+                // Hand-pinned issue order (sched_group_barrier): the wave's 12 fragment reads, 4 staging writes and 4 prefetch loads are
+                // spread over the gaps between its 24 MFMAs instead of clustered in front of them (an MFMA holds the issue port for 8 of
+                // its 32 cycles): only the first six reads and the barrier stay exposed.
+                half8 bh[4], bl[4];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    bh[m] = wb[m * 128];
+                    bl[m] = wb[m * 128 + 64];
+                }
+                auto tile6 = [&](int m) {
+#pragma unroll
+                    for (int term = 0; term < 3; ++term)
+#pragma unroll
+                        for (int t = 0; t < 2; ++t)
+                            acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(term == 2 ? al[t] : ah[t], term == 1 ? bl[m] : bh[m], acc[t][m], 0, 0, 0);
+                };
+                tile6(0);
+                tile6(1);
+                stage_write(set_c, (g + 1) & 1);
+                tile6(2);
+                stage_load(set_c, q + 3 < nchunk ? gsrc + (size_t)(q + 3) * 1024 : gnext + (size_t)(q + 3 - nchunk) * 1024);
+                tile6(3);
+                __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);  // A (4) + B tile 0 (2)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {  // tile 0: the reads of tile 1 in its first gaps
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {  // tile 1: reads of tile 2, then the staging writes
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {  // tile 2: reads of tile 3, then the prefetch loads
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+            } else if (NT == 2) {
                 gate_tiles(0, std::integral_constant<int, 2>(), ah, al, wb);
                 stage_write(set_c, (g + 1) & 1);
                 stage_load(set_c, q + 3 < nchunk ? gsrc + (size_t)(q + 3) * 1024 : gnext + (size_t)(q + 3 - nchunk) * 1024);
@@ -365,7 +419,7 @@ __global__ __launch_bounds__(NT == 2 ? 256 : 512, NT == 2 ? 2 : 4) void dp16s_ke
     // ---------------- ConvTranspose1d(64->64, k=8) + bias + residual (rnn_layers.py:153-156), transposed:
     //   y[co][t] = bt[co] + sum_{kk,ci} Wt[co][kk*64+ci] * H[t-kk][ci];  wave = (sequence, co tile, position part)
     {
-        // four accumulators: the sum over k is split by ks parity, so no MFMA follows a dependent one (see the issue-order note above)
+        // two partial sums per position tile (k steps of even / odd parity)
         f32x16 acc[NT], accB[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t)

@@ -205,6 +205,9 @@ struct Dp16Args {
     // the same three images in MFMA fragment order (generation 3, k_dualpath16s.hip): [K step 16][dir][gate tile m][hi|lo][lane] x half8 with
     // lane (h, r) = W[k = 16 step + 8 h + j][col = dir*128 + m*32 + r]; conv-transpose: [tap][co tile][ks][hi|lo][lane], W[co = 32 tile + r][k = 16 ks + 8 h + j]
     const half8 *wf_l0 = nullptr, *wf_l = nullptr, *wf_ct = nullptr;
+    // ... and split by GEMM pass (generation 4, k_dualpath16t.hip): [pass][K step][dir][gate tile of the pass 2][hi|lo][lane] (8 KB per step);
+    // conv-transpose: [tap][k half][co tile][ks' 2][hi|lo][lane]
+    const half8 *wg_l0 = nullptr, *wg_l = nullptr, *wg_ct = nullptr;
     const float* wc16 = nullptr;    // 4 x (128): v_f, v_r scaled by -log2(e)
     const float* bias16 = nullptr;  // 4 x (128): b_f, b_r scaled by -log2(e)
     const float* bt = nullptr;      // (64)
@@ -217,6 +220,7 @@ int launch_dualpath16(const Dp16Args& a, hipStream_t st);
 // generation 3 (k_dualpath16s.hip): 256-thread workgroups, two per CU, L <= 128; launch_dualpath16 routes to it
 size_t dp16s_lds_bytes(int Ls, int nseq_per_wg);
 int launch_dualpath16s(const Dp16Args& a, hipStream_t st);
+int launch_dualpath16t(const Dp16Args& a, hipStream_t st);  // generation 4 (experiment): two GEMM passes per layer, three workgroups per CU
 void* dualpath_timing_begin(int Ls, int nseq, hipStream_t st);
 void dualpath_timing_end(void* slot, hipStream_t st);
 

@@ -12,6 +12,8 @@ torch.manual_seed(0)
 m = R.AVNet(print_macs=False, **copy.deepcopy(RTFS4_AUDIONET)).cuda().eval()
 blk = m.refinement_module.audio_net.blocks
 names = ["start", "load+LN", "L0 gemm", "L0 scan", "L1 gemm", "L1 scan", "L2 gemm", "L2 scan", "L3 gemm", "L3 scan", "convT gemm", "epilogue"]
+if os.environ.get("RTFS_SWEEP_GEN4"):
+    names = ["start", "load+LN"] + [f"L{l} {w}" for l in range(4) for w in ("gemm A", "chain", "gemm B + gates")] + ["convT gemm", "epilogue"]
 GEN2 = bool(os.environ.get("RTFS_SWEEP_GEN2"))  # generation 2: 4 / 2 sequences per 512-thread workgroup; generation 3: 2 / 1 per 256-thread workgroup
 for label, dp, Rr, Ls, per in [("F-path", blk.globalatt[0], 125, 64, 4 if GEN2 else 2), ("T-path", blk.globalatt[1], 64, 125, 2 if GEN2 else 1)]:
     B = int(os.environ.get('STAMP_B', '32'))
@@ -23,14 +25,15 @@ for label, dp, Rr, Ls, per in [("F-path", blk.globalatt[0], 125, 64, 4 if GEN2 e
         _lib.check(lib.rtfs_debug_sweep_stamps(_lib.ptr(x), _lib.ptr(dp.pack()), _lib.ptr(out), B, Rr, Ls, _lib.ptr(st), _lib.stream_of(x)), "stamps")
     torch.cuda.synchronize()
     s = st.cpu().numpy().astype(np.float64)
-    d = np.diff(s[:, :12], axis=1)
-    print(f"== {label}: {nwg} workgroups; cycles per phase (median / mean), total median {np.median(s[:,11]-s[:,0]):.0f}")
-    for i in range(11):
+    NS = len(names)
+    d = np.diff(s[:, :NS], axis=1)
+    print(f"== {label}: {nwg} workgroups; cycles per phase (median / mean), total median {np.median(s[:,NS-1]-s[:,0]):.0f}")
+    for i in range(NS - 1):
         print(f"   {names[i+1]:12s} {np.median(d[:, i]):9.0f} {d[:, i].mean():9.0f}")
     raw = st.cpu().numpy()[:, 12:15].astype(np.uint64)
     dl = np.stack([raw & np.uint64(0xFFFFFFFF), raw >> np.uint64(32)], -1).reshape(len(raw), 6).astype(np.float64)
     if dl.any():
         print("   inside K step 9 of layer 0, wave 0, issue-time deltas (median): B tiles 2-3 read issue %.0f | tiles 0-1 (12 MFMA) %.0f | staging %.0f | "
               "barrier %.0f | next-step reads issue %.0f | tiles 2-3 (12 MFMA) %.0f" % tuple(np.median(dl, axis=0)))
-    t0 = s[:, 0].min(); t1 = s[:, 11].max()
+    t0 = s[:, 0].min(); t1 = s[:, NS - 1].max()
     print(f"   kernel span {t1 - t0:.0f} ticks (s_memtime 100MHz?)")
