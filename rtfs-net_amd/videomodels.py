@@ -1,6 +1,6 @@
 """Video front-end of the reference on the MI355X path: ``FRCNNVideoModel`` (ResNet-18 trunk, PReLU), reference
-``src/models/videomodels/frcnn_videomodel.py:16-72`` / ``resnet.py:23-118`` -- same class names, constructor keywords and
-``state_dict`` keys.  ``forward`` (eval mode) marshals one call into ``rtfs_video_frontend_f32`` (implicit-GEMM convolutions
+``src/models/videomodels/frcnn_videomodel.py:16-72`` / ``resnet.py:23-118`` -- same model class, constructor keywords and
+``state_dict`` keys (the trunk is a table-built tree of parameter holders).  ``forward`` (eval mode) marshals one call into ``rtfs_video_frontend_f32`` (implicit-GEMM convolutions
 on the f16 matrix cores, ``csrc/k_video.hip``); there is no CPU fallback.  Only the ``resnet`` backbone with
 ``relu_type="prelu"`` (what the RTFS-Net recipes load) is on this path.
 """
@@ -14,66 +14,57 @@ import torch.nn as nn
 from . import _lib, packing
 
 
-def conv3x3(in_planes, out_planes, stride=1):
-    return nn.Conv2d(in_planes, out_planes, kernel_size=3, stride=stride, padding=1, bias=False)
+# The trunk holds no arithmetic here (the fused front-end call does it all): it is a tree of parameter holders whose
+# state_dict keys, order, shapes and default initialisation are those a reference checkpoint carries (resnet.py:23-118).
+# One row per residual stage: (stage name, input width, width, stride of its first unit); two units per stage.
+_TRUNK_STAGES = (("layer1", 64, 64, 1), ("layer2", 64, 128, 2), ("layer3", 128, 256, 2), ("layer4", 256, 512, 2))
+_UNITS_PER_STAGE = 2
 
 
-def downsample_basic_block(inplanes, outplanes, stride):
-    return nn.Sequential(nn.Conv2d(inplanes, outplanes, kernel_size=1, stride=stride, bias=False), nn.BatchNorm2d(outplanes))
+def _unit_entries(cin: int, width: int, stride: int):
+    """(key, kind, dims) of one residual unit, in checkpoint order.  kind: 'c' conv (cout, cin, k, stride), 'n' batch norm
+    (channels), 'a' per-channel PReLU slope (channels)."""
+    rows = [("conv1", "c", (width, cin, 3, stride)), ("bn1", "n", (width,)), ("relu1", "a", (width,)), ("relu2", "a", (width,)),
+            ("conv2", "c", (width, width, 3, 1)), ("bn2", "n", (width,))]
+    if stride != 1 or cin != width:  # the 1x1 projection on the skip path where the shape changes
+        rows.append(("downsample", "s", (("0", "c", (width, cin, 1, stride)), ("1", "n", (width,)))))
+    return rows
 
 
-class BasicBlock(nn.Module):
-    """Parameter container with the reference's keys (resnet.py:23-66); the arithmetic runs in the fused front-end call."""
-    expansion = 1
+def _holder(kind: str, dims) -> nn.Module:
+    if kind == "c":
+        cout, cin, k, stride = dims
+        m = nn.Conv2d(cin, cout, k, stride, k // 2, bias=False)
+        nn.init.normal_(m.weight, 0.0, math.sqrt(2.0 / (k * k * cout)))  # resnet.py:90-94
+        return m
+    if kind == "n":
+        return nn.BatchNorm2d(*dims)  # weight 1, bias 0 (resnet.py:95-97 == torch's default)
+    if kind == "a":
+        return nn.PReLU(num_parameters=dims[0])
+    seq = nn.Sequential()
+    for key, k2, d2 in dims:
+        seq.add_module(key, _holder(k2, d2))
+    return seq
 
-    def __init__(self, inplanes, planes, stride=1, downsample=None, relu_type="relu"):
+
+class _Holders(nn.Module):
+    """A module that only owns named children built from a table."""
+
+    def __init__(self, rows):
         super().__init__()
-        if relu_type != "prelu":
-            raise ValueError("MI355X BasicBlock supports relu_type='prelu'")
-        self.conv1 = conv3x3(inplanes, planes, stride)
-        self.bn1 = nn.BatchNorm2d(planes)
-        self.relu1 = nn.PReLU(num_parameters=planes)
-        self.relu2 = nn.PReLU(num_parameters=planes)
-        self.conv2 = conv3x3(planes, planes)
-        self.bn2 = nn.BatchNorm2d(planes)
-        self.downsample = downsample
-        self.stride = stride
+        for key, kind, dims in rows:
+            self.add_module(key, _holder(kind, dims))
 
 
-class ResNet(nn.Module):
-    """resnet.py:69-118 (layers [2,2,2,2], BasicBlock): parameter container."""
-
-    def __init__(self, block, layers, num_classes=1000, relu_type="relu", gamma_zero=False, avg_pool_downsample=False):
-        super().__init__()
-        if list(layers) != [2, 2, 2, 2] or avg_pool_downsample or block is not BasicBlock:
-            raise ValueError("MI355X ResNet supports BasicBlock [2,2,2,2] with the 1x1-conv downsample")
-        self.inplanes, self.relu_type, self.gamma_zero = 64, relu_type, gamma_zero
-        self.layer1 = self._make_layer(block, 64, layers[0])
-        self.layer2 = self._make_layer(block, 128, layers[1], stride=2)
-        self.layer3 = self._make_layer(block, 256, layers[2], stride=2)
-        self.layer4 = self._make_layer(block, 512, layers[3], stride=2)
-        self.avgpool = nn.AdaptiveAvgPool2d(1)
-        for m in self.modules():  # the reference's default init (resnet.py:90-98)
-            if isinstance(m, nn.Conv2d):
-                n = m.kernel_size[0] * m.kernel_size[1] * m.out_channels
-                m.weight.data.normal_(0, math.sqrt(2.0 / n))
-            elif isinstance(m, nn.BatchNorm2d):
-                m.weight.data.fill_(1)
-                m.bias.data.zero_()
+def _trunk(gamma_zero: bool = False) -> nn.Module:
+    trunk = nn.Module()
+    for name, cin, width, stride in _TRUNK_STAGES:
+        units = [_Holders(_unit_entries(cin if u == 0 else width, width, stride if u == 0 else 1)) for u in range(_UNITS_PER_STAGE)]
         if gamma_zero:
-            for m in self.modules():
-                if isinstance(m, BasicBlock):
-                    m.bn2.weight.data.zero_()
-
-    def _make_layer(self, block, planes, blocks, stride=1):
-        downsample = None
-        if stride != 1 or self.inplanes != planes * block.expansion:
-            downsample = downsample_basic_block(self.inplanes, planes * block.expansion, stride)
-        layers = [block(self.inplanes, planes, stride, downsample, relu_type=self.relu_type)]
-        self.inplanes = planes * block.expansion
-        for _ in range(1, blocks):
-            layers.append(block(self.inplanes, planes, relu_type=self.relu_type))
-        return nn.Sequential(*layers)
+            for u in units:
+                nn.init.zeros_(u.bn2.weight)
+        trunk.add_module(name, nn.Sequential(*units))
+    return trunk
 
 
 class FRCNNVideoModel(nn.Module):
@@ -84,7 +75,7 @@ class FRCNNVideoModel(nn.Module):
         if backbone_type != "resnet" or relu_type != "prelu":
             raise ValueError("MI355X FRCNNVideoModel supports backbone_type='resnet' with relu_type='prelu'")
         self.backbone_type, self.frontend_nout, self.backend_out = backbone_type, 64, 512
-        self.trunk = ResNet(BasicBlock, [2, 2, 2, 2], relu_type=relu_type)
+        self.trunk = _trunk()
         self.frontend3D = nn.Sequential(
             nn.Conv3d(1, 64, kernel_size=(5, 7, 7), stride=(1, 2, 2), padding=(2, 3, 3), bias=False),
             nn.BatchNorm3d(64), nn.PReLU(num_parameters=64),
