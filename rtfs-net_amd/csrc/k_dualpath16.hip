@@ -446,7 +446,10 @@ int launch_dualpath16(const Dp16Args& a, hipStream_t st) {
     static const bool gen2 = getenv("RTFS_SWEEP_GEN2") != nullptr;
     static const bool gen4 = getenv("RTFS_SWEEP_GEN4") != nullptr;  // experiment: two-pass GEMM, three workgroups per CU
     if (L <= 128 && gen4) return launch_dualpath16t(a, st);
-    if (L <= 128 && !gen2) return launch_dualpath16s(a, st);
+    if (L <= 128 && !gen2) {
+        const int rc = launch_dualpath16s(a, st);
+        if (rc != RTFS_ERR_SHAPE) return rc;  // (a tensor spanning >= 4 GB: this file's kernels address with 64 bits)
+    }
     if (a.stamps) {
         if (L <= 64) return launch_dp16_stamp_t<4, 2, true>(a, st);
         if (L <= 128) return launch_dp16_stamp_t<2, 4, true>(a, st);

@@ -31,11 +31,19 @@
 #include <stdlib.h>
 #include <type_traits>
 
-#define HLD 72          // activation row stride (halfs): 144-byte rows -> conflict-free b128 fragment reads
+#define HLD 136         // activation row (halfs): [hi 64 | lo 64 | pad 8] = 272 bytes = 68 dwords (4 mod 32): conflict-free b128 fragment reads,
+#define HLO 64          // and the lo half of an element sits a constant 128 bytes behind its hi half (one address, two immediates)
+#define PADR 8          // rows in front of a sequence's plane that the backward write-back may overshoot into
 #define WBUF 16384      // one staged K step of the weight stream (bytes)
 #define WINV (1.0f / 256.0f)
 #ifndef DP16S_SGB
 #define DP16S_SGB 1
+#endif
+#ifndef DP16S_WBG
+#define DP16S_WBG 8     // write-back steps evaluated together (stage by stage)
+#endif
+#ifndef DP16S_SGB_CT
+#define DP16S_SGB_CT 1  // the conv-transpose taps pinned the same way
 #endif
 
 namespace {
@@ -47,6 +55,18 @@ __device__ __forceinline__ void split8(const float (&v)[8], half8& hi, half8& lo
         hi[i] = hh;
         lo[i] = (_Float16)(v[i] - (float)hh);
     }
+}
+
+// element at (wave-uniform base) + (32-bit lane BYTE offset): global_load / global_store in their saddr + voffset form, no 64-bit vector
+// address arithmetic and no 64-bit address registers (the launcher checks that the whole tensor spans < 4 GB); the empty asm keeps the
+// zero-extension next to the access
+__device__ __forceinline__ float ldo(const float* __restrict__ base, unsigned boff) {
+    asm volatile("" : "+v"(boff));
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + boff);
+}
+__device__ __forceinline__ void sto(float* __restrict__ base, unsigned boff, float v) {
+    asm volatile("" : "+v"(boff));
+    *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + boff) = v;
 }
 
 // sigmoid with the -log2(e) factor already folded into z
@@ -76,11 +96,11 @@ __global__ __launch_bounds__(NT == 2 ? 256 : 512, NT == 2 ? 2 : 4) void dp16s_ke
     constexpr int NTHR = 128 * NPART;               // 2 directions x NPART waves
     constexpr int NPIECE = 1024 / NTHR;             // 16-byte pieces of a staged K step per thread
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
-    const int Ls = a.Ls, L = Ls - 7, rowsH = Ls + 1;  // one extra all-zero row for the conv-transpose borders
+    const int Ls = a.Ls, L = Ls - 7, rowsH = Ls + 1 + PADR;  // per sequence: PADR scratch rows (-PADR .. -1), rows 0 .. Ls - 1, row Ls all zero (conv-transpose borders)
     half8* Wst = reinterpret_cast<half8*>(smem);                          // [2 buffers][1024 pieces of 16 B], fragment order
-    _Float16* Hh = reinterpret_cast<_Float16*>(smem + 2 * WBUF);          // [NSEQ][rowsH][HLD]
-    _Float16* Hl = Hh + NSEQ * rowsH * HLD;
-    float* chand = reinterpret_cast<float*>(Hl + NSEQ * rowsH * HLD);     // [NSEQ][2 dirs][32]
+    _Float16* Hh = reinterpret_cast<_Float16*>(smem + 2 * WBUF) + PADR * HLD;  // row 0 of sequence 0; [NSEQ][rowsH][HLD]: hi halves of a row, then its lo halves
+    _Float16* Hl = Hh + HLO;
+    float* chand = reinterpret_cast<float*>(Hh + (NSEQ * rowsH - PADR) * HLD);  // [NSEQ][2 dirs][32]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -99,6 +119,15 @@ __global__ __launch_bounds__(NT == 2 ? 256 : 512, NT == 2 ? 2 : 4) void dp16s_ke
             __builtin_amdgcn_s_waitcnt(0xC07F);
             if (tid == 0 && nstamp < 16) a.stamps[(size_t)blockIdx.x * 16 + nstamp] = t;
             ++nstamp;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto stamp_at = [&](int slot) {  // diagnostic sub-stamps of layer 1's scan (slots 12-15, thread 0 = time part 0, forward)
+        if (STAMP) {
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            if (tid == 0) a.stamps[(size_t)blockIdx.x * 16 + slot] = t;
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -146,10 +175,10 @@ __global__ __launch_bounds__(NT == 2 ? 256 : 512, NT == 2 ? 2 : 4) void dp16s_ke
         const bool live = task < ntask;
         const int tk = live ? task : ntask - 1;
         const int s = (NSEQ == 2 && tk >= Ls) ? 1 : 0, pos = tk - s * Ls;
-        const float* xp = a.x + seq_base(s) + pos + (size_t)(32 * h) * a.cstride;
+        const unsigned xoff = (unsigned)(seq_base(s) + pos + (size_t)(32 * h) * a.cstride) * 4u;
         float v[32];
 #pragma unroll
-        for (int c = 0; c < 32; ++c) v[c] = xp[(size_t)c * a.cstride];
+        for (int c = 0; c < 32; ++c) v[c] = ldo(a.x + (size_t)c * a.cstride, xoff);
         float sum = 0.f;
 #pragma unroll
         for (int c = 0; c < 32; ++c) sum += v[c];
@@ -175,13 +204,12 @@ __global__ __launch_bounds__(NT == 2 ? 256 : 512, NT == 2 ? 2 : 4) void dp16s_ke
                 *reinterpret_cast<half8*>(dl + c8 * 8) = lo;
             }
         }
-        if (tid < NSEQ * 9) {  // the zero rows (72 halfs = 9 x 16 B each)
+        if (tid < NSEQ * 16) {  // the zero rows (hi + lo: 128 halfs = 16 x 16 B each)
             half8 z;
 #pragma unroll
             for (int i = 0; i < 8; ++i) z[i] = (_Float16)0.f;
-            const int zs = tid / 9, pc = tid % 9;
+            const int zs = tid / 16, pc = tid % 16;
             *reinterpret_cast<half8*>(Hh + (zs * rowsH + Ls) * HLD + pc * 8) = z;
-            *reinterpret_cast<half8*>(Hl + (zs * rowsH + Ls) * HLD + pc * 8) = z;
         }
     }
 
@@ -330,18 +358,27 @@ __global__ __launch_bounds__(NT == 2 ? 256 : 512, NT == 2 ? 2 : 4) void dp16s_ke
         if (a.prio) __builtin_amdgcn_s_setprio(0);
         // (that barrier also means: every wave has finished reading the activation planes - the scan may overwrite them in place)
         stamp();  // 2,4,6,8: GEMM of layer done
-        // undo the 2^8 weight prescale on all 128 accumulators now, on every wave at once, so the serialised per-part recurrence
-        // below is the bare dependency chain
+        // undo the 2^8 weight prescale.  Time part 0 is on the critical path: only what its chain reads (gates 0, 1) now, the rest in
+        // front of its write-back; the later parts scale everything while they wait for the hand-off.  (The empty asm pins the products
+        // here: the compiler sinks the multiplies into the serialised sections otherwise.)
+        auto unscale = [&](int m0) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+            for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
+                for (int m = m0; m < m0 + 2; ++m) {
 #pragma unroll
-                for (int q = 0; q < 16; ++q) acc[t][m][q] *= WINV;
+                    for (int q = 0; q < 16; ++q) acc[t][m][q] *= WINV;
+                    asm volatile("" : "+v"(acc[t][m]));
+                }
+        };
+        unscale(0);
+        if (part != 0) unscale(2);
         __builtin_amdgcn_sched_barrier(0);
+        if (layer == 1) stamp_at(12);  // prescale undone
         float cin[NT];  // c_{t-1} of register 0 of tile t (this lane's run)
 #pragma unroll
         for (int t = 0; t < NT; ++t) cin[t] = 0.f;
+        if (a.prio >= 3) __builtin_amdgcn_s_setprio(3);  // the serial chain is this workgroup's critical path: issue it ahead of the neighbour's GEMM
         for (int hp = 0; hp < NPART; ++hp) {
             if (part == hp) {
                 float c = hp > 0 ? chand[(seq * 2 + dir) * 32 + r] : 0.f;
@@ -362,20 +399,21 @@ __global__ __launch_bounds__(NT == 2 ? 256 : 512, NT == 2 ? 2 : 4) void dp16s_ke
                     }
                     chand[(seq * 2 + dir) * 32 + r] = c;
                 } else {
-                    // the two lane halves hold steps 16 h + q of a tile: they take turns, 16 steps each; the idle half runs the same
-                    // instructions on its own (not yet / no longer needed) registers and keeps them unchanged
+                    // the two lane halves hold steps 16 h + q of a tile: they take turns, 16 steps each
 #pragma unroll
                     for (int t = 0; t < NT; ++t) {
 #pragma unroll
                         for (int ph = 0; ph < 2; ++ph) {
-                            if (h == ph) cin[t] = c;
                             float cr = c;
+                            if (h == ph) {  // (an exec mask, not a select per step: the other half's registers stay as they are)
+                                cin[t] = c;
 #pragma unroll
-                            for (int q = 0; q < 16; ++q) {
-                                const float u0 = acc[t][0][q];
-                                const float f = sig2(fmaf(vf, cr, acc[t][1][q]));
-                                cr = fmaf(cr - u0, f, u0);
-                                acc[t][0][q] = h == ph ? cr : u0;
+                                for (int q = 0; q < 16; ++q) {
+                                    const float u0 = acc[t][0][q];
+                                    const float f = sig2(fmaf(vf, cr, acc[t][1][q]));
+                                    cr = fmaf(cr - u0, f, u0);
+                                    acc[t][0][q] = cr;
+                                }
                             }
                             c = take_half(cr, ph);
                         }
@@ -383,35 +421,78 @@ __global__ __launch_bounds__(NT == 2 ? 256 : 512, NT == 2 ? 2 : 4) void dp16s_ke
                     if (h == 0) chand[dir * 32 + r] = c;
                 }
             }
-            __syncthreads();  // cell state published: the next time part starts while this one writes back
+            if (layer == 1 && hp == 0) stamp_at(13);  // part 0's chain done
+            if (hp + 1 < NPART) __syncthreads();  // cell state published: the next time part starts while this one writes back
+            if (layer == 1 && hp == 0) stamp_at(14);
+            if (a.prio == 4 && part == hp) __builtin_amdgcn_s_setprio(0);  // (4: only the chain itself runs at high priority)
             if (part == hp) {
+                if (hp == 0) unscale(2);
                 // deferred reset gate + highway: h = x' + (c_t - x') r(c_{t-1}); hidden outputs (this wave's direction half of the
-                // channels) go back into the planes in place
+                // channels) go back into the planes in place: 9 vector instructions + 2 two-byte stores a step, no branch per step (that
+                // made every step its own basic block - exp, rcp, converts and stores at their full latencies, ~125 cycles a step).
+                // Addresses in BYTES: one lane base + an IMMEDIATE per step (the direction is a compile-time constant inside `wb`: per-step scalar
+                // row arithmetic - add, min, multiply, all dependent - cost 20 of a step's 85 cycles, tools/chain_rate.hip).  WBG steps at a
+                // time, stage by stage (a step is a chain of dependent instructions with two transcendentals in it); a group is skipped when
+                // its first step lies beyond the sequence end, the up to WBG - 1 steps behind the end inside a group land in rows L .. L + WBG - 2
+                // (forward; free since layer 0's GEMM) or in the PADR rows in front of the plane (backward).
                 const int tau0 = STEPS * part;
-                int o0 = (seq * rowsH + (dir ? L - 1 - tau0 : tau0)) * HLD + dir * 32 + r;
-                asm volatile("" : "+v"(o0));  // opaque per layer: keeps 32 derived addresses from being hoisted + spilled
-                const int ostep = dir ? -HLD : HLD;
-                const int nvalid = L - tau0;
+                char* const Hb = reinterpret_cast<char*>(Hh);
+                constexpr int ROWB = HLD * 2, TSTEP = PAIRED ? 16 : 32, KMAX = (NT - 1) * TSTEP + 15, WBG = DP16S_WBG;
+                static_assert(WBG <= PADR && WBG <= 8 && 16 % WBG == 0, "overshoot of a group: at most WBG - 1 rows, 7 free rows behind the sequence end");
+                const int lane_t0 = PAIRED ? tau0 : tau0 + 16 * h;  // first step of this lane's run in tile 0
+                const int col = (seq * rowsH * HLD + dir * 32 + r) * 2;
+                auto wb = [&](auto bw_c) {
+                    constexpr bool BW = decltype(bw_c)::value;
+                    int base = col + (BW ? L - 1 - lane_t0 - KMAX : lane_t0) * ROWB;
+                    asm volatile("" : "+v"(base));  // opaque per layer
 #pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    float cprev = cin[t];
+                    for (int t = 0; t < NT; ++t) {
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) {
-                        const int idx = PAIRED ? 16 * t + q : 32 * t + 16 * h + q;
-                        const float ct = acc[t][0][q];
-                        const float gte = sig2(fmaf(vr, cprev, acc[t][2][q])), xp = acc[t][3][q];
-                        cprev = ct;
-                        const float hv = fmaf(ct - xp, gte, xp);
-                        if (idx < nvalid) {
-                            const _Float16 hh = (_Float16)hv;
-                            const int o = o0 + idx * ostep;
-                            Hh[o] = hh;
-                            Hl[o] = (_Float16)(hv - (float)hh);
+                        for (int q4 = 0; q4 < 16; q4 += WBG) {
+                            if (lane_t0 + TSTEP * t + q4 < L) {
+                                float z[WBG], d[WBG], hv[WBG];
+                                _Float16 hh[WBG];
+                                unsigned lo[WBG];
+#pragma unroll
+                                for (int i = 0; i < WBG; ++i) {
+                                    const int q = q4 + i;
+                                    z[i] = fmaf(vr, q == 0 ? cin[t] : acc[t][0][q - 1], acc[t][2][q]);
+                                    d[i] = acc[t][0][q] - acc[t][3][q];
+                                }
+#pragma unroll
+                                for (int i = 0; i < WBG; ++i) z[i] = __builtin_amdgcn_exp2f(z[i]);
+#pragma unroll
+                                for (int i = 0; i < WBG; ++i) z[i] = 1.0f + z[i];
+#pragma unroll
+                                for (int i = 0; i < WBG; ++i) z[i] = __builtin_amdgcn_rcpf(z[i]);
+#pragma unroll
+                                for (int i = 0; i < WBG; ++i) {
+                                    hv[i] = fmaf(d[i], z[i], acc[t][3][q4 + i]);
+                                    hh[i] = (_Float16)hv[i];
+                                }
+#pragma unroll
+                                for (int i = 0; i < WBG; ++i)  // (f16)(hv - hh) in one instruction
+                                    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(lo[i]) : "v"(hv[i]), "v"(hh[i]));
+#pragma unroll
+                                for (int i = 0; i < WBG; ++i) {
+                                    const int k = TSTEP * t + q4 + i;
+                                    char* const o = Hb + base + (BW ? KMAX - k : k) * ROWB;
+                                    *reinterpret_cast<_Float16*>(o) = hh[i];
+                                    *reinterpret_cast<unsigned short*>(o + HLO * 2) = (unsigned short)lo[i];
+                                }
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
                         }
                     }
-                }
+                };
+                if (dir)
+                    wb(std::true_type());
+                else
+                    wb(std::false_type());
             }
         }
+        if (layer == 1) stamp_at(15);  // part 0's write-back done and the loop's last barrier passed: waiting for part 1's write-back
+        if (a.prio >= 3) __builtin_amdgcn_s_setprio(0);
         __syncthreads();  // all hidden outputs of this layer are in the planes
         stamp();  // 3,5,7,9: scan of layer done
     }
@@ -419,25 +500,29 @@ __global__ __launch_bounds__(NT == 2 ? 256 : 512, NT == 2 ? 2 : 4) void dp16s_ke
     // ---------------- ConvTranspose1d(64->64, k=8) + bias + residual (rnn_layers.py:153-156), transposed:
     //   y[co][t] = bt[co] + sum_{kk,ci} Wt[co][kk*64+ci] * H[t-kk][ci];  wave = (sequence, co tile, position part)
     {
-        // two partial sums per position tile (k steps of even / odd parity)
-        f32x16 acc[NT], accB[NT];
+        // one accumulator per position tile (a dependent MFMA chain issues at the full rate, tools/mfma_rate.hip: separate partial sums
+        // per k-step parity bought nothing and cost 32 registers)
+        f32x16 acc[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int q = 0; q < 16; ++q) acc[t][q] = accB[t][q] = 0.f;
+            for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
         // the residual rows of the epilogue are requested now and arrive under the GEMM (clamped addresses: dead
         // sequences / positions read a valid element that is never stored)
+        // channel co = 32 ccot + (q & 3) + 8 (q >> 2) + 4 h: the q part of the address is wave-uniform (scalar base), the rest one lane offset
         float res[NT][16];
-        const size_t rbase = seq_base(cseq);
+        const size_t rbase = seq_base(cseq) + (size_t)(ccot * 32) * a.cstride;  // uniform
+        unsigned eoff[NT];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int p = min(32 * NT * cpart + 32 * t + r, Ls - 1);
+        for (int t = 0; t < NT; ++t) eoff[t] = (unsigned)(rbase + (size_t)(4 * h) * a.cstride + min(32 * NT * cpart + 32 * t + r, Ls - 1)) * 4u;
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int co = ccot * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
-                res[t][q] = a.x[rbase + (size_t)co * a.cstride + p] + a.bt[co];  // residual + conv-transpose bias, both fetched under the GEMM
-            }
+        for (int q = 0; q < 16; ++q) {
+            const int cq = (q & 3) + 8 * (q >> 2);
+            const float btq = a.bt[ccot * 32 + cq + 4 * h];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) res[t][q] = ldo(a.x + (size_t)cq * a.cstride, eoff[t]) + btq;  // residual + conv-transpose bias, fetched under the GEMM
         }
+        __builtin_amdgcn_sched_barrier(0);  // (the residual requests stay out of the taps' pinned schedule)
         // tap 0 is staged in buffer g & 1, taps 1 and 2 in the register sets; 8 taps of 64 k' each
         auto tap = [&](int q, auto set_c) {
             int hrow[NT];
@@ -447,29 +532,55 @@ __global__ __launch_bounds__(NT == 2 ? 256 : 512, NT == 2 ? 2 : 4) void dp16s_ke
                 hrow[t] = (cseq * rowsH + ((p >= 0 && p < L) ? p : Ls)) * HLD + 8 * h;
             }
             const half8* wb = Wst + (g & 1) * 1024 + ccot * 512 + lane;
+            // all fragment reads of the tap first in program order, in the order they are needed (the staging write below may alias the
+            // weight reads as far as the compiler knows, so it can only be scheduled behind the last of them); two k steps x two position
+            // tiles = four accumulators.  Term order (wh xh), (wl xh), (wh xl): xh and wl are dead after eight of a block's twelve MFMAs,
+            // so the next block's fragments arrive into their registers (with xl last the pinned order needed 18 live fragments and spilled)
+            half8 xh[4][NT], xl[4][NT], wh[4], wl[4];
 #pragma unroll
-            for (int k2 = 0; k2 < 4; k2 += 2) {  // two k steps x two position tiles = four accumulators, issued term-major
-                half8 xh[2][NT], xl[2][NT];
+            for (int k2 = 0; k2 < 4; k2 += 2) {
 #pragma unroll
-                for (int kk = 0; kk < 2; ++kk)
+                for (int kk = k2; kk < k2 + 2; ++kk) wh[kk] = wb[kk * 128];
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) {
-                        xh[kk][t] = *reinterpret_cast<const half8*>(Hh + hrow[t] + (k2 + kk) * 16);
-                        xl[kk][t] = *reinterpret_cast<const half8*>(Hl + hrow[t] + (k2 + kk) * 16);
-                    }
-                const half8 w0h = wb[k2 * 128], w0l = wb[k2 * 128 + 64], w1h = wb[(k2 + 1) * 128], w1l = wb[(k2 + 1) * 128 + 64];
+                for (int kk = k2; kk < k2 + 2; ++kk)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) xh[kk][t] = *reinterpret_cast<const half8*>(Hh + hrow[t] + kk * 16);
+#pragma unroll
+                for (int kk = k2; kk < k2 + 2; ++kk) wl[kk] = wb[kk * 128 + 64];
+#pragma unroll
+                for (int kk = k2; kk < k2 + 2; ++kk)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) xl[kk][t] = *reinterpret_cast<const half8*>(Hl + hrow[t] + kk * 16);
+            }
+            stage_write(set_c, (g + 1) & 1);  // (the last tap rewrites tap 7's neighbour with a clamped copy: never read)
+#pragma unroll
+            for (int k2 = 0; k2 < 4; k2 += 2) {
 #pragma unroll
                 for (int term = 0; term < 3; ++term) {
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) {
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(term == 2 ? w0l : w0h, term == 1 ? xl[0][t] : xh[0][t], acc[t], 0, 0, 0);
-                        accB[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(term == 2 ? w1l : w1h, term == 1 ? xl[1][t] : xh[1][t], accB[t], 0, 0, 0);
-                    }
+                    for (int kk = k2; kk < k2 + 2; ++kk)
+#pragma unroll
+                        for (int t = 0; t < NT; ++t)
+                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(term == 1 ? wl[kk] : wh[kk], term == 2 ? xl[kk][t] : xh[kk][t], acc[t], 0, 0, 0);
                 }
-                if (k2 == 0) {
-                    stage_write(set_c, (g + 1) & 1);  // (the last tap rewrites tap 7's neighbour with a clamped copy: never read)
-                    stage_load(set_c, a.wf_ct + (size_t)(q + 3 < 8 ? q + 3 : 7) * 1024);  // unconditional, clamped
+            }
+            stage_load(set_c, a.wf_ct + (size_t)(q + 3 < 8 ? q + 3 : 7) * 1024);  // unconditional, clamped
+            if (NT == 2 && DP16S_SGB_CT) {
+                // issue order of a tap pinned like a gate step's: 24 fragment reads (a tap reads twice a gate step's - each fragment feeds
+                // six MFMAs, not twelve), 4 staging writes and 4 prefetch loads in the gaps between the 24 MFMAs
+                __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);  // k2 = 0: hi fragments
+#pragma unroll
+                for (int i = 0; i < 18; ++i) {  // then one read per gap: k2 = 0 lo activations, lo weights; k2 = 2 the same way
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    if (i >= 14) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // the staging writes behind the last weight read
                 }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {  // prefetch loads of the tap three ahead
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
             }
             __syncthreads();
             ++g;
@@ -480,16 +591,13 @@ __global__ __launch_bounds__(NT == 2 ? 256 : 512, NT == 2 ? 2 : 4) void dp16s_ke
         }
         stamp();  // 10: conv-transpose GEMM done
         if (n0 + cseq < a.nseq) {
-            const size_t base = seq_base(cseq);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const int p = 32 * NT * cpart + 32 * t + r;
-                if (p < Ls) {
+                if (p < Ls) {  // (then the clamped position of eoff is p itself)
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) {
-                        const int co = ccot * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
-                        a.out[base + (size_t)co * a.cstride + p] = fmaf(acc[t][q] + accB[t][q], WINV, res[t][q]);
-                    }
+                    for (int q = 0; q < 16; ++q)
+                        sto(a.out + (size_t)((q & 3) + 8 * (q >> 2)) * a.cstride, eoff[t], fmaf(acc[t][q], WINV, res[t][q]));
                 }
             }
         }
@@ -498,7 +606,7 @@ __global__ __launch_bounds__(NT == 2 ? 256 : 512, NT == 2 ? 2 : 4) void dp16s_ke
 }
 
 size_t dp16s_lds_bytes(int Ls, int nseq_per_wg) {
-    return (size_t)2 * WBUF + (size_t)2 * nseq_per_wg * (Ls + 1) * HLD * 2 + (size_t)nseq_per_wg * 2 * 32 * 4;
+    return (size_t)2 * WBUF + (size_t)nseq_per_wg * (Ls + 1 + PADR) * HLD * 2 + (size_t)nseq_per_wg * 2 * 32 * 4;
 }
 
 template <int NSEQ, bool PAIRED, int NT>
@@ -522,6 +630,8 @@ static int launch_dp16s_t(const Dp16Args& a, hipStream_t st) {
 int launch_dualpath16s(const Dp16Args& a0, hipStream_t st) {
     const int L = a0.Ls - 7;
     if (L < 1 || L > 128) return RTFS_ERR_SHAPE;
+    // 32-bit byte offsets from the tensor base inside the kernel
+    if ((((size_t)(a0.nseq - 1) / a0.R) * a0.bstride + (size_t)(a0.R - 1) * a0.rstride + 63 * a0.cstride + a0.Ls) * 4 >= ((size_t)1 << 32)) return RTFS_ERR_SHAPE;
     static const int stagger = getenv("RTFS_SWEEP_STAGGER") ? atoi(getenv("RTFS_SWEEP_STAGGER")) : 0;
     static const int prio = getenv("RTFS_SWEEP_PRIO") ? atoi(getenv("RTFS_SWEEP_PRIO")) : 0;
     static const int nt = getenv("RTFS_SWEEP_NT") ? atoi(getenv("RTFS_SWEEP_NT")) : 2;  // row tiles per wave: 2 = 4-wave, 1 = 8-wave workgroups

@@ -30,6 +30,12 @@ for label, dp, Rr, Ls, per in [("F-path", blk.globalatt[0], 125, 64, 4 if GEN2 e
     print(f"== {label}: {nwg} workgroups; cycles per phase (median / mean), total median {np.median(s[:,NS-1]-s[:,0]):.0f}")
     for i in range(NS - 1):
         print(f"   {names[i+1]:12s} {np.median(d[:, i]):9.0f} {d[:, i].mean():9.0f}")
+    if not GEN2 and not os.environ.get("RTFS_SWEEP_GEN4"):
+        sub = s[:, 12:16]
+        base = s[:, 4]  # "L1 gemm" done
+        print("   layer 1 scan, thread 0 (time part 0): prescale undone +%.0f | its chain +%.0f | barrier +%.0f | (loop: part 1's chain, own write-back, barrier) +%.0f | to scan done +%.0f"
+              % (np.median(sub[:, 0] - base), np.median(sub[:, 1] - sub[:, 0]), np.median(sub[:, 2] - sub[:, 1]), np.median(sub[:, 3] - sub[:, 2]), np.median(s[:, 5] - sub[:, 3])))
+        continue
     raw = st.cpu().numpy()[:, 12:15].astype(np.uint64)
     dl = np.stack([raw & np.uint64(0xFFFFFFFF), raw >> np.uint64(32)], -1).reshape(len(raw), 6).astype(np.float64)
     if dl.any():
