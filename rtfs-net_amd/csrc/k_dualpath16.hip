@@ -441,21 +441,22 @@ static int launch_dp16_t(const Dp16Args& a, hipStream_t st) {
 
 int launch_dualpath16(const Dp16Args& a, hipStream_t st) {
     const int L = a.Ls - 7;
-    if (L < 1 || L > 256) return RTFS_ERR_SHAPE;
-    // 2 s inputs (L <= 128): the two-workgroups-per-CU generation (k_dualpath16s.hip); RTFS_SWEEP_GEN2=1 keeps this file's kernels for A/B
+    if (L < 1 || a.Ls > 256) return RTFS_ERR_SHAPE;
+    // (all routing is by Ls = L + 7: the load phase and the conv-transpose output cover Ls rows - 64 / 128 / 256 per configuration)
+    // 2 s inputs (Ls <= 128): the two-workgroups-per-CU generation (k_dualpath16s.hip); RTFS_SWEEP_GEN2=1 keeps this file's kernels for A/B
     static const bool gen2 = getenv("RTFS_SWEEP_GEN2") != nullptr;
     static const bool gen4 = getenv("RTFS_SWEEP_GEN4") != nullptr;  // experiment: two-pass GEMM, three workgroups per CU
-    if (L <= 128 && gen4) return launch_dualpath16t(a, st);
-    if (L <= 128 && !gen2) {
+    if (a.Ls <= 128 && gen4) return launch_dualpath16t(a, st);
+    if (a.Ls <= 128 && !gen2) {
         const int rc = launch_dualpath16s(a, st);
         if (rc != RTFS_ERR_SHAPE) return rc;  // (a tensor spanning >= 4 GB: this file's kernels address with 64 bits)
     }
     if (a.stamps) {
-        if (L <= 64) return launch_dp16_stamp_t<4, 2, true>(a, st);
-        if (L <= 128) return launch_dp16_stamp_t<2, 4, true>(a, st);
+        if (a.Ls <= 64) return launch_dp16_stamp_t<4, 2, true>(a, st);
+        if (a.Ls <= 128) return launch_dp16_stamp_t<2, 4, true>(a, st);
         return launch_dp16_stamp_t<1, 4, false>(a, st);
     }
-    if (L <= 64) return launch_dp16_t<4, 2, true>(a, st);    // 4 sequences: 2 pairs x 2 dirs x 2 parts of 32 steps
-    if (L <= 128) return launch_dp16_t<2, 4, true>(a, st);   // 2 sequences: 1 pair  x 2 dirs x 4 parts of 32 steps
+    if (a.Ls <= 64) return launch_dp16_t<4, 2, true>(a, st);    // 4 sequences: 2 pairs x 2 dirs x 2 parts of 32 steps
+    if (a.Ls <= 128) return launch_dp16_t<2, 4, true>(a, st);   // 2 sequences: 1 pair  x 2 dirs x 4 parts of 32 steps
     return launch_dp16_t<1, 4, false>(a, st);                // 4 s inputs: 1 sequence x 2 dirs x 4 parts of 64 steps
 }

@@ -18,9 +18,9 @@
 //     60+ cycles and the barrier drains it; B fragments straight from L2 to registers with no LDS at all 1063 alone but 1750
 //     with the second workgroup present - the L1 delivers ~35 B/clk/CU of 16-byte fragment loads, four waves x 8 KB per step
 //     saturate it.)
-//   * F sweep (L <= 64): 2 sequences per workgroup as one PAIR - accumulator register q of lane half h is time step q of
+//   * F sweep (Ls <= 64): 2 sequences per workgroup as one PAIR - accumulator register q of lane half h is time step q of
 //     sequence h, wave = (time part of 32 steps, direction);
-//   * T sweep (L <= 128): 1 sequence per workgroup, wave = (time part of 64 steps, direction): the A-operand rows of a tile are
+//   * T sweep (Ls <= 128): 1 sequence per workgroup, wave = (time part of 64 steps, direction): the A-operand rows of a tile are
 //     ordered so that lane half h holds 16 CONSECUTIVE steps (16 h + q); the halves take turns 16 steps at a time (one
 //     v_permlane32_swap per hand-off) - the chain is latency-bound, so the idle half costs nothing.
 // Both variants keep the generation-2 tricks: only the cell-state chain c_t = u0 + (c_{t-1} - u0) sigmoid(u1 + v_f c_{t-1}) is
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(NT == 2 ? 256 : 512, NT == 2 ? 2 : 4) void dp16s_ke
     // ---------------- phase 0: load rows, LayerNorm over channels, split to f16 planes (normalizations.py:33-37).
     // lane = (position, channel half): 32 consecutive positions x 2 halves per wave, the halves meet in one permlane swap
     if (wave < 4) {  // (NT = 1: waves 4-7 have nothing to load; the phase is latency-bound)
-        const int task = wave * 32 + r, ntask = NSEQ * Ls;  // <= 128
+        const int task = wave * 32 + r, ntask = NSEQ * Ls;  // <= 128: the launcher routes by Ls (<= 64 paired, <= 128 unpaired)
         const bool live = task < ntask;
         const int tk = live ? task : ntask - 1;
         const int s = (NSEQ == 2 && tk >= Ls) ? 1 : 0, pos = tk - s * Ls;
@@ -626,10 +626,12 @@ static int launch_dp16s_t(const Dp16Args& a, hipStream_t st) {
     return rtfs_launch_status();
 }
 
-// L <= 64 (the F sweep: L = 57): one sequence pair per workgroup; L <= 128 (the 2 s T sweep: L = 118): one sequence per workgroup
+// Ls <= 64 (the F sweep: 64): one sequence pair per workgroup; Ls <= 128 (the 2 s T sweep: 125): one sequence per workgroup.  The limits are
+// on Ls = L + 7, the row count of the load phase and of the conv-transpose output (routing by L left Ls = 65 .. 71 and 129 .. 135 with their
+// last positions unwritten - found by tests/test_hip_parity.py::test_dualpath_sweep_lengths)
 int launch_dualpath16s(const Dp16Args& a0, hipStream_t st) {
     const int L = a0.Ls - 7;
-    if (L < 1 || L > 128) return RTFS_ERR_SHAPE;
+    if (L < 1 || a0.Ls > 128) return RTFS_ERR_SHAPE;
     // 32-bit byte offsets from the tensor base inside the kernel
     if ((((size_t)(a0.nseq - 1) / a0.R) * a0.bstride + (size_t)(a0.R - 1) * a0.rstride + 63 * a0.cstride + a0.Ls) * 4 >= ((size_t)1 << 32)) return RTFS_ERR_SHAPE;
     static const int stagger = getenv("RTFS_SWEEP_STAGGER") ? atoi(getenv("RTFS_SWEEP_STAGGER")) : 0;
@@ -637,7 +639,8 @@ int launch_dualpath16s(const Dp16Args& a0, hipStream_t st) {
     static const int nt = getenv("RTFS_SWEEP_NT") ? atoi(getenv("RTFS_SWEEP_NT")) : 2;  // row tiles per wave: 2 = 4-wave, 1 = 8-wave workgroups
     Dp16Args a = a0;
     a.prio = prio;
-    a.stagger = cdiv(a.nseq, L <= 64 ? 2 : 1) > 512 ? stagger : 0;  // only when a CU's two slots run several workgroups each
-    if (nt == 1) return L <= 64 ? launch_dp16s_t<2, true, 1>(a, st) : launch_dp16s_t<1, false, 1>(a, st);
-    return L <= 64 ? launch_dp16s_t<2, true, 2>(a, st) : launch_dp16s_t<1, false, 2>(a, st);
+    const bool pair = a0.Ls <= 64;
+    a.stagger = cdiv(a.nseq, pair ? 2 : 1) > 512 ? stagger : 0;  // only when a CU's two slots run several workgroups each
+    if (nt == 1) return pair ? launch_dp16s_t<2, true, 1>(a, st) : launch_dp16s_t<1, false, 1>(a, st);
+    return pair ? launch_dp16s_t<2, true, 2>(a, st) : launch_dp16s_t<1, false, 2>(a, st);
 }

@@ -383,6 +383,6 @@ static int launch_dp16t_t(const Dp16Args& a, hipStream_t st) {
 
 int launch_dualpath16t(const Dp16Args& a, hipStream_t st) {
     const int L = a.Ls - 7;
-    if (L < 1 || L > 128 || !a.wg_l0) return RTFS_ERR_SHAPE;
-    return L <= 64 ? launch_dp16t_t<2, true>(a, st) : launch_dp16t_t<1, false>(a, st);
+    if (L < 1 || a.Ls > 128 || !a.wg_l0) return RTFS_ERR_SHAPE;
+    return a.Ls <= 64 ? launch_dp16t_t<2, true>(a, st) : launch_dp16t_t<1, false>(a, st);
 }

@@ -145,6 +145,17 @@ def test_dualpath_full_size_rows(dim, shape):
     close(f"dualpath dim{dim} {shape}", y, O.dualpath_rnn(x, O._sub(BLK, f"globalatt.{idx}"), dim))
 
 
+@pytest.mark.parametrize("Ls", [15, 23, 24, 39, 40, 47, 70, 71, 72, 87, 103, 104, 119, 134, 135, 136])
+def test_dualpath_sweep_lengths(Ls):
+    """Sweep lengths L = Ls - 7 around every tile / time-part / kernel boundary of the fused sweep (8, 16, 17, 32, 33, 40, 63, 64 | 65, 80, 96, 97,
+    112, 127, 128 | 129): the write-back stores whole groups of steps and lets the ones behind the sequence end land in scratch rows, so every
+    remainder is its own case.  Both directions and both kernels (sequence pair, L <= 64; single sequence, L <= 128; generation 2 above)."""
+    m = model()
+    x = rand((1, 64, Ls, 10), 500 + Ls)
+    y = host(m.refinement_module.audio_net.blocks.globalatt[1](dev(x)))
+    close(f"dualpath sweep length {Ls - 7}", y, O.dualpath_rnn(x, O._sub(BLK, "globalatt.1"), 3))
+
+
 def test_dualpath_short_axis_raises():
     m = model()
     with pytest.raises(ValueError):

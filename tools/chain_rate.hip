@@ -8,7 +8,7 @@
 // MODE 0: the chain alone.  1: chain, exp/rcp replaced by multiplies.  2: two independent chains interleaved.
 // 3: write-back, arithmetic only.  4: write-back with the two 2-byte LDS stores at an immediate offset.  5: with the kernel's scalar clamped row
 // address (s_add, s_min, s_mul per step).  6: same, incremental scalar address (s_add, s_min).  7: chain on waves 0-1 while waves 2-3 wait at a barrier.
-template <int MODE>
+template <int MODE, int G = 4, int VAR = 0>
 __global__ __launch_bounds__(256, 2) void chain_kernel(unsigned long long* out, float* sink, int reps, int L, int dirsel) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -53,34 +53,40 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(unsigned long long* out, 
             int srow = r0w * 272;
             const int sstep = dir ? -272 : 272;
 #pragma unroll
-            for (int q4 = 0; q4 < 32; q4 += 4) {
-                float z[4], d[4], hv[4];
-                _Float16 hh[4];
-                unsigned lo[4];
+            for (int q4 = 0; q4 < 32; q4 += G) {
+                // VAR 0: everything.  1: no f16 split (the f32 value's low half is stored).  2: exp / rcp replaced by multiplies.  3: only the gate (fma, exp, add, rcp).
+                float z[G], d[G], hv[G];
+                _Float16 hh[G];
+                unsigned lo[G];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                for (int i = 0; i < G; ++i) {
                     const int q = q4 + i;
                     z[i] = fmaf(vrr, q == 0 ? c : u[0][q - 1], u[2][q]);
-                    d[i] = u[0][q] - u[3][q];
+                    d[i] = fmaf(-vrr, u[3][q], u[0][q]);
                 }
 #pragma unroll
-                for (int i = 0; i < 4; ++i) z[i] = __builtin_amdgcn_exp2f(z[i]);
+                for (int i = 0; i < G; ++i) z[i] = VAR == 2 ? z[i] * 1.0001f : __builtin_amdgcn_exp2f(z[i]);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) z[i] = 1.0f + z[i];
+                for (int i = 0; i < G; ++i) z[i] = 1.0f + z[i];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) z[i] = __builtin_amdgcn_rcpf(z[i]);
+                for (int i = 0; i < G; ++i) z[i] = VAR == 2 ? z[i] * 0.9999f : __builtin_amdgcn_rcpf(z[i]);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    hv[i] = fmaf(d[i], z[i], u[3][q4 + i]);
+                for (int i = 0; i < G; ++i) {
+                    hv[i] = VAR == 3 ? z[i] : fmaf(d[i], z[i], u[3][q4 + i]);
                     hh[i] = (_Float16)hv[i];
                 }
+                if (VAR == 0 || VAR == 2) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(lo[i]) : "v"(hv[i]), "v"(hh[i]));
+                    for (int i = 0; i < G; ++i) asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(lo[i]) : "v"(hv[i]), "v"(hh[i]));
+                } else {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                    for (int i = 0; i < G; ++i) lo[i] = __float_as_uint(hv[i]);
+                }
+#pragma unroll
+                for (int i = 0; i < G; ++i) {
                     const int k = q4 + i;
                     if (MODE == 3) {
-                        c2 += (float)hh[i] + __uint_as_float(lo[i] << 16);
+                        c2 += VAR == 3 ? hv[i] : (float)hh[i] + __uint_as_float(lo[i] << 16);
                     } else {
                         int o;
                         if (MODE == 4)
@@ -112,7 +118,7 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(unsigned long long* out, 
     }
 }
 
-template <int MODE>
+template <int MODE, int G = 4, int VAR = 0>
 void run(int nblocks, const char* what) {
     unsigned long long* out;
     float* sink;
@@ -120,8 +126,8 @@ void run(int nblocks, const char* what) {
     (void)hipMalloc(&sink, nblocks * 256 * 4);
     const int reps = 64;  // 2048 steps
     const size_t lds = 2 * 66 * 272 + 32768;
-    (void)hipFuncSetAttribute((const void*)chain_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(chain_kernel<MODE>, dim3(nblocks), dim3(256), lds, 0, out, sink, reps, 57, 0);
+    (void)hipFuncSetAttribute((const void*)(chain_kernel<MODE, G, VAR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    for (int w = 0; w < 2; ++w) hipLaunchKernelGGL((chain_kernel<MODE, G, VAR>), dim3(nblocks), dim3(256), lds, 0, out, sink, reps, 57, 0);
     (void)hipDeviceSynchronize();
     unsigned long long h[2];
     (void)hipMemcpy(h, out, sizeof(h), hipMemcpyDeviceToHost);
@@ -138,10 +144,15 @@ int main() {
     run<1>(256, "chain, exp/rcp replaced by multiplies");
     run<2>(256, "two independent chains interleaved");
     run<7>(256, "chain on waves 0-1, waves 2-3 at the barrier");
-    run<3>(256, "write-back, arithmetic only");
-    run<4>(256, "write-back + 2 LDS stores, immediate offsets");
-    run<5>(256, "write-back + stores, scalar clamped row (add, min, mul)");
-    run<6>(256, "write-back + stores, incremental scalar row (add, min)");
-    run<6>(512, "write-back + stores, incremental (two waves per SIMD)");
+    run<3>(256, "write-back, arithmetic only, groups of 4");
+    run<3, 8>(256, "write-back, arithmetic only, groups of 8");
+    run<3, 8, 1>(256, "  ... without the f16 split");
+    run<3, 8, 2>(256, "  ... exp / rcp replaced by multiplies");
+    run<3, 8, 3>(256, "  ... the gate only (fma, exp, add, rcp)");
+    run<4, 4>(256, "write-back + 2 LDS stores, immediate offsets, groups of 4");
+    run<4, 8>(256, "write-back + 2 LDS stores, immediate offsets, groups of 8");
+    run<4, 8>(512, "  ... two waves per SIMD");
+    run<4, 8, 1>(256, "  ... without the f16 split");
+    run<5, 4>(256, "write-back + stores, scalar clamped row (add, min, mul)");
     return 0;
 }
