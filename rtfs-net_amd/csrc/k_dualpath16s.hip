@@ -233,8 +233,11 @@ __global__ __launch_bounds__(NT == 2 ? 256 : 512, NT == 2 ? 2 : 4) void dp16s_ke
 
     int g = 0;  // steps consumed so far: step g sits in buffer g & 1, steps g + 1 and g + 2 in the register sets (g + 1) in set g & 1
     // ---------------- four SRU layers
-    for (int layer = 0; layer < 4; ++layer) {
-        const int nchunk = layer == 0 ? 32 : 4;
+    // (layer 0 - K = 512, 32 steps in a loop - and layers 1-3 - K = 64, four unrolled steps with the identity tile's zeros skipped - are two
+    // instantiations of the layer body: as two branches inside ONE loop body the register allocator spilled around both)
+    auto do_layer = [&](const int layer, auto first_c) {
+        constexpr bool FIRST = decltype(first_c)::value;
+        const int nchunk = FIRST ? 32 : 4;
         const float vf = a.wc16[layer * 128 + dir * 32 + r], vr = a.wc16[layer * 128 + 64 + dir * 32 + r];
         const float bf = a.bias16[layer * 128 + dir * 32 + r] * 256.f, br = a.bias16[layer * 128 + 64 + dir * 32 + r] * 256.f;
         f32x16 acc[NT][4];
@@ -247,7 +250,7 @@ __global__ __launch_bounds__(NT == 2 ? 256 : 512, NT == 2 ? 2 : 4) void dp16s_ke
                 acc[t][2][q] = br;
                 acc[t][3][q] = 0.f;
             }
-        const half8* const gsrc = layer == 0 ? a.wf_l0 : a.wf_l + (size_t)(layer - 1) * 4 * 1024;
+        const half8* const gsrc = FIRST ? a.wf_l0 : a.wf_l + (size_t)(layer - 1) * 4 * 1024;
         // what follows this layer in the stream: the next layer's steps, then the conv-transpose's taps
         const half8* const gnext = layer < 3 ? a.wf_l + (size_t)layer * 4 * 1024 : a.wf_ct;
         // (MFMA order: tools/mfma_rate.hip measures 32.5 ticks per v_mfma_f32_32x32x16_f16 whether 1, 2, 4 or 8 accumulators rotate - a
@@ -276,8 +279,15 @@ __global__ __launch_bounds__(NT == 2 ? 256 : 512, NT == 2 ? 2 : 4) void dp16s_ke
         // (Cycles per step of a 4-wave workgroup alone on its CU, 768 of them MFMA issue: ~1350; variants measured on the way, none better
         // alone: LDS-DMA staging 1420; all fragment reads pinned to the top of the step 1350; a mid-step barrier with the next step's first
         // fragments requested behind it 1360-1490 (+36 registers); gate tile 3 deferred across the barrier 1650.)
-        auto kstep = [&](int q, auto set_c) {
-            const int aoff = layer == 0 ? (q >> 2) * HLD + (q & 3) * 16 : q * 16;
+        // N3 = MFMAs of gate tile 3 in this step.  Layer 0: 6 like every tile.  Layers 1-3: tile 3 is the highway input, an IDENTITY block
+        // of the weight image (packing._dualpath_parts: 256 at k = 32 dir + j, exactly representable, lo half zero): only the two K steps
+        // that hold this direction's 32 input channels contribute - stream steps 0, 1 for both directions, the backward one's steps are
+        // rotated - and only through the two terms with the hi weights: 4 MFMAs there, none in steps 2, 3 (the skipped products are
+        // exact zeros): 80 instead of 96 MFMAs per layer and wave.
+        auto kstep = [&](int q, auto set_c, auto n3_c) {
+            constexpr int N3 = (NT == 2 && DP16S_SGB) ? decltype(n3_c)::value : 6;
+            // (layers 1-3: the backward direction's K steps come rotated by two, packing.frag_image_gate_rot)
+            const int aoff = FIRST ? (q >> 2) * HLD + (q & 3) * 16 : ((q + 2 * dir) & 3) * 16;
             half8 ah[NT], al[NT];
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
@@ -292,8 +302,8 @@ __global__ __launch_bounds__(NT == 2 ? 256 : 512, NT == 2 ? 2 : 4) void dp16s_ke
                 half8 bh[4], bl[4];
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
-                    bh[m] = wb[m * 128];
-                    bl[m] = wb[m * 128 + 64];
+                    if (m < 3 || N3 > 0) bh[m] = wb[m * 128];
+                    if (m < 3 || N3 == 6) bl[m] = wb[m * 128 + 64];
                 }
                 auto tile6 = [&](int m) {
 #pragma unroll
@@ -307,7 +317,13 @@ __global__ __launch_bounds__(NT == 2 ? 256 : 512, NT == 2 ? 2 : 4) void dp16s_ke
                 stage_write(set_c, (g + 1) & 1);
                 tile6(2);
                 stage_load(set_c, q + 3 < nchunk ? gsrc + (size_t)(q + 3) * 1024 : gnext + (size_t)(q + 3 - nchunk) * 1024);
-                tile6(3);
+                if (N3 == 6) tile6(3);
+                if (N3 == 4) {
+#pragma unroll
+                    for (int term = 0; term < 3; term += 2)
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) acc[t][3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(term == 2 ? al[t] : ah[t], bh[3], acc[t][3], 0, 0, 0);
+                }
                 __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);  // A (4) + B tile 0 (2)
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {  // tile 0: the reads of tile 1 in its first gaps
@@ -325,17 +341,18 @@ __global__ __launch_bounds__(NT == 2 ? 256 : 512, NT == 2 ? 2 : 4) void dp16s_ke
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
                 }
+                constexpr int R3 = N3 == 6 ? 2 : (N3 == 4 ? 1 : 0);  // fragment reads of tile 3
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {  // tile 2: reads of tile 3, then the prefetch loads
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    if (i < R3) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                 }
-                __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+                if (N3 > 0) __builtin_amdgcn_sched_group_barrier(0x008, N3, 0);
             } else if (NT == 2) {
                 gate_tiles(0, std::integral_constant<int, 2>(), ah, al, wb);
                 stage_write(set_c, (g + 1) & 1);
@@ -351,9 +368,19 @@ __global__ __launch_bounds__(NT == 2 ? 256 : 512, NT == 2 ? 2 : 4) void dp16s_ke
         };
         if (a.prio == 1) __builtin_amdgcn_s_setprio(1);  // GEMM phases over the co-resident workgroup's (latency-bound) recurrence
         if (a.prio == 2) __builtin_amdgcn_s_setprio(3);
-        for (int q = 0; q < nchunk; q += 2) {
-            kstep(q, S0);
-            kstep(q + 1, S1);
+        const std::integral_constant<int, 6> N6;
+        const std::integral_constant<int, 4> N4;
+        const std::integral_constant<int, 0> N0;
+        if (FIRST) {
+            for (int q = 0; q < nchunk; q += 2) {
+                kstep(q, S0, N6);
+                kstep(q + 1, S1, N6);
+            }
+        } else {
+            kstep(0, S0, N4);
+            kstep(1, S1, N4);
+            kstep(2, S0, N0);
+            kstep(3, S1, N0);
         }
         if (a.prio) __builtin_amdgcn_s_setprio(0);
         // (that barrier also means: every wave has finished reading the activation planes - the scan may overwrite them in place)
@@ -495,7 +522,9 @@ __global__ __launch_bounds__(NT == 2 ? 256 : 512, NT == 2 ? 2 : 4) void dp16s_ke
         if (a.prio >= 3) __builtin_amdgcn_s_setprio(0);
         __syncthreads();  // all hidden outputs of this layer are in the planes
         stamp();  // 3,5,7,9: scan of layer done
-    }
+    };
+    do_layer(0, std::true_type());
+    for (int layer = 1; layer < 4; ++layer) do_layer(layer, std::false_type());
 
     // ---------------- ConvTranspose1d(64->64, k=8) + bias + residual (rnn_layers.py:153-156), transposed:
     //   y[co][t] = bt[co] + sum_{kk,ci} Wt[co][kk*64+ci] * H[t-kk][ci];  wave = (sequence, co tile, position part)

@@ -63,6 +63,16 @@ def frag_image_gate(img):
     return h16.permute(0, 5, 2, 3, 1, 6, 4, 7).contiguous().view(torch.float32).reshape(-1)
 
 
+def frag_image_gate_rot(img):
+    """frag_image_gate of a layer 1-3 gate image (K = 64: four K steps) with the BACKWARD direction's K steps rotated by two: stream step s
+    holds input channels 16 ((s + 2 dir) mod 4) .. + 15 of direction dir.  Gate tile 3 of these layers is the identity block of the highway
+    input (rows 32 dir + j), so for BOTH directions it is non-zero in stream steps 0-1 only: the sweep kernel runs one code path that
+    multiplies tile 3 in the first two steps and skips it in the last two."""
+    h16 = frag_image_gate(img).view(torch.float16).reshape(4, 2, -1)
+    h16 = torch.stack([h16[:, 0], torch.roll(h16[:, 1], -2, 0)], 1)
+    return h16.contiguous().view(torch.float32).reshape(-1)
+
+
 def frag_image_ct(img):
     """split16_image(., 64) of the (64 co, 512 k') conv-transpose weight ([8 taps][hi|lo][64 co][64] halfs) -> A fragments in order
     [tap 8][co tile 2][ks 4][hi|lo][lane = h*32 + r][8]: element j of lane (h, r) = W[co = 32 tile + r][k' = 64 tap + 16 ks + 8 h + j]."""
@@ -123,13 +133,13 @@ def _dualpath_parts(sd):
     parts.append(torch.stack([sd[f"rnn.rnn_lst.{i}.weight_c"] for i in range(4)]) * (-LOG2E))
     parts.append(torch.stack([sd[f"rnn.rnn_lst.{i}.bias"] for i in range(4)]) * (-LOG2E))
     # the same three images in fragment order (generation-3 sweep kernel: B fragments straight from L2, no LDS staging)
-    f0, fl, fct = frag_image_gate(img0), [frag_image_gate(i) for i in imgs], frag_image_ct(imgct)
+    f0, fl, fct = frag_image_gate(img0), [frag_image_gate_rot(i) for i in imgs], frag_image_ct(imgct)
     parts.append(f0)
     parts.append(torch.stack(fl))
     parts.append(fct)
     # ... and split by GEMM pass (generation-4 sweep kernel, experiment)
     parts.append(frag_image_gate2(f0))
-    parts.append(torch.stack([frag_image_gate2(i) for i in fl]))
+    parts.append(torch.stack([frag_image_gate2(frag_image_gate(i)) for i in imgs]))
     parts.append(frag_image_ct2(fct))
     return parts
 
