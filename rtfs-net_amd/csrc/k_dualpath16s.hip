@@ -40,7 +40,7 @@
 #define DP16S_SGB 1
 #endif
 #ifndef DP16S_WBG
-#define DP16S_WBG 8     // write-back steps evaluated together (stage by stage)
+#define DP16S_WBG 4     // write-back steps evaluated together (stage by stage); 8 costs the same per step but skips less behind the sequence end
 #endif
 #ifndef DP16S_SGB_CT
 #define DP16S_SGB_CT 1  // the conv-transpose taps pinned the same way
@@ -417,11 +417,16 @@ __global__ __launch_bounds__(NT == 2 ? 256 : 512, NT == 2 ? 2 : 4) void dp16s_ke
                     for (int t = 0; t < NT; ++t) {
                         cin[t] = c;
 #pragma unroll
-                        for (int q = 0; q < 16; ++q) {
-                            const float u0 = acc[t][0][q];
-                            const float f = sig2(fmaf(vf, c, acc[t][1][q]));
-                            c = fmaf(c - u0, f, u0);
-                            acc[t][0][q] = c;
+                        for (int q4 = 0; q4 < 16; q4 += 4) {
+                            if (STEPS * hp + 16 * t + q4 < L) {  // (uniform: groups of four steps behind the sequence end are not walked)
+#pragma unroll
+                                for (int q = q4; q < q4 + 4; ++q) {
+                                    const float u0 = acc[t][0][q];
+                                    const float f = sig2(fmaf(vf, c, acc[t][1][q]));
+                                    c = fmaf(c - u0, f, u0);
+                                    acc[t][0][q] = c;
+                                }
+                            }
                         }
                     }
                     chand[(seq * 2 + dir) * 32 + r] = c;
@@ -435,11 +440,16 @@ __global__ __launch_bounds__(NT == 2 ? 256 : 512, NT == 2 ? 2 : 4) void dp16s_ke
                             if (h == ph) {  // (an exec mask, not a select per step: the other half's registers stay as they are)
                                 cin[t] = c;
 #pragma unroll
-                                for (int q = 0; q < 16; ++q) {
-                                    const float u0 = acc[t][0][q];
-                                    const float f = sig2(fmaf(vf, cr, acc[t][1][q]));
-                                    cr = fmaf(cr - u0, f, u0);
-                                    acc[t][0][q] = cr;
+                                for (int q4 = 0; q4 < 16; q4 += 4) {
+                                    if (STEPS * hp + 32 * t + 16 * ph + q4 < L) {  // (uniform)
+#pragma unroll
+                                        for (int q = q4; q < q4 + 4; ++q) {
+                                            const float u0 = acc[t][0][q];
+                                            const float f = sig2(fmaf(vf, cr, acc[t][1][q]));
+                                            cr = fmaf(cr - u0, f, u0);
+                                            acc[t][0][q] = cr;
+                                        }
+                                    }
                                 }
                             }
                             c = take_half(cr, ph);
