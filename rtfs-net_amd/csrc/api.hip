@@ -1,6 +1,8 @@
 // C-ABI layer: parameter-pack layouts, workspace carving and the launch sequences of each module.
 // See include/rtfs_amd.h for the contract and the reference interfaces each entry point replaces.
 #include "api_common.h"
+#include <atomic>
+#include <vector>
 
 namespace {
 
@@ -352,7 +354,7 @@ int block_head(const BlockPack& p, const float* x, const float* x_res, int B, in
 }
 
 // steps 2-17: everything between the projection (x_enc, residual in the workspace) and `expanded`
-int block_body(const BlockPack& p, int B, int T, int F, const BlockWs& w, hipStream_t st, bool zero_stats = true) {
+int block_body(const BlockPack& p, int B, int T, int F, const BlockWs& w, hipStream_t st, bool zero_stats = true, bool side_pass = true) {
     const int Tp = T / 2, Fp = F / 2;
     const int P = T * F, Pg = Tp * Fp;
     const double icF = 1.0 / ((double)CH * P), icG = 1.0 / ((double)CH * Pg);
@@ -367,6 +369,25 @@ int block_body(const BlockPack& p, int B, int T, int F, const BlockWs& w, hipStr
         a.stats_out[0] = w.st(W::S_C0, B);
         a.C = CH; a.H = T; a.W = F; a.TH = 64;
         CHECK(launch_dw_s1(a, 1, false, 0, B, st));
+    }
+    // Step 14 (statistics of fusion 0's local conv on d0: one full-resolution read, HBM-bound) needs only c0 and its statistics; steps 3-13 are
+    // the low-resolution chain (sweeps, attention: latency-bound, HBM at < 10 %): it runs on a side stream beside them (14.43 -> 14.25 ms per
+    // forward, sweep launch times unchanged).  Not when the batch is split into parts (the other part already fills those gaps: 13.5 -> 14.5),
+    // RTFS_OVERLAP=0 switches it off.
+    static const bool overlap_env = !(getenv("RTFS_OVERLAP") && atoi(getenv("RTFS_OVERLAP")) == 0);
+    const bool overlap = overlap_env && side_pass;
+    RtfsSide side{};
+    if (overlap) {
+        CHECK(rtfs_side_stream(st, 0, &side));
+        if (hipEventRecord(side.fork, st) != hipSuccess || hipStreamWaitEvent(side.stream, side.fork, 0) != hipSuccess) return RTFS_ERR_LAUNCH;
+        DwArgs a;
+        a.x = w.c0;
+        a.in_stats = w.st(W::S_C0, B); a.in_inv_count = icF; a.in_gamma = p.ds0_g; a.in_beta = p.ds0_be;
+        a.C = CH; a.H = T; a.W = F; a.TH = 64; a.Hg = Tp; a.Wg = Fp;
+        a.w[0] = p.fus0.loc_w;
+        a.stats_out[0] = w.st(W::S_L0, B);
+        CHECK(launch_dw_s1(a, 1, true, 1, B, side.stream));
+        if (hipEventRecord(side.join, side.stream) != hipSuccess) return RTFS_ERR_LAUNCH;
     }
     {  // 3. downsample[1] on d0 = gLN(c0): dw 4x4 s2 -> c1 + stats; p0 = adaptive_avg_pool2d(d0)   tdanet.py:111-116
         DwArgs a;
@@ -432,7 +453,9 @@ int block_body(const BlockPack& p, int B, int T, int F, const BlockWs& w, hipStr
     d0in.x = w.c0;
     d0in.in_stats = w.st(W::S_C0, B); d0in.in_inv_count = icF; d0in.in_gamma = p.ds0_g; d0in.in_beta = p.ds0_be;
     d0in.C = CH; d0in.H = T; d0in.W = F; d0in.TH = 64; d0in.Hg = Tp; d0in.Wg = Fp;
-    {  // 14. fusion 0 local_embedding conv on d0: statistics only
+    if (overlap) {
+        if (hipStreamWaitEvent(st, side.join, 0) != hipSuccess) return RTFS_ERR_LAUNCH;
+    } else {  // 14. fusion 0 local_embedding conv on d0: statistics only
         DwArgs a = d0in;
         a.w[0] = p.fus0.loc_w;
         a.stats_out[0] = w.st(W::S_L0, B);
@@ -851,31 +874,25 @@ struct SepWs {
 };
 }  // namespace
 
-size_t rtfs_separator_workspace_bytes(int B, int L, int Tv) {
-    Arena ar(nullptr, 0);
-    SepWs w(ar, B, rtfs_num_frames(L), Tv);
-    return ar.off + 256;
-}
+namespace {
+struct SepPacks {
+    EncPack pe;
+    BnPack pb;
+    BlockPack pk;
+    CafPack pc;
+    S3Pack ps;
+    DecPack pd;
+};
 
-int rtfs_separator_forward_f32(const float* wav, const float* video_vp, const float* pack_enc, const float* pack_bn, const float* pack_block,
-                               const float* pack_caf, const float* pack_s3, const float* pack_dec, float* out, int B, int L, int Tv,
-                               int repeats, void* ws, size_t ws_bytes, void* stream, void* video_ready, int rnn_kind) {
-    RTFS_RETURN_IF(!wav || !video_vp || !pack_enc || !pack_bn || !pack_block || !pack_caf || !pack_s3 || !pack_dec || !out, RTFS_ERR_ARG);
-    RTFS_RETURN_IF(B < 1 || L <= 128 || Tv < 1 || repeats < 1, RTFS_ERR_ARG);
-    const int T = rtfs_num_frames(L);
-    RTFS_RETURN_IF(!shape_ok_block(B, T, NF), RTFS_ERR_SHAPE);
-    Arena ar(ws, ws_bytes);
-    SepWs w(ar, B, T, Tv);
-    RTFS_RETURN_IF(!ws || !ar.ok(), RTFS_ERR_WORKSPACE);
-    hipStream_t st = S(stream);
-    Cursor ce(pack_enc), cb(pack_bn), ck(pack_block), cc(pack_caf), cs(pack_s3), cd(pack_dec);
-    EncPack pe(ce);
-    BnPack pb(cb);
-    RTFS_RETURN_IF(rnn_kind != 0 && rnn_kind != 1, RTFS_ERR_ARG);
-    BlockPack pk = BlockPack::make(ck, rnn_kind);
-    CafPack pc(cc);
-    S3Pack ps(cs);
-    DecPack pd(cd);
+// the whole chain for mixtures [first, first + B) of the call: wav / video_vp / out already point at mixture `first`
+int separator_part(const SepPacks& k, const float* wav, const float* video_vp, float* out, int B, int L, int T, int Tv, int repeats, SepWs& w,
+                   hipStream_t st, void* video_ready, bool single_chain) {
+    const EncPack& pe = k.pe;
+    const BnPack& pb = k.pb;
+    const BlockPack& pk = k.pk;
+    const CafPack& pc = k.pc;
+    const S3Pack& ps = k.ps;
+    const DecPack& pd = k.pd;
     const int P = T * NF;
     if (hipMemsetAsync(w.st0, 0, sizeof(double) * 2 * B, st) != hipSuccess) return RTFS_ERR_LAUNCH;
     CHECK(launch_stft(wav, w.spec, B, L, T, st));
@@ -913,7 +930,7 @@ int rtfs_separator_forward_f32(const float* wav, const float* video_vp, const fl
             for (int first = 0; first < B; first += sb) {
                 const int nb = B - first < sb ? B - first : sb;
                 const BlockWs view = w.blk.sub(first);
-                CHECK(block_body(pk, nb, T, NF, view, st, false));
+                CHECK(block_body(pk, nb, T, NF, view, st, false, single_chain));
             }
             if (i == 0) {
                 if (video_ready && hipStreamWaitEvent(st, (hipEvent_t)video_ready, 0) != hipSuccess) return RTFS_ERR_LAUNCH;
@@ -932,6 +949,70 @@ int rtfs_separator_forward_f32(const float* wav, const float* video_vp, const fl
     }
     CHECK(s3_mask(ps, cur, w.a0, nxt, B, P, st));
     return decoder(pd, nxt, out, w.z, B, T, L, st);
+}
+}  // namespace
+
+// How many parts the batch is cut into (default 1).  Two half batches on two streams overlap the HBM-bound streaming kernels of one half with
+// the latency-bound sweeps / attention of the other (the sweep kernels keep HBM at < 10 %, the streaming kernels keep the matrix cores at
+// < 10 %): 14.2 -> 13.0 ms at batch 32, three parts 13.4 on a box where two gave 13.5, four lose again (the quarter-batch launches are too
+// small); tools/probe_two_streams.py measured the same from two host-side calls before this was built in.  It is NOT the default because
+// every kernel then shares the chip with a kernel of the other half: a sweep launch takes 0.236 ms for half the sequences instead of 0.31 for
+// all of them, so per-kernel durations (and the roofline figure bench.py derives from them) stop describing the kernel.
+// rtfs_set_batch_split(n) or RTFS_SPLIT=n select it; a part is never smaller than 8 mixtures.
+static std::atomic<int> g_split{0};
+int rtfs_set_batch_split(int n) {
+    if (n < 0 || n > 8) return RTFS_ERR_ARG;
+    g_split.store(n);
+    return RTFS_OK;
+}
+static int separator_parts(int B) {
+    static const int env = getenv("RTFS_SPLIT") ? atoi(getenv("RTFS_SPLIT")) : 0;
+    int n = g_split.load();
+    if (n <= 0) n = env > 0 ? env : 1;
+    while (n > 1 && B / n < 8) --n;
+    return n;
+}
+
+size_t rtfs_separator_workspace_bytes(int B, int L, int Tv) {
+    Arena ar(nullptr, 0);
+    const int T = rtfs_num_frames(L), np = separator_parts(B);
+    for (int i = 0; i < np; ++i) SepWs w(ar, (B * (i + 1)) / np - (B * i) / np, T, Tv);
+    return ar.off + 256;
+}
+
+int rtfs_separator_forward_f32(const float* wav, const float* video_vp, const float* pack_enc, const float* pack_bn, const float* pack_block,
+                               const float* pack_caf, const float* pack_s3, const float* pack_dec, float* out, int B, int L, int Tv,
+                               int repeats, void* ws, size_t ws_bytes, void* stream, void* video_ready, int rnn_kind) {
+    RTFS_RETURN_IF(!wav || !video_vp || !pack_enc || !pack_bn || !pack_block || !pack_caf || !pack_s3 || !pack_dec || !out, RTFS_ERR_ARG);
+    RTFS_RETURN_IF(B < 1 || L <= 128 || Tv < 1 || repeats < 1, RTFS_ERR_ARG);
+    const int T = rtfs_num_frames(L);
+    RTFS_RETURN_IF(!shape_ok_block(B, T, NF), RTFS_ERR_SHAPE);
+    RTFS_RETURN_IF(rnn_kind != 0 && rnn_kind != 1, RTFS_ERR_ARG);
+    const int np = separator_parts(B);
+    Arena ar(ws, ws_bytes);
+    std::vector<SepWs> parts;
+    parts.reserve(np);
+    for (int i = 0; i < np; ++i) parts.emplace_back(ar, (B * (i + 1)) / np - (B * i) / np, T, Tv);
+    RTFS_RETURN_IF(!ws || !ar.ok(), RTFS_ERR_WORKSPACE);
+    hipStream_t st = S(stream);
+    Cursor ce(pack_enc), cb(pack_bn), ck(pack_block), cc(pack_caf), cs(pack_s3), cd(pack_dec);
+    const SepPacks k{EncPack(ce), BnPack(cb), BlockPack::make(ck, rnn_kind), CafPack(cc), S3Pack(cs), DecPack(cd)};
+    if (np == 1) return separator_part(k, wav, video_vp, out, B, L, T, Tv, repeats, parts[0], st, video_ready, true);
+    // part 0 on the caller's stream, parts 1.. on side streams forked from it and joined back into it
+    std::vector<RtfsSide> side(np);
+    for (int i = 1; i < np; ++i) {
+        CHECK(rtfs_side_stream(st, i, &side[i]));
+        if (hipEventRecord(side[i].fork, st) != hipSuccess || hipStreamWaitEvent(side[i].stream, side[i].fork, 0) != hipSuccess) return RTFS_ERR_LAUNCH;
+    }
+    int rc = RTFS_OK;
+    for (int i = 0; i < np && rc == RTFS_OK; ++i) {
+        const int first = (B * i) / np, nb = (B * (i + 1)) / np - first;
+        rc = separator_part(k, wav + (size_t)first * L, video_vp + (size_t)first * 512 * Tv, out + (size_t)first * L, nb, L, T, Tv, repeats, parts[i],
+                            i == 0 ? st : side[i].stream, video_ready, false);
+    }
+    for (int i = 1; i < np; ++i)  // join even after a failed launch: the caller's stream must not run ahead of work already queued
+        if (hipEventRecord(side[i].join, side[i].stream) != hipSuccess || hipStreamWaitEvent(st, side[i].join, 0) != hipSuccess) return RTFS_ERR_LAUNCH;
+    return rc;
 }
 
 // ------------------------------------------------------------ stand-alone SRU operator

@@ -24,6 +24,11 @@ static inline int rtfs_launch_status() {
 // (and the library may be driven from several host threads / devices in one process): the cache is keyed by (device, kernel) and
 // guarded by a mutex (runtime.hip).
 int rtfs_set_max_lds(const void* kernel, size_t bytes);
+struct RtfsSide {
+    hipStream_t stream;
+    hipEvent_t fork, join;
+};
+int rtfs_side_stream(hipStream_t owner, int slot, RtfsSide* out);
 
 #define RTFS_RETURN_IF(cond, code) \
     do {                           \

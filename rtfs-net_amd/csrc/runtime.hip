@@ -30,3 +30,36 @@ int rtfs_set_max_lds(const void* kernel, size_t bytes) {
     g_lds.push_back({kernel, dev, bytes});
     return RTFS_OK;
 }
+
+
+// ---- side streams: slot 0 for the one full-resolution pass of a block that does not depend on the low-resolution chain (api.hip block_body
+// step 14), slots 1.. for the batch parts of the separator call (rtfs_separator_forward_f32).
+// One (stream, fork event, join event) triple per (device, caller stream, slot), created on first use and kept for the life of the process.
+namespace {
+struct SideEntry {
+    int device;
+    hipStream_t owner;
+    int slot;
+    RtfsSide side;
+};
+std::mutex g_side_mu;
+std::vector<SideEntry> g_side;
+}  // namespace
+
+int rtfs_side_stream(hipStream_t owner, int slot, RtfsSide* out) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return RTFS_ERR_LAUNCH;
+    std::lock_guard<std::mutex> lock(g_side_mu);
+    for (auto& e : g_side)
+        if (e.device == dev && e.owner == owner && e.slot == slot) {
+            *out = e.side;
+            return RTFS_OK;
+        }
+    RtfsSide s;
+    if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) return RTFS_ERR_LAUNCH;
+    if (hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&s.join, hipEventDisableTiming) != hipSuccess)
+        return RTFS_ERR_LAUNCH;
+    g_side.push_back({dev, owner, slot, s});
+    *out = s;
+    return RTFS_OK;
+}

@@ -358,6 +358,26 @@ def test_input_rank_variants_match():
     assert rel_err(b, a) <= 2e-6 and rel_err(c, a) <= 2e-6
 
 
+def test_batch_split_option_changes_nothing_but_the_schedule():
+    """rtfs_set_batch_split(2): two half batches as independent chains on forked streams - every mixture as in the single chain (not
+    bitwise: the gLN statistics are f64 atomics), odd batch sizes split unevenly, parts below 8 mixtures are not split."""
+    import rtfs_net_amd as R
+    m = model()
+    try:
+        for B in (17, 16, 9):
+            wav, emb = make_inputs(B, 4096, 7, 300 + B)
+            R.set_batch_split(1)
+            a = host(m(dev(wav), dev(emb)))
+            R.set_batch_split(2)
+            b = host(m(dev(wav), dev(emb)))
+            R.set_batch_split(3)
+            c = host(m(dev(wav), dev(emb)))
+            for i in range(B):
+                assert rel_err(b[i], a[i]) <= 2e-6 and rel_err(c[i], a[i]) <= 2e-6, (B, i)
+    finally:
+        R.set_batch_split(0)
+
+
 def test_batch_independence_property():
     """Size-independent property at bench batch size: every mixture of a batch separates exactly as it does alone
     (all norms are per-sample in eval mode)."""
