@@ -87,12 +87,16 @@ __device__ __forceinline__ float sum_halves(float v) {
 // NT = row tiles per wave.  NT = 2: 4 waves (2 time parts x 2 directions), 128 accumulators per wave, <= 256 registers: one wave of the
 // workgroup per SIMD.  NT = 1: 8 waves (4 time parts x 2 directions), 64 accumulators, <= 128 registers: two waves of the workgroup per SIMD
 // and, with the CU's second workgroup, four per SIMD.
-template <int NSEQ, bool PAIRED, int NT, bool STAMP = false>
-__global__ __launch_bounds__(NT == 2 ? 256 : 512, NT == 2 ? 2 : 4) void dp16s_kernel(Dp16Args a) {
+// NP = time parts per workgroup (default 4 / NT: 128 covered steps unpaired, 64 paired).  NT = 2 with NP = 4 is the LONG variant for the 4 s
+// shapes (Ls <= 256: one sequence, 4 time parts x 2 directions = 512 threads, 102 KB of LDS, ONE workgroup per CU with two of its own waves per
+// SIMD): the same program, the chain handed through four parts.
+template <int NSEQ, bool PAIRED, int NT, bool STAMP = false, int NP = 4 / NT>
+__global__ __launch_bounds__(128 * NP, NT == 2 ? 2 : 4) void dp16s_kernel(Dp16Args a) {
     static_assert((NSEQ == 2 && PAIRED) || (NSEQ == 1 && !PAIRED), "F sweep: one sequence pair; T sweep: one sequence");
     static_assert(NT == 1 || NT == 2, "row tiles per wave");
+    static_assert(NP == 2 || NP == 4, "time parts");
     constexpr int STEPS = (PAIRED ? 16 : 32) * NT;  // time steps covered by one wave
-    constexpr int NPART = 4 / NT;                   // time parts per workgroup
+    constexpr int NPART = NP;                       // time parts per workgroup
     constexpr int NTHR = 128 * NPART;               // 2 directions x NPART waves
     constexpr int NPIECE = 1024 / NTHR;             // 16-byte pieces of a staged K step per thread
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
@@ -107,7 +111,7 @@ __global__ __launch_bounds__(NT == 2 ? 256 : 512, NT == 2 ? 2 : 4) void dp16s_ke
     const int r = lane & 31, h = lane >> 5;
     const int part = wave >> 1, dir = wave & 1;           // time part MAJOR (the two waves of a part run their chains together)
     const int seq = PAIRED ? h : 0;                       // the sequence this LANE's accumulator registers belong to
-    constexpr int CPART = (NSEQ == 2 ? 64 : 128) / (32 * NT);  // conv-transpose roles: (sequence, co tile, part of 32 NT positions)
+    constexpr int CPART = PAIRED ? NPART / 2 : NPART;     // conv-transpose roles: (sequence, co tile, part of 32 NT positions); STEPS NPART positions in all
     const int cseq = wave / (2 * CPART), ccot = (wave / CPART) & 1, cpart = wave % CPART;
     const int n0 = blockIdx.x * NSEQ;
 
@@ -170,8 +174,8 @@ __global__ __launch_bounds__(NT == 2 ? 256 : 512, NT == 2 ? 2 : 4) void dp16s_ke
 
     // ---------------- phase 0: load rows, LayerNorm over channels, split to f16 planes (normalizations.py:33-37).
     // lane = (position, channel half): 32 consecutive positions x 2 halves per wave, the halves meet in one permlane swap
-    if (wave < 4) {  // (NT = 1: waves 4-7 have nothing to load; the phase is latency-bound)
-        const int task = wave * 32 + r, ntask = NSEQ * Ls;  // <= 128: the launcher routes by Ls (<= 64 paired, <= 128 unpaired)
+    if (wave * 32 < NSEQ * Ls) {  // (uniform; 32 rows a wave: Ls <= 64 paired, <= 128 / 256 unpaired - the launcher routes by Ls)
+        const int task = wave * 32 + r, ntask = NSEQ * Ls;
         const bool live = task < ntask;
         const int tk = live ? task : ntask - 1;
         const int s = (NSEQ == 2 && tk >= Ls) ? 1 : 0, pos = tk - s * Ls;
@@ -648,29 +652,31 @@ size_t dp16s_lds_bytes(int Ls, int nseq_per_wg) {
     return (size_t)2 * WBUF + (size_t)nseq_per_wg * (Ls + 1 + PADR) * HLD * 2 + (size_t)nseq_per_wg * 2 * 32 * 4;
 }
 
-template <int NSEQ, bool PAIRED, int NT>
+template <int NSEQ, bool PAIRED, int NT, int NP = 4 / NT>
 static int launch_dp16s_t(const Dp16Args& a, hipStream_t st) {
     const size_t lds = dp16s_lds_bytes(a.Ls, NSEQ);
-    if (lds > 80 * 1024) return RTFS_ERR_SHAPE;  // two workgroups per CU
-    constexpr int NTHR = NT == 2 ? 256 : 512;
+    constexpr bool LONG = NT == 2 && NP == 4;             // one 512-thread workgroup per CU
+    if (lds > (LONG ? 160 : 80) * 1024) return RTFS_ERR_SHAPE;  // (else: two workgroups per CU)
+    constexpr int NTHR = 128 * NP;
     if (a.stamps) {
-        if (rtfs_set_max_lds((const void*)dp16s_kernel<NSEQ, PAIRED, NT, true>, lds) != RTFS_OK) return RTFS_ERR_LAUNCH;
-        hipLaunchKernelGGL((dp16s_kernel<NSEQ, PAIRED, NT, true>), dim3(cdiv(a.nseq, NSEQ)), dim3(NTHR), lds, st, a);
+        if (rtfs_set_max_lds((const void*)dp16s_kernel<NSEQ, PAIRED, NT, true, NP>, lds) != RTFS_OK) return RTFS_ERR_LAUNCH;
+        hipLaunchKernelGGL((dp16s_kernel<NSEQ, PAIRED, NT, true, NP>), dim3(cdiv(a.nseq, NSEQ)), dim3(NTHR), lds, st, a);
         return rtfs_launch_status();
     }
-    if (rtfs_set_max_lds((const void*)dp16s_kernel<NSEQ, PAIRED, NT>, lds) != RTFS_OK) return RTFS_ERR_LAUNCH;
+    if (rtfs_set_max_lds((const void*)dp16s_kernel<NSEQ, PAIRED, NT, false, NP>, lds) != RTFS_OK) return RTFS_ERR_LAUNCH;
     void* slot = dualpath_timing_begin(a.Ls, a.nseq, st);
-    hipLaunchKernelGGL((dp16s_kernel<NSEQ, PAIRED, NT>), dim3(cdiv(a.nseq, NSEQ)), dim3(NTHR), lds, st, a);
+    hipLaunchKernelGGL((dp16s_kernel<NSEQ, PAIRED, NT, false, NP>), dim3(cdiv(a.nseq, NSEQ)), dim3(NTHR), lds, st, a);
     dualpath_timing_end(slot, st);
     return rtfs_launch_status();
 }
 
-// Ls <= 64 (the F sweep: 64): one sequence pair per workgroup; Ls <= 128 (the 2 s T sweep: 125): one sequence per workgroup.  The limits are
+// Ls <= 64 (the F sweep: 64): one sequence pair per workgroup; Ls <= 128 (the 2 s T sweep: 125): one sequence per workgroup; Ls <= 256 (the
+// 4 s T sweep: 250): one sequence per 512-thread workgroup.  The limits are
 // on Ls = L + 7, the row count of the load phase and of the conv-transpose output (routing by L left Ls = 65 .. 71 and 129 .. 135 with their
 // last positions unwritten - found by tests/test_hip_parity.py::test_dualpath_sweep_lengths)
 int launch_dualpath16s(const Dp16Args& a0, hipStream_t st) {
     const int L = a0.Ls - 7;
-    if (L < 1 || a0.Ls > 128) return RTFS_ERR_SHAPE;
+    if (L < 1 || a0.Ls > 256) return RTFS_ERR_SHAPE;
     // 32-bit byte offsets from the tensor base inside the kernel
     if ((((size_t)(a0.nseq - 1) / a0.R) * a0.bstride + (size_t)(a0.R - 1) * a0.rstride + 63 * a0.cstride + a0.Ls) * 4 >= ((size_t)1 << 32)) return RTFS_ERR_SHAPE;
     static const int stagger = getenv("RTFS_SWEEP_STAGGER") ? atoi(getenv("RTFS_SWEEP_STAGGER")) : 0;
@@ -680,6 +686,7 @@ int launch_dualpath16s(const Dp16Args& a0, hipStream_t st) {
     a.prio = prio;
     const bool pair = a0.Ls <= 64;
     a.stagger = cdiv(a.nseq, pair ? 2 : 1) > 512 ? stagger : 0;  // only when a CU's two slots run several workgroups each
+    if (a0.Ls > 128) return launch_dp16s_t<1, false, 2, 4>(a, st);  // the 4 s shapes: four time parts, one workgroup per CU
     if (nt == 1) return pair ? launch_dp16s_t<2, true, 1>(a, st) : launch_dp16s_t<1, false, 1>(a, st);
     return pair ? launch_dp16s_t<2, true, 2>(a, st) : launch_dp16s_t<1, false, 2>(a, st);
 }

@@ -145,10 +145,10 @@ def test_dualpath_full_size_rows(dim, shape):
     close(f"dualpath dim{dim} {shape}", y, O.dualpath_rnn(x, O._sub(BLK, f"globalatt.{idx}"), dim))
 
 
-@pytest.mark.parametrize("Ls", [15, 23, 24, 39, 40, 47, 70, 71, 72, 87, 103, 104, 119, 134, 135, 136])
+@pytest.mark.parametrize("Ls", [15, 23, 24, 39, 40, 47, 70, 71, 72, 87, 103, 104, 119, 134, 135, 136, 160, 198, 199, 200, 231, 249, 250])
 def test_dualpath_sweep_lengths(Ls):
     """Sweep lengths L = Ls - 7 around every tile / time-part / kernel boundary of the fused sweep (8, 16, 17, 32, 33, 40, 63, 64 | 65, 80, 96, 97,
-    112, 127, 128 | 129): the write-back stores whole groups of steps and lets the ones behind the sequence end land in scratch rows, so every
+    112, 127, 128 | 129, 153, 191-193, 224, 242, 243 in the four-part variant of the 4 s shapes): the write-back stores whole groups of steps and lets the ones behind the sequence end land in scratch rows, so every
     remainder is its own case.  Both directions and both kernels (sequence pair, L <= 64; single sequence, L <= 128; generation 2 above)."""
     m = model()
     x = rand((1, 64, Ls, 10), 500 + Ls)
