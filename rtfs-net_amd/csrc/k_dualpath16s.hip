@@ -7,12 +7,12 @@
 // under its serial phases - the recurrences (24 % / 35 % of the F / T sweep), the load + LayerNorm phase, the epilogue, the
 // barrier waits of the weight stream (profiles/r01_sweep_stamps.txt).  Here a workgroup is 256 threads (one wave per SIMD) that
 // owns HALF as many sequences and needs < 80 KB of LDS, so two independent workgroups share every CU and every SIMD: while one
-// wave walks its recurrence (latency-bound on two dependent transcendentals per step, ~25 % of the VALU issue slots) its
-// neighbour from the other workgroup has the matrix pipe.  What had to change for the 80 KB:
+// wave walks its recurrence (38 cycles a step alone, issue-bound: tools/chain_rate.hip) its neighbour from the other workgroup has
+// the matrix pipe.  What had to change for the 80 KB:
 //   * the weight stream is double-buffered in K = 16 steps of 16 KB (was K = 32, 2 x 40 KB of padded rows).  The pack carries a
 //     second copy of the f16 hi / lo images in FRAGMENT ORDER ([K step][direction][gate tile][hi|lo][lane] x 16 bytes,
 //     packing.frag_image_gate / frag_image_ct): staging a step is a straight 16 KB copy (four coalesced 16-byte loads per thread,
-//     one step ahead in registers, then four ds_write_b128) and every fragment read is 64 consecutive 16-byte pieces - conflict
+//     two steps ahead in registers, then four ds_write_b128) and every fragment read is 64 consecutive 16-byte pieces - conflict
 //     free without padding or swizzling.  (Tried and measured on the way, tools/sweep_stamps.py, cycles per K step of a workgroup
 //     alone on its CU against 768 of MFMA issue: the same steps written by LDS-DMA 1420 - a DMA piece costs the issuing wave
 //     60+ cycles and the barrier drains it; B fragments straight from L2 to registers with no LDS at all 1063 alone but 1750
@@ -22,10 +22,12 @@
 //     sequence h, wave = (time part of 32 steps, direction);
 //   * T sweep (Ls <= 128): 1 sequence per workgroup, wave = (time part of 64 steps, direction): the A-operand rows of a tile are
 //     ordered so that lane half h holds 16 CONSECUTIVE steps (16 h + q); the halves take turns 16 steps at a time (one
-//     v_permlane32_swap per hand-off) - the chain is latency-bound, so the idle half costs nothing.
+//     v_permlane32_swap per hand-off), the resting half masked by EXEC;
+//   * Ls <= 256 (the 4 s time sweep): the same single-sequence program with FOUR time parts - 512 threads, 102 KB, one workgroup per CU.
 // Both variants keep the generation-2 tricks: only the cell-state chain c_t = u0 + (c_{t-1} - u0) sigmoid(u1 + v_f c_{t-1}) is
 // serial, the reset gate / highway output are evaluated after the hand-off; sigmoid = rcp(1 + exp2(z)) with -log2(e) folded into
-// the gate weights; the highway input of layers 1-3 comes out of the same MFMAs through an identity block in the weight image.
+// the gate weights; the highway input of layers 1-3 comes out of the same MFMAs through an identity block in the weight image (whose
+// exact zeros are not multiplied: kstep's N3).  The write-back after the hand-off is branch-free with immediate row offsets (see there).
 #include "common.h"
 #include "kernels.h"
 #include <stdlib.h>
