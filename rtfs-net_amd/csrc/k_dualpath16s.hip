@@ -55,7 +55,9 @@ __device__ __forceinline__ void split8(const float (&v)[8], half8& hi, half8& lo
     for (int i = 0; i < 8; ++i) {
         const _Float16 hh = (_Float16)v[i];
         hi[i] = hh;
-        lo[i] = (_Float16)(v[i] - (float)hh);
+        unsigned lb;  // (f16)(v - hh) in one instruction (the compiler emits convert, subtract, convert)
+        asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(lb) : "v"(v[i]), "v"(hh));
+        lo[i] = __builtin_bit_cast(_Float16, (unsigned short)lb);
     }
 }
 

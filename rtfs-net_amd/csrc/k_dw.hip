@@ -714,7 +714,11 @@ typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 __global__ __launch_bounds__(256) void transpose64_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W) {
     __shared__ float t[64][65];
     const size_t base = (size_t)blockIdx.z * H * W;
-    const int w0 = blockIdx.x * 64, h0 = blockIdx.y * 64;
+    // the last tile of a ragged axis is moved back so that it is whole (it overlaps its neighbour, which writes the same values): with
+    // H = 125, W = 64 - the low-resolution planes around the time sweep - half of all tiles were ragged and took the dword path below
+    int w0 = blockIdx.x * 64, h0 = blockIdx.y * 64;
+    if (W >= 64 && w0 + 64 > W) w0 = W - 64;
+    if (H >= 64 && h0 + 64 > H) h0 = H - 64;
     const int tx = (threadIdx.x & 15) * 4, ty = threadIdx.x >> 4;
     if (h0 + 64 <= H && w0 + 64 <= W) {
         f32x4u v[4];
