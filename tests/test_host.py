@@ -427,3 +427,22 @@ def test_no_hazardous_packed_f32_instructions_in_the_code_object():
     assert not bad, bad[:5]
     assert mod.PAT.search("v_pk_fma_f32 v[72:73], v[168:169], v[76:77], v[72:73] op_sel:[0,1,1]")
     assert not mod.PAT.search("v_pk_fma_f32 v[154:155], v[154:155], v[76:77], v[72:73] op_sel_hi:[1,0,0]")
+
+
+def test_batch_split_setter_and_workspace_layout():
+    """rtfs_set_batch_split: argument range, and the separator workspace follows the setting (parts of >= 8 mixtures only); the Python
+    helper clears the memoised size query."""
+    import rtfs_net_amd as R
+    from rtfs_net_amd import _lib
+    lib = _lib.load()
+    try:
+        assert lib.rtfs_set_batch_split(9) != 0 and lib.rtfs_set_batch_split(-1) != 0
+        R.set_batch_split(1)
+        one = [lib.rtfs_separator_workspace_bytes(B, 4096, 7) for B in (32, 17, 15, 9)]
+        R.set_batch_split(2)
+        two = [lib.rtfs_separator_workspace_bytes(B, 4096, 7) for B in (32, 17, 15, 9)]
+        assert two[0] != one[0] and two[1] != one[1]      # 16 + 16, 8 + 9: two arenas, different padding
+        assert two[2] == one[2] and two[3] == one[3]      # 15 and 9 mixtures are not split (a part would be < 8)
+        assert all(0 <= t - o < 4096 for t, o in zip(two, one))
+    finally:
+        R.set_batch_split(0)
