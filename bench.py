@@ -350,6 +350,7 @@ def main():
     ap.add_argument("--split", type=int, default=1,
                     help="rtfs_set_batch_split for the timed region (default 1: one chain, per-kernel durations undisturbed); the two-part "
                          "throughput mode is measured as well, after the timed region, and reported under 'batch_split_2'")
+    ap.add_argument("--no-batch-split", action="store_true", help="skip the extra 'batch_split_2' measurement (profiling runs: one mode per trace)")
     ap.add_argument("--train", action="store_true",
                     help="measure the training step instead (forward_train + PIT loss + HIP backward + one flattened gradient all-reduce "
                          "over RCCL + clip + AdamW; SyncBatchNorm at N > 1); not the contract metric, a separate JSON line")
@@ -410,7 +411,7 @@ def main():
     # the throughput option (two half batches as independent chains on forked streams), outside the contract's timed region: it makes every
     # kernel share the chip with a kernel of the other half, so it is reported beside the contract numbers, not instead of them
     split2 = None
-    if args.split == 1 and B >= 16:
+    if args.split == 1 and B >= 16 and not args.no_batch_split:
         R.set_batch_split(2)
         with torch.no_grad():
             for _ in range(2):

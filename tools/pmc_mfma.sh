@@ -8,6 +8,6 @@ B="SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_
 i=0
 for set in "$A" "$B"; do
   i=$((i+1)); n=$( [ $i = 1 ] && echo a || echo b )
-  timeout -k 10 300 rocprofv3 --pmc $set --output-format csv -d $R/gpurun_out/pmc_mfma -o $n -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $R/gpurun_out/pmc_mfma_$n.log 2>&1 || echo "pass $n failed"
+  timeout -k 10 300 rocprofv3 --pmc $set --output-format csv -d $R/gpurun_out/pmc_mfma -o $n -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-batch-split > $R/gpurun_out/pmc_mfma_$n.log 2>&1 || echo "pass $n failed"
 done
 find $R/gpurun_out/pmc_mfma -name "*counter_collection.csv" | head
