@@ -17,8 +17,10 @@
  *     allocate, never call back; workspace contents are scratch
  *   - return 0 on success; <0 on error: -1 bad shape, -2 workspace too small, -3 launch failure, -4 bad argument
  *   - eval-mode semantics (BatchNorm running statistics, no dropout); re-entrant: the only host-side state is a mutex-guarded cache
- *     of per-(device, kernel) launch attributes and the diagnostic sweep-timing log (off by default), so the library may be driven from
- *     several host threads / devices in one process.
+ *     of per-(device, kernel) launch attributes, the per-(device, caller stream) internal side streams of rtfs_block_f32 /
+ *     rtfs_separator_forward_f32 (forked from `stream` by an event and joined back into it inside the call: from outside all work of a call
+ *     is ordered on `stream`), the process-wide rtfs_set_batch_split option and the diagnostic sweep-timing log (off by default), so the
+ *     library may be driven from several host threads / devices in one process (one thread per stream).
  *   - length limits of the FUSED entry points (they keep a whole sweep / score row / video pyramid on chip and return -1 beyond):
  *       sweep axis of rtfs_dualpath_* / rtfs_block_f32 / rtfs_separator_forward_f32   <= 250 positions (T/2 <= 250: 4 s of audio)
  *       keys of rtfs_tf_attention_f32                                                 <= 256
