@@ -378,6 +378,38 @@ def test_batch_split_option_changes_nothing_but_the_schedule():
         R.set_batch_split(0)
 
 
+def test_two_host_threads_on_two_streams():
+    """The re-entrancy note of include/rtfs_amd.h: two host threads drive the separator concurrently, each on its own stream (each gets its
+    own internal side streams); every result equals the one the same input gives alone."""
+    import threading
+    m = model()
+    inputs = [make_inputs(3, 6000 + 512 * k, 9 + k, 400 + k) for k in range(2)]
+    alone = [host(m(dev(w), dev(e))) for w, e in inputs]   # also warms the parameter packs (the pack caches are filled once, then read)
+    results, errors = [None, None], []
+
+    def run(k):
+        try:
+            s = torch.cuda.Stream()
+            w, e = dev(inputs[k][0]), dev(inputs[k][1])
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                for _ in range(6):
+                    out = m(w, e)
+            s.synchronize()
+            results[k] = host(out)
+        except Exception as ex:  # noqa: BLE001
+            errors.append(ex)
+
+    th = [threading.Thread(target=run, args=(k,)) for k in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
+    for k in range(2):
+        assert rel_err(results[k], alone[k]) <= 2e-6, k
+
+
 def test_batch_independence_property():
     """Size-independent property at bench batch size: every mixture of a batch separates exactly as it does alone
     (all norms are per-sample in eval mode)."""
