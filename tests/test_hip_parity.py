@@ -378,6 +378,29 @@ def test_batch_split_option_changes_nothing_but_the_schedule():
         R.set_batch_split(0)
 
 
+def test_forward_can_be_captured_in_a_hip_graph():
+    """torch.cuda.graph capture of AVNet.forward (library-internal side streams are forked from / joined into the capturing stream by events,
+    the workspace comes from torch's graph pool) and replay on new input values written into the captured tensors."""
+    m = model()
+    wav, emb = make_inputs(2, 8000, 12, 61)
+    w, e = dev(wav), dev(emb)
+    ref = host(m(w, e))
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        m(w, e)
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = m(w, e)
+    g.replay()
+    assert rel_err(host(out), ref) <= 2e-6
+    wav2, emb2 = make_inputs(2, 8000, 12, 62)
+    w.copy_(dev(wav2)); e.copy_(dev(emb2))
+    g.replay()
+    assert rel_err(host(out), host(m(w, e))) <= 2e-6
+
+
 def test_two_host_threads_on_two_streams():
     """The re-entrancy note of include/rtfs_amd.h: two host threads drive the separator concurrently, each on its own stream (each gets its
     own internal side streams); every result equals the one the same input gives alone."""
