@@ -156,6 +156,19 @@ def test_dualpath_sweep_lengths(Ls):
     close(f"dualpath sweep length {Ls - 7}", y, O.dualpath_rnn(x, O._sub(BLK, "globalatt.1"), 3))
 
 
+def test_generation2_sweep_kernels_still_pass():
+    """The generation-2 sweep kernels stay in the library as the fall-back for tensors spanning >= 4 GB (generation 3 addresses with 32-bit
+    offsets) and behind RTFS_SWEEP_GEN2=1; the switch is read once per process, so the length sweep is re-run in a child process."""
+    import subprocess, sys
+    if os.environ.get("RTFS_SWEEP_GEN2"):
+        pytest.skip("already inside the generation-2 run")
+    env = dict(os.environ, RTFS_SWEEP_GEN2="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pr = subprocess.run([sys.executable, "-m", "pytest", "tests/test_hip_parity.py", "-q", "-x", "-m", "gpu", "-k", "test_dualpath_sweep_lengths or test_dualpath_full_size_rows"],
+                        cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert pr.returncode == 0, pr.stdout[-3000:]
+
+
 def test_dualpath_short_axis_raises():
     m = model()
     with pytest.raises(ValueError):
