@@ -313,6 +313,27 @@ def test_end_to_end_odd_lengths_vs_oracle(L, Tv):
     close(f"e2e {L} samples R=2", out, ref)
 
 
+@pytest.mark.parametrize("T", [63, 64, 65, 66, 127, 128, 129, 130, 191, 192, 193])
+def test_end_to_end_frame_counts_around_tile_boundaries(T):
+    """Utterances of T STFT frames (T' = T // 2 low-resolution frames) around every row-band / tile boundary the kernels use: 64-row bands
+    of the depthwise family at full resolution (T = 64, 128, 192) and at low resolution (T' = 32, 64, 96), 64 x 64 transpose tiles (T' = 63,
+    64, 65: small path / exact / overlapping last tile), the sweep kernels' 32-row tiles and 64-position limit (T' = 64, 65), attention
+    frame groups of 8.  The oracle is the checker (no reference vector at these sizes); R = 2 keeps the CPU side short."""
+    m = model(4)
+    import copy, rtfs_net_amd as R
+    from rtfs_net_amd.configs import RTFS4_AUDIONET
+    c = copy.deepcopy(RTFS4_AUDIONET); c["audio_params"]["repeats"] = 2
+    m2 = R.AVNet(print_macs=False, **c)
+    m2.load_state_dict(m.state_dict())
+    m2 = m2.cuda().eval()
+    L = (T - 1) * 128 + 17
+    Tv = max(2, round(L / 16000 * 25))
+    wav, emb = make_inputs(1, L, Tv, 900 + T)
+    out = host(m2(dev(wav), dev(emb)))
+    ref = O.avnet_forward(wav, emb, SD, repeats=2)
+    close(f"e2e T = {T} frames", out, ref)
+
+
 # ---------------- rnn_type LSTM: every number in these vectors is the reference's own arithmetic (stock nn.LSTM)
 _LSTM = {}
 
