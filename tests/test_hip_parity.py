@@ -478,6 +478,18 @@ def test_batch_independence_property():
         assert rel_err(full[i:i + 1], one) <= 2e-6
 
 
+@pytest.mark.parametrize("B", [3, 5, 7, 13, 17, 31, 33])
+def test_every_mixture_of_an_odd_batch_equals_its_own_run(B):
+    """Odd batch sizes (grids that do not divide evenly over 8 XCDs / 256 CUs, persistent workgroups with a ragged last tile, pixel tiles that
+    straddle samples): every mixture of the batch against its batch-1 run.  Short utterances keep it cheap; no oracle needed."""
+    m = model()
+    wav, emb = make_inputs(B, 3000 + 128 * (B % 5), 5, 700 + B)
+    full = host(m(dev(wav), dev(emb)))
+    for i in range(B):
+        one = host(m(dev(wav[i:i + 1]), dev(emb[i:i + 1])))
+        assert rel_err(full[i:i + 1], one) <= 2e-6, (B, i)
+
+
 def test_relocated_package_runs_the_forward(tmp_path):
     """train.py:95 copies the models package into the experiment directory, test.py:33-36 imports the copy as `<exp>.models` and calls
     AVNet.from_pretrain(...)(mix, mouth_emb): the copied package (with its librtfs_amd.so) must produce the reference's output."""
