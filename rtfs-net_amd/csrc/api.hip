@@ -292,28 +292,15 @@ struct BlockWs {
     float *c1, *p0, *g, *gF, *tA, *tB, *gT, *gA, *q, *k, *v, *o;         // compressed resolution
     float *E0, *G0, *E1, *G1, *L1, *xf1, *E2, *G2;
     double* stats;  // 11 slots x (B,2)
-    int Bfull = 0, b0 = 0;  // batch size the statistic slots are laid out for, first mixture of this view
-    size_t P_ = 0, Pg_ = 0;
+    int Bfull = 0;  // batch size the statistic slots are laid out for
+    int cs = 0;     // channel stride (floats) of the full-resolution tensors: T * F, or padded to whole 128-byte lines (pitch())
     static constexpr int NSTAT = 11;
     enum { S_C0, S_C1, S_E0, S_G0, S_E1, S_G1, S_L1, S_E2, S_G2, S_L0, S_L2 };
-    // the same buffers seen from mixture `first` on (a sub-batch of the block's inner part, see separator_forward)
-    BlockWs sub(int first) const {
-        BlockWs v = *this;
-        v.b0 = b0 + first;
-        v.residual += (size_t)first * CA * P_;
-        float** full[] = {&v.x_enc, &v.c0, &v.xf0, &v.expanded};
-        for (float** q_ : full) *q_ += (size_t)first * CH * P_;
-        float** gs[] = {&v.c1, &v.p0, &v.g, &v.gF, &v.tA, &v.tB, &v.gT, &v.gA, &v.v, &v.o, &v.E0, &v.G0, &v.E1, &v.G1, &v.L1, &v.xf1, &v.E2, &v.G2};
-        for (float** q_ : gs) *q_ += (size_t)first * CH * Pg_;
-        v.q += (size_t)first * CH * Pg_ / 4;
-        v.k += (size_t)first * CH * Pg_ / 4;
-        return v;
-    }
-    BlockWs(Arena& a, int B, int T, int F) {
-        const size_t P = (size_t)T * F, Pg = (size_t)(T / 2) * (F / 2);
+    BlockWs(Arena& a, int B, int T, int F, int cs_ = 0) {
+        const size_t Pg = (size_t)(T / 2) * (F / 2);
+        cs = cs_ ? cs_ : T * F;
+        const size_t P = (size_t)cs;
         Bfull = B;
-        P_ = P;
-        Pg_ = Pg;
         residual = a.take<float>(B * CA * P);
         x_enc = a.take<float>(B * CH * P);
         c0 = a.take<float>(B * CH * P);
@@ -325,7 +312,7 @@ struct BlockWs {
         k = a.take<float>(B * CH * Pg / 4);
         stats = a.take<double>((size_t)NSTAT * B * 2);
     }
-    double* st(int slot, int /*B of the view*/) const { return stats ? stats + ((size_t)slot * Bfull + b0) * 2 : nullptr; }
+    double* st(int slot, int /*B*/) const { return stats ? stats + (size_t)slot * Bfull * 2 : nullptr; }
 };
 
 int block_head(const BlockPack& p, const float* x, const float* x_res, int B, int T, int F, BlockWs& w, hipStream_t st, const CafArgs* caf) {
@@ -343,6 +330,7 @@ int block_head(const BlockPack& p, const float* x, const float* x_res, int B, in
         a.gb = p.gb;
         a.slope = p.gslope;
         a.P = P;
+        a.cs = w.cs;
         if (caf && !gemm_f32()) {  // block input = CAF(x, video) + x_res, applied while streaming x (fused separator path)
             a.caf_r = caf->r_out; a.caf_att = caf->att_out;
             a.caf_w_key = caf->w_key; a.caf_bn_key = caf->bn_key; a.caf_w_val = caf->w_val; a.caf_bn_val = caf->bn_val;
@@ -354,12 +342,12 @@ int block_head(const BlockPack& p, const float* x, const float* x_res, int B, in
 }
 
 // steps 2-17: everything between the projection (x_enc, residual in the workspace) and `expanded`
-int block_body(const BlockPack& p, int B, int T, int F, const BlockWs& w, hipStream_t st, bool zero_stats = true, bool side_pass = true) {
+int block_body(const BlockPack& p, int B, int T, int F, const BlockWs& w, hipStream_t st, bool side_pass = true) {
     const int Tp = T / 2, Fp = F / 2;
     const int P = T * F, Pg = Tp * Fp;
     const double icF = 1.0 / ((double)CH * P), icG = 1.0 / ((double)CH * Pg);
     typedef BlockWs W;
-    if (zero_stats && hipMemsetAsync(w.stats, 0, sizeof(double) * W::NSTAT * w.Bfull * 2, st) != hipSuccess) return RTFS_ERR_LAUNCH;
+    if (hipMemsetAsync(w.stats, 0, sizeof(double) * W::NSTAT * w.Bfull * 2, st) != hipSuccess) return RTFS_ERR_LAUNCH;
     {  // 2. downsample[0]: dw 4x4 s1 + bias -> c0 (pre-gLN) + stats                         tdanet.py:110
         DwArgs a;
         a.x = w.x_enc;
@@ -367,7 +355,7 @@ int block_body(const BlockPack& p, int B, int T, int F, const BlockWs& w, hipStr
         a.bias[0] = p.ds0_b;
         a.out[0] = w.c0;
         a.stats_out[0] = w.st(W::S_C0, B);
-        a.C = CH; a.H = T; a.W = F; a.TH = 64;
+        a.C = CH; a.H = T; a.W = F; a.TH = 64; a.cs = w.cs;
         CHECK(launch_dw_s1(a, 1, false, 0, B, st));
     }
     // Step 14 (statistics of fusion 0's local conv on d0: one full-resolution read, HBM-bound) needs only c0 and its statistics; steps 3-13 are
@@ -383,7 +371,7 @@ int block_body(const BlockPack& p, int B, int T, int F, const BlockWs& w, hipStr
         DwArgs a;
         a.x = w.c0;
         a.in_stats = w.st(W::S_C0, B); a.in_inv_count = icF; a.in_gamma = p.ds0_g; a.in_beta = p.ds0_be;
-        a.C = CH; a.H = T; a.W = F; a.TH = 64; a.Hg = Tp; a.Wg = Fp;
+        a.C = CH; a.H = T; a.W = F; a.TH = 64; a.Hg = Tp; a.Wg = Fp; a.cs = w.cs;
         a.w[0] = p.fus0.loc_w;
         a.stats_out[0] = w.st(W::S_L0, B);
         CHECK(launch_dw_s1(a, 1, true, 1, B, side.stream));
@@ -398,7 +386,7 @@ int block_body(const BlockPack& p, int B, int T, int F, const BlockWs& w, hipStr
         a.out[0] = w.c1;
         a.out[1] = w.p0;
         a.stats_out[0] = w.st(W::S_C1, B);
-        a.C = CH; a.H = T; a.W = F; a.Hg = Tp; a.Wg = Fp; a.TH = 64;
+        a.C = CH; a.H = T; a.W = F; a.Hg = Tp; a.Wg = Fp; a.TH = 64; a.cs = w.cs;
         CHECK(launch_dw_s2_pool(a, B, st));
     }
     // 4. g = pool(d0) + d1
@@ -452,7 +440,7 @@ int block_body(const BlockPack& p, int B, int T, int F, const BlockWs& w, hipStr
     DwArgs d0in;  // common: read d0 = gLN(c0) at full resolution
     d0in.x = w.c0;
     d0in.in_stats = w.st(W::S_C0, B); d0in.in_inv_count = icF; d0in.in_gamma = p.ds0_g; d0in.in_beta = p.ds0_be;
-    d0in.C = CH; d0in.H = T; d0in.W = F; d0in.TH = 64; d0in.Hg = Tp; d0in.Wg = Fp;
+    d0in.C = CH; d0in.H = T; d0in.W = F; d0in.TH = 64; d0in.Hg = Tp; d0in.Wg = Fp; d0in.cs = w.cs;
     if (overlap) {
         if (hipStreamWaitEvent(st, side.join, 0) != hipSuccess) return RTFS_ERR_LAUNCH;
     } else {  // 14. fusion 0 local_embedding conv on d0: statistics only
@@ -473,7 +461,7 @@ int block_body(const BlockPack& p, int B, int T, int F, const BlockWs& w, hipStr
     }
     DwArgs xin;  // common: read xf0
     xin.x = w.xf0;
-    xin.C = CH; xin.H = T; xin.W = F; xin.TH = 64; xin.Hg = Tp; xin.Wg = Fp;
+    xin.C = CH; xin.H = T; xin.W = F; xin.TH = 64; xin.Hg = Tp; xin.Wg = Fp; xin.cs = w.cs;
     {  // 16. concat layer local_embedding conv on xf0: statistics only
         DwArgs a = xin;
         a.w[0] = p.cat0.loc_w;
@@ -505,6 +493,7 @@ int block_tail(const BlockPack& p, float* out, int B, int T, int F, BlockWs& w, 
         a.aux = w.residual;
         a.out = out;
         a.P = P;
+        a.cs = w.cs;
         CHECK(gemm_f32() ? launch_pw_residual(a, B, st) : launch_pws_residual(a, B, st));
     }
     return RTFS_OK;
@@ -518,7 +507,7 @@ int block_forward(const BlockPack& p, const float* x, const float* x_res, float*
 }
 
 // block boundary of the fused separator: residual_conv(i) + [CAF] + a1 + gateway + projection(i+1) in one kernel
-int block_boundary(const BlockPack& p, const float* a1, int B, int T, int F, BlockWs& w, hipStream_t st, const CafArgs* caf) {
+int block_boundary(const BlockPack& p, const float* a1, int B, int T, int F, BlockWs& w, hipStream_t st, const CafArgs* caf, unsigned* ctr = nullptr) {
     B2bArgs a;
     a.x = w.expanded;
     a.res = w.residual;
@@ -532,15 +521,17 @@ int block_boundary(const BlockPack& p, const float* a1, int B, int T, int F, Blo
     a.gb = p.gb;
     a.slope = p.gslope;
     a.P = T * F;
+    a.cs = w.cs;
     if (caf) {
         a.caf_r = caf->r_out; a.caf_att = caf->att_out;
         a.caf_w_key = caf->w_key; a.caf_bn_key = caf->bn_key; a.caf_w_val = caf->w_val; a.caf_bn_val = caf->bn_val;
         a.caf_T = caf->T; a.caf_F = caf->F; a.caf_Tv = caf->Tv;
     }
-    return launch_pws_b2b(a, B, st);
+    const int rc = launch_pws_b2b4(a, B, ctr, st);  // padded rows, no CAF: the pipelined kernel (k_b2b.hip)
+    return rc == RTFS_ERR_ARG ? launch_pws_b2b(a, B, st) : rc;
 }
 
-int audio_bn(const BnPack& p, const float* x, const double* stats, float* out, int B, int P, hipStream_t st) {
+int audio_bn(const BnPack& p, const float* x, const double* stats, float* out, int B, int P, hipStream_t st, int cs = 0) {
     PwArgs a;
     a.x = x;
     a.wt = p.wt;
@@ -551,6 +542,7 @@ int audio_bn(const BnPack& p, const float* x, const double* stats, float* out, i
     a.gamma = p.gamma;
     a.beta = p.beta;
     a.P = P;
+    a.cs = cs;
     a.w16 = p.w16;
     return gemm_f32() ? launch_pw_audio_bn(a, B, st) : launch_pwr_audio_bn(a, B, st);
 }
@@ -856,21 +848,33 @@ int rtfs_istft_decoder_f32(const float* x, const float* pack, float* wav, int B,
 
 // ------------------------------------------------------------ whole separator
 namespace {
+// Channel stride of the separator's full-resolution tensors.  T * F = T * 129 floats is odd, so in a contiguous (B, C, T, F) tensor every
+// channel row starts somewhere inside a 128-byte line and every 64-pixel wave segment of the pointwise kernels writes two PARTIAL lines;
+// partial lines whose halves come from workgroups on different XCDs cannot merge in an L2 and reach memory as masked writes.  Measured
+// (tools/bench_stream5.hip, row-walk pattern of the pointwise kernels): stores 3.35 TB/s at pitch 32379, 5.5 TB/s at 32384; two reads +
+// one write 4.55 -> 5.35 TB/s.  All of these tensors are workspace (never seen by the caller), so their rows are padded - to a multiple of 64 floats, so that
+// every 64-pixel wave segment also lies INSIDE its row's allocation and the padded-row kernels need no bounds predicates (k_b2b.hip).
+inline int pitch(int P) { return (P + 63) / 64 * 64; }
+
 struct SepWs {
     float *spec, *a0, *a1, *cur, *nxt, *r, *att, *z;
     double* st0;
+    unsigned* ctr;  // 64 tile counters (one per persistent launch of the call), zeroed together with st0
+    int cs;
     BlockWs blk;
-    SepWs(Arena& a, int B, int T, int Tv)
+    SepWs(Arena& a, int B, int T, int Tv, int cs_)
         : spec(a.take<float>((size_t)B * 2 * T * NF)),
-          a0(a.take<float>((size_t)B * CA * T * NF)),
-          a1(a.take<float>((size_t)B * CA * T * NF)),
-          cur(a.take<float>((size_t)B * CA * T * NF)),
-          nxt(a.take<float>((size_t)B * CA * T * NF)),
+          a0(a.take<float>((size_t)B * CA * cs_)),
+          a1(a.take<float>((size_t)B * CA * cs_)),
+          cur(a.take<float>((size_t)B * CA * cs_)),
+          nxt(a.take<float>((size_t)B * CA * cs_)),
           r(a.take<float>((size_t)B * CA * Tv)),
           att(a.take<float>((size_t)B * CA * Tv)),
-          z(a.take<float>((size_t)B * 18 * T * NF)),
-          st0(a.take<double>(2 * B)),
-          blk(a, B, T, NF) {}
+          z(a.take<float>((size_t)B * 18 * cs_)),
+          st0(a.take<double>(2 * B + 32)),
+          ctr(reinterpret_cast<unsigned*>(st0 ? st0 + 2 * B : nullptr)),
+          cs(cs_),
+          blk(a, B, T, NF, cs_) {}
 };
 }  // namespace
 
@@ -893,16 +897,18 @@ int separator_part(const SepPacks& k, const float* wav, const float* video_vp, f
     const CafPack& pc = k.pc;
     const S3Pack& ps = k.ps;
     const DecPack& pd = k.pd;
-    const int P = T * NF;
-    if (hipMemsetAsync(w.st0, 0, sizeof(double) * 2 * B, st) != hipSuccess) return RTFS_ERR_LAUNCH;
+    const int P = T * NF, cs = w.cs;
+    if (hipMemsetAsync(w.st0, 0, sizeof(double) * (2 * B + 32), st) != hipSuccess) return RTFS_ERR_LAUNCH;  // + the tile counters
+    int nctr = 0;
     CHECK(launch_stft(wav, w.spec, B, L, T, st));
-    CHECK(launch_enc_conv(w.spec, pe.w, w.a0, w.st0, B, CA, T, NF, (size_t)P, (size_t)CA * P, st));
-    CHECK(audio_bn(pb, w.a0, w.st0, w.a1, B, P, st));
+    CHECK(launch_enc_conv(w.spec, pe.w, w.a0, w.st0, B, CA, T, NF, (size_t)cs, (size_t)CA * cs, st));
+    CHECK(audio_bn(pb, w.a0, w.st0, w.a1, B, P, st, cs));
     // refinement_module.py:45-62: block(a1); CAF; then (repeats-1) x block(audio + a1), shared weights
     // refinement_module.py:45-62: block(a1); CAF; then (repeats-1) x block(audio + a1), shared weights.
     CafArgs ca = caf_args(pc, w.cur, video_vp, w.nxt, w.r, w.att, T, NF, Tv);
     float *cur = w.cur, *nxt = w.nxt;
-    if (gemm_f32() || repeats == 1) {  // unfused reference sequence (A/B path)
+    if (gemm_f32() || repeats == 1) {  // unfused reference sequence (A/B path); contiguous tensors (cs == P, see rtfs_separator_forward_f32)
+        RTFS_RETURN_IF(cs != P, RTFS_ERR_ARG);
         CHECK(block_forward(pk, w.a1, nullptr, w.cur, B, T, NF, w.blk, st));
         if (video_ready && hipStreamWaitEvent(st, (hipEvent_t)video_ready, 0) != hipSuccess) return RTFS_ERR_LAUNCH;
         CHECK(launch_caf_video(ca, B, st));
@@ -919,33 +925,22 @@ int separator_part(const SepPacks& k, const float* wav, const float* video_vp, f
         // block outputs between applications never reach HBM: the residual conv of block i, the CAF (after block 0),
         // the "+ a1" and the gateway + projection of block i+1 run back to back in one kernel (block_boundary).
         CHECK(block_head(pk, w.a1, nullptr, B, T, NF, w.blk, st, nullptr));
-        // Experiment knob (default off): RTFS_SUBBATCH=n runs the inner part of a block (the 21 launches between the projection and
-        // `expanded`) per sub-batch of n mixtures.  Idea: at batch 32 a 64-channel full-resolution tensor is 265 MB, just past the 256 MB
-        // Infinity Cache, and is read by two to four consecutive kernels; at 16 it is 133 MB.  Measured (bench, one box): whole batch
-        // 15.5 ms, n = 16 16.8, n = 8 19.0, n = 4 26.6 - the smaller launches cost more than the on-die re-reads save.
-        static const int sb_env = getenv("RTFS_SUBBATCH") ? atoi(getenv("RTFS_SUBBATCH")) : 0;
-        const int sb = sb_env > 0 && sb_env < B ? sb_env : B;
         for (int i = 0; i < repeats; ++i) {
-            if (hipMemsetAsync(w.blk.stats, 0, sizeof(double) * BlockWs::NSTAT * B * 2, st) != hipSuccess) return RTFS_ERR_LAUNCH;
-            for (int first = 0; first < B; first += sb) {
-                const int nb = B - first < sb ? B - first : sb;
-                const BlockWs view = w.blk.sub(first);
-                CHECK(block_body(pk, nb, T, NF, view, st, false, single_chain));
-            }
+            CHECK(block_body(pk, B, T, NF, w.blk, st, single_chain));
             if (i == 0) {
                 if (video_ready && hipStreamWaitEvent(st, (hipEvent_t)video_ready, 0) != hipSuccess) return RTFS_ERR_LAUNCH;
                 CHECK(launch_caf_video(ca, B, st));
             }
-            if (i + 1 < repeats) CHECK(block_boundary(pk, w.a1, B, T, NF, w.blk, st, i == 0 ? &ca : nullptr));
+            if (i + 1 < repeats) CHECK(block_boundary(pk, w.a1, B, T, NF, w.blk, st, i == 0 ? &ca : nullptr, nctr < 64 ? w.ctr + nctr++ : nullptr));
             else CHECK(block_tail(pk, cur, B, T, NF, w.blk, st));
         }
     }
     if (!gemm_f32() && !getenv("RTFS_NO_S3T")) {  // S3 + decoder taps in one kernel: the separated spectrum never goes to HBM
         PwArgs a;
-        a.x = cur; a.bias = ps.bias; a.aux = w.a0; a.out = w.z; a.slope = ps.slope; a.P = P; a.w16 = ps.w16; a.w16b = pd.w16p; a.cout_live = 18;
+        a.x = cur; a.bias = ps.bias; a.aux = w.a0; a.out = w.z; a.slope = ps.slope; a.P = P; a.cs = cs; a.w16 = ps.w16; a.w16b = pd.w16p; a.cout_live = 18;
         a.stats = w.st0; a.inv_count = 1.0 / ((double)CA * P);  // rms(a0) per mixture: the amplitude the taps GEMM's operand is normalised by
         CHECK(launch_pwr_s3_taps(a, B, st));
-        return launch_dec_istft(w.z, out, B, T, NF, L, (size_t)T * NF, (size_t)18 * T * NF, st);
+        return launch_dec_istft(w.z, out, B, T, NF, L, (size_t)cs, (size_t)18 * cs, st);
     }
     CHECK(s3_mask(ps, cur, w.a0, nxt, B, P, st));
     return decoder(pd, nxt, out, w.z, B, T, L, st);
@@ -976,7 +971,7 @@ static int separator_parts(int B) {
 size_t rtfs_separator_workspace_bytes(int B, int L, int Tv) {
     Arena ar(nullptr, 0);
     const int T = rtfs_num_frames(L), np = separator_parts(B);
-    for (int i = 0; i < np; ++i) SepWs w(ar, (B * (i + 1)) / np - (B * i) / np, T, Tv);
+    for (int i = 0; i < np; ++i) SepWs w(ar, (B * (i + 1)) / np - (B * i) / np, T, Tv, pitch(T * NF));  // upper bound: the unfused path carves less
     return ar.off + 256;
 }
 
@@ -992,7 +987,11 @@ int rtfs_separator_forward_f32(const float* wav, const float* video_vp, const fl
     Arena ar(ws, ws_bytes);
     std::vector<SepWs> parts;
     parts.reserve(np);
-    for (int i = 0; i < np; ++i) parts.emplace_back(ar, (B * (i + 1)) / np - (B * i) / np, T, Tv);
+    // padded channel rows on the fused path; the unfused A/B sequence (exact-f32 GEMMs, or a single repeat) runs kernels that know only
+    // contiguous tensors
+    const bool no_s3t = getenv("RTFS_NO_S3T") != nullptr;
+    const int cstride = (gemm_f32() || repeats == 1 || no_s3t) ? T * NF : pitch(T * NF);
+    for (int i = 0; i < np; ++i) parts.emplace_back(ar, (B * (i + 1)) / np - (B * i) / np, T, Tv, cstride);
     RTFS_RETURN_IF(!ws || !ar.ok(), RTFS_ERR_WORKSPACE);
     hipStream_t st = S(stream);
     Cursor ce(pack_enc), cb(pack_bn), ck(pack_block), cc(pack_caf), cs(pack_s3), cd(pack_dec);

@@ -1,0 +1,253 @@
+// Block boundary of the fused separator, second generation (padded channel rows only; launch_pws_b2b routes here).
+//   out_i          = residual_conv(expanded_i) + residual_i                 separators/tdanet.py:129
+//   x              = out_i + a1                                             TDAVNet/refinement_module.py:58-60 (shared block, "+ residual")
+//   residual_{i+1} = PReLU(dw1x1(x)),  x_enc_{i+1} = proj(residual_{i+1})   separators/tdanet.py:106-107
+// Same arithmetic and GEMM chaining as pws_b2b_kernel (k_pws.hip): GEMM 1 (64 -> 256) one 32-channel tile at a time, its accumulator
+// registers rewritten in place as residual_{i+1} and fed back as the B operand of GEMM 2 (256 -> 64, K-permuted weight image).
+//
+// What changed, and why (round 3, tools/bench_stream{2..5}.hip + the ISA of the old kernel):
+//  * The old kernel issued 8 loads, waited for (nearly) all of them, did a quarter tile of arithmetic, stored, and only then issued the next 8:
+//    the memory pipe drained four times per 32-channel tile, 8 waves x <= 4 KB in flight per CU.  Its conditional stores (ragged last tile
+//    of a sample) put every store in its own basic block, which made the compiler's in-order vmcnt waits conservative on top.
+//  * Here a wave is a software pipeline over 32-channel tiles: the 32 loads (residual + a1 rows, 16 KB per wave) of tile m + 1 are issued
+//    before tile m's arithmetic, into a second register buffer.  That needs 128 registers of load buffers, so a workgroup is 4 waves with
+//    the 512-register budget (one wave per SIMD) instead of 8 with 256.
+//  * Channel rows are padded to a multiple of 64 floats (api.hip pitch()): every wave's 64-pixel segment of a row is two whole 128-byte lines
+//    INSIDE the row's allocation, so loads and stores are unconditional - no live / tail predicates anywhere in the loop.  (Partial lines
+//    shared by workgroups on different XCDs were what held row-walk stores at 3.35 TB/s; whole lines: 5.5.)
+//  * Tiles are handed out by an atomic counter instead of a static stride: CUs do not stream at equal rates, and a static partition ends with
+//    the slowest (4.1 -> 4.9 TB/s on the skeleton of this kernel, one workgroup per CU).
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2a __attribute__((ext_vector_type(2), aligned(8)));
+typedef _Float16 half2_ __attribute__((ext_vector_type(2)));
+
+// Two adjacent floats through a raw buffer descriptor: address = descriptor base (this wave's first pixel of the sample, wave-uniform) +
+// lane byte offset (one VGPR for the whole kernel) + row byte offset (an SGPR: one s_add per access).  The flat global_load form needs a
+// 64-bit scalar base per channel row: 64 SGPR pairs per tile, which the first version of this kernel spilled (276 v_readlane per two tiles).
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_of(const float* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ f32x2 ld2(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0));
+}
+__device__ __forceinline__ void st2(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, f32x2 v) {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), rs, voff, soff, 0);
+}
+
+// f16 hi / lo split of two values: hi = RNE(v) (one v_cvt_pk_f16_f32), lo = (f16)(v - hi) (one v_fma_mix per value)
+__device__ __forceinline__ void split2(float v0, float v1, unsigned& hi, unsigned& lo) {
+    const half2_ h = __builtin_convertvector(f32x2{v0, v1}, half2_);
+    hi = __builtin_bit_cast(unsigned, h);
+    unsigned l;
+    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(l) : "v"(v0), "v"(hi));
+    asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(v1), "v"(hi));
+    lo = l;
+}
+
+constexpr int B4_NT = 256;              // threads per workgroup: 4 waves, one per SIMD, 512 registers each
+constexpr int B4_L1 = 64 + 8, B4_L2 = 256 + 8;
+constexpr size_t B4_LDS = (size_t)2 * 256 * B4_L1 * 2 + (size_t)2 * 64 * B4_L2 * 2 + (size_t)(3 * 256 + 64) * 4 + 16;
+
+__global__ __launch_bounds__(B4_NT) void pws_b2b4_kernel(B2bArgs a, int ntiles, int tiles_per_sample, unsigned* __restrict__ ctr) {
+    constexpr int L1 = B4_L1, L2 = B4_L2;
+    constexpr float WINV = 1.0f / 256.0f;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    _Float16* W1h = reinterpret_cast<_Float16*>(smem);  // [256][L1]
+    _Float16* W1l = W1h + 256 * L1;
+    _Float16* W2h = W1l + 256 * L1;                      // [64][L2], K permuted
+    _Float16* W2l = W2h + 64 * L2;
+    float* cA = reinterpret_cast<float*>(W2l + 64 * L2);  // per output channel of GEMM 1: gateway scale / 256
+    float* cB = cA + 256;                                 //   gateway scale
+    float* cC = cB + 256;                                 //   residual_conv bias * gateway scale + gateway bias
+    float* bp = cC + 256;                                 // projection bias (64)
+    int* s_next = reinterpret_cast<int*>(bp + 64);        // [2]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    {
+        const half8* s1 = reinterpret_cast<const half8*>(a.w1_16);  // [2 chunks][hi|lo][256][32]
+        for (int i = tid; i < 2 * 2 * 256 * 4; i += B4_NT) {
+            const int pc = i & 3, co = (i >> 2) & 255, part = (i >> 10) & 1, chunk = i >> 11;
+            *reinterpret_cast<half8*>((part ? W1l : W1h) + co * L1 + chunk * 32 + pc * 8) = s1[i];
+        }
+        const half8* s2 = reinterpret_cast<const half8*>(a.w2_16);  // [8 chunks][hi|lo][64][32]
+        for (int i = tid; i < 8 * 2 * 64 * 4; i += B4_NT) {
+            const int pc = i & 3, co = (i >> 2) & 63, part = (i >> 8) & 1, chunk = i >> 9;
+            *reinterpret_cast<half8*>((part ? W2l : W2h) + co * L2 + chunk * 32 + pc * 8) = s2[i];
+        }
+        {
+            const float g = a.gw[tid];
+            cA[tid] = g * WINV;
+            cB[tid] = g;
+            cC[tid] = fmaf(a.b1[tid], g, a.gb[tid]);
+            if (tid < 64) bp[tid] = a.bp[tid];
+        }
+    }
+    const float slope = a.slope[0];
+    const int P = a.P;
+    const unsigned CS = (unsigned)a.cs;
+    // lane (r, h): pixels 2r, 2r + 1 of its wave's 64; B-fragment rows are channels 8h + j of a 16-channel K step, accumulator rows are
+    // channels 4h + (q & 3) + 8 (q >> 2) of a 32-channel tile: two lane byte offsets serve every access of the kernel
+    const unsigned voffB = ((unsigned)(8 * h) * CS + 2u * r) * 4u;
+    const unsigned voffC = ((unsigned)(4 * h) * CS + 2u * r) * 4u;
+    int it = 0;
+    int tile = blockIdx.x;
+    while (tile < ntiles) {
+        if (tid == 0) s_next[it & 1] = (ctr ? (int)atomicAdd(ctr, 1u) : tile) + (int)gridDim.x;
+        if (it == 0) __syncthreads();  // resident weights visible
+        const int b = tile / tiles_per_sample;
+        const int wp0 = (tile - b * tiles_per_sample) * (B4_NT / 64 * 64) + wave * 64;  // first pixel of this wave (wave-uniform)
+        if (wp0 < P) {
+            const __amdgpu_buffer_rsrc_t xs = rsrc_of(a.x + (size_t)b * 64 * CS + wp0);
+            const __amdgpu_buffer_rsrc_t ress = rsrc_of(a.res + (size_t)b * 256 * CS + wp0);
+            const __amdgpu_buffer_rsrc_t a1s = rsrc_of(a.a1 + (size_t)b * 256 * CS + wp0);
+            const __amdgpu_buffer_rsrc_t xes = rsrc_of(a.xenc + (size_t)b * 64 * CS + wp0);
+            const unsigned CS4 = CS * 4u;  // row pitch in bytes
+            // ---- loads of 32-channel tile m (residual_i and a1 rows): 32 x 8 bytes per lane
+            f32x2 R[2][16], A[2][16];
+            auto load_tile = [&](int m, f32x2 (&Rb)[16], f32x2 (&Ab)[16]) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const unsigned ro = (unsigned)(m * 32 + (q & 3) + 8 * (q >> 2)) * CS4;  // uniform
+                    Rb[q] = ld2(ress, voffC, ro);
+                    Ab[q] = ld2(a1s, voffC, ro);
+                }
+            };
+            // ---- B fragments of GEMM 1 (expanded_i: 64 channels of this lane's two pixels)
+            half8 xh[4][2], xl[4][2];
+            {
+                f32x2 v[4][8];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[ks][j] = ld2(xs, voffB, (unsigned)(ks * 16 + j) * CS4);
+                load_tile(0, R[0], A[0]);
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    unsigned hi0[4], lo0[4], hi1[4], lo1[4];
+#pragma unroll
+                    for (int jp = 0; jp < 4; ++jp) {
+                        split2(v[ks][2 * jp].x, v[ks][2 * jp + 1].x, hi0[jp], lo0[jp]);
+                        split2(v[ks][2 * jp].y, v[ks][2 * jp + 1].y, hi1[jp], lo1[jp]);
+                    }
+                    xh[ks][0] = __builtin_bit_cast(half8, *reinterpret_cast<f32x4*>(hi0));
+                    xl[ks][0] = __builtin_bit_cast(half8, *reinterpret_cast<f32x4*>(lo0));
+                    xh[ks][1] = __builtin_bit_cast(half8, *reinterpret_cast<f32x4*>(hi1));
+                    xl[ks][1] = __builtin_bit_cast(half8, *reinterpret_cast<f32x4*>(lo1));
+                }
+            }
+            f32x16 acc2[2][2];  // [projection tile][pixel slot]
+#pragma unroll
+            for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+                for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) acc2[m2][sl][q] = 0.f;
+            // one 32-channel tile: GEMM 1 -> epilogue (residual_{i+1} written through) -> two K steps of GEMM 2
+            auto tile_body = [&](int m, const f32x2 (&Rb)[16], const f32x2 (&Ab)[16]) {
+                f32x16 acc1[2];
+#pragma unroll
+                for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) acc1[sl][q] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const half8 ah = *reinterpret_cast<const half8*>(W1h + (m * 32 + r) * L1 + ks * 16 + 8 * h);
+                    const half8 al = *reinterpret_cast<const half8*>(W1l + (m * 32 + r) * L1 + ks * 16 + 8 * h);
+#pragma unroll
+                    for (int sl = 0; sl < 2; ++sl) {
+                        acc1[sl] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xh[ks][sl], acc1[sl], 0, 0, 0);
+                        acc1[sl] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xl[ks][sl], acc1[sl], 0, 0, 0);
+                        acc1[sl] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, xh[ks][sl], acc1[sl], 0, 0, 0);
+                    }
+                }
+                const int cob = m * 32 + 4 * h;  // channel of accumulator register q: cob + (q & 3) + 8 (q >> 2)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {  // accumulator registers 8s .. 8s+7 = K step 2m + s of GEMM 2
+                    float y0[8], y1[8];
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) {  // four consecutive channels: one 16-byte LDS read per constant
+                        const int c4 = cob + 8 * (2 * s + g);
+                        const f32x4 kA = *reinterpret_cast<const f32x4*>(cA + c4);
+                        const f32x4 kB = *reinterpret_cast<const f32x4*>(cB + c4);
+                        const f32x4 kC = *reinterpret_cast<const f32x4*>(cC + c4);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int j = 4 * g + i, q = 8 * s + j;
+                            const f32x2 ra = Rb[q] + Ab[q];
+                            const float t0 = fmaf(acc1[0][q], kA[i], fmaf(ra.x, kB[i], kC[i]));
+                            const float t1 = fmaf(acc1[1][q], kA[i], fmaf(ra.y, kB[i], kC[i]));
+                            y0[j] = preluf_(t0, slope);
+                            y1[j] = preluf_(t1, slope);
+                            st2(ress, voffC, (unsigned)(m * 32 + (q & 3) + 8 * (q >> 2)) * CS4, f32x2{y0[j], y1[j]});
+                        }
+                    }
+                    unsigned h0[4], l0[4], h1[4], l1[4];
+#pragma unroll
+                    for (int jp = 0; jp < 4; ++jp) {
+                        split2(y0[2 * jp], y0[2 * jp + 1], h0[jp], l0[jp]);
+                        split2(y1[2 * jp], y1[2 * jp + 1], h1[jp], l1[jp]);
+                    }
+                    const half8 bh0 = __builtin_bit_cast(half8, *reinterpret_cast<f32x4*>(h0)), bl0 = __builtin_bit_cast(half8, *reinterpret_cast<f32x4*>(l0));
+                    const half8 bh1 = __builtin_bit_cast(half8, *reinterpret_cast<f32x4*>(h1)), bl1 = __builtin_bit_cast(half8, *reinterpret_cast<f32x4*>(l1));
+                    const int kk = (2 * m + s) * 16 + 8 * h;
+#pragma unroll
+                    for (int m2 = 0; m2 < 2; ++m2) {
+                        const half8 ah = *reinterpret_cast<const half8*>(W2h + (m2 * 32 + r) * L2 + kk);
+                        const half8 al = *reinterpret_cast<const half8*>(W2l + (m2 * 32 + r) * L2 + kk);
+                        acc2[m2][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh0, acc2[m2][0], 0, 0, 0);
+                        acc2[m2][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl0, acc2[m2][0], 0, 0, 0);
+                        acc2[m2][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh0, acc2[m2][0], 0, 0, 0);
+                        acc2[m2][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh1, acc2[m2][1], 0, 0, 0);
+                        acc2[m2][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl1, acc2[m2][1], 0, 0, 0);
+                        acc2[m2][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh1, acc2[m2][1], 0, 0, 0);
+                    }
+                }
+            };
+#pragma unroll 1
+            for (int m = 0; m < 8; m += 2) {
+                load_tile(m + 1, R[1], A[1]);
+                __builtin_amdgcn_sched_barrier(0);
+                tile_body(m, R[0], A[0]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (m + 2 < 8) load_tile(m + 2, R[0], A[0]);  // uniform
+                __builtin_amdgcn_sched_barrier(0);
+                tile_body(m + 1, R[1], A[1]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int m2 = 0; m2 < 2; ++m2) {
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(bp + m2 * 32 + 4 * h), b1_ = *reinterpret_cast<const f32x4*>(bp + m2 * 32 + 4 * h + 8);
+                const f32x4 b2 = *reinterpret_cast<const f32x4*>(bp + m2 * 32 + 4 * h + 16), b3 = *reinterpret_cast<const f32x4*>(bp + m2 * 32 + 4 * h + 24);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const float bq = (q >> 2) == 0 ? b0[q & 3] : (q >> 2) == 1 ? b1_[q & 3] : (q >> 2) == 2 ? b2[q & 3] : b3[q & 3];
+                    st2(xes, voffC, (unsigned)(m2 * 32 + (q & 3) + 8 * (q >> 2)) * CS4, f32x2{fmaf(acc2[m2][0][q], WINV, bq), fmaf(acc2[m2][1][q], WINV, bq)});
+                }
+            }
+        }
+        __syncthreads();
+        tile = s_next[it & 1];
+        ++it;
+    }
+}
+
+}  // namespace
+
+// cs must be a multiple of 64 floats covering every wave segment (api.hip pitch()); ctr: one zeroed counter word for this launch, or null
+// (static stride).  Returns RTFS_ERR_ARG when the call does not qualify (the caller then uses the first-generation kernel).
+int launch_pws_b2b4(const B2bArgs& a, int B, unsigned* ctr, hipStream_t st) {
+    if (a.caf_r || a.cs <= 0 || (a.cs & 63) || a.cs < (a.P + 63) / 64 * 64 || a.P < 2) return RTFS_ERR_ARG;
+    if ((size_t)256 * a.cs * 4 >= ((size_t)1 << 31)) return RTFS_ERR_ARG;  // buffer offsets inside one sample: 31 bits
+    if (rtfs_set_max_lds((const void*)pws_b2b4_kernel, B4_LDS) != RTFS_OK) return RTFS_ERR_LAUNCH;
+    const int tps = cdiv(a.P, B4_NT / 64 * 64), ntiles = tps * B;
+    const int grid = ntiles < 256 ? ntiles : 256;  // one resident workgroup per CU
+    hipLaunchKernelGGL(pws_b2b4_kernel, dim3(grid), dim3(B4_NT), B4_LDS, st, a, ntiles, tps, ctr);
+    return rtfs_launch_status();
+}

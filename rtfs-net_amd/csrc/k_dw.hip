@@ -28,7 +28,7 @@ __device__ __forceinline__ void dw_s1_body(const DwArgs& a, const float* __restr
     const bool live = g < C * W;
     const int c = live ? g / W : 0, f = live ? g - c * W : 0;
     const int r0 = blockIdx.y * a.TH, r1 = min(r0 + a.TH, H);
-    const size_t plane = ((size_t)b * C + c) * H * W;
+    const size_t plane = ((size_t)b * C + c) * (size_t)a.cs;  // channel stride: H * W or padded (DwArgs.cs)
     const float* __restrict__ xp = X + plane;
     float isc = 1.f, ish = 0.f;
     if (IN_AFFINE) gln_fold(a.in_stats + 2 * b, a.in_inv_count, a.in_gamma[c], a.in_beta[c], isc, ish);
@@ -190,9 +190,9 @@ __device__ __forceinline__ void dw1p_body(const DwArgs& a, const float* __restri
     const int r0 = blockIdx.y * a.TH, r1 = min(r0 + a.TH, H);
     // addressing: wave-uniform 64-bit bases (sample, row) + 32-bit lane BYTE offsets (channel plane + column), so a load
     // costs no vector address arithmetic (global_load saddr + voffset); the launcher checks that C*H*W*4 fits 31 bits
-    const size_t sample = (size_t)b * C * H * W;
+    const size_t sample = (size_t)b * C * (size_t)a.cs;  // channel stride a.cs: H * W or padded
     const float* __restrict__ Xs_ = X + sample;
-    const unsigned pa = (unsigned)c * (unsigned)(H * W) * 4u;
+    const unsigned pa = (unsigned)c * (unsigned)a.cs * 4u;
     auto col = [&](int x) { return pa + 4u * (unsigned)(x < 0 ? 0 : (x < W ? x : W - 1)); };
     const unsigned o0 = col(x0), o1 = col(x1);
     // the pair as ONE 8-byte access at column x0; the odd-width row's last pair (x1 == W) reads (x0-1, x0) instead
@@ -287,9 +287,15 @@ __device__ __forceinline__ void dw1p_body(const DwArgs& a, const float* __restri
             for (int j = 0; j < 5; ++j) v[j] = 0.f;
         }
     };
-    // ---- start-up: every load the first trip needs (window rows r0-1 .. r0+1+RQ, the weights) is requested before the
-    // first wait and before the f64 gLN folds below, so a workgroup pays one memory latency, not three
-    constexpr int RQ = 2;  // rows per trip = prefetch distance
+    // ---- start-up: every load the first rows need (window rows r0-1 .. r0+1+RQ, the weights) is requested before the
+    // first wait and before the f64 gLN folds below, so a workgroup pays one memory latency, not three.
+    // RQ = rows in flight per wave = ring depth.  Round 3: with RQ = 2 the compiler waited for a trip's two loads at the END of the same
+    // trip (vmcnt(0) behind ~90 instructions of arithmetic): one kilobyte per wave and memory latency, 3-4 TB/s whatever the band height.
+    // The ring keeps the load of row t + 2 + RQ in flight while row t is computed (tools/bench_dw.hip for the sweep over RQ).
+#ifndef DW1P_RQ
+#define DW1P_RQ (MODE == 2 ? 4 : 8)
+#endif
+    constexpr int RQ = DW1P_RQ;
     Raw st0 = load_raw(r0 - 1), st1 = load_raw(r0), st2 = load_raw(r0 + 1);
     Raw q[RQ];
 #pragma unroll
@@ -392,34 +398,21 @@ __device__ __forceinline__ void dw1p_body(const DwArgs& a, const float* __restri
             }
         }
     };
-    // RQ output rows per trip; the loads of the next trip's RQ window rows are issued before this trip's arithmetic
+    // RQ output rows per trip, fully unrolled so that the ring index is static; the slot of row t + 2 + k is re-loaded (row t + 2 + RQ + k) as
+    // soon as its value has been moved into the window, RQ rows before that value is needed
     for (int t = r0; t < r1; t += RQ) {
-        float n[RQ][5];
-        Raw e[RQ];
 #pragma unroll
         for (int k = 0; k < RQ; ++k) {
-            complete(t + 2 + k, q[k], n[k]);
-            e[k] = q[k];
-        }
-#pragma unroll
-        for (int k = 0; k < RQ; ++k) q[k] = load_raw(t + 2 + RQ + k);
-        do_row(t, win[0], win[1], win[2], n[0], e[0]);
-        if (t + 1 < r1) do_row(t + 1, win[1], win[2], n[0], n[1], e[1]);  // uniform
-        if (RQ == 4) {
-            if (t + 2 < r1) do_row(t + 2, win[2], n[0], n[1], n[RQ - 2], e[RQ - 2]);
-            if (t + 3 < r1) do_row(t + 3, n[0], n[1], n[RQ - 2], n[RQ - 1], e[RQ - 1]);
+            float n[5];
+            const Raw e = q[k];
+            complete(t + 2 + k, e, n);
+            q[k] = load_raw(t + 2 + RQ + k);
+            if (t + k < r1) do_row(t + k, win[0], win[1], win[2], n, e);  // uniform
 #pragma unroll
             for (int j = 0; j < 5; ++j) {
-                win[0][j] = n[1][j];
-                win[1][j] = n[RQ - 2][j];
-                win[2][j] = n[RQ - 1][j];
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 5; ++j) {
-                win[0][j] = win[2][j];
-                win[1][j] = n[0][j];
-                win[2][j] = n[1][j];
+                win[0][j] = win[1][j];
+                win[1][j] = win[2][j];
+                win[2][j] = n[j];
             }
         }
     }
@@ -434,7 +427,7 @@ __device__ __forceinline__ void dw1p_body(const DwArgs& a, const float* __restri
 
 // single-conv variants are held to 128 VGPRs (4 waves per SIMD): these passes live on bytes in flight
 template <int NCONV, bool IN_AFFINE, int MODE>
-__global__ __launch_bounds__(256, NCONV == 1 && !(IN_AFFINE && MODE == 2) ? 4 : 2) void dw1p_kernel(DwArgs a) {
+__global__ __launch_bounds__(256, NCONV == 1 && MODE != 2 ? 4 : 2) void dw1p_kernel(DwArgs a) {
     dw1p_body<NCONV, IN_AFFINE, MODE>(a, a.x, a.gate, a.emb, a.addend, a.out[0], a.out[1], a.out[2], a.out[3]);
 }
 
@@ -452,7 +445,7 @@ __device__ __forceinline__ void dw_s2_pool_body(const DwArgs& a, const float* __
     const bool live = g < C * Wo;
     const int c = live ? g / Wo : 0, j = live ? g - c * Wo : 0;
     const int i0 = blockIdx.y * a.TH, i1 = min(i0 + a.TH, Ho);
-    const size_t plane = ((size_t)b * C + c) * H * W;
+    const size_t plane = ((size_t)b * C + c) * (size_t)a.cs;
     const float* __restrict__ xp = X + plane;
     float isc, ish;
     gln_fold(a.in_stats + 2 * b, a.in_inv_count, a.in_gamma[c], a.in_beta[c], isc, ish);
@@ -539,9 +532,9 @@ __device__ __forceinline__ void dw_s2x_body(const DwArgs& a, const float* __rest
     const bool live = lane >= 1 && lane <= DW1P_PAIRS && gi < C * NP && j < Wo;
     const int x0 = 2 * j, x1 = 2 * j + 1;
     const int i0 = blockIdx.y * a.TH, i1 = min(i0 + a.TH, Ho);
-    const size_t sample = (size_t)b * C * H * W;
+    const size_t sample = (size_t)b * C * (size_t)a.cs;
     const float* __restrict__ Xs_ = X + sample;
-    const unsigned pa = (unsigned)c * (unsigned)(H * W) * 4u;
+    const unsigned pa = (unsigned)c * (unsigned)a.cs * 4u;
     const bool whole = x1 < W;
     const unsigned o2 = pa + 4u * (unsigned)(whole ? x0 : x0 - 1);  // the odd-width row's last pair reads (x0-1, x0)
     auto load_raw = [&](int t) {
@@ -782,8 +775,11 @@ static int launch_dw1p_t(const DwArgs& a, int B, hipStream_t st) {
     return rtfs_launch_status();
 }
 
-int launch_dw_s1(const DwArgs& a, int nconv, bool in_affine, int mode, int B, hipStream_t st) {
-    if ((size_t)a.C * a.H * a.W * 4 >= ((size_t)1 << 31)) return RTFS_ERR_SHAPE;  // 32-bit lane offsets
+int launch_dw_s1(const DwArgs& a_, int nconv, bool in_affine, int mode, int B, hipStream_t st) {
+    if (a_.cs && a_.cs < a_.H * a_.W) return RTFS_ERR_SHAPE;
+    DwArgs a = a_;
+    if (!a.cs) a.cs = a.H * a.W;
+    if ((size_t)a.C * a.cs * 4 >= ((size_t)1 << 31)) return RTFS_ERR_SHAPE;  // 32-bit lane offsets
     if (a.W >= 16) {  // packed two-column variant (v_pk_fma_f32); the scalar kernel below only serves very narrow inputs
         if (nconv == 1) {
             if (mode == 0) return in_affine ? launch_dw1p_t<1, true, 0>(a, B, st) : launch_dw1p_t<1, false, 0>(a, B, st);
@@ -813,8 +809,11 @@ int launch_dw_s1(const DwArgs& a, int nconv, bool in_affine, int mode, int B, hi
     return RTFS_ERR_ARG;
 }
 
-int launch_dw_s2_pool(const DwArgs& a, int B, hipStream_t st) {
-    if (a.Wg >= 16 && a.W >= 2 && (a.W + 1) / 2 >= a.Wg && (size_t)a.C * a.H * a.W * 4 < ((size_t)1 << 31)) {
+int launch_dw_s2_pool(const DwArgs& a_, int B, hipStream_t st) {
+    if (a_.cs && a_.cs < a_.H * a_.W) return RTFS_ERR_SHAPE;
+    DwArgs a = a_;
+    if (!a.cs) a.cs = a.H * a.W;
+    if (a.Wg >= 16 && a.W >= 2 && (a.W + 1) / 2 >= a.Wg && (size_t)a.C * a.cs * 4 < ((size_t)1 << 31)) {
         hipLaunchKernelGGL(dw_s2x_kernel, dim3(cdiv(cdiv(a.C * ((a.W + 1) / 2), DW1P_PAIRS), 4), cdiv(a.Hg, a.TH), B), dim3(256), 0, st, a);
         return rtfs_launch_status();
     }

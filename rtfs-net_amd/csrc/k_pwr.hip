@@ -42,6 +42,7 @@ __device__ __forceinline__ void pwr_body(const PwArgs& a, const float* __restric
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int P = a.P;
+    const unsigned CS = (unsigned)a.cs;  // channel stride of x / aux / out (the launcher checks 256 * cs < 2^31)
     bs[tid] = a.bias[tid];  // visible after the first barrier
     const float slope = MODE != PWR_BN ? a.slope[0] : 0.f;
 
@@ -83,14 +84,14 @@ __device__ __forceinline__ void pwr_body(const PwArgs& a, const float* __restric
         }
         __syncthreads();  // sc/sh visible; weight buffer 0 (written at the end of the previous tile) visible
         // ---- this wave's pixels: 16 k-steps of B fragments, hi and lo
-        const float* __restrict__ Xb = X + (size_t)b * 256 * P;
-        const unsigned lofs = (unsigned)(8 * h) * (unsigned)P + pc;
+        const float* __restrict__ Xb = X + (size_t)b * 256 * CS;
+        const unsigned lofs = (unsigned)(8 * h) * CS + pc;
         half8 bh[16], bl[16];
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) {
             float v[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = Xb[lofs + (unsigned)((ks * 16 + j) * P)];
+            for (int j = 0; j < 8; ++j) v[j] = Xb[lofs + (unsigned)(ks * 16 + j) * CS];
             float s[8], t[8];
             if (MODE == PWR_BN) {
                 *reinterpret_cast<f32x4*>(s) = *reinterpret_cast<const f32x4*>(sc + ks * 16 + 8 * h);
@@ -136,12 +137,12 @@ __device__ __forceinline__ void pwr_body(const PwArgs& a, const float* __restric
             stage_load(tile_of((i + 1) & 7));  // i == 7: tile 0 again, for the next pixel tile
             if (MODE == PWR_S3 && (i & 1)) {  // (S3T loads them in halves at the point of use: register budget)
                 // encoder output rows of this pair, requested under the second tile's MFMAs
-                const float* __restrict__ Ab = AUX + ((size_t)b * 256 + (ct - 4) * 32 + 4 * h) * P + pc;
+                const float* __restrict__ Ab = AUX + ((size_t)b * 256 + (ct - 4) * 32 + 4 * h) * CS + pc;
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {
-                    const unsigned ro = (unsigned)((q & 3) + 8 * (q >> 2)) * (unsigned)P;
+                    const unsigned ro = (unsigned)((q & 3) + 8 * (q >> 2)) * CS;
                     er[q] = Ab[ro];
-                    ei[q] = Ab[ro + (unsigned)(128 * P)];
+                    ei[q] = Ab[ro + 128u * CS];
                 }
             }
             const _Float16* wb = Wb + (i & 1) * PWR_BUF + r * PWR_LDW + 8 * h;
@@ -158,12 +159,12 @@ __device__ __forceinline__ void pwr_body(const PwArgs& a, const float* __restric
             }
             // accumulator register q: output row ct*32 + (q&3) + 8(q>>2) + 4h, pixel r
             if (MODE == PWR_BN) {
-                float* __restrict__ Ob = OUT + ((size_t)b * 256 + ct * 32 + 4 * h) * P + pc;
+                float* __restrict__ Ob = OUT + ((size_t)b * 256 + ct * 32 + 4 * h) * CS + pc;
                 if (live) {
 #pragma unroll
                     for (int q = 0; q < 16; ++q) {
                         const int row = (q & 3) + 8 * (q >> 2);
-                        Ob[(unsigned)row * (unsigned)P] = fmaf(acc[q], WINV, bs[ct * 32 + 4 * h + row]);
+                        Ob[(unsigned)row * CS] = fmaf(acc[q], WINV, bs[ct * 32 + 4 * h + row]);
                     }
                 }
             } else if (!(i & 1)) {
@@ -173,16 +174,16 @@ __device__ __forceinline__ void pwr_body(const PwArgs& a, const float* __restric
                 // K step of the taps GEMM) at a time; they feed the matrix cores as they stand: the taps weight image
                 // (packing.taps_perm_image) has its K axis in accumulator-register order
                 const int m = ct - 4;
-                const float* __restrict__ Ab = AUX + ((size_t)b * 256 + m * 32 + 4 * h) * P + pc;
+                const float* __restrict__ Ab = AUX + ((size_t)b * 256 + m * 32 + 4 * h) * CS + pc;
                 const half8* __restrict__ TW = reinterpret_cast<const half8*>(a.w16b);
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
                     float er[8], ei[8];
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        const unsigned ro = (unsigned)((j & 3) + 8 * (2 * s2 + (j >> 2))) * (unsigned)P;
+                        const unsigned ro = (unsigned)((j & 3) + 8 * (2 * s2 + (j >> 2))) * CS;
                         er[j] = Ab[ro] * esc;
-                        ei[j] = Ab[ro + (unsigned)(128 * P)] * esc;
+                        ei[j] = Ab[ro + 128u * CS] * esc;
                     }
                     half8 rh, rl, ih, il;
 #pragma unroll
@@ -210,7 +211,7 @@ __device__ __forceinline__ void pwr_body(const PwArgs& a, const float* __restric
                     acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(til, ih, acc2, 0, 0, 0);
                 }
             } else {
-                float* __restrict__ Ob = OUT + ((size_t)b * 256 + (ct - 4) * 32 + 4 * h) * P + pc;
+                float* __restrict__ Ob = OUT + ((size_t)b * 256 + (ct - 4) * 32 + 4 * h) * CS + pc;
                 if (live) {
 #pragma unroll
                     for (int q = 0; q < 16; ++q) {
@@ -218,9 +219,9 @@ __device__ __forceinline__ void pwr_body(const PwArgs& a, const float* __restric
                         const int c = (ct - 4) * 32 + 4 * h + row;
                         const float mr = fmaxf(fmaf(keep[q], WINV, bs[c]), 0.f);
                         const float mi = fmaxf(fmaf(acc[q], WINV, bs[c + 128]), 0.f);
-                        const unsigned ro = (unsigned)row * (unsigned)P;
+                        const unsigned ro = (unsigned)row * CS;
                         Ob[ro] = er[q] * mr - ei[q] * mi;
-                        Ob[ro + (unsigned)(128 * P)] = er[q] * mi + ei[q] * mr;
+                        Ob[ro + 128u * CS] = er[q] * mi + ei[q] * mr;
                     }
                 }
             }
@@ -228,11 +229,11 @@ __device__ __forceinline__ void pwr_body(const PwArgs& a, const float* __restric
             if (i < 7) __syncthreads();  // after i == 7 the barrier at the top of the next pixel tile orders buffer 0
         }
         if (MODE == PWR_S3T && live) {  // z (B, 18, P): tap row (q&3) + 8(q>>2) + 4h of the accumulator tile
-            float* __restrict__ Zb = OUT + (size_t)b * a.cout_live * P + pc;
+            float* __restrict__ Zb = OUT + (size_t)b * a.cout_live * CS + pc;  // z (B, 18, cs)
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const int tap = (q & 3) + 8 * (q >> 2) + 4 * h;
-                if (tap < a.cout_live) Zb[(unsigned)tap * (unsigned)P] = acc2[q] * eisc;
+                if (tap < a.cout_live) Zb[(unsigned)tap * CS] = acc2[q] * eisc;
             }
         }
     }
@@ -244,7 +245,11 @@ __global__ __launch_bounds__(256, 2) void pwr_kernel(PwArgs a, int ntiles, int t
 }
 
 template <int MODE>
-int launch_pwr_t(const PwArgs& a, int B, hipStream_t st) {
+int launch_pwr_t(const PwArgs& a_, int B, hipStream_t st) {
+    if (a_.cs && a_.cs < a_.P) return RTFS_ERR_SHAPE;
+    PwArgs a = a_;
+    if (!a.cs) a.cs = a.P;
+    if ((size_t)256 * a.cs >= ((size_t)1 << 31)) return RTFS_ERR_SHAPE;  // 32-bit element offsets inside a sample
     if (rtfs_set_max_lds((const void*)pwr_kernel<MODE>, PWR_LDS) != RTFS_OK) return RTFS_ERR_LAUNCH;
     const int tps = cdiv(a.P, PWR_PT), ntiles = tps * B;
     const int grid = ntiles < 512 ? ntiles : 512;  // persistent: 2 workgroups per CU

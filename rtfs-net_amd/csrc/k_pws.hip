@@ -60,6 +60,7 @@ __device__ __forceinline__ void pws_body(const PwArgs& a, int ntiles, int tiles_
     __syncthreads();
 
     const int P = a.P;
+    const size_t CS = (size_t)a.cs;  // channel stride (>= P; the fused separator pads it to whole 128-byte lines)
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int b = tile / tiles_per_sample;
         // lane r owns the S adjacent pixels p0 .. p0+S-1 (slot s = column r of MFMA tile s); S == 2: one unaligned 8-byte
@@ -72,7 +73,7 @@ __device__ __forceinline__ void pws_body(const PwArgs& a, int ntiles, int tiles_
         // S == 2 load position: (p0, p0+1) normally; the sample's last pixel and dead lanes read (P-2, P-1)
         const int pl = S == 2 ? min(p0, P - 2) : (live[0] ? p0 : P - 1);
         const bool tail = S == 2 && p0 == P - 1;  // lane holds pixel P-1 in .y
-        const size_t xb = (size_t)b * CIN * P + pl;
+        const size_t xb = (size_t)b * CIN * CS + pl;
         size_t cafb[S];
         if (CAF) {  // nearest up-sampling of the video-side terms: tv = floor(t * Tv / T)
 #pragma unroll
@@ -100,7 +101,7 @@ __device__ __forceinline__ void pws_body(const PwArgs& a, int ntiles, int tiles_
                 if (live[0]) dst[off] = d[0];
             }
         };
-        const size_t ob_in = (size_t)b * CIN * P + p0;  // store position (pixel p0) in a CIN-channel tensor
+        const size_t ob_in = (size_t)b * CIN * CS + p0;  // store position (pixel p0) in a CIN-channel tensor
         f32x16 acc[MTW][S];
 #pragma unroll
         for (int m = 0; m < MTW; ++m)
@@ -113,7 +114,7 @@ __device__ __forceinline__ void pws_body(const PwArgs& a, int ntiles, int tiles_
             float v[8][S];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const size_t off = xb + (size_t)(ks + 8 * h + j) * P;
+                const size_t off = xb + (size_t)(ks + 8 * h + j) * CS;
                 load(X, off, v[j]);  // dead lanes read valid (clamped) pixels; nothing of theirs is stored
                 if (CAF) {
                     const int ci = ks + 8 * h + j;
@@ -138,7 +139,7 @@ __device__ __forceinline__ void pws_body(const PwArgs& a, int ntiles, int tiles_
 #pragma unroll
                     for (int sl = 0; sl < S; ++sl)
                         v[j][sl] = preluf_(fmaf(v[j][sl], j < 4 ? s0[j & 3] : s1[j & 3], j < 4 ? t0[j & 3] : t1[j & 3]), slope);
-                    store(RES, ob_in + (size_t)(ks + 8 * h + j) * P, v[j]);
+                    store(RES, ob_in + (size_t)(ks + 8 * h + j) * CS, v[j]);
                 }
             }
             half8 bh[S], bl[S];
@@ -163,7 +164,7 @@ __device__ __forceinline__ void pws_body(const PwArgs& a, int ntiles, int tiles_
             }
         }
         if (live[0]) {
-            const size_t ob = (size_t)b * COUT * P + p0, lb = (size_t)b * COUT * P + pl;
+            const size_t ob = (size_t)b * COUT * CS + p0, lb = (size_t)b * COUT * CS + pl;
 #pragma unroll
             for (int m = 0; m < MTW; ++m) {
                 float res[16][S];
@@ -172,7 +173,7 @@ __device__ __forceinline__ void pws_body(const PwArgs& a, int ntiles, int tiles_
                     const int co = (m0 + m) * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
 #pragma unroll
                     for (int sl = 0; sl < S; ++sl) res[q][sl] = 0.f;
-                    if (EPI == EPI_BIAS_RES) load(AUX, lb + (size_t)co * P, res[q]);
+                    if (EPI == EPI_BIAS_RES) load(AUX, lb + (size_t)co * CS, res[q]);
                 }
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {
@@ -180,7 +181,7 @@ __device__ __forceinline__ void pws_body(const PwArgs& a, int ntiles, int tiles_
                     float o_[S];
 #pragma unroll
                     for (int sl = 0; sl < S; ++sl) o_[sl] = fmaf(acc[m][sl][q], WINV, a.bias[co]) + res[q][sl];
-                    store(OUT, ob + (size_t)co * P, o_);
+                    store(OUT, ob + (size_t)co * CS, o_);
                 }
                 __builtin_amdgcn_sched_barrier(0);  // keep the 16-load / 16-store groups apart (register pressure)
             }
@@ -194,9 +195,11 @@ __global__ __launch_bounds__(256, 2) void pws_kernel(PwArgs a, int ntiles, int t
 }
 
 template <int CIN, int COUT, int PRO, int EPI, bool HAS_X2, bool CAF = false>
-static int launch_pws_t(const PwArgs& a, int B, hipStream_t st) {
+static int launch_pws_t(const PwArgs& a_, int B, hipStream_t st) {
     constexpr int S = COUT <= 64 ? 2 : 1;  // two pixels per lane where the accumulators allow it (COUT 64: 64 registers)
-    if (a.P < 2) return RTFS_ERR_SHAPE;
+    if (a_.P < 2 || (a_.cs && a_.cs < a_.P)) return RTFS_ERR_SHAPE;
+    PwArgs a = a_;
+    if (!a.cs) a.cs = a.P;
     const size_t lds = (size_t)2 * COUT * (CIN + 8) * 2 + (size_t)(CAF ? 6 : 2) * CIN * 4;
     if (rtfs_set_max_lds((const void*)pws_kernel<CIN, COUT, PRO, EPI, HAS_X2, CAF, S>, lds) != RTFS_OK) return RTFS_ERR_LAUNCH;
     constexpr int PTB = 32 * S * (4 / (COUT / 32 > 4 ? COUT / 32 / 4 : 1));
@@ -238,21 +241,22 @@ __device__ __forceinline__ void pws_res2_body(const PwArgs& a, int ntiles, int t
     }
     __syncthreads();
     const int P = a.P;
+    const unsigned CS = (unsigned)a.cs;  // channel stride (the launcher checks 256 * cs < 2^31)
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int b = tile / tiles_per_sample;
         const int p0 = (tile - b * tiles_per_sample) * 256 + wave * 64 + 2 * r;  // this lane's pixels p0, p0 + 1
         const bool live0 = p0 < P, live1 = p0 + 1 < P;
         const int pl = min(p0, P - 2);     // load position: the sample's last pixel and dead lanes read (P-2, P-1)
         const bool tail = p0 == P - 1;     // ... and take pixel P-1 from .y
-        const float* __restrict__ xs = X + (size_t)b * 64 * P;
-        const float* __restrict__ rs = AUX + (size_t)b * 256 * P;
-        float* __restrict__ os = OUT + (size_t)b * 256 * P;
+        const float* __restrict__ xs = X + (size_t)b * 64 * CS;
+        const float* __restrict__ rs = AUX + (size_t)b * 256 * CS;
+        float* __restrict__ os = OUT + (size_t)b * 256 * CS;
         half8 xh[4][2], xl[4][2];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             f32x2u_ v[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const f32x2u_*>(xs + (unsigned)((ks * 16 + 8 * h + j) * P + pl));
+            for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const f32x2u_*>(xs + ((unsigned)(ks * 16 + 8 * h + j) * CS + pl));
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float v0 = tail ? v[j].y : v[j].x, v1 = v[j].y;
@@ -268,7 +272,7 @@ __device__ __forceinline__ void pws_res2_body(const PwArgs& a, int ntiles, int t
             const int cob = m * 32 + 4 * h;  // channel of accumulator register q: cob + (q&3) + 8*(q>>2)
             f32x2u_ res[16];
 #pragma unroll
-            for (int q = 0; q < 16; ++q) res[q] = *reinterpret_cast<const f32x2u_*>(rs + (unsigned)((cob + (q & 3) + 8 * (q >> 2)) * P + pl));
+            for (int q = 0; q < 16; ++q) res[q] = *reinterpret_cast<const f32x2u_*>(rs + ((unsigned)(cob + (q & 3) + 8 * (q >> 2)) * CS + pl));
             f32x16 acc[2];
 #pragma unroll
             for (int sl = 0; sl < 2; ++sl)
@@ -291,8 +295,8 @@ __device__ __forceinline__ void pws_res2_body(const PwArgs& a, int ntiles, int t
                 const float bq = b1[co];
                 const float y0 = fmaf(acc[0][q], WINV, bq) + (tail ? res[q].y : res[q].x);
                 const float y1 = fmaf(acc[1][q], WINV, bq) + res[q].y;
-                if (live1) *reinterpret_cast<f32x2u_*>(os + (unsigned)(co * P + p0)) = f32x2u_{y0, y1};
-                else if (live0) os[(unsigned)(co * P + p0)] = y0;
+                if (live1) *reinterpret_cast<f32x2u_*>(os + ((unsigned)co * CS + p0)) = f32x2u_{y0, y1};
+                else if (live0) os[(unsigned)co * CS + p0] = y0;
             }
         }
     }
@@ -300,8 +304,11 @@ __device__ __forceinline__ void pws_res2_body(const PwArgs& a, int ntiles, int t
 __global__ __launch_bounds__(256, 2) void pws_res2_kernel(PwArgs a, int ntiles, int tiles_per_sample) {
     pws_res2_body(a, ntiles, tiles_per_sample, a.x, a.aux, a.out);
 }
-static int launch_pws_res2(const PwArgs& a, int B, hipStream_t st) {
-    if (a.P < 2) return RTFS_ERR_SHAPE;
+static int launch_pws_res2(const PwArgs& a_, int B, hipStream_t st) {
+    if (a_.P < 2 || (a_.cs && a_.cs < a_.P)) return RTFS_ERR_SHAPE;
+    PwArgs a = a_;
+    if (!a.cs) a.cs = a.P;
+    if ((size_t)256 * a.cs >= ((size_t)1 << 31)) return RTFS_ERR_SHAPE;  // 32-bit element offsets inside a sample
     const size_t lds = (size_t)2 * 256 * 72 * 2 + 256 * 4;
     if (rtfs_set_max_lds((const void*)pws_res2_kernel, lds) != RTFS_OK) return RTFS_ERR_LAUNCH;
     const int tps = cdiv(a.P, 256), ntiles = tps * B;
@@ -366,6 +373,7 @@ __device__ __forceinline__ void pws_b2b_body(const B2bArgs& a, int ntiles, int t
     const float slope = a.slope[0];
     __syncthreads();
     const int P = a.P;
+    const unsigned CS = (unsigned)a.cs;  // channel stride (the launcher checks 256 * cs < 2^31)
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int b = tile / tiles_per_sample;
         // two adjacent pixels per lane (slots 0 / 1 = column r of two MFMA tiles): every row access is one unaligned
@@ -383,12 +391,12 @@ __device__ __forceinline__ void pws_b2b_body(const B2bArgs& a, int ntiles, int t
         // ---- B fragments of GEMM 1 (expanded_i, 64 channels of this lane's pixels): loaded once per tile
         half8 xh[4][2], xl[4][2];
         {
-            const float* __restrict__ xs = X + (size_t)b * 64 * P;
+            const float* __restrict__ xs = X + (size_t)b * 64 * CS;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 f32x2u_ v[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const f32x2u_*>(xs + (unsigned)((ks * 16 + 8 * h + j) * P + pl));
+                for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const f32x2u_*>(xs + ((unsigned)(ks * 16 + 8 * h + j) * CS + pl));
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const float v0 = tail ? v[j].y : v[j].x, v1 = v[j].y;
@@ -407,8 +415,8 @@ __device__ __forceinline__ void pws_b2b_body(const B2bArgs& a, int ntiles, int t
             for (int sl = 0; sl < 2; ++sl)
 #pragma unroll
                 for (int q = 0; q < 16; ++q) acc2[m2][sl][q] = 0.f;
-        float* __restrict__ ress = RES + (size_t)b * 256 * P;
-        const float* __restrict__ a1s = A1 + (size_t)b * 256 * P;
+        float* __restrict__ ress = RES + (size_t)b * 256 * CS;
+        const float* __restrict__ a1s = A1 + (size_t)b * 256 * CS;
         // ---- one output-channel tile of the residual conv at a time: GEMM 1 tile (both slots) -> epilogue 1 in two halves
         //      of 8 accumulator registers (-> residual_{i+1}) -> each half is one K step of GEMM 2
 #pragma unroll 1
@@ -440,7 +448,7 @@ __device__ __forceinline__ void pws_b2b_body(const B2bArgs& a, int ntiles, int t
 #pragma unroll
                     for (int jj = 0; jj < 4; ++jj) {
                         const int q = 8 * s + 4 * u + jj;
-                        const unsigned o = (unsigned)((cob + (q & 3) + 8 * (q >> 2)) * P + pl);
+                        const unsigned o = (unsigned)(cob + (q & 3) + 8 * (q >> 2)) * CS + pl;
                         res[jj] = *reinterpret_cast<const f32x2u_*>(ress + o);
                         a1v[jj] = *reinterpret_cast<const f32x2u_*>(a1s + o);
                     }
@@ -463,8 +471,8 @@ __device__ __forceinline__ void pws_b2b_body(const B2bArgs& a, int ntiles, int t
                             bh[sl][j] = hi;
                             bl[sl][j] = (_Float16)(t - (float)hi);
                         }
-                        if (live1) *reinterpret_cast<f32x2u_*>(ress + (unsigned)(co * P + p0)) = f32x2u_{y[0], y[1]};
-                        else if (live0) ress[(unsigned)(co * P + p0)] = y[0];
+                        if (live1) *reinterpret_cast<f32x2u_*>(ress + ((unsigned)co * CS + p0)) = f32x2u_{y[0], y[1]};
+                        else if (live0) ress[(unsigned)co * CS + p0] = y[0];
                     }
                 }
                 const int kk = (2 * m + s) * 16 + 8 * h;
@@ -483,15 +491,15 @@ __device__ __forceinline__ void pws_b2b_body(const B2bArgs& a, int ntiles, int t
             }
         }
         if (live0) {
-            float* __restrict__ xes = XENC + (size_t)b * 64 * P;
+            float* __restrict__ xes = XENC + (size_t)b * 64 * CS;
 #pragma unroll
             for (int m2 = 0; m2 < 2; ++m2)
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {
                     const int co = m2 * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
                     const float y0 = fmaf(acc2[m2][0][q], WINV, a.bp[co]), y1 = fmaf(acc2[m2][1][q], WINV, a.bp[co]);
-                    if (live1) *reinterpret_cast<f32x2u_*>(xes + (unsigned)(co * P + p0)) = f32x2u_{y0, y1};
-                    else xes[(unsigned)(co * P + p0)] = y0;
+                    if (live1) *reinterpret_cast<f32x2u_*>(xes + ((unsigned)co * CS + p0)) = f32x2u_{y0, y1};
+                    else xes[(unsigned)co * CS + p0] = y0;
                 }
         }
     }
@@ -503,7 +511,11 @@ __global__ __launch_bounds__(B2B_NT) void pws_b2b_kernel(B2bArgs a, int ntiles, 
 }
 
 template <bool CAF>
-static int launch_b2b_t(const B2bArgs& a, int B, hipStream_t st) {
+static int launch_b2b_t(const B2bArgs& a_, int B, hipStream_t st) {
+    if (a_.cs && a_.cs < a_.P) return RTFS_ERR_SHAPE;
+    B2bArgs a = a_;
+    if (!a.cs) a.cs = a.P;
+    if ((size_t)256 * a.cs >= ((size_t)1 << 31)) return RTFS_ERR_SHAPE;  // 32-bit element offsets inside a sample
     const size_t lds = (size_t)2 * 256 * 72 * 2 + (size_t)2 * 64 * 264 * 2 + (size_t)(CAF ? 7 : 3) * 256 * 4;
     if (rtfs_set_max_lds((const void*)pws_b2b_kernel<CAF>, lds) != RTFS_OK) return RTFS_ERR_LAUNCH;
     if (a.P < 2) return RTFS_ERR_SHAPE;

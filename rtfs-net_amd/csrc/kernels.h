@@ -22,6 +22,8 @@ struct PwArgs {
     const float* gb = nullptr;  // gateway depthwise bias (CIN)
     const float* slope = nullptr;  // PReLU slope (1)
     int P = 0;
+    int cs = 0;         // channel stride (floats) of every (B, C, P) tensor of the call; 0 = P (contiguous).  The fused separator pads it
+                        // to a multiple of 32 floats so that every 64-pixel wave segment is whole 128-byte lines ("pitch")
     int cout_live = 0;  // EPI_TAPS: number of real output channels
     // optional CAF prologue of the gateway kernel (fused separator path): x <- CAF(x, video) before the residual add
     const float* caf_r = nullptr;    // (B,256,Tv) resize(video)
@@ -61,10 +63,14 @@ struct B2bArgs {
     const float* bp = nullptr;    // (64)
     const float *gw = nullptr, *gb = nullptr, *slope = nullptr;
     int P = 0;
+    int cs = 0;  // channel stride of x / res / a1 / xenc (floats); 0 = P
     const float *caf_r = nullptr, *caf_att = nullptr, *caf_w_key = nullptr, *caf_bn_key = nullptr, *caf_w_val = nullptr, *caf_bn_val = nullptr;
     int caf_T = 0, caf_F = 0, caf_Tv = 0;
 };
 int launch_pws_b2b(const B2bArgs& a, int B, hipStream_t st);
+// second generation (k_b2b.hip): padded channel rows (cs % 64 == 0), no CAF; ctr = zeroed tile counter of this launch or null.
+// RTFS_ERR_ARG = call does not qualify, use launch_pws_b2b
+int launch_pws_b2b4(const B2bArgs& a, int B, unsigned* ctr, hipStream_t st);
 int launch_pws_gateway_proj(const PwArgs& a, int B, hipStream_t st);
 int launch_pws_residual(const PwArgs& a, int B, hipStream_t st);
 int launch_mfma_f16_selftest(const float* A, const float* B, float* D, hipStream_t st);
@@ -82,6 +88,7 @@ struct DwArgs {
     float* out[4] = {nullptr, nullptr, nullptr, nullptr};
     double* stats_out[4] = {nullptr, nullptr, nullptr, nullptr};  // (B,2) each
     int C = 0, H = 0, W = 0, TH = 8;
+    int cs = 0;  // channel stride (floats) of the (B, C, H, W) tensors x / out[] / addend; 0 = H * W.  gate / emb (Hg x Wg) stay contiguous
     // MODE 2 (TFAR apply) / stride-2 kernel: the low-resolution side
     int Hg = 0, Wg = 0;
     const double* loc_stats = nullptr;

@@ -6,8 +6,9 @@
 #include <vector>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("err %s line %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 int main(int argc, char** argv) {
-    const int B = 32, C = 64, H = 251, W = 129, Hg = 125, Wg = 64;
+    const int C = 64, H = 251, W = 129, Hg = 125, Wg = 64;
     const int TH = argc > 1 ? atoi(argv[1]) : 64;
+    const int B = argc > 2 ? atoi(argv[2]) : 32;
     const size_t n = (size_t)B * C * H * W, ng = (size_t)B * C * Hg * Wg;
     float *x, *y, *add, *gate, *emb, *par;
     double* st;
@@ -40,7 +41,7 @@ int main(int argc, char** argv) {
         (void)hipEventRecord(e1);
         (void)hipEventSynchronize(e1);
         float ms; (void)hipEventElapsedTime(&ms, e0, e1);
-        printf("TH=%3d %-34s %8.1f us  %6.2f TB/s\n", TH, name, ms / R * 1e3, bytes / (ms / R * 1e-3) / 1e12);
+        printf("B=%2d TH=%3d %-34s %8.1f us  %6.2f TB/s\n", B, TH, name, ms / R * 1e3, bytes / (ms / R * 1e-3) / 1e12);
     };
     const double T = n * 4.0;
     timeit("stats   <1,false,1>", T, [&] { launch_dw_s1(a, 1, false, 1, B, 0); });
