@@ -20,6 +20,29 @@ struct Cursor {
     }
 };
 
+// A piece of work forked onto a library-internal side stream: begin() orders the side stream behind everything queued on `st` so far,
+// join() (or the destructor, on EVERY exit path - also after a failed launch in between) orders `st` behind the side stream again, so
+// the caller's stream never runs ahead of work this call queued elsewhere (include/rtfs_amd.h: all work of a call is ordered on `stream`).
+struct Fork {
+    hipStream_t st = nullptr;
+    RtfsSide side{};
+    bool open = false;
+    int begin(hipStream_t owner, int slot) {
+        st = owner;
+        CHECK(rtfs_side_stream(owner, slot, &side));
+        if (hipEventRecord(side.fork, st) != hipSuccess || hipStreamWaitEvent(side.stream, side.fork, 0) != hipSuccess) return RTFS_ERR_LAUNCH;
+        open = true;
+        return RTFS_OK;
+    }
+    int join() {
+        if (!open) return RTFS_OK;
+        open = false;
+        if (hipEventRecord(side.join, side.stream) != hipSuccess || hipStreamWaitEvent(st, side.join, 0) != hipSuccess) return RTFS_ERR_LAUNCH;
+        return RTFS_OK;
+    }
+    ~Fork() { (void)join(); }
+};
+
 struct EncPack {
     const float* w;  // (256, 18)
     explicit EncPack(Cursor& c) { w = c.take(CA * 18); }
@@ -315,7 +338,7 @@ struct BlockWs {
     double* st(int slot, int /*B*/) const { return stats ? stats + (size_t)slot * Bfull * 2 : nullptr; }
 };
 
-int block_head(const BlockPack& p, const float* x, const float* x_res, int B, int T, int F, BlockWs& w, hipStream_t st, const CafArgs* caf) {
+int block_head(const BlockPack& p, const float* x, const float* x_res, int B, int T, int F, BlockWs& w, hipStream_t st, const CafArgs* caf, unsigned* ctr = nullptr) {
     const int P = T * F;
     {  // 1. gateway (dw 1x1 + PReLU) -> residual; projection 1x1 256->64 -> x_enc          tdanet.py:106-107
         PwArgs a;
@@ -331,6 +354,7 @@ int block_head(const BlockPack& p, const float* x, const float* x_res, int B, in
         a.slope = p.gslope;
         a.P = P;
         a.cs = w.cs;
+        a.tile_ctr = ctr;
         if (caf && !gemm_f32()) {  // block input = CAF(x, video) + x_res, applied while streaming x (fused separator path)
             a.caf_r = caf->r_out; a.caf_att = caf->att_out;
             a.caf_w_key = caf->w_key; a.caf_bn_key = caf->bn_key; a.caf_w_val = caf->w_val; a.caf_bn_val = caf->bn_val;
@@ -364,18 +388,16 @@ int block_body(const BlockPack& p, int B, int T, int F, const BlockWs& w, hipStr
     // RTFS_OVERLAP=0 switches it off.
     static const bool overlap_env = !(getenv("RTFS_OVERLAP") && atoi(getenv("RTFS_OVERLAP")) == 0);
     const bool overlap = overlap_env && side_pass;
-    RtfsSide side{};
+    Fork side14;  // joined before step 15, or by its destructor on an early return
     if (overlap) {
-        CHECK(rtfs_side_stream(st, 0, &side));
-        if (hipEventRecord(side.fork, st) != hipSuccess || hipStreamWaitEvent(side.stream, side.fork, 0) != hipSuccess) return RTFS_ERR_LAUNCH;
+        CHECK(side14.begin(st, 0));
         DwArgs a;
         a.x = w.c0;
         a.in_stats = w.st(W::S_C0, B); a.in_inv_count = icF; a.in_gamma = p.ds0_g; a.in_beta = p.ds0_be;
         a.C = CH; a.H = T; a.W = F; a.TH = 64; a.Hg = Tp; a.Wg = Fp; a.cs = w.cs;
         a.w[0] = p.fus0.loc_w;
         a.stats_out[0] = w.st(W::S_L0, B);
-        CHECK(launch_dw_s1(a, 1, true, 1, B, side.stream));
-        if (hipEventRecord(side.join, side.stream) != hipSuccess) return RTFS_ERR_LAUNCH;
+        CHECK(launch_dw_s1(a, 1, true, 1, B, side14.side.stream));
     }
     {  // 3. downsample[1] on d0 = gLN(c0): dw 4x4 s2 -> c1 + stats; p0 = adaptive_avg_pool2d(d0)   tdanet.py:111-116
         DwArgs a;
@@ -442,7 +464,7 @@ int block_body(const BlockPack& p, int B, int T, int F, const BlockWs& w, hipStr
     d0in.in_stats = w.st(W::S_C0, B); d0in.in_inv_count = icF; d0in.in_gamma = p.ds0_g; d0in.in_beta = p.ds0_be;
     d0in.C = CH; d0in.H = T; d0in.W = F; d0in.TH = 64; d0in.Hg = Tp; d0in.Wg = Fp; d0in.cs = w.cs;
     if (overlap) {
-        if (hipStreamWaitEvent(st, side.join, 0) != hipSuccess) return RTFS_ERR_LAUNCH;
+        CHECK(side14.join());
     } else {  // 14. fusion 0 local_embedding conv on d0: statistics only
         DwArgs a = d0in;
         a.w[0] = p.fus0.loc_w;
@@ -482,7 +504,7 @@ int block_body(const BlockPack& p, int B, int T, int F, const BlockWs& w, hipStr
     return RTFS_OK;
 }
 
-int block_tail(const BlockPack& p, float* out, int B, int T, int F, BlockWs& w, hipStream_t st) {
+int block_tail(const BlockPack& p, float* out, int B, int T, int F, BlockWs& w, hipStream_t st, unsigned* ctr = nullptr) {
     const int P = T * F;
     {  // 18. out = residual_conv(expanded) + residual                                        tdanet.py:129
         PwArgs a;
@@ -494,6 +516,7 @@ int block_tail(const BlockPack& p, float* out, int B, int T, int F, BlockWs& w, 
         a.out = out;
         a.P = P;
         a.cs = w.cs;
+        a.tile_ctr = ctr;
         CHECK(gemm_f32() ? launch_pw_residual(a, B, st) : launch_pws_residual(a, B, st));
     }
     return RTFS_OK;
@@ -524,6 +547,7 @@ int block_boundary(const BlockPack& p, const float* a1, int B, int T, int F, Blo
     a.cs = w.cs;
     if (caf) {
         a.caf_r = caf->r_out; a.caf_att = caf->att_out;
+        a.caf_rt = caf->r_t; a.caf_attt = caf->att_t;
         a.caf_w_key = caf->w_key; a.caf_bn_key = caf->bn_key; a.caf_w_val = caf->w_val; a.caf_bn_val = caf->bn_val;
         a.caf_T = caf->T; a.caf_F = caf->F; a.caf_Tv = caf->Tv;
     }
@@ -531,7 +555,7 @@ int block_boundary(const BlockPack& p, const float* a1, int B, int T, int F, Blo
     return rc == RTFS_ERR_ARG ? launch_pws_b2b(a, B, st) : rc;
 }
 
-int audio_bn(const BnPack& p, const float* x, const double* stats, float* out, int B, int P, hipStream_t st, int cs = 0) {
+int audio_bn(const BnPack& p, const float* x, const double* stats, float* out, int B, int P, hipStream_t st, int cs = 0, unsigned* ctr = nullptr) {
     PwArgs a;
     a.x = x;
     a.wt = p.wt;
@@ -543,6 +567,7 @@ int audio_bn(const BnPack& p, const float* x, const double* stats, float* out, i
     a.beta = p.beta;
     a.P = P;
     a.cs = cs;
+    a.tile_ctr = ctr;
     a.w16 = p.w16;
     return gemm_f32() ? launch_pw_audio_bn(a, B, st) : launch_pwr_audio_bn(a, B, st);
 }
@@ -857,7 +882,7 @@ namespace {
 inline int pitch(int P) { return (P + 63) / 64 * 64; }
 
 struct SepWs {
-    float *spec, *a0, *a1, *cur, *nxt, *r, *att, *z;
+    float *spec, *a0, *a1, *cur, *nxt, *r, *att, *rt, *attt, *z;
     double* st0;
     unsigned* ctr;  // 64 tile counters (one per persistent launch of the call), zeroed together with st0
     int cs;
@@ -870,6 +895,8 @@ struct SepWs {
           nxt(a.take<float>((size_t)B * CA * cs_)),
           r(a.take<float>((size_t)B * CA * Tv)),
           att(a.take<float>((size_t)B * CA * Tv)),
+          rt(a.take<float>((size_t)B * CA * Tv)),
+          attt(a.take<float>((size_t)B * CA * Tv)),
           z(a.take<float>((size_t)B * 18 * cs_)),
           st0(a.take<double>(2 * B + 32)),
           ctr(reinterpret_cast<unsigned*>(st0 ? st0 + 2 * B : nullptr)),
@@ -902,10 +929,12 @@ int separator_part(const SepPacks& k, const float* wav, const float* video_vp, f
     int nctr = 0;
     CHECK(launch_stft(wav, w.spec, B, L, T, st));
     CHECK(launch_enc_conv(w.spec, pe.w, w.a0, w.st0, B, CA, T, NF, (size_t)cs, (size_t)CA * cs, st));
-    CHECK(audio_bn(pb, w.a0, w.st0, w.a1, B, P, st, cs));
+    CHECK(audio_bn(pb, w.a0, w.st0, w.a1, B, P, st, cs, w.ctr + nctr++));
     // refinement_module.py:45-62: block(a1); CAF; then (repeats-1) x block(audio + a1), shared weights
     // refinement_module.py:45-62: block(a1); CAF; then (repeats-1) x block(audio + a1), shared weights.
     CafArgs ca = caf_args(pc, w.cur, video_vp, w.nxt, w.r, w.att, T, NF, Tv);
+    ca.r_t = w.rt;
+    ca.att_t = w.attt;
     float *cur = w.cur, *nxt = w.nxt;
     if (gemm_f32() || repeats == 1) {  // unfused reference sequence (A/B path); contiguous tensors (cs == P, see rtfs_separator_forward_f32)
         RTFS_RETURN_IF(cs != P, RTFS_ERR_ARG);
@@ -924,20 +953,24 @@ int separator_part(const SepPacks& k, const float* wav, const float* video_vp, f
     } else {
         // block outputs between applications never reach HBM: the residual conv of block i, the CAF (after block 0),
         // the "+ a1" and the gateway + projection of block i+1 run back to back in one kernel (block_boundary).
-        CHECK(block_head(pk, w.a1, nullptr, B, T, NF, w.blk, st, nullptr));
+        // the video side of the CAF (one workgroup per mixture, ~85 us) needs only the VP block's output: side stream, joined before the
+        // first block boundary
+        Fork cafv;
+        CHECK(cafv.begin(st, 15));
+        if (video_ready && hipStreamWaitEvent(cafv.side.stream, (hipEvent_t)video_ready, 0) != hipSuccess) return RTFS_ERR_LAUNCH;
+        CHECK(launch_caf_video(ca, B, cafv.side.stream));
+        CHECK(block_head(pk, w.a1, nullptr, B, T, NF, w.blk, st, nullptr, w.ctr + nctr++));
         for (int i = 0; i < repeats; ++i) {
             CHECK(block_body(pk, B, T, NF, w.blk, st, single_chain));
-            if (i == 0) {
-                if (video_ready && hipStreamWaitEvent(st, (hipEvent_t)video_ready, 0) != hipSuccess) return RTFS_ERR_LAUNCH;
-                CHECK(launch_caf_video(ca, B, st));
-            }
+            if (i == 0) CHECK(cafv.join());
             if (i + 1 < repeats) CHECK(block_boundary(pk, w.a1, B, T, NF, w.blk, st, i == 0 ? &ca : nullptr, nctr < 64 ? w.ctr + nctr++ : nullptr));
-            else CHECK(block_tail(pk, cur, B, T, NF, w.blk, st));
+            else CHECK(block_tail(pk, cur, B, T, NF, w.blk, st, nctr < 64 ? w.ctr + nctr++ : nullptr));
         }
     }
     if (!gemm_f32() && !getenv("RTFS_NO_S3T")) {  // S3 + decoder taps in one kernel: the separated spectrum never goes to HBM
         PwArgs a;
         a.x = cur; a.bias = ps.bias; a.aux = w.a0; a.out = w.z; a.slope = ps.slope; a.P = P; a.cs = cs; a.w16 = ps.w16; a.w16b = pd.w16p; a.cout_live = 18;
+        a.tile_ctr = nctr < 64 ? w.ctr + nctr++ : nullptr;
         a.stats = w.st0; a.inv_count = 1.0 / ((double)CA * P);  // rms(a0) per mixture: the amplitude the taps GEMM's operand is normalised by
         CHECK(launch_pwr_s3_taps(a, B, st));
         return launch_dec_istft(w.z, out, B, T, NF, L, (size_t)cs, (size_t)18 * cs, st);

@@ -52,8 +52,12 @@ __device__ __forceinline__ void split2(float v0, float v1, unsigned& hi, unsigne
 
 constexpr int B4_NT = 256;              // threads per workgroup: 4 waves, one per SIMD, 512 registers each
 constexpr int B4_L1 = 64 + 8, B4_L2 = 256 + 8;
-constexpr size_t B4_LDS = (size_t)2 * 256 * B4_L1 * 2 + (size_t)2 * 64 * B4_L2 * 2 + (size_t)(3 * 256 + 64) * 4 + 16;
+constexpr size_t B4_LDS = (size_t)2 * 256 * B4_L1 * 2 + (size_t)2 * 64 * B4_L2 * 2 + (size_t)(7 * 256 + 64) * 4 + 16;
 
+// CAF: the block input is CAF(out_0, video) + a1 (TDAVNet/fusion.py:204-212 after the first block): out <- ReLU(key(out)) * r[tv] + att[tv] * value(out)
+// with key / value = dw 1x1 . eval BatchNorm (layers/fusion.py:205-226, folded to one FMA each) and r / att the video-side terms of
+// caf_video_kernel, read from their (B, Tv, 256) transposed copies: four consecutive channels of one video frame are one 16-byte load.
+template <bool CAF>
 __global__ __launch_bounds__(B4_NT) void pws_b2b4_kernel(B2bArgs a, int ntiles, int tiles_per_sample, unsigned* __restrict__ ctr) {
     constexpr int L1 = B4_L1, L2 = B4_L2;
     constexpr float WINV = 1.0f / 256.0f;
@@ -66,7 +70,11 @@ __global__ __launch_bounds__(B4_NT) void pws_b2b4_kernel(B2bArgs a, int ntiles, 
     float* cB = cA + 256;                                 //   gateway scale
     float* cC = cB + 256;                                 //   residual_conv bias * gateway scale + gateway bias
     float* bp = cC + 256;                                 // projection bias (64)
-    int* s_next = reinterpret_cast<int*>(bp + 64);        // [2]
+    float* cks = bp + 64;                                 // CAF: folded key / value embeddings (4 x 256)
+    float* ckb = cks + 256;
+    float* cvs = ckb + 256;
+    float* cvb = cvs + 256;
+    int* s_next = reinterpret_cast<int*>(cvb + 256);      // [2]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
@@ -83,9 +91,21 @@ __global__ __launch_bounds__(B4_NT) void pws_b2b4_kernel(B2bArgs a, int ntiles, 
         }
         {
             const float g = a.gw[tid];
-            cA[tid] = g * WINV;
-            cB[tid] = g;
-            cC[tid] = fmaf(a.b1[tid], g, a.gb[tid]);
+            if (CAF) {  // the CAF sits between the residual conv and the gateway: the constants stay separate (cA = 1/256, cB = gateway scale, cC = gateway bias)
+                cA[tid] = a.b1[tid];
+                cB[tid] = g;
+                cC[tid] = a.gb[tid];
+                const float sk = a.caf_bn_key[tid] / sqrtf(a.caf_bn_key[768 + tid] + RTFS_EPS);
+                const float sv = a.caf_bn_val[tid] / sqrtf(a.caf_bn_val[768 + tid] + RTFS_EPS);
+                cks[tid] = a.caf_w_key[tid] * sk;
+                ckb[tid] = a.caf_bn_key[256 + tid] - a.caf_bn_key[512 + tid] * sk;
+                cvs[tid] = a.caf_w_val[tid] * sv;
+                cvb[tid] = a.caf_bn_val[256 + tid] - a.caf_bn_val[512 + tid] * sv;
+            } else {
+                cA[tid] = g * WINV;
+                cB[tid] = g;
+                cC[tid] = fmaf(a.b1[tid], g, a.gb[tid]);
+            }
             if (tid < 64) bp[tid] = a.bp[tid];
         }
     }
@@ -109,6 +129,16 @@ __global__ __launch_bounds__(B4_NT) void pws_b2b4_kernel(B2bArgs a, int ntiles, 
             const __amdgpu_buffer_rsrc_t a1s = rsrc_of(a.a1 + (size_t)b * 256 * CS + wp0);
             const __amdgpu_buffer_rsrc_t xes = rsrc_of(a.xenc + (size_t)b * 64 * CS + wp0);
             const unsigned CS4 = CS * 4u;  // row pitch in bytes
+            // CAF: this lane's two video frames (legacy nearest: tv = floor(t Tv / T), t = pixel / F) in the (B, Tv, 256) tables
+            const float *crt0 = nullptr, *crt1 = nullptr, *cat0 = nullptr, *cat1 = nullptr;
+            if (CAF) {
+                const int px = wp0 + 2 * r;
+                const int tv0 = nearest_src(min(px, P - 1) / a.caf_F, a.caf_Tv, a.caf_T), tv1 = nearest_src(min(px + 1, P - 1) / a.caf_F, a.caf_Tv, a.caf_T);
+                crt0 = a.caf_rt + ((size_t)b * a.caf_Tv + tv0) * 256;
+                crt1 = a.caf_rt + ((size_t)b * a.caf_Tv + tv1) * 256;
+                cat0 = a.caf_attt + ((size_t)b * a.caf_Tv + tv0) * 256;
+                cat1 = a.caf_attt + ((size_t)b * a.caf_Tv + tv1) * 256;
+            }
             // ---- loads of 32-channel tile m (residual_i and a1 rows): 32 x 8 bytes per lane
             f32x2 R[2][16], A[2][16];
             auto load_tile = [&](int m, f32x2 (&Rb)[16], f32x2 (&Ab)[16]) {
@@ -168,6 +198,16 @@ __global__ __launch_bounds__(B4_NT) void pws_b2b4_kernel(B2bArgs a, int ntiles, 
                     }
                 }
                 const int cob = m * 32 + 4 * h;  // channel of accumulator register q: cob + (q & 3) + 8 (q >> 2)
+                f32x4 vr0[4], vr1[4], va0[4], va1[4];  // CAF: video terms of the tile's 16 channels, both pixels (L2-resident tables)
+                if (CAF) {
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        vr0[g4] = *reinterpret_cast<const f32x4*>(crt0 + cob + 8 * g4);
+                        vr1[g4] = *reinterpret_cast<const f32x4*>(crt1 + cob + 8 * g4);
+                        va0[g4] = *reinterpret_cast<const f32x4*>(cat0 + cob + 8 * g4);
+                        va1[g4] = *reinterpret_cast<const f32x4*>(cat1 + cob + 8 * g4);
+                    }
+                }
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {  // accumulator registers 8s .. 8s+7 = K step 2m + s of GEMM 2
                     float y0[8], y1[8];
@@ -177,12 +217,28 @@ __global__ __launch_bounds__(B4_NT) void pws_b2b4_kernel(B2bArgs a, int ntiles, 
                         const f32x4 kA = *reinterpret_cast<const f32x4*>(cA + c4);
                         const f32x4 kB = *reinterpret_cast<const f32x4*>(cB + c4);
                         const f32x4 kC = *reinterpret_cast<const f32x4*>(cC + c4);
+                        f32x4 kks, kkb, kvs, kvb;
+                        if (CAF) {
+                            kks = *reinterpret_cast<const f32x4*>(cks + c4);
+                            kkb = *reinterpret_cast<const f32x4*>(ckb + c4);
+                            kvs = *reinterpret_cast<const f32x4*>(cvs + c4);
+                            kvb = *reinterpret_cast<const f32x4*>(cvb + c4);
+                        }
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
                             const int j = 4 * g + i, q = 8 * s + j;
-                            const f32x2 ra = Rb[q] + Ab[q];
-                            const float t0 = fmaf(acc1[0][q], kA[i], fmaf(ra.x, kB[i], kC[i]));
-                            const float t1 = fmaf(acc1[1][q], kA[i], fmaf(ra.y, kB[i], kC[i]));
+                            float t0, t1;
+                            if (CAF) {
+                                float o0 = fmaf(acc1[0][q], WINV, kA[i]) + Rb[q].x, o1 = fmaf(acc1[1][q], WINV, kA[i]) + Rb[q].y;  // out_0
+                                o0 = fmaf(fmaxf(fmaf(o0, kks[i], kkb[i]), 0.f), vr0[2 * s + g][i], va0[2 * s + g][i] * fmaf(o0, kvs[i], kvb[i]));
+                                o1 = fmaf(fmaxf(fmaf(o1, kks[i], kkb[i]), 0.f), vr1[2 * s + g][i], va1[2 * s + g][i] * fmaf(o1, kvs[i], kvb[i]));
+                                t0 = fmaf(o0 + Ab[q].x, kB[i], kC[i]);
+                                t1 = fmaf(o1 + Ab[q].y, kB[i], kC[i]);
+                            } else {
+                                const f32x2 ra = Rb[q] + Ab[q];
+                                t0 = fmaf(acc1[0][q], kA[i], fmaf(ra.x, kB[i], kC[i]));
+                                t1 = fmaf(acc1[1][q], kA[i], fmaf(ra.y, kB[i], kC[i]));
+                            }
                             y0[j] = preluf_(t0, slope);
                             y1[j] = preluf_(t1, slope);
                             st2(ress, voffC, (unsigned)(m * 32 + (q & 3) + 8 * (q >> 2)) * CS4, f32x2{y0[j], y1[j]});
@@ -243,11 +299,16 @@ __global__ __launch_bounds__(B4_NT) void pws_b2b4_kernel(B2bArgs a, int ntiles, 
 // cs must be a multiple of 64 floats covering every wave segment (api.hip pitch()); ctr: one zeroed counter word for this launch, or null
 // (static stride).  Returns RTFS_ERR_ARG when the call does not qualify (the caller then uses the first-generation kernel).
 int launch_pws_b2b4(const B2bArgs& a, int B, unsigned* ctr, hipStream_t st) {
-    if (a.caf_r || a.cs <= 0 || (a.cs & 63) || a.cs < (a.P + 63) / 64 * 64 || a.P < 2) return RTFS_ERR_ARG;
+    if ((a.caf_r && !(a.caf_rt && a.caf_attt)) || a.cs <= 0 || (a.cs & 63) || a.cs < (a.P + 63) / 64 * 64 || a.P < 2) return RTFS_ERR_ARG;
     if ((size_t)256 * a.cs * 4 >= ((size_t)1 << 31)) return RTFS_ERR_ARG;  // buffer offsets inside one sample: 31 bits
-    if (rtfs_set_max_lds((const void*)pws_b2b4_kernel, B4_LDS) != RTFS_OK) return RTFS_ERR_LAUNCH;
     const int tps = cdiv(a.P, B4_NT / 64 * 64), ntiles = tps * B;
     const int grid = ntiles < 256 ? ntiles : 256;  // one resident workgroup per CU
-    hipLaunchKernelGGL(pws_b2b4_kernel, dim3(grid), dim3(B4_NT), B4_LDS, st, a, ntiles, tps, ctr);
+    if (a.caf_r) {
+        if (rtfs_set_max_lds((const void*)pws_b2b4_kernel<true>, B4_LDS) != RTFS_OK) return RTFS_ERR_LAUNCH;
+        hipLaunchKernelGGL(pws_b2b4_kernel<true>, dim3(grid), dim3(B4_NT), B4_LDS, st, a, ntiles, tps, ctr);
+    } else {
+        if (rtfs_set_max_lds((const void*)pws_b2b4_kernel<false>, B4_LDS) != RTFS_OK) return RTFS_ERR_LAUNCH;
+        hipLaunchKernelGGL(pws_b2b4_kernel<false>, dim3(grid), dim3(B4_NT), B4_LDS, st, a, ntiles, tps, ctr);
+    }
     return rtfs_launch_status();
 }

@@ -78,6 +78,12 @@ __global__ __launch_bounds__(256) void caf_video_kernel(CafArgs a) {
     }
     const float inv = 1.0f / s;
     for (int t = 0; t < Tv; ++t) ao[t] *= inv;
+    if (a.r_t && a.att_t) {  // (B, Tv, 256) copies: the block-boundary kernel reads four consecutive channels of a frame at once
+        for (int t = 0; t < Tv; ++t) {
+            a.r_t[((size_t)b * Tv + t) * 256 + c] = ro[t];
+            a.att_t[((size_t)b * Tv + t) * 256 + c] = ao[t];
+        }
+    }
 }
 
 __device__ __forceinline__ void caf_apply_body(const CafArgs& a, const float* __restrict__ AUDIO, float* __restrict__ OUT) {

@@ -27,7 +27,7 @@ enum { PWR_BN = 0, PWR_S3 = 1, PWR_S3T = 2 };  // S3T: S3 fused with the decoder
 constexpr int PWR_LDW = 264;                       // staged weight row: 256 k + 8 pad halfs (528 B, ds_read_b128 conflict-free)
 constexpr int PWR_BUF = 2 * 32 * PWR_LDW;          // halfs per buffer: [hi|lo][32 co][PWR_LDW]
 constexpr int PWR_PT = 128;                        // pixels per workgroup tile (4 waves x 32)
-constexpr size_t PWR_LDS = (size_t)2 * PWR_BUF * 2 + 3 * 256 * 4;
+constexpr size_t PWR_LDS = (size_t)2 * PWR_BUF * 2 + 3 * 256 * 4 + 16;
 
 template <int MODE>
 __device__ __forceinline__ void pwr_body(const PwArgs& a, const float* __restrict__ X, const float* __restrict__ AUX,
@@ -37,6 +37,7 @@ __device__ __forceinline__ void pwr_body(const PwArgs& a, const float* __restric
     float* sc = reinterpret_cast<float*>(smem + (size_t)2 * PWR_BUF * 2);
     float* sh = sc + 256;
     float* bs = sh + 256;
+    int* s_next = reinterpret_cast<int*>(bs + 256);  // [2] next tile from the counter
     constexpr float WINV = 1.0f / 256.0f;
 
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
@@ -72,7 +73,9 @@ __device__ __forceinline__ void pwr_body(const PwArgs& a, const float* __restric
     stage_load(tile_of(0));
     stage_write(0);
     int cur_b = -1;
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int it = 0;
+    for (int tile = blockIdx.x; tile < ntiles; ++it) {
+        if (a.tile_ctr && tid == 0) s_next[it & 1] = (int)atomicAdd(a.tile_ctr, 1u) + (int)gridDim.x;
         const int b = tile / tps;
         const int p = (tile - b * tps) * PWR_PT + wave * 32 + r;
         const bool live = p < P;
@@ -235,6 +238,12 @@ __device__ __forceinline__ void pwr_body(const PwArgs& a, const float* __restric
                 const int tap = (q & 3) + 8 * (q >> 2) + 4 * h;
                 if (tap < a.cout_live) Zb[(unsigned)tap * CS] = acc2[q] * eisc;
             }
+        }
+        if (a.tile_ctr) {  // uniform (the barrier at the top of the next tile orders the s_next slot's reuse two tiles on)
+            __syncthreads();
+            tile = s_next[it & 1];
+        } else {
+            tile += gridDim.x;
         }
     }
 }

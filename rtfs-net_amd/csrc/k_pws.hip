@@ -32,6 +32,7 @@ __device__ __forceinline__ void pws_body(const PwArgs& a, int ntiles, int tiles_
     float* ckb = cks + (CAF ? CIN : 0);
     float* cvs = ckb + (CAF ? CIN : 0);
     float* cvb = cvs + (CAF ? CIN : 0);
+    int* s_next = reinterpret_cast<int*>(cvb + (CAF ? CIN : 0));  // [2] next tile from the counter (launcher: + 16 bytes)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -61,7 +62,9 @@ __device__ __forceinline__ void pws_body(const PwArgs& a, int ntiles, int tiles_
 
     const int P = a.P;
     const size_t CS = (size_t)a.cs;  // channel stride (>= P; the fused separator pads it to whole 128-byte lines)
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int it = 0;
+    for (int tile = blockIdx.x; tile < ntiles; ++it) {
+        if (a.tile_ctr && tid == 0) s_next[it & 1] = (int)atomicAdd(a.tile_ctr, 1u) + (int)gridDim.x;
         const int b = tile / tiles_per_sample;
         // lane r owns the S adjacent pixels p0 .. p0+S-1 (slot s = column r of MFMA tile s); S == 2: one unaligned 8-byte
         // access per channel row instead of two dword accesses (a dword stream tops out at 4.9 TB/s, dwordx2 at 7)
@@ -186,6 +189,12 @@ __device__ __forceinline__ void pws_body(const PwArgs& a, int ntiles, int tiles_
                 __builtin_amdgcn_sched_barrier(0);  // keep the 16-load / 16-store groups apart (register pressure)
             }
         }
+        if (a.tile_ctr) {  // uniform
+            __syncthreads();
+            tile = s_next[it & 1];
+        } else {
+            tile += gridDim.x;
+        }
     }
 }
 
@@ -200,7 +209,7 @@ static int launch_pws_t(const PwArgs& a_, int B, hipStream_t st) {
     if (a_.P < 2 || (a_.cs && a_.cs < a_.P)) return RTFS_ERR_SHAPE;
     PwArgs a = a_;
     if (!a.cs) a.cs = a.P;
-    const size_t lds = (size_t)2 * COUT * (CIN + 8) * 2 + (size_t)(CAF ? 6 : 2) * CIN * 4;
+    const size_t lds = (size_t)2 * COUT * (CIN + 8) * 2 + (size_t)(CAF ? 6 : 2) * CIN * 4 + 16;
     if (rtfs_set_max_lds((const void*)pws_kernel<CIN, COUT, PRO, EPI, HAS_X2, CAF, S>, lds) != RTFS_OK) return RTFS_ERR_LAUNCH;
     constexpr int PTB = 32 * S * (4 / (COUT / 32 > 4 ? COUT / 32 / 4 : 1));
     const int tps = cdiv(a.P, PTB), ntiles = tps * B;
@@ -229,6 +238,7 @@ __device__ __forceinline__ void pws_res2_body(const PwArgs& a, int ntiles, int t
     _Float16* W1h = reinterpret_cast<_Float16*>(smem);  // [256][L1]
     _Float16* W1l = W1h + 256 * L1;
     float* b1 = reinterpret_cast<float*>(W1l + 256 * L1);
+    int* s_next = reinterpret_cast<int*>(b1 + 256);  // [2]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     {
@@ -242,7 +252,9 @@ __device__ __forceinline__ void pws_res2_body(const PwArgs& a, int ntiles, int t
     __syncthreads();
     const int P = a.P;
     const unsigned CS = (unsigned)a.cs;  // channel stride (the launcher checks 256 * cs < 2^31)
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int it = 0;
+    for (int tile = blockIdx.x; tile < ntiles; ++it) {
+        if (a.tile_ctr && tid == 0) s_next[it & 1] = (int)atomicAdd(a.tile_ctr, 1u) + (int)gridDim.x;
         const int b = tile / tiles_per_sample;
         const int p0 = (tile - b * tiles_per_sample) * 256 + wave * 64 + 2 * r;  // this lane's pixels p0, p0 + 1
         const bool live0 = p0 < P, live1 = p0 + 1 < P;
@@ -299,6 +311,12 @@ __device__ __forceinline__ void pws_res2_body(const PwArgs& a, int ntiles, int t
                 else if (live0) os[(unsigned)co * CS + p0] = y0;
             }
         }
+        if (a.tile_ctr) {  // uniform
+            __syncthreads();
+            tile = s_next[it & 1];
+        } else {
+            tile += gridDim.x;
+        }
     }
 }
 __global__ __launch_bounds__(256, 2) void pws_res2_kernel(PwArgs a, int ntiles, int tiles_per_sample) {
@@ -309,7 +327,7 @@ static int launch_pws_res2(const PwArgs& a_, int B, hipStream_t st) {
     PwArgs a = a_;
     if (!a.cs) a.cs = a.P;
     if ((size_t)256 * a.cs >= ((size_t)1 << 31)) return RTFS_ERR_SHAPE;  // 32-bit element offsets inside a sample
-    const size_t lds = (size_t)2 * 256 * 72 * 2 + 256 * 4;
+    const size_t lds = (size_t)2 * 256 * 72 * 2 + 256 * 4 + 16;
     if (rtfs_set_max_lds((const void*)pws_res2_kernel, lds) != RTFS_OK) return RTFS_ERR_LAUNCH;
     const int tps = cdiv(a.P, 256), ntiles = tps * B;
     const int grid = ntiles < 512 ? ntiles : 512;  // 2 resident workgroups per CU

@@ -25,6 +25,7 @@ struct PwArgs {
     int cs = 0;         // channel stride (floats) of every (B, C, P) tensor of the call; 0 = P (contiguous).  The fused separator pads it
                         // to a multiple of 32 floats so that every 64-pixel wave segment is whole 128-byte lines ("pitch")
     int cout_live = 0;  // EPI_TAPS: number of real output channels
+    unsigned* tile_ctr = nullptr;  // persistent kernels: zeroed counter word that hands out tiles (null: static stride)
     // optional CAF prologue of the gateway kernel (fused separator path): x <- CAF(x, video) before the residual add
     const float* caf_r = nullptr;    // (B,256,Tv) resize(video)
     const float* caf_att = nullptr;  // (B,256,Tv) softmax attention
@@ -65,6 +66,7 @@ struct B2bArgs {
     int P = 0;
     int cs = 0;  // channel stride of x / res / a1 / xenc (floats); 0 = P
     const float *caf_r = nullptr, *caf_att = nullptr, *caf_w_key = nullptr, *caf_bn_key = nullptr, *caf_w_val = nullptr, *caf_bn_val = nullptr;
+    const float *caf_rt = nullptr, *caf_attt = nullptr;  // (B, Tv, 256) transposed copies of caf_r / caf_att (k_b2b.hip)
     int caf_T = 0, caf_F = 0, caf_Tv = 0;
 };
 int launch_pws_b2b(const B2bArgs& a, int B, hipStream_t st);
@@ -187,6 +189,7 @@ struct CafArgs {
     float* out = nullptr;          // (B,256,T,F)
     float* r_out = nullptr;        // (B,256,Tv) workspace: resize(video)
     float* att_out = nullptr;      // (B,256,Tv) workspace: softmax attention
+    float *r_t = nullptr, *att_t = nullptr;  // optional (B,Tv,256) transposed copies of the two (fused separator)
     int T = 0, F = 0, Tv = 0;
     const float *w_key = nullptr, *bn_key = nullptr;  // (256), (4,256) = [weight | bias | running_mean | running_var]
     const float *w_val = nullptr, *bn_val = nullptr;
