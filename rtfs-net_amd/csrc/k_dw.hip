@@ -136,6 +136,25 @@ __global__ __launch_bounds__(256) void dw_s1_kernel(DwArgs a) {
 // per-lane weight pairs, out-of-image ROWS are zeroed only in the first / last row band; the input gLN fold is applied to
 // the result: conv(pad0(s*x+b)) = s*conv(pad0(x)) + b*sum(valid w).
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+// XCD-contiguous block order.  The hardware deals the workgroups of a launch round-robin over the 8 XCDs (linear id mod 8), so neighbours in x -
+// which share the cache lines their waves split - sat on different XCDs: each L2 fetched the shared lines again and wrote its part of a line
+// back as a partial line.  The launch is 1-D (padded to a multiple of 8); XCD k takes the k-th contiguous eighth of the logical (x, y, z) grid.
+#ifndef DW_XCD
+#define DW_XCD 1
+#endif
+struct DwBlk { int x, y, z; bool ok; };
+__device__ __forceinline__ DwBlk dw_block(const DwArgs& a) {
+    int id = blockIdx.x;
+    if (DW_XCD) id = (id & 7) * (int)(gridDim.x >> 3) + (id >> 3);
+    DwBlk k;
+    k.ok = id < a.nblk;
+    id = k.ok ? id : 0;
+    k.x = id % a.gx;
+    const int t = id / a.gx;
+    k.y = t % a.gy;
+    k.z = t / a.gy;
+    return k;
+}
 #define DW1P_PAIRS 62  // column pairs a wave produces (64 lanes - 2 halo lanes)
 
 // element at (wave-uniform base) + (32-bit lane BYTE offset): the form global_load/store take as saddr + voffset
@@ -168,45 +187,73 @@ __device__ __forceinline__ float from_prev_lane(float v) {
 __device__ __forceinline__ float from_next_lane(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, false));  // wave_shl:1
 }
+// raw-buffer accesses: address = descriptor base (wave-uniform) + lane byte offset (VGPR) + row byte offset (SGPR)
+typedef __amdgpu_buffer_rsrc_t BufRsrc;
+typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ BufRsrc buf_rsrc(const float* base) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0x7fffffff, 0x00020000); }
+__device__ __forceinline__ f32x2 buf_ld2(BufRsrc rs, unsigned voff, unsigned soff) { return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0)); }
+__device__ __forceinline__ float buf_ld1(BufRsrc rs, unsigned voff, unsigned soff) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0)); }
+__device__ __forceinline__ void buf_st2(BufRsrc rs, unsigned voff, unsigned soff, f32x2 v) { __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_, v), rs, voff, soff, 0); }
+__device__ __forceinline__ void buf_st1(BufRsrc rs, unsigned voff, unsigned soff, float v) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, voff, soff, 0); }
 
-template <int NCONV, bool IN_AFFINE, int MODE>
+// VAR (MODE 2 only): bit 0 = an addend tensor is present, bit 1 = the pair's two gate / embedding columns are shared with the next lane
+// (2 Wg <= W).  Compile-time so that a row's loads are straight-line code: with these as run-time branches every row's loads sat in blocks
+// of their own and the compiler flushed vmcnt(0) behind them.
+//
+// Round 3 rewrite of the inner loop.  Counters (tools/pmc_dw.sh) had these passes 50-66 % VALU-busy at 3-4 TB/s, and the ISA showed why: of
+// ~60-85 vector instructions per output row only 18 were the packed FMAs - the rest built operand pairs (v_pk_fma_f32 wants even-aligned
+// register pairs and the four taps of a row are OVERLAPPING pairs of five values: ~24 v_mov per row), zero-padded columns by select, copied
+// lane offsets for every access and (scalar unit) recomputed 64-bit row pointers.  Now:
+//   * a window row is kept as its four operand pairs (v0 v1)(v1 v2)(v2 v3)(v3 v4), built once when the row enters the window (it serves four
+//     output rows): 2 selects + 4 DPP moves + 2 moves per row;
+//   * out-of-image COLUMNS, halo lanes and lanes past the end are folded into per-lane weight PAIRS (one weight per output of the pair): no
+//     selects, and a dead output is exactly 0, so the statistics need no mask;
+//   * raw-buffer addressing: one lane offset per tensor for the whole kernel, the row offset is an SGPR (one s_mul per access).
+template <int NCONV, bool IN_AFFINE, int MODE, int VAR = 0>
 __device__ __forceinline__ void dw1p_body(const DwArgs& a, const float* __restrict__ X, const float* __restrict__ GATE,
-                                          const float* __restrict__ EMB, const float* __restrict__ ADD, float* __restrict__ OUT,
+                                          const float* __restrict__ EMB, const float* __restrict__ ADD_, float* __restrict__ OUT,
                                           float* __restrict__ OUT1, float* __restrict__ OUT2, float* __restrict__ OUT3) {
     static_assert(NCONV == 1 || (MODE == 0 && !IN_AFFINE), "multi-conv: plain write + stats only");
     __shared__ double red[8];
+    constexpr bool gshare = MODE == 2 && (VAR & 2);  // the launcher checks 2 Wg <= W
+    constexpr bool HAS_ADD = MODE == 2 && (VAR & 1);
     const int H = a.H, W = a.W, C = a.C;
     const int NP = (W + 1) >> 1;  // column pairs per row
-    const int b = blockIdx.z;
+    const DwBlk blk = dw_block(a);
+    if (!blk.ok) return;  // block-uniform (padding of the 1-D launch)
+    const int b = blk.z;
     const int lane = threadIdx.x & 63;
     // flattened (channel, pair) index: wave-slot ws covers [62 ws - 1, 62 ws + 62]; lanes 0 and 63 are halo lanes
-    const int ws = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int ws = blk.x * 4 + (threadIdx.x >> 6);
     const int gi = ws * DW1P_PAIRS - 1 + lane;
     const bool live = lane >= 1 && lane <= DW1P_PAIRS && gi < C * NP;  // gi >= 0 follows from lane >= 1
     const int gc = gi < 0 ? 0 : (gi < C * NP ? gi : C * NP - 1);      // halo / dead lanes still load real, finite data
     const int c = gc / NP, p = gc - c * NP;
     const int x0 = 2 * p, x1 = 2 * p + 1;
     const bool liveb = live && x1 < W;
-    const int r0 = blockIdx.y * a.TH, r1 = min(r0 + a.TH, H);
-    // addressing: wave-uniform 64-bit bases (sample, row) + 32-bit lane BYTE offsets (channel plane + column), so a load
-    // costs no vector address arithmetic (global_load saddr + voffset); the launcher checks that C*H*W*4 fits 31 bits
-    const size_t sample = (size_t)b * C * (size_t)a.cs;  // channel stride a.cs: H * W or padded
-    const float* __restrict__ Xs_ = X + sample;
+    const int r0 = blk.y * a.TH, r1 = min(r0 + a.TH, H);
+    const bool whole = x1 < W;  // the odd-width row's last pair (x1 == W) loads (x0 - 1, x0) instead and takes x0 from .y
+    // addressing: one descriptor per tensor (base = this sample), one lane byte offset (channel plane + column), row offsets are scalars;
+    // the launcher checks that C * cs * 4 fits 31 bits
     const unsigned pa = (unsigned)c * (unsigned)a.cs * 4u;
-    auto col = [&](int x) { return pa + 4u * (unsigned)(x < 0 ? 0 : (x < W ? x : W - 1)); };
-    const unsigned o0 = col(x0), o1 = col(x1);
-    // the pair as ONE 8-byte access at column x0; the odd-width row's last pair (x1 == W) reads (x0-1, x0) instead
-    const bool whole = x1 < W;
-    const unsigned o2 = whole ? o0 : o0 - 4u;
-    // MODE 2: the gate / embedding tensors live at low resolution (Hg x Wg); output (t, x) reads ('nearest', legacy)
-    // row floor(t Hg / H), column floor(x Wg / W).  When 2 Wg <= W the pair's two source columns are s0 and s0 or s0 + 1, and
-    // s0 + 1 is then exactly the NEXT lane's s0: one load per lane and row instead of two, the neighbour's by DPP.  The
-    // source row changes only every H / Hg output rows (a wave-uniform event): the loads and the sigmoid are redone only
-    // then.  Together 4 gathers + 2 sigmoids per output row become ~1 + ~1.
+    const unsigned vld = pa + 4u * (unsigned)(whole ? x0 : x0 - 1);  // pair load position
+    const unsigned vst = pa + 4u * (unsigned)x0;                     // store position
+    const unsigned W4 = (unsigned)W * 4u;
+    const size_t sample = (size_t)b * C * (size_t)a.cs;
+    const BufRsrc xs = buf_rsrc(X + sample);
+    BufRsrc os[NCONV];
+    if (MODE != 1) {
+#pragma unroll
+        for (int n = 0; n < NCONV; ++n) os[n] = buf_rsrc((n == 0 ? OUT : n == 1 ? OUT1 : n == 2 ? OUT2 : OUT3) + sample);
+    }
+    // MODE 2: the gate / embedding tensors live at low resolution (Hg x Wg); output (t, x) reads ('nearest', legacy) row floor(t Hg / H),
+    // column floor(x Wg / W).  When 2 Wg <= W the pair's two source columns are s0 and s0 or s0 + 1, and s0 + 1 is then exactly the NEXT
+    // lane's s0: one load per lane and row, the neighbour's by DPP.
     unsigned fga = 0, fgb = 0;
     bool gnext = false;
-    const bool gshare = MODE == 2 && 2 * a.Wg <= W;  // uniform
     const size_t gsample = MODE == 2 ? (size_t)b * C * a.Hg * a.Wg : 0;
+    const BufRsrc gs = buf_rsrc(MODE == 2 ? GATE + gsample : X), es = buf_rsrc(MODE == 2 ? EMB + gsample : X);
+    const BufRsrc as_ = buf_rsrc(HAS_ADD ? ADD_ + sample : X);
     if (MODE == 2) {
         const unsigned gpa = (unsigned)c * (unsigned)(a.Hg * a.Wg) * 4u;
         const unsigned xb_ = (unsigned)(x1 < W ? x1 : W - 1);
@@ -218,84 +265,62 @@ __device__ __forceinline__ void dw1p_body(const DwArgs& a, const float* __restri
     }
     const bool border = r0 == 0 || r1 + 3 > H;  // block-uniform: only these bands ever see an out-of-image row
     // MODE 2: low-resolution source row floor(t Hg / H) as an incremental quotient / remainder, advanced in LOAD order
-    // (a 64-bit division per row on the scalar unit costs more than the row's vector work)
     int tgq = 0, tgr = 0;
     if (MODE == 2) {
         tgq = (int)(((long long)r0 * a.Hg) / H);
         tgr = (int)(((long long)r0 * a.Hg) % H);
     }
-    // A row in flight: own pair + the edge lanes' extra columns (raw) and, for MODE 2, everything else output row t-2 will
-    // need (gate / embedding gathers, addend) -- these passes are bound by bytes in flight (a wave with two rows
-    // outstanding sustains 2.6 TB/s chip-wide), so every load of a row is issued RQ rows before its use.
-    struct Raw { float v0, v1, g0, g1, m0, m1, a0, a1; int fresh; };
-    int tg_loaded = -1;
+    // A row in flight: own pair (raw, as loaded - the odd row end's select is applied by the consumer: a use next to the load would pull the
+    // wait there) and, for MODE 2, the epilogue operands of OUTPUT row t - 2 (gate / embedding gathers, addend)
+    struct Raw { f32x2 pr, ar; float g0, g1, m0, m1; };
     auto load_raw = [&](int t) {  // window row t, and the epilogue operands of OUTPUT row t - 2
         const int tc = t < 0 ? 0 : (t < H ? t : H - 1);
-        const float* __restrict__ rp = Xs_ + (size_t)tc * W;  // uniform
         Raw r;
-        const f32x2 pr = ldo2(rp, o2);
-        r.v0 = whole ? pr.x : pr.y;
-        r.v1 = pr.y;  // x1 == W: zeroed in complete()
-        r.g0 = r.g1 = r.m0 = r.m1 = r.a0 = r.a1 = 0.f;
-        r.fresh = 0;
+        r.pr = buf_ld2(xs, vld, (unsigned)tc * W4);
+        r.ar = f32x2{0.f, 0.f};
+        r.g0 = r.g1 = r.m0 = r.m1 = 0.f;
         if (MODE == 2) {
             const int to = min(max(t - 2, r0), H - 1);  // output row served (clamped: the extra rows of the last trip are dropped)
             const int tg = tgq < a.Hg - 1 ? tgq : a.Hg - 1;
-            if (t - 2 >= r0) {  // uniform: advance once per output row
-                tgr += a.Hg;
-                while (tgr >= H) {  // one step when Hg <= H
-                    tgr -= H;
-                    ++tgq;
-                }
+            {  // advance once per output row: scalar selects, no branch (Hg <= H: at most one step)
+                const bool adv = t - 2 >= r0;
+                tgr += adv ? a.Hg : 0;
+                const bool wrap = tgr >= H;
+                tgr -= wrap ? H : 0;
+                tgq += wrap ? 1 : 0;
             }
-            r.fresh = 0;
-            if (t - 2 >= r0 && tg != tg_loaded) {  // uniform
-                tg_loaded = tg;
-                r.fresh = 1;
-                const size_t grow = gsample + (size_t)tg * a.Wg;  // uniform
-                const float* __restrict__ gp = GATE + grow;
-                const float* __restrict__ ep = EMB + grow;
-                r.g0 = ldo(gp, fga);
-                r.m0 = ldo(ep, fga);
-                if (!gshare) {
-                    r.g1 = ldo(gp, fgb);
-                    r.m1 = ldo(ep, fgb);
-                }
+            const unsigned grow = (unsigned)tg * (unsigned)a.Wg * 4u;
+            r.g0 = buf_ld1(gs, fga, grow);  // every row (the source row repeats for two output rows: L1 hits): a branch around the gathers
+            r.m0 = buf_ld1(es, fga, grow);  // would put a basic-block boundary in front of every wait
+            if (!gshare) {
+                r.g1 = buf_ld1(gs, fgb, grow);
+                r.m1 = buf_ld1(es, fgb, grow);
             }
-            if (ADD) {
-                const float* __restrict__ ap = ADD + sample + (size_t)to * W;
-                const f32x2 ar = ldo2(ap, o2);
-                r.a0 = whole ? ar.x : ar.y;
-                r.a1 = ar.y;
-            }
+            if (HAS_ADD) r.ar = buf_ld2(as_, vld, (unsigned)to * W4);
         }
         return r;
     };
-    auto complete = [&](int t, const Raw& r, float (&v)[5]) {
-        v[1] = r.v0;
-        v[2] = r.v1;
-        v[0] = from_prev_lane(r.v1);
-        v[3] = from_next_lane(r.v0);
-        v[4] = from_next_lane(r.v1);
-        // zero padding of the COLUMNS (and whatever a lane of another channel / a halo lane delivered for them)
-        if (x0 == 0) v[0] = 0.f;
-        if (x0 + 1 >= W) v[2] = 0.f;
-        if (x0 + 2 >= W) v[3] = 0.f;
-        if (x0 + 3 >= W) v[4] = 0.f;
-        if (border && (t < 0 || t >= H)) {
+    // a window row as the four operand pairs of its taps
+    struct Row { f32x2 p[4]; };
+    auto complete = [&](int t, const Raw& r) {
+        const float v1 = whole ? r.pr.x : r.pr.y, v2 = r.pr.y;  // x1 == W: v2 only ever meets zero weights
+        const float v0 = from_prev_lane(v2), v3 = from_next_lane(v1), v4 = from_next_lane(v2);
+        Row w;
+        w.p[0] = f32x2{v0, v1};
+        w.p[1] = f32x2{v1, v2};
+        w.p[2] = f32x2{v2, v3};
+        w.p[3] = f32x2{v3, v4};
+        if (border && (t < 0 || t >= H)) {  // uniform
 #pragma unroll
-            for (int j = 0; j < 5; ++j) v[j] = 0.f;
+            for (int j = 0; j < 4; ++j) w.p[j] = f32x2{0.f, 0.f};
         }
+        return w;
     };
-    // ---- start-up: every load the first rows need (window rows r0-1 .. r0+1+RQ, the weights) is requested before the
-    // first wait and before the f64 gLN folds below, so a workgroup pays one memory latency, not three.
-    // RQ = rows in flight per wave = ring depth.  Round 3: with RQ = 2 the compiler waited for a trip's two loads at the END of the same
-    // trip (vmcnt(0) behind ~90 instructions of arithmetic): one kilobyte per wave and memory latency, 3-4 TB/s whatever the band height.
-    // The ring keeps the load of row t + 2 + RQ in flight while row t is computed (tools/bench_dw.hip for the sweep over RQ).
+    // ---- start-up: every load the first rows need is requested before the first wait and before the f64 gLN folds below
 #ifndef DW1P_RQ
 #define DW1P_RQ (MODE == 2 ? 4 : 8)
 #endif
-    constexpr int RQ = DW1P_RQ;
+    constexpr int RQ = DW1P_RQ;  // rows in flight per wave = ring depth
     Raw st0 = load_raw(r0 - 1), st1 = load_raw(r0), st2 = load_raw(r0 + 1);
     Raw q[RQ];
 #pragma unroll
@@ -312,55 +337,60 @@ __device__ __forceinline__ void dw1p_body(const DwArgs& a, const float* __restri
         gln_fold(a.loc_stats + 2 * b, a.loc_inv_count, a.loc_gamma[c], a.loc_beta[c], lsc, lsh);
         gln_fold(a.gate_stats + 2 * b, a.g_inv_count, a.gate_gamma[c], a.gate_beta[c], gsc, gsh);
         gln_fold(a.emb_stats + 2 * b, a.g_inv_count, a.emb_gamma[c], a.emb_beta[c], esc, esh);
-        if (ADD) gln_fold(a.add_stats + 2 * b, a.add_inv_count, a.add_gamma[c], a.add_beta[c], asc, ash);
+        if (HAS_ADD) gln_fold(a.add_stats + 2 * b, a.add_inv_count, a.add_gamma[c], a.add_beta[c], asc, ash);
     }
-    // weights are per-channel scalars (the column padding lives in the window values, see complete()); rowsum = per-row sum
-    // of the weights whose tap column is inside the image, for the input-fold correction of each output of the pair
-    float wgt[NCONV][16];
-    f32x2 rowsum[4];
+    // weight pairs: tap (i, j) of output x0 meets column x0 - 1 + j, of output x1 column x1 - 1 + j; a weight whose tap column is outside the
+    // image - or whose output does not exist (halo lane, lane past the end, x1 == W) - is 0
+    bool okA[4], okB[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) rowsum[i] = f32x2{0.f, 0.f};
+    for (int j = 0; j < 4; ++j) {
+        const int xa = x0 - 1 + j, xb = x1 - 1 + j;
+        okA[j] = live && xa >= 0 && xa < W;
+        okB[j] = liveb && xb >= 0 && xb < W;
+    }
+    f32x2 wp[NCONV][16];
+    f32x2 rowsum[4];
 #pragma unroll
     for (int n = 0; n < NCONV; ++n)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) wgt[n][i * 4 + j] = wraw[n][i][j];
+            for (int j = 0; j < 4; ++j) wp[n][i * 4 + j] = f32x2{okA[j] ? wraw[n][i][j] : 0.f, okB[j] ? wraw[n][i][j] : 0.f};
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int xa = x0 - 1 + j, xb = x1 - 1 + j;
-        const bool oka = xa >= 0 && xa < W, okb = xb >= 0 && xb < W;
+    for (int i = 0; i < 4; ++i) rowsum[i] = (wp[0][i * 4] + wp[0][i * 4 + 1]) + (wp[0][i * 4 + 2] + wp[0][i * 4 + 3]);
+    f32x2 bias[NCONV];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) rowsum[i] += f32x2{oka ? wgt[0][i * 4 + j] : 0.f, okb ? wgt[0][i * 4 + j] : 0.f};
+    for (int n = 0; n < NCONV; ++n) {
+        const float bv = a.bias[n] ? a.bias[n][c] : 0.f;
+        bias[n] = f32x2{live ? bv : 0.f, liveb ? bv : 0.f};
     }
-    float bias[NCONV];
-#pragma unroll
-    for (int n = 0; n < NCONV; ++n) bias[n] = a.bias[n] ? a.bias[n][c] : 0.f;
-    float win[3][5];
-    complete(r0 - 1, st0, win[0]);
-    complete(r0, st1, win[1]);
-    complete(r0 + 1, st2, win[2]);
+    Row win[3];
+    win[0] = complete(r0 - 1, st0);
+    win[1] = complete(r0, st1);
+    win[2] = complete(r0 + 1, st2);
     f32x2 s2[NCONV], ss2[NCONV];
 #pragma unroll
     for (int n = 0; n < NCONV; ++n) s2[n] = ss2[n] = f32x2{0.f, 0.f};
-    const f32x2 wv_full = rowsum[0] + rowsum[1] + rowsum[2] + rowsum[3];
-    const f32x2 m = {live ? 1.f : 0.f, liveb ? 1.f : 0.f};
-    f32x2 cur_gate = {0.f, 0.f}, cur_emb = {0.f, 0.f};
+    const f32x2 wv_full = (rowsum[0] + rowsum[1]) + (rowsum[2] + rowsum[3]);
     // one output row t (both columns of the pair) from window rows t-1 .. t+2; e = the raw record that came with row t+2
-    auto do_row = [&](int t, const float (&w0)[5], const float (&w1)[5], const float (&w2)[5], const float (&w3)[5], const Raw& e) {
-        const size_t orow = sample + (size_t)t * W;  // uniform
+    auto do_row = [&](int t, const Row& w0, const Row& w1, const Row& w2, const Row& w3, const Raw& e) {
+        const unsigned orow = (unsigned)t * W4;  // uniform
 #pragma unroll
         for (int n = 0; n < NCONV; ++n) {
-            f32x2 acc = {0.f, 0.f};
+            // two independent chains (window rows 0-1 and 2-3): a single 16-deep chain of packed FMAs stalls on its own latency
+            f32x2 accA = w0.p[0] * wp[n][0], accB = w2.p[0] * wp[n][8];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc = f32x2{w0[j], w0[j + 1]} * wgt[n][j] + acc;
+            for (int j = 1; j < 4; ++j) {
+                accA = w0.p[j] * wp[n][j] + accA;
+                accB = w2.p[j] * wp[n][8 + j] + accB;
+            }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc = f32x2{w1[j], w1[j + 1]} * wgt[n][4 + j] + acc;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc = f32x2{w2[j], w2[j + 1]} * wgt[n][8 + j] + acc;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc = f32x2{w3[j], w3[j + 1]} * wgt[n][12 + j] + acc;
-            if (IN_AFFINE) {
+            for (int j = 0; j < 4; ++j) {
+                accA = w1.p[j] * wp[n][4 + j] + accA;
+                accB = w3.p[j] * wp[n][12 + j] + accB;
+            }
+            f32x2 acc = accA + accB;
+            if (IN_AFFINE) {  // conv(pad0(s x + b)) = s conv(pad0(x)) + b * (sum of the weights whose tap is inside the image)
                 f32x2 wv = wv_full;
                 if (border) {
                     if (t - 1 < 0) wv -= rowsum[0];
@@ -371,49 +401,43 @@ __device__ __forceinline__ void dw1p_body(const DwArgs& a, const float* __restri
             }
             acc += bias[n];
             if (MODE == 0) {
-                float* __restrict__ o_ = (n == 0 ? OUT : n == 1 ? OUT1 : n == 2 ? OUT2 : OUT3) + orow;
-                if (liveb) sto2(o_, o0, acc);
-                else if (live) sto(o_, o0, acc.x);
+                if (liveb) buf_st2(os[n], vst, orow, acc);
+                else if (live) buf_st1(os[n], vst, orow, acc.x);
             }
             if (MODE != 2) {
-                const f32x2 am = acc * m;
-                s2[n] += am;
-                ss2[n] = am * am + ss2[n];
+                s2[n] += acc;  // dead outputs are exactly 0
+                ss2[n] = acc * acc + ss2[n];
             } else {
-                if (e.fresh) {  // uniform: new low-resolution source row
-                    float g1 = e.g1, m1 = e.m1;
-                    if (gshare) {
-                        const float gn = from_next_lane(e.g0), mn = from_next_lane(e.m0);
-                        g1 = gnext ? gn : e.g0;
-                        m1 = gnext ? mn : e.m0;
-                    }
-                    cur_gate = f32x2{sigmoidf_(fmaf(e.g0, gsc, gsh)), sigmoidf_(fmaf(g1, gsc, gsh))};
-                    cur_emb = f32x2{fmaf(e.m0, esc, esh), fmaf(m1, esc, esh)};
+                float g1 = e.g1, m1 = e.m1;
+                if (gshare) {
+                    const float gn = from_next_lane(e.g0), mn = from_next_lane(e.m0);
+                    g1 = gnext ? gn : e.g0;
+                    m1 = gnext ? mn : e.m0;
                 }
-                f32x2 y = (acc * lsc + lsh) * cur_gate + cur_emb;
-                if (ADD) y += f32x2{fmaf(e.a0, asc, ash), fmaf(e.a1, asc, ash)};
-                float* __restrict__ o_ = OUT + orow;
-                if (liveb) sto2(o_, o0, y);
-                else if (live) sto(o_, o0, y.x);
+                const f32x2 gate = {sigmoidf_(fmaf(e.g0, gsc, gsh)), sigmoidf_(fmaf(g1, gsc, gsh))};
+                const f32x2 emb = {fmaf(e.m0, esc, esh), fmaf(m1, esc, esh)};
+                f32x2 y = (acc * lsc + lsh) * gate + emb;
+                if (HAS_ADD) y += f32x2{fmaf(whole ? e.ar.x : e.ar.y, asc, ash), fmaf(e.ar.y, asc, ash)};
+                if (liveb) buf_st2(os[0], vst, orow, y);
+                else if (live) buf_st1(os[0], vst, orow, y.x);
             }
         }
     };
-    // RQ output rows per trip, fully unrolled so that the ring index is static; the slot of row t + 2 + k is re-loaded (row t + 2 + RQ + k) as
-    // soon as its value has been moved into the window, RQ rows before that value is needed
+    // RQ output rows per trip, fully unrolled so that the ring index is static; the slot of row t + 2 + k is re-loaded (row t + 2 + RQ + k)
+    // RQ rows before that value is needed
     for (int t = r0; t < r1; t += RQ) {
 #pragma unroll
         for (int k = 0; k < RQ; ++k) {
-            float n[5];
             const Raw e = q[k];
-            complete(t + 2 + k, e, n);
-            q[k] = load_raw(t + 2 + RQ + k);
+            const Row n = complete(t + 2 + k, e);
+            // MODE 2 re-loads the slot only after the row's last use of it (do_row reads the epilogue operands): while the old and the new
+            // value of a slot overlap they live in different registers, and the copy at the loop's back edge then waits for EVERY load
+            if (MODE != 2) q[k] = load_raw(t + 2 + RQ + k);
             if (t + k < r1) do_row(t + k, win[0], win[1], win[2], n, e);  // uniform
-#pragma unroll
-            for (int j = 0; j < 5; ++j) {
-                win[0][j] = win[1][j];
-                win[1][j] = win[2][j];
-                win[2][j] = n[j];
-            }
+            if (MODE == 2) q[k] = load_raw(t + 2 + RQ + k);
+            win[0] = win[1];
+            win[1] = win[2];
+            win[2] = n;
         }
     }
     if (MODE != 2) {
@@ -426,9 +450,9 @@ __device__ __forceinline__ void dw1p_body(const DwArgs& a, const float* __restri
 }
 
 // single-conv variants are held to 128 VGPRs (4 waves per SIMD): these passes live on bytes in flight
-template <int NCONV, bool IN_AFFINE, int MODE>
+template <int NCONV, bool IN_AFFINE, int MODE, int VAR = 0>
 __global__ __launch_bounds__(256, NCONV == 1 && MODE != 2 ? 4 : 2) void dw1p_kernel(DwArgs a) {
-    dw1p_body<NCONV, IN_AFFINE, MODE>(a, a.x, a.gate, a.emb, a.addend, a.out[0], a.out[1], a.out[2], a.out[3]);
+    dw1p_body<NCONV, IN_AFFINE, MODE, VAR>(a, a.x, a.gate, a.emb, a.addend, a.out[0], a.out[1], a.out[2], a.out[3]);
 }
 
 // ---------------------------------------------------------------- stride-2 pad-1 4x4 + adaptive average pool
@@ -523,15 +547,17 @@ __device__ __forceinline__ void dw_s2x_body(const DwArgs& a, const float* __rest
     __shared__ double red[8];
     const int H = a.H, W = a.W, C = a.C, Ho = a.Hg, Wo = a.Wg;
     const int NP = (W + 1) >> 1;  // input column pairs per row (slot j >= Wo only loads)
-    const int b = blockIdx.z;
+    const DwBlk blk = dw_block(a);
+    if (!blk.ok) return;
+    const int b = blk.z;
     const int lane = threadIdx.x & 63;
-    const int ws = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int ws = blk.x * 4 + (threadIdx.x >> 6);
     const int gi = ws * DW1P_PAIRS - 1 + lane;
     const int gc = gi < 0 ? 0 : (gi < C * NP ? gi : C * NP - 1);
     const int c = gc / NP, j = gc - c * NP;
     const bool live = lane >= 1 && lane <= DW1P_PAIRS && gi < C * NP && j < Wo;
     const int x0 = 2 * j, x1 = 2 * j + 1;
-    const int i0 = blockIdx.y * a.TH, i1 = min(i0 + a.TH, Ho);
+    const int i0 = blk.y * a.TH, i1 = min(i0 + a.TH, Ho);
     const size_t sample = (size_t)b * C * (size_t)a.cs;
     const float* __restrict__ Xs_ = X + sample;
     const unsigned pa = (unsigned)c * (unsigned)a.cs * 4u;
@@ -669,10 +695,19 @@ __global__ __launch_bounds__(256) void g_form_kernel(const float* __restrict__ p
                                                      const double* __restrict__ st1, double inv_count,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      float* __restrict__ g, int C, int HW) {
+    // one workgroup per (channel, sample) plane, 16-byte accesses: the f64 fold (~100 instructions) used to be paid per FOUR elements
+    // (16 k workgroups of 1024 elements: 59 us for 196 MB of Infinity-Cache-resident data)
     const int c = blockIdx.y, b = blockIdx.z;
     float sc, sh;
     gln_fold(st1 + 2 * b, inv_count, gamma[c], beta[c], sc, sh);
     const size_t base = ((size_t)b * C + c) * HW;
+    if ((HW & 3) == 0) {
+        const f32x4* __restrict__ p4 = reinterpret_cast<const f32x4*>(p0 + base);
+        const f32x4* __restrict__ c4 = reinterpret_cast<const f32x4*>(c1 + base);
+        f32x4* __restrict__ g4 = reinterpret_cast<f32x4*>(g + base);
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < HW / 4; i += gridDim.x * 256) g4[i] = p4[i] + (c4[i] * sc + sh);
+        return;
+    }
     for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) g[base + i] = p0[base + i] + fmaf(c1[base + i], sc, sh);
 }
 
@@ -684,6 +719,20 @@ __global__ __launch_bounds__(256) void g_combine_kernel(GCombineArgs a) {
     gln_fold(a.gate_stats + 2 * b, a.inv_count, a.gate_gamma[c], a.gate_beta[c], gsc, gsh);
     gln_fold(a.emb_stats + 2 * b, a.inv_count, a.emb_gamma[c], a.emb_beta[c], esc, esh);
     const size_t base = ((size_t)b * a.C + c) * a.HW;
+    if ((a.HW & 3) == 0) {  // one workgroup per plane, 16-byte accesses (see g_form_kernel)
+        const f32x4* __restrict__ l4 = reinterpret_cast<const f32x4*>(a.l + base);
+        const f32x4* __restrict__ g4 = reinterpret_cast<const f32x4*>(a.gate + base);
+        const f32x4* __restrict__ e4 = reinterpret_cast<const f32x4*>(a.emb + base);
+        f32x4* __restrict__ o4 = reinterpret_cast<f32x4*>(a.out + base);
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < a.HW / 4; i += gridDim.x * 256) {
+            const f32x4 lv = l4[i], gv = g4[i], ev = e4[i];
+            f32x4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = fmaf(fmaf(lv[k], lsc, lsh), sigmoidf_(fmaf(gv[k], gsc, gsh)), fmaf(ev[k], esc, esh));
+            o4[i] = o;
+        }
+        return;
+    }
     for (int i = blockIdx.x * 256 + threadIdx.x; i < a.HW; i += gridDim.x * 256)
         a.out[base + i] = fmaf(fmaf(a.l[base + i], lsc, lsh), sigmoidf_(fmaf(a.gate[base + i], gsc, gsh)), fmaf(a.emb[base + i], esc, esh));
 }
@@ -768,10 +817,14 @@ static int launch_dw_s1_t(const DwArgs& a, int B, hipStream_t st) {
     return rtfs_launch_status();
 }
 
-template <int NCONV, bool IN_AFFINE, int MODE>
-static int launch_dw1p_t(const DwArgs& a, int B, hipStream_t st) {
+template <int NCONV, bool IN_AFFINE, int MODE, int VAR = 0>
+static int launch_dw1p_t(const DwArgs& a_, int B, hipStream_t st) {
+    DwArgs a = a_;
     const int half = (a.W + 1) / 2;
-    hipLaunchKernelGGL((dw1p_kernel<NCONV, IN_AFFINE, MODE>), dim3(cdiv(cdiv(a.C * half, DW1P_PAIRS), 4), cdiv(a.H, a.TH), B), dim3(256), 0, st, a);
+    a.gx = cdiv(cdiv(a.C * half, DW1P_PAIRS), 4);
+    a.gy = cdiv(a.H, a.TH);
+    a.nblk = a.gx * a.gy * B;
+    hipLaunchKernelGGL((dw1p_kernel<NCONV, IN_AFFINE, MODE, VAR>), dim3((a.nblk + 7) / 8 * 8), dim3(256), 0, st, a);
     return rtfs_launch_status();
 }
 
@@ -784,7 +837,23 @@ int launch_dw_s1(const DwArgs& a_, int nconv, bool in_affine, int mode, int B, h
         if (nconv == 1) {
             if (mode == 0) return in_affine ? launch_dw1p_t<1, true, 0>(a, B, st) : launch_dw1p_t<1, false, 0>(a, B, st);
             if (mode == 1) return in_affine ? launch_dw1p_t<1, true, 1>(a, B, st) : launch_dw1p_t<1, false, 1>(a, B, st);
-            if (mode == 2) return in_affine ? launch_dw1p_t<1, true, 2>(a, B, st) : launch_dw1p_t<1, false, 2>(a, B, st);
+            if (mode == 2) {
+                const int var = (a.addend ? 1 : 0) | (2 * a.Wg <= a.W ? 2 : 0);
+                if (in_affine) {
+                    switch (var) {
+                        case 0: return launch_dw1p_t<1, true, 2, 0>(a, B, st);
+                        case 1: return launch_dw1p_t<1, true, 2, 1>(a, B, st);
+                        case 2: return launch_dw1p_t<1, true, 2, 2>(a, B, st);
+                        default: return launch_dw1p_t<1, true, 2, 3>(a, B, st);
+                    }
+                }
+                switch (var) {
+                    case 0: return launch_dw1p_t<1, false, 2, 0>(a, B, st);
+                    case 1: return launch_dw1p_t<1, false, 2, 1>(a, B, st);
+                    case 2: return launch_dw1p_t<1, false, 2, 2>(a, B, st);
+                    default: return launch_dw1p_t<1, false, 2, 3>(a, B, st);
+                }
+            }
         } else if (mode == 0 && !in_affine) {
             if (nconv == 2) return launch_dw1p_t<2, false, 0>(a, B, st);
             if (nconv == 4) {  // two 2-conv launches: the 4-conv kernel needs 256 VGPRs and runs slower than both together
@@ -814,7 +883,10 @@ int launch_dw_s2_pool(const DwArgs& a_, int B, hipStream_t st) {
     DwArgs a = a_;
     if (!a.cs) a.cs = a.H * a.W;
     if (a.Wg >= 16 && a.W >= 2 && (a.W + 1) / 2 >= a.Wg && (size_t)a.C * a.cs * 4 < ((size_t)1 << 31)) {
-        hipLaunchKernelGGL(dw_s2x_kernel, dim3(cdiv(cdiv(a.C * ((a.W + 1) / 2), DW1P_PAIRS), 4), cdiv(a.Hg, a.TH), B), dim3(256), 0, st, a);
+        a.gx = cdiv(cdiv(a.C * ((a.W + 1) / 2), DW1P_PAIRS), 4);
+        a.gy = cdiv(a.Hg, a.TH);
+        a.nblk = a.gx * a.gy * B;
+        hipLaunchKernelGGL(dw_s2x_kernel, dim3((a.nblk + 7) / 8 * 8), dim3(256), 0, st, a);
         return rtfs_launch_status();
     }
     hipLaunchKernelGGL(dw_s2_pool_kernel, dim3(cdiv(a.C * a.Wg, 256), cdiv(a.Hg, a.TH), B), dim3(256), 0, st, a);
@@ -823,12 +895,12 @@ int launch_dw_s2_pool(const DwArgs& a_, int B, hipStream_t st) {
 
 int launch_g_form(const float* p0, const float* c1, const double* st1, double inv_count, const float* gamma,
                   const float* beta, float* g, int B, int C, int HW, hipStream_t st) {
-    hipLaunchKernelGGL(g_form_kernel, dim3(cdiv(HW, 256 * 4), C, B), dim3(256), 0, st, p0, c1, st1, inv_count, gamma, beta, g, C, HW);
+    hipLaunchKernelGGL(g_form_kernel, dim3(1, C, B), dim3(256), 0, st, p0, c1, st1, inv_count, gamma, beta, g, C, HW);
     return rtfs_launch_status();
 }
 
 int launch_g_combine(const GCombineArgs& a, int B, hipStream_t st) {
-    hipLaunchKernelGGL(g_combine_kernel, dim3(cdiv(a.HW, 256 * 4), a.C, B), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(g_combine_kernel, dim3(1, a.C, B), dim3(256), 0, st, a);
     return rtfs_launch_status();
 }
 

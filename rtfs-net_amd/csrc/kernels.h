@@ -91,6 +91,7 @@ struct DwArgs {
     double* stats_out[4] = {nullptr, nullptr, nullptr, nullptr};  // (B,2) each
     int C = 0, H = 0, W = 0, TH = 8;
     int cs = 0;  // channel stride (floats) of the (B, C, H, W) tensors x / out[] / addend; 0 = H * W.  gate / emb (Hg x Wg) stay contiguous
+    int gx = 0, gy = 0, nblk = 0;  // set by the launchers of the lane-exchange kernels: logical grid (gx, gy, B) behind a 1-D launch (XCD order)
     // MODE 2 (TFAR apply) / stride-2 kernel: the low-resolution side
     int Hg = 0, Wg = 0;
     const double* loc_stats = nullptr;
