@@ -360,7 +360,10 @@ int block_head(const BlockPack& p, const float* x, const float* x_res, int B, in
             a.caf_w_key = caf->w_key; a.caf_bn_key = caf->bn_key; a.caf_w_val = caf->w_val; a.caf_bn_val = caf->bn_val;
             a.caf_T = caf->T; a.caf_F = caf->F; a.caf_Tv = caf->Tv;
         }
-        CHECK(gemm_f32() ? launch_pw_gateway_proj(a, B, st) : launch_pws_gateway_proj(a, B, st));
+        if (gemm_f32()) return launch_pw_gateway_proj(a, B, st);
+        const int rc = launch_pws_head4(a, B, st);  // padded rows, plain input: the ring kernel
+        if (rc == RTFS_ERR_ARG) CHECK(launch_pws_gateway_proj(a, B, st));
+        else CHECK(rc);
     }
     return RTFS_OK;
 }
@@ -419,6 +422,7 @@ int block_body(const BlockPack& p, int B, int T, int F, const BlockWs& w, hipStr
     // 9. TF self-attention                                                                  yaml layer_3
     CHECK(attention(p.attn, w.gT, w.gA, B, Tp, w.q, w.k, w.v, w.o, st));
     {  // 10. the four G-level convs on the attention output (fusion 0/1: global_embedding, global_gate)
+       // 11. fusion 1 local_embedding on d1 = gLN(c1) - independent of step 10: one launch for the three jobs
         DwArgs a;
         a.x = w.gA;
         a.w[0] = p.fus0.emb_w; a.w[1] = p.fus0.gate_w; a.w[2] = p.fus1.emb_w; a.w[3] = p.fus1.gate_w;
@@ -426,17 +430,20 @@ int block_body(const BlockPack& p, int B, int T, int F, const BlockWs& w, hipStr
         a.stats_out[0] = w.st(W::S_E0, B); a.stats_out[1] = w.st(W::S_G0, B);
         a.stats_out[2] = w.st(W::S_E1, B); a.stats_out[3] = w.st(W::S_G1, B);
         a.C = CH; a.H = Tp; a.W = Fp; a.TH = 64;
-        CHECK(launch_dw_s1(a, 4, false, 0, B, st));
-    }
-    {  // 11. fusion 1 local_embedding on d1 = gLN(c1)
-        DwArgs a;
-        a.x = w.c1;
-        a.in_stats = w.st(W::S_C1, B); a.in_inv_count = icG; a.in_gamma = p.ds1_g; a.in_beta = p.ds1_be;
-        a.w[0] = p.fus1.loc_w;
-        a.out[0] = w.L1;
-        a.stats_out[0] = w.st(W::S_L1, B);
-        a.C = CH; a.H = Tp; a.W = Fp; a.TH = 64;
-        CHECK(launch_dw_s1(a, 1, true, 0, B, st));
+        DwArgs l;
+        l.x = w.c1;
+        l.in_stats = w.st(W::S_C1, B); l.in_inv_count = icG; l.in_gamma = p.ds1_g; l.in_beta = p.ds1_be;
+        l.w[0] = p.fus1.loc_w;
+        l.out[0] = w.L1;
+        l.stats_out[0] = w.st(W::S_L1, B);
+        l.C = CH; l.H = Tp; l.W = Fp; l.TH = 64;
+        const int rc = launch_dw_g3(a, l, B, st);
+        if (rc == RTFS_ERR_ARG) {
+            CHECK(launch_dw_s1(a, 4, false, 0, B, st));
+            CHECK(launch_dw_s1(l, 1, true, 0, B, st));
+        } else {
+            CHECK(rc);
+        }
     }
     {  // 12. xf1 = gLN(L1) * sigmoid(gLN(G1)) + gLN(E1)                                      fusion.py:62-67
         GCombineArgs a;

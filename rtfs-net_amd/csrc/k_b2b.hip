@@ -294,6 +294,129 @@ __global__ __launch_bounds__(B4_NT) void pws_b2b4_kernel(B2bArgs a, int ntiles, 
     }
 }
 
+
+// ---------------------------------------------------------------- block head (first application): gateway + projection, padded rows
+//   residual = PReLU(dw1x1(x)),  x_enc = proj(residual)                                  separators/tdanet.py:106-107
+// Same arithmetic as pws_kernel<256, 64, PRO_GATEWAY> (k_pws.hip); the K loop is a ring: the eight rows of K step ks + 3 are requested
+// before step ks is consumed, stores are unconditional (padded rows), tiles come from the counter.  Two workgroups per CU (68 KB of LDS each).
+constexpr int H4_L = 256 + 8;
+constexpr size_t H4_LDS = (size_t)2 * 64 * H4_L * 2 + (size_t)(2 * 256 + 64) * 4 + 16;
+
+__global__ __launch_bounds__(256, 2) void pws_head4_kernel(PwArgs a, int ntiles, int tiles_per_sample) {
+    constexpr int L = H4_L;
+    constexpr float WINV = 1.0f / 256.0f;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    _Float16* Wh = reinterpret_cast<_Float16*>(smem);  // [64][L]
+    _Float16* Wl = Wh + 64 * L;
+    float* gsc = reinterpret_cast<float*>(Wl + 64 * L);
+    float* gsh = gsc + 256;
+    float* bp = gsh + 256;
+    int* s_next = reinterpret_cast<int*>(bp + 64);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    {
+        const half8* src = reinterpret_cast<const half8*>(a.w16);  // [8 chunks][hi|lo][64][32]
+        for (int i = tid; i < 8 * 2 * 64 * 4; i += 256) {
+            const int pc = i & 3, co = (i >> 2) & 63, part = (i >> 8) & 1, chunk = i >> 9;
+            *reinterpret_cast<half8*>((part ? Wl : Wh) + co * L + chunk * 32 + pc * 8) = src[i];
+        }
+        gsc[tid] = a.gw[tid];
+        gsh[tid] = a.gb[tid];
+        if (tid < 64) bp[tid] = a.bias[tid];
+    }
+    const float slope = a.slope[0];
+    const int P = a.P;
+    const unsigned CS = (unsigned)a.cs, CS4 = CS * 4u;
+    const unsigned voffB = ((unsigned)(8 * h) * CS + 2u * r) * 4u;
+    const unsigned voffC = ((unsigned)(4 * h) * CS + 2u * r) * 4u;
+    int it = 0;
+    int tile = blockIdx.x;
+    while (tile < ntiles) {
+        if (tid == 0) s_next[it & 1] = (a.tile_ctr ? (int)atomicAdd(a.tile_ctr, 1u) : tile) + (int)gridDim.x;
+        if (it == 0) __syncthreads();
+        const int b = tile / tiles_per_sample;
+        const int wp0 = (tile - b * tiles_per_sample) * 256 + wave * 64;
+        if (wp0 < P) {
+            const __amdgpu_buffer_rsrc_t xs = rsrc_of(a.x + (size_t)b * 256 * CS + wp0);
+            const __amdgpu_buffer_rsrc_t rs = rsrc_of(a.res_out + (size_t)b * 256 * CS + wp0);
+            const __amdgpu_buffer_rsrc_t os = rsrc_of(a.out + (size_t)b * 64 * CS + wp0);
+            f32x2 X[4][8];
+            auto load_x = [&](int ks, f32x2 (&d)[8]) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) d[j] = ld2(xs, voffB, (unsigned)(ks * 16 + j) * CS4);
+            };
+            load_x(0, X[0]);
+            load_x(1, X[1]);
+            load_x(2, X[2]);
+            f32x16 acc[2][2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) acc[m][sl][q] = 0.f;
+            auto k_step = [&](int ks, const f32x2 (&v)[8]) {
+                const f32x4 s0 = *reinterpret_cast<const f32x4*>(gsc + ks * 16 + 8 * h), s1 = *reinterpret_cast<const f32x4*>(gsc + ks * 16 + 8 * h + 4);
+                const f32x4 t0 = *reinterpret_cast<const f32x4*>(gsh + ks * 16 + 8 * h), t1 = *reinterpret_cast<const f32x4*>(gsh + ks * 16 + 8 * h + 4);
+                float y0[8], y1[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float sc_ = j < 4 ? s0[j & 3] : s1[j & 3], sh_ = j < 4 ? t0[j & 3] : t1[j & 3];
+                    y0[j] = preluf_(fmaf(v[j].x, sc_, sh_), slope);
+                    y1[j] = preluf_(fmaf(v[j].y, sc_, sh_), slope);
+                    st2(rs, voffB, (unsigned)(ks * 16 + j) * CS4, f32x2{y0[j], y1[j]});
+                }
+                unsigned h0[4], l0[4], h1[4], l1[4];
+#pragma unroll
+                for (int jp = 0; jp < 4; ++jp) {
+                    split2(y0[2 * jp], y0[2 * jp + 1], h0[jp], l0[jp]);
+                    split2(y1[2 * jp], y1[2 * jp + 1], h1[jp], l1[jp]);
+                }
+                const half8 bh0 = __builtin_bit_cast(half8, *reinterpret_cast<f32x4*>(h0)), bl0 = __builtin_bit_cast(half8, *reinterpret_cast<f32x4*>(l0));
+                const half8 bh1 = __builtin_bit_cast(half8, *reinterpret_cast<f32x4*>(h1)), bl1 = __builtin_bit_cast(half8, *reinterpret_cast<f32x4*>(l1));
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const half8 ah = *reinterpret_cast<const half8*>(Wh + (m * 32 + r) * L + ks * 16 + 8 * h);
+                    const half8 al = *reinterpret_cast<const half8*>(Wl + (m * 32 + r) * L + ks * 16 + 8 * h);
+                    acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh0, acc[m][0], 0, 0, 0);
+                    acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl0, acc[m][0], 0, 0, 0);
+                    acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh0, acc[m][0], 0, 0, 0);
+                    acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh1, acc[m][1], 0, 0, 0);
+                    acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl1, acc[m][1], 0, 0, 0);
+                    acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh1, acc[m][1], 0, 0, 0);
+                }
+            };
+#pragma unroll 1
+            for (int k4 = 0; k4 < 16; k4 += 4) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int ks = k4 + u;
+                    if (ks + 3 < 16) load_x(ks + 3, X[(u + 3) & 3]);  // uniform
+                    __builtin_amdgcn_sched_barrier(0);
+                    k_step(ks, X[u]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 bq = *reinterpret_cast<const f32x4*>(bp + m * 32 + 4 * h + 8 * g);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int q = 4 * g + i;
+                        st2(os, voffC, (unsigned)(m * 32 + i + 8 * g) * CS4, f32x2{fmaf(acc[m][0][q], WINV, bq[i]), fmaf(acc[m][1][q], WINV, bq[i])});
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        tile = s_next[it & 1];
+        ++it;
+    }
+}
+
 }  // namespace
 
 // cs must be a multiple of 64 floats covering every wave segment (api.hip pitch()); ctr: one zeroed counter word for this launch, or null
@@ -310,5 +433,16 @@ int launch_pws_b2b4(const B2bArgs& a, int B, unsigned* ctr, hipStream_t st) {
         if (rtfs_set_max_lds((const void*)pws_b2b4_kernel<false>, B4_LDS) != RTFS_OK) return RTFS_ERR_LAUNCH;
         hipLaunchKernelGGL(pws_b2b4_kernel<false>, dim3(grid), dim3(B4_NT), B4_LDS, st, a, ntiles, tps, ctr);
     }
+    return rtfs_launch_status();
+}
+
+// block head on padded rows, no second addend, no CAF; RTFS_ERR_ARG = use pws_kernel
+int launch_pws_head4(const PwArgs& a, int B, hipStream_t st) {
+    if (a.x2 || a.caf_r || a.cs <= 0 || (a.cs & 63) || a.cs < (a.P + 63) / 64 * 64 || a.P < 2) return RTFS_ERR_ARG;
+    if ((size_t)256 * a.cs * 4 >= ((size_t)1 << 31)) return RTFS_ERR_ARG;
+    if (rtfs_set_max_lds((const void*)pws_head4_kernel, H4_LDS) != RTFS_OK) return RTFS_ERR_LAUNCH;
+    const int tps = cdiv(a.P, 256), ntiles = tps * B;
+    const int grid = ntiles < 512 ? ntiles : 512;  // two resident workgroups per CU
+    hipLaunchKernelGGL(pws_head4_kernel, dim3(grid), dim3(256), H4_LDS, st, a, ntiles, tps);
     return rtfs_launch_status();
 }

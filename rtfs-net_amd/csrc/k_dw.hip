@@ -146,8 +146,9 @@ struct DwBlk { int x, y, z; bool ok; };
 __device__ __forceinline__ DwBlk dw_block(const DwArgs& a) {
     int id = blockIdx.x;
     if (DW_XCD) id = (id & 7) * (int)(gridDim.x >> 3) + (id >> 3);
+    id -= a.blk0;
     DwBlk k;
-    k.ok = id < a.nblk;
+    k.ok = id >= 0 && id < a.nblk;
     id = k.ok ? id : 0;
     k.x = id % a.gx;
     const int t = id / a.gx;
@@ -453,6 +454,15 @@ __device__ __forceinline__ void dw1p_body(const DwArgs& a, const float* __restri
 template <int NCONV, bool IN_AFFINE, int MODE, int VAR = 0>
 __global__ __launch_bounds__(256, NCONV == 1 && MODE != 2 ? 4 : 2) void dw1p_kernel(DwArgs a) {
     dw1p_body<NCONV, IN_AFFINE, MODE, VAR>(a, a.x, a.gate, a.emb, a.addend, a.out[0], a.out[1], a.out[2], a.out[3]);
+}
+
+// three jobs in one launch (launch_dw_g3): block-uniform dispatch on the permuted block id
+__global__ __launch_bounds__(256, 2) void dw_g3_kernel(DwArgs a0, DwArgs a1, DwArgs a2) {
+    int id = blockIdx.x;
+    if (DW_XCD) id = (id & 7) * (int)(gridDim.x >> 3) + (id >> 3);
+    if (id < a1.blk0) dw1p_body<2, false, 0>(a0, a0.x, a0.gate, a0.emb, a0.addend, a0.out[0], a0.out[1], a0.out[2], a0.out[3]);
+    else if (id < a2.blk0) dw1p_body<2, false, 0>(a1, a1.x, a1.gate, a1.emb, a1.addend, a1.out[0], a1.out[1], a1.out[2], a1.out[3]);
+    else dw1p_body<1, true, 0>(a2, a2.x, a2.gate, a2.emb, a2.addend, a2.out[0], a2.out[1], a2.out[2], a2.out[3]);
 }
 
 // ---------------------------------------------------------------- stride-2 pad-1 4x4 + adaptive average pool
@@ -876,6 +886,27 @@ int launch_dw_s1(const DwArgs& a_, int nconv, bool in_affine, int mode, int B, h
     if (mode == 2 && nconv == 1 && in_affine) return launch_dw_s1_t<1, true, 2>(a, B, st);
     if (mode == 2 && nconv == 1 && !in_affine) return launch_dw_s1_t<1, false, 2>(a, B, st);
     return RTFS_ERR_ARG;
+}
+
+int launch_dw_g3(const DwArgs& conv4, const DwArgs& aff1, int B, hipStream_t st) {
+    DwArgs j[3] = {conv4, conv4, aff1};
+    for (int i = 0; i < 2; ++i) {
+        j[1].w[i] = conv4.w[2 + i]; j[1].bias[i] = conv4.bias[2 + i]; j[1].out[i] = conv4.out[2 + i]; j[1].stats_out[i] = conv4.stats_out[2 + i];
+    }
+    int off = 0;
+    for (int i = 0; i < 3; ++i) {
+        DwArgs& a = j[i];
+        if (a.W < 16 || (a.cs && a.cs < a.H * a.W)) return RTFS_ERR_ARG;  // the caller falls back to separate launches
+        if (!a.cs) a.cs = a.H * a.W;
+        if ((size_t)a.C * a.cs * 4 >= ((size_t)1 << 31)) return RTFS_ERR_ARG;
+        a.gx = cdiv(cdiv(a.C * ((a.W + 1) / 2), DW1P_PAIRS), 4);
+        a.gy = cdiv(a.H, a.TH);
+        a.nblk = a.gx * a.gy * B;
+        a.blk0 = off;
+        off += a.nblk;
+    }
+    hipLaunchKernelGGL(dw_g3_kernel, dim3((off + 7) / 8 * 8), dim3(256), 0, st, j[0], j[1], j[2]);
+    return rtfs_launch_status();
 }
 
 int launch_dw_s2_pool(const DwArgs& a_, int B, hipStream_t st) {

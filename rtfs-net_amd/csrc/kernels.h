@@ -73,6 +73,7 @@ int launch_pws_b2b(const B2bArgs& a, int B, hipStream_t st);
 // second generation (k_b2b.hip): padded channel rows (cs % 64 == 0), no CAF; ctr = zeroed tile counter of this launch or null.
 // RTFS_ERR_ARG = call does not qualify, use launch_pws_b2b
 int launch_pws_b2b4(const B2bArgs& a, int B, unsigned* ctr, hipStream_t st);
+int launch_pws_head4(const PwArgs& a, int B, hipStream_t st);  // block head on padded rows (k_b2b.hip); RTFS_ERR_ARG = use launch_pws_gateway_proj
 int launch_pws_gateway_proj(const PwArgs& a, int B, hipStream_t st);
 int launch_pws_residual(const PwArgs& a, int B, hipStream_t st);
 int launch_mfma_f16_selftest(const float* A, const float* B, float* D, hipStream_t st);
@@ -91,7 +92,8 @@ struct DwArgs {
     double* stats_out[4] = {nullptr, nullptr, nullptr, nullptr};  // (B,2) each
     int C = 0, H = 0, W = 0, TH = 8;
     int cs = 0;  // channel stride (floats) of the (B, C, H, W) tensors x / out[] / addend; 0 = H * W.  gate / emb (Hg x Wg) stay contiguous
-    int gx = 0, gy = 0, nblk = 0;  // set by the launchers of the lane-exchange kernels: logical grid (gx, gy, B) behind a 1-D launch (XCD order)
+    int gx = 0, gy = 0, nblk = 0, blk0 = 0;  // set by the launchers of the lane-exchange kernels: logical grid (gx, gy, B) behind a 1-D launch
+                                              // (XCD order); blk0 = first block of this job when several jobs share one launch
     // MODE 2 (TFAR apply) / stride-2 kernel: the low-resolution side
     int Hg = 0, Wg = 0;
     const double* loc_stats = nullptr;
@@ -124,6 +126,9 @@ struct GCombineArgs {
 };
 
 int launch_dw_s1(const DwArgs& a, int nconv, bool in_affine, int mode, int B, hipStream_t st);
+// One launch for the block's three independent low-resolution conv jobs (steps 10 and 11: four plain convs on one input as two 2-conv
+// jobs + one conv on a gLN-folded input): each alone is 576 workgroups, too few to fill the chip
+int launch_dw_g3(const DwArgs& conv4, const DwArgs& aff1, int B, hipStream_t st);
 int launch_dw_s2_pool(const DwArgs& a, int B, hipStream_t st);
 int launch_g_form(const float* p0, const float* c1, const double* st1, double inv_count, const float* gamma,
                   const float* beta, float* g, int B, int C, int HW, hipStream_t st);
