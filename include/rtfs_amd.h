@@ -19,7 +19,8 @@
  *   - eval-mode semantics (BatchNorm running statistics, no dropout); re-entrant: the only host-side state is a mutex-guarded cache
  *     of per-(device, kernel) launch attributes, the per-(device, caller stream) internal side streams of rtfs_block_f32 /
  *     rtfs_separator_forward_f32 (forked from `stream` by an event and joined back into it inside the call: from outside all work of a call
- *     is ordered on `stream`), the process-wide rtfs_set_batch_split option and the diagnostic sweep-timing log (off by default), so the
+ *     is ordered on `stream`), the process-wide DEFAULT of the batch split (rtfs_set_batch_split; the _ex entry points take it per call) and
+ *     the diagnostic sweep-timing log (off by default), so the
  *     library may be driven from several host threads / devices in one process (one thread per stream).
  *   - length limits of the FUSED entry points (they keep a whole sweep / score row / video pyramid on chip and return -1 beyond):
  *       sweep axis of rtfs_dualpath_* / rtfs_block_f32 / rtfs_separator_forward_f32   <= 250 positions (T/2 <= 250: 4 s of audio)
@@ -136,6 +137,13 @@ size_t rtfs_separator_workspace_bytes(int B, int L, int Tv);
  * HBM-bound kernels of one part run beside the latency-bound sweeps of another (batch 32: 14.2 -> 13.0 ms with n = 2).  Results per mixture
  * do not depend on it.  Call it before rtfs_separator_workspace_bytes: the workspace layout follows the setting. */
 int rtfs_set_batch_split(int n);
+/* The same option PER CALL (re-entrant: two host threads can pick different schedules): split = 1 .. 8 parts for this call, 0 = the process
+ * default above.  The workspace query and the forward call must be given the same value. */
+size_t rtfs_separator_workspace_bytes_ex(int B, int L, int Tv, int split);
+int rtfs_separator_forward_ex_f32(const float* wav, const float* video_vp, const float* pack_enc, const float* pack_bn,
+                                  const float* pack_block, const float* pack_caf, const float* pack_s3,
+                                  const float* pack_dec, float* out, int B, int L, int Tv, int repeats, void* ws,
+                                  size_t ws_bytes, void* stream, void* video_ready, int rnn_kind, int split);
 int rtfs_separator_forward_f32(const float* wav, const float* video_vp, const float* pack_enc, const float* pack_bn,
                                const float* pack_block, const float* pack_caf, const float* pack_s3,
                                const float* pack_dec, float* out, int B, int L, int Tv, int repeats, void* ws,

@@ -22,6 +22,7 @@ def set_batch_split(n: int):
     lib = _lib.load()
     _lib.check(lib.rtfs_set_batch_split(int(n)), "rtfs_set_batch_split")
     lib.rtfs_separator_workspace_bytes.cache_clear()  # (the size queries are memoised; this one follows the setting)
+    lib.rtfs_separator_workspace_bytes_ex.cache_clear()  # (split = 0 means this setting)
 
 
 def load_config(path):

@@ -61,7 +61,6 @@ struct DpPack {
     const float *ln_g, *ln_b, *W0, *Wl, *wc = nullptr, *bias, *Wt, *bt;
     const float *w16_l0 = nullptr, *w16_l = nullptr, *w16_ct = nullptr, *wc16 = nullptr, *bias16 = nullptr;  // f16x3 images (k_dualpath16.hip)
     const float *wf_l0 = nullptr, *wf_l = nullptr, *wf_ct = nullptr;  // the same images in fragment order (k_dualpath16s.hip)
-    const float *wg_l0 = nullptr, *wg_l = nullptr, *wg_ct = nullptr;  // ... split by GEMM pass (k_dualpath16t.hip)
     const float* whh = nullptr;  // LSTM cell only
     explicit DpPack(Cursor& c, int rnn_kind = 0) {
         ln_g = c.take(CH);
@@ -89,9 +88,6 @@ struct DpPack {
         wf_l0 = c.take(512 * 256);
         wf_l = c.take(3 * 64 * 256);
         wf_ct = c.take(512 * 64);
-        wg_l0 = c.take(512 * 256);
-        wg_l = c.take(3 * 64 * 256);
-        wg_ct = c.take(512 * 64);
     }
 };
 struct AttnPack {
@@ -239,9 +235,6 @@ Dp16Args dp16_args(const DpPack& p, const float* x, float* out, int nseq, int R,
     a.wf_l0 = reinterpret_cast<const half8*>(p.wf_l0);
     a.wf_l = reinterpret_cast<const half8*>(p.wf_l);
     a.wf_ct = reinterpret_cast<const half8*>(p.wf_ct);
-    a.wg_l0 = reinterpret_cast<const half8*>(p.wg_l0);
-    a.wg_l = reinterpret_cast<const half8*>(p.wg_l);
-    a.wg_ct = reinterpret_cast<const half8*>(p.wg_ct);
     a.wc16 = p.wc16;
     a.bias16 = p.bias16;
     a.bt = p.bt;
@@ -387,10 +380,8 @@ int block_body(const BlockPack& p, int B, int T, int F, const BlockWs& w, hipStr
     }
     // Step 14 (statistics of fusion 0's local conv on d0: one full-resolution read, HBM-bound) needs only c0 and its statistics; steps 3-13 are
     // the low-resolution chain (sweeps, attention: latency-bound, HBM at < 10 %): it runs on a side stream beside them (14.43 -> 14.25 ms per
-    // forward, sweep launch times unchanged).  Not when the batch is split into parts (the other part already fills those gaps: 13.5 -> 14.5),
-    // RTFS_OVERLAP=0 switches it off.
-    static const bool overlap_env = !(getenv("RTFS_OVERLAP") && atoi(getenv("RTFS_OVERLAP")) == 0);
-    const bool overlap = overlap_env && side_pass;
+    // forward, sweep launch times unchanged).  Not when the batch is split into parts (the other part already fills those gaps: 13.5 -> 14.5).
+    const bool overlap = side_pass;
     Fork side14;  // joined before step 15, or by its destructor on an early return
     if (overlap) {
         CHECK(side14.begin(st, 0));
@@ -445,26 +436,34 @@ int block_body(const BlockPack& p, int B, int T, int F, const BlockWs& w, hipStr
             CHECK(rc);
         }
     }
-    {  // 12. xf1 = gLN(L1) * sigmoid(gLN(G1)) + gLN(E1)                                      fusion.py:62-67
-        GCombineArgs a;
-        a.l = w.L1; a.gate = w.G1; a.emb = w.E1;
-        a.l_stats = w.st(W::S_L1, B); a.gate_stats = w.st(W::S_G1, B); a.emb_stats = w.st(W::S_E1, B);
-        a.l_gamma = p.fus1.loc_g; a.l_beta = p.fus1.loc_b;
+    {  // 12 + 13. xf1 = gLN(L1) * sigmoid(gLN(G1)) + gLN(E1) (fusion.py:62-67) is only ever read by the concat layer's two global convs:
+       // they form it at load time, xf1 itself is never written
+        DwArgs a;
+        a.x = w.L1; a.gate = w.G1; a.emb = w.E1;
+        a.in_combine = 1;
+        a.loc_stats = w.st(W::S_L1, B); a.gate_stats = w.st(W::S_G1, B); a.emb_stats = w.st(W::S_E1, B);
+        a.loc_gamma = p.fus1.loc_g; a.loc_beta = p.fus1.loc_b;
         a.gate_gamma = p.fus1.gate_g; a.gate_beta = p.fus1.gate_b;
         a.emb_gamma = p.fus1.emb_g; a.emb_beta = p.fus1.emb_b;
-        a.inv_count = icG;
-        a.out = w.xf1;
-        a.C = CH; a.HW = Pg;
-        CHECK(launch_g_combine(a, B, st));
-    }
-    {  // 13. concat layer's global convs on xf1
-        DwArgs a;
-        a.x = w.xf1;
+        a.g_inv_count = icG;
         a.w[0] = p.cat0.emb_w; a.w[1] = p.cat0.gate_w;
         a.out[0] = w.E2; a.out[1] = w.G2;
         a.stats_out[0] = w.st(W::S_E2, B); a.stats_out[1] = w.st(W::S_G2, B);
         a.C = CH; a.H = Tp; a.W = Fp; a.TH = 64;
-        CHECK(launch_dw_s1(a, 2, false, 0, B, st));
+        if (Fp >= 16) {
+            CHECK(launch_dw_s1(a, 2, false, 0, B, st));
+        } else {  // (narrow inputs run the scalar kernels: separate combination pass)
+            GCombineArgs g;
+            g.l = w.L1; g.gate = w.G1; g.emb = w.E1;
+            g.l_stats = a.loc_stats; g.gate_stats = a.gate_stats; g.emb_stats = a.emb_stats;
+            g.l_gamma = a.loc_gamma; g.l_beta = a.loc_beta; g.gate_gamma = a.gate_gamma; g.gate_beta = a.gate_beta; g.emb_gamma = a.emb_gamma; g.emb_beta = a.emb_beta;
+            g.inv_count = icG;
+            g.out = w.xf1;
+            g.C = CH; g.HW = Pg;
+            CHECK(launch_g_combine(g, B, st));
+            a.x = w.xf1; a.gate = nullptr; a.emb = nullptr; a.in_combine = 0;
+            CHECK(launch_dw_s1(a, 2, false, 0, B, st));
+        }
     }
     DwArgs d0in;  // common: read d0 = gLN(c0) at full resolution
     d0in.x = w.c0;
@@ -974,7 +973,7 @@ int separator_part(const SepPacks& k, const float* wav, const float* video_vp, f
             else CHECK(block_tail(pk, cur, B, T, NF, w.blk, st, nctr < 64 ? w.ctr + nctr++ : nullptr));
         }
     }
-    if (!gemm_f32() && !getenv("RTFS_NO_S3T")) {  // S3 + decoder taps in one kernel: the separated spectrum never goes to HBM
+    if (!gemm_f32()) {  // S3 + decoder taps in one kernel: the separated spectrum never goes to HBM
         PwArgs a;
         a.x = cur; a.bias = ps.bias; a.aux = w.a0; a.out = w.z; a.slope = ps.slope; a.P = P; a.cs = cs; a.w16 = ps.w16; a.w16b = pd.w16p; a.cout_live = 18;
         a.tile_ctr = nctr < 64 ? w.ctr + nctr++ : nullptr;
@@ -1000,17 +999,20 @@ int rtfs_set_batch_split(int n) {
     g_split.store(n);
     return RTFS_OK;
 }
-static int separator_parts(int B) {
+static int separator_parts(int B, int split = 0) {  // split > 0: this call's own setting; 0: the process default (setter, else RTFS_SPLIT, else 1)
     static const int env = getenv("RTFS_SPLIT") ? atoi(getenv("RTFS_SPLIT")) : 0;
-    int n = g_split.load();
+    int n = split > 0 ? split : g_split.load();
     if (n <= 0) n = env > 0 ? env : 1;
     while (n > 1 && B / n < 8) --n;
     return n;
 }
 
-size_t rtfs_separator_workspace_bytes(int B, int L, int Tv) {
+size_t rtfs_separator_workspace_bytes(int B, int L, int Tv) { return rtfs_separator_workspace_bytes_ex(B, L, Tv, 0); }
+
+size_t rtfs_separator_workspace_bytes_ex(int B, int L, int Tv, int split) {
+    if (split < 0 || split > 8) return 0;
     Arena ar(nullptr, 0);
-    const int T = rtfs_num_frames(L), np = separator_parts(B);
+    const int T = rtfs_num_frames(L), np = separator_parts(B, split);
     for (int i = 0; i < np; ++i) SepWs w(ar, (B * (i + 1)) / np - (B * i) / np, T, Tv, pitch(T * NF));  // upper bound: the unfused path carves less
     return ar.off + 256;
 }
@@ -1018,19 +1020,26 @@ size_t rtfs_separator_workspace_bytes(int B, int L, int Tv) {
 int rtfs_separator_forward_f32(const float* wav, const float* video_vp, const float* pack_enc, const float* pack_bn, const float* pack_block,
                                const float* pack_caf, const float* pack_s3, const float* pack_dec, float* out, int B, int L, int Tv,
                                int repeats, void* ws, size_t ws_bytes, void* stream, void* video_ready, int rnn_kind) {
+    return rtfs_separator_forward_ex_f32(wav, video_vp, pack_enc, pack_bn, pack_block, pack_caf, pack_s3, pack_dec, out, B, L, Tv, repeats, ws, ws_bytes,
+                                         stream, video_ready, rnn_kind, 0);
+}
+
+int rtfs_separator_forward_ex_f32(const float* wav, const float* video_vp, const float* pack_enc, const float* pack_bn, const float* pack_block,
+                                  const float* pack_caf, const float* pack_s3, const float* pack_dec, float* out, int B, int L, int Tv,
+                                  int repeats, void* ws, size_t ws_bytes, void* stream, void* video_ready, int rnn_kind, int split) {
+    RTFS_RETURN_IF(split < 0 || split > 8, RTFS_ERR_ARG);
     RTFS_RETURN_IF(!wav || !video_vp || !pack_enc || !pack_bn || !pack_block || !pack_caf || !pack_s3 || !pack_dec || !out, RTFS_ERR_ARG);
     RTFS_RETURN_IF(B < 1 || L <= 128 || Tv < 1 || repeats < 1, RTFS_ERR_ARG);
     const int T = rtfs_num_frames(L);
     RTFS_RETURN_IF(!shape_ok_block(B, T, NF), RTFS_ERR_SHAPE);
     RTFS_RETURN_IF(rnn_kind != 0 && rnn_kind != 1, RTFS_ERR_ARG);
-    const int np = separator_parts(B);
+    const int np = separator_parts(B, split);
     Arena ar(ws, ws_bytes);
     std::vector<SepWs> parts;
     parts.reserve(np);
     // padded channel rows on the fused path; the unfused A/B sequence (exact-f32 GEMMs, or a single repeat) runs kernels that know only
     // contiguous tensors
-    const bool no_s3t = getenv("RTFS_NO_S3T") != nullptr;
-    const int cstride = (gemm_f32() || repeats == 1 || no_s3t) ? T * NF : pitch(T * NF);
+    const int cstride = (gemm_f32() || repeats == 1) ? T * NF : pitch(T * NF);
     for (int i = 0; i < np; ++i) parts.emplace_back(ar, (B * (i + 1)) / np - (B * i) / np, T, Tv, cstride);
     RTFS_RETURN_IF(!ws || !ar.ok(), RTFS_ERR_WORKSPACE);
     hipStream_t st = S(stream);

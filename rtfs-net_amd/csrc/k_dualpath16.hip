@@ -446,8 +446,6 @@ int launch_dualpath16(const Dp16Args& a, hipStream_t st) {
     // generation 3 (k_dualpath16s.hip: two workgroups per CU up to Ls = 128, its 512-thread variant above); RTFS_SWEEP_GEN2=1 keeps this file's
     // kernels for A/B
     static const bool gen2 = getenv("RTFS_SWEEP_GEN2") != nullptr;
-    static const bool gen4 = getenv("RTFS_SWEEP_GEN4") != nullptr;  // experiment: two-pass GEMM, three workgroups per CU
-    if (a.Ls <= 128 && gen4) return launch_dualpath16t(a, st);
     if (!gen2) {
         const int rc = launch_dualpath16s(a, st);
         if (rc != RTFS_ERR_SHAPE) return rc;  // (a tensor spanning >= 4 GB: this file's kernels address with 64 bits)

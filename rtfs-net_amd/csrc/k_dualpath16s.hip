@@ -140,15 +140,6 @@ __global__ __launch_bounds__(128 * NP, NT == 2 ? 2 : 4) void dp16s_kernel(Dp16Ar
         }
     };
     stamp();  // 0: start
-    // Two workgroups share a CU.  Dispatched together and running the same program they would stay in lockstep - both in their GEMM
-    // phases (fighting for the matrix pipe), then both in their recurrences (matrix pipe idle) - which is the one arrangement that gains
-    // nothing from sharing.  The workgroup that got the CU's second LDS allocation in the first resident round starts `a.stagger`
-    // x 4096 cycles late; every later workgroup inherits the offset of the slot it is dispatched into.
-    if (a.stagger > 0 && blockIdx.x < 512) {
-        const unsigned lds_base = __builtin_amdgcn_s_getreg(6 | (0 << 6) | (11 << 11)) & 0xFFF;  // HW_REG_LDS_ALLOC.LDS_BASE
-        if (lds_base != 0)
-            for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(64);  // 64 x 64 cycles
-    }
     auto seq_base = [&](int s) {
         int n = n0 + s;
         n = n < a.nseq ? n : a.nseq - 1;
@@ -374,8 +365,6 @@ __global__ __launch_bounds__(128 * NP, NT == 2 ? 2 : 4) void dp16s_kernel(Dp16Ar
             __syncthreads();  // step g consumed by every wave, step g + 1 visible
             ++g;
         };
-        if (a.prio == 1) __builtin_amdgcn_s_setprio(1);  // GEMM phases over the co-resident workgroup's (latency-bound) recurrence
-        if (a.prio == 2) __builtin_amdgcn_s_setprio(3);
         const std::integral_constant<int, 6> N6;
         const std::integral_constant<int, 4> N4;
         const std::integral_constant<int, 0> N0;
@@ -390,7 +379,6 @@ __global__ __launch_bounds__(128 * NP, NT == 2 ? 2 : 4) void dp16s_kernel(Dp16Ar
             kstep(2, S0, N0);
             kstep(3, S1, N0);
         }
-        if (a.prio) __builtin_amdgcn_s_setprio(0);
         // (that barrier also means: every wave has finished reading the activation planes - the scan may overwrite them in place)
         stamp();  // 2,4,6,8: GEMM of layer done
         // undo the 2^8 weight prescale.  Time part 0 is on the critical path: only what its chain reads (gates 0, 1) now, the rest in
@@ -413,7 +401,6 @@ __global__ __launch_bounds__(128 * NP, NT == 2 ? 2 : 4) void dp16s_kernel(Dp16Ar
         float cin[NT];  // c_{t-1} of register 0 of tile t (this lane's run)
 #pragma unroll
         for (int t = 0; t < NT; ++t) cin[t] = 0.f;
-        if (a.prio >= 3) __builtin_amdgcn_s_setprio(3);  // the serial chain is this workgroup's critical path: issue it ahead of the neighbour's GEMM
         for (int hp = 0; hp < NPART; ++hp) {
             if (part == hp) {
                 float c = hp > 0 ? chand[(seq * 2 + dir) * 32 + r] : 0.f;
@@ -469,7 +456,6 @@ __global__ __launch_bounds__(128 * NP, NT == 2 ? 2 : 4) void dp16s_kernel(Dp16Ar
             if (layer == 1 && hp == 0) stamp_at(13);  // part 0's chain done
             if (hp + 1 < NPART) __syncthreads();  // cell state published: the next time part starts while this one writes back
             if (layer == 1 && hp == 0) stamp_at(14);
-            if (a.prio == 4 && part == hp) __builtin_amdgcn_s_setprio(0);  // (4: only the chain itself runs at high priority)
             if (part == hp) {
                 if (hp == 0) unscale(2);
                 // deferred reset gate + highway: h = x' + (c_t - x') r(c_{t-1}); hidden outputs (this wave's direction half of the
@@ -537,7 +523,6 @@ __global__ __launch_bounds__(128 * NP, NT == 2 ? 2 : 4) void dp16s_kernel(Dp16Ar
             }
         }
         if (layer == 1) stamp_at(15);  // part 0's write-back done and the loop's last barrier passed: waiting for part 1's write-back
-        if (a.prio >= 3) __builtin_amdgcn_s_setprio(0);
         __syncthreads();  // all hidden outputs of this layer are in the planes
         stamp();  // 3,5,7,9: scan of layer done
     };
@@ -683,14 +668,8 @@ int launch_dualpath16s(const Dp16Args& a0, hipStream_t st) {
     if (L < 1 || a0.Ls > 256) return RTFS_ERR_SHAPE;
     // 32-bit byte offsets from the tensor base inside the kernel
     if ((((size_t)(a0.nseq - 1) / a0.R) * a0.bstride + (size_t)(a0.R - 1) * a0.rstride + 63 * a0.cstride + a0.Ls) * 4 >= ((size_t)1 << 32)) return RTFS_ERR_SHAPE;
-    static const int stagger = getenv("RTFS_SWEEP_STAGGER") ? atoi(getenv("RTFS_SWEEP_STAGGER")) : 0;
-    static const int prio = getenv("RTFS_SWEEP_PRIO") ? atoi(getenv("RTFS_SWEEP_PRIO")) : 0;
-    static const int nt = getenv("RTFS_SWEEP_NT") ? atoi(getenv("RTFS_SWEEP_NT")) : 2;  // row tiles per wave: 2 = 4-wave, 1 = 8-wave workgroups
-    Dp16Args a = a0;
-    a.prio = prio;
+    const Dp16Args& a = a0;
     const bool pair = a0.Ls <= 64;
-    a.stagger = cdiv(a.nseq, pair ? 2 : 1) > 512 ? stagger : 0;  // only when a CU's two slots run several workgroups each
     if (a0.Ls > 128) return launch_dp16s_t<1, false, 2, 4>(a, st);  // the 4 s shapes: four time parts, one workgroup per CU
-    if (nt == 1) return pair ? launch_dp16s_t<2, true, 1>(a, st) : launch_dp16s_t<1, false, 1>(a, st);
     return pair ? launch_dp16s_t<2, true, 2>(a, st) : launch_dp16s_t<1, false, 2>(a, st);
 }

@@ -218,6 +218,7 @@ __device__ __forceinline__ void dw1p_body(const DwArgs& a, const float* __restri
     __shared__ double red[8];
     constexpr bool gshare = MODE == 2 && (VAR & 2);  // the launcher checks 2 Wg <= W
     constexpr bool HAS_ADD = MODE == 2 && (VAR & 1);
+    constexpr bool COMBINE = MODE == 0 && (VAR & 4);  // input = TFAR combination of x / gate / emb, formed at load time (DwArgs.in_combine)
     const int H = a.H, W = a.W, C = a.C;
     const int NP = (W + 1) >> 1;  // column pairs per row
     const DwBlk blk = dw_block(a);
@@ -253,7 +254,7 @@ __device__ __forceinline__ void dw1p_body(const DwArgs& a, const float* __restri
     unsigned fga = 0, fgb = 0;
     bool gnext = false;
     const size_t gsample = MODE == 2 ? (size_t)b * C * a.Hg * a.Wg : 0;
-    const BufRsrc gs = buf_rsrc(MODE == 2 ? GATE + gsample : X), es = buf_rsrc(MODE == 2 ? EMB + gsample : X);
+    const BufRsrc gs = buf_rsrc(MODE == 2 ? GATE + gsample : (COMBINE ? GATE + sample : X)), es = buf_rsrc(MODE == 2 ? EMB + gsample : (COMBINE ? EMB + sample : X));
     const BufRsrc as_ = buf_rsrc(HAS_ADD ? ADD_ + sample : X);
     if (MODE == 2) {
         const unsigned gpa = (unsigned)c * (unsigned)(a.Hg * a.Wg) * 4u;
@@ -273,12 +274,16 @@ __device__ __forceinline__ void dw1p_body(const DwArgs& a, const float* __restri
     }
     // A row in flight: own pair (raw, as loaded - the odd row end's select is applied by the consumer: a use next to the load would pull the
     // wait there) and, for MODE 2, the epilogue operands of OUTPUT row t - 2 (gate / embedding gathers, addend)
-    struct Raw { f32x2 pr, ar; float g0, g1, m0, m1; };
+    struct Raw { f32x2 pr, ar, gr, er; float g0, g1, m0, m1; };
     auto load_raw = [&](int t) {  // window row t, and the epilogue operands of OUTPUT row t - 2
         const int tc = t < 0 ? 0 : (t < H ? t : H - 1);
         Raw r;
         r.pr = buf_ld2(xs, vld, (unsigned)tc * W4);
-        r.ar = f32x2{0.f, 0.f};
+        r.ar = r.gr = r.er = f32x2{0.f, 0.f};
+        if (COMBINE) {
+            r.gr = buf_ld2(gs, vld, (unsigned)tc * W4);
+            r.er = buf_ld2(es, vld, (unsigned)tc * W4);
+        }
         r.g0 = r.g1 = r.m0 = r.m1 = 0.f;
         if (MODE == 2) {
             const int to = min(max(t - 2, r0), H - 1);  // output row served (clamped: the extra rows of the last trip are dropped)
@@ -301,10 +306,16 @@ __device__ __forceinline__ void dw1p_body(const DwArgs& a, const float* __restri
         }
         return r;
     };
+    float lsc = 1.f, lsh = 0.f, gsc = 1.f, gsh = 0.f, esc = 1.f, esh = 0.f, asc = 1.f, ash = 0.f;  // set below, before the first complete()
     // a window row as the four operand pairs of its taps
     struct Row { f32x2 p[4]; };
     auto complete = [&](int t, const Raw& r) {
-        const float v1 = whole ? r.pr.x : r.pr.y, v2 = r.pr.y;  // x1 == W: v2 only ever meets zero weights
+        float v1 = whole ? r.pr.x : r.pr.y, v2 = r.pr.y;  // x1 == W: v2 only ever meets zero weights
+        if (COMBINE) {
+            const float g1_ = whole ? r.gr.x : r.gr.y, e1_ = whole ? r.er.x : r.er.y;
+            v1 = fmaf(fmaf(v1, lsc, lsh), sigmoidf_(fmaf(g1_, gsc, gsh)), fmaf(e1_, esc, esh));
+            v2 = fmaf(fmaf(v2, lsc, lsh), sigmoidf_(fmaf(r.gr.y, gsc, gsh)), fmaf(r.er.y, esc, esh));
+        }
         const float v0 = from_prev_lane(v2), v3 = from_next_lane(v1), v4 = from_next_lane(v2);
         Row w;
         w.p[0] = f32x2{v0, v1};
@@ -333,9 +344,8 @@ __device__ __forceinline__ void dw1p_body(const DwArgs& a, const float* __restri
         for (int i = 0; i < 4; ++i) wraw[n][i] = *reinterpret_cast<const f32x4*>(a.w[n] + c * 16 + i * 4);
     float isc = 1.f, ish = 0.f;
     if (IN_AFFINE) gln_fold(a.in_stats + 2 * b, a.in_inv_count, a.in_gamma[c], a.in_beta[c], isc, ish);
-    float lsc = 1.f, lsh = 0.f, gsc = 1.f, gsh = 0.f, esc = 1.f, esh = 0.f, asc = 1.f, ash = 0.f;
-    if (MODE == 2) {
-        gln_fold(a.loc_stats + 2 * b, a.loc_inv_count, a.loc_gamma[c], a.loc_beta[c], lsc, lsh);
+    if (MODE == 2 || COMBINE) {
+        gln_fold(a.loc_stats + 2 * b, COMBINE ? a.g_inv_count : a.loc_inv_count, a.loc_gamma[c], a.loc_beta[c], lsc, lsh);
         gln_fold(a.gate_stats + 2 * b, a.g_inv_count, a.gate_gamma[c], a.gate_beta[c], gsc, gsh);
         gln_fold(a.emb_stats + 2 * b, a.g_inv_count, a.emb_gamma[c], a.emb_beta[c], esc, esh);
         if (HAS_ADD) gln_fold(a.add_stats + 2 * b, a.add_inv_count, a.add_gamma[c], a.add_beta[c], asc, ash);
@@ -865,7 +875,7 @@ int launch_dw_s1(const DwArgs& a_, int nconv, bool in_affine, int mode, int B, h
                 }
             }
         } else if (mode == 0 && !in_affine) {
-            if (nconv == 2) return launch_dw1p_t<2, false, 0>(a, B, st);
+            if (nconv == 2) return a.in_combine ? launch_dw1p_t<2, false, 0, 4>(a, B, st) : launch_dw1p_t<2, false, 0>(a, B, st);
             if (nconv == 4) {  // two 2-conv launches: the 4-conv kernel needs 256 VGPRs and runs slower than both together
                 DwArgs b = a;
                 for (int i = 0; i < 2; ++i) {

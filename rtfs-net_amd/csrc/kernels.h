@@ -92,6 +92,8 @@ struct DwArgs {
     double* stats_out[4] = {nullptr, nullptr, nullptr, nullptr};  // (B,2) each
     int C = 0, H = 0, W = 0, TH = 8;
     int cs = 0;  // channel stride (floats) of the (B, C, H, W) tensors x / out[] / addend; 0 = H * W.  gate / emb (Hg x Wg) stay contiguous
+    int in_combine = 0;  // lane-exchange kernels, MODE 0: the input is the same-size TFAR combination gLN(x) * sigmoid(gLN(gate)) + gLN(emb) of three
+                         // pre-norm tensors (folds: loc_* / gate_* / emb_*, all with g_inv_count), formed at load time (fusion.py:62-67)
     int gx = 0, gy = 0, nblk = 0, blk0 = 0;  // set by the launchers of the lane-exchange kernels: logical grid (gx, gy, B) behind a 1-D launch
                                               // (XCD order); blk0 = first block of this job when several jobs share one launch
     // MODE 2 (TFAR apply) / stride-2 kernel: the low-resolution side
@@ -221,22 +223,16 @@ struct Dp16Args {
     // the same three images in MFMA fragment order (generation 3, k_dualpath16s.hip): [K step 16][dir][gate tile m][hi|lo][lane] x half8 with
     // lane (h, r) = W[k = 16 step + 8 h + j][col = dir*128 + m*32 + r]; conv-transpose: [tap][co tile][ks][hi|lo][lane], W[co = 32 tile + r][k = 16 ks + 8 h + j]
     const half8 *wf_l0 = nullptr, *wf_l = nullptr, *wf_ct = nullptr;
-    // ... and split by GEMM pass (generation 4, k_dualpath16t.hip): [pass][K step][dir][gate tile of the pass 2][hi|lo][lane] (8 KB per step);
-    // conv-transpose: [tap][k half][co tile][ks' 2][hi|lo][lane]
-    const half8 *wg_l0 = nullptr, *wg_l = nullptr, *wg_ct = nullptr;
     const float* wc16 = nullptr;    // 4 x (128): v_f, v_r scaled by -log2(e)
     const float* bias16 = nullptr;  // 4 x (128): b_f, b_r scaled by -log2(e)
     const float* bt = nullptr;      // (64)
     unsigned long long* stamps = nullptr;  // diagnostic build only: [workgroups][16] s_memtime stamps
-    int stagger = 0;                       // generation 3: start delay of a CU's second workgroup, units of 4096 cycles
-    int prio = 0;                          // generation 3: s_setprio level of the GEMM phases (experiment knob)
 };
 size_t dp16_lds_bytes(int Ls, int nseq_per_wg);
 int launch_dualpath16(const Dp16Args& a, hipStream_t st);
 // generation 3 (k_dualpath16s.hip): 256-thread workgroups, two per CU, L <= 128; launch_dualpath16 routes to it
 size_t dp16s_lds_bytes(int Ls, int nseq_per_wg);
 int launch_dualpath16s(const Dp16Args& a, hipStream_t st);
-int launch_dualpath16t(const Dp16Args& a, hipStream_t st);  // generation 4 (experiment): two GEMM passes per layer, three workgroups per CU
 void* dualpath_timing_begin(int Ls, int nseq, hipStream_t st);
 void dualpath_timing_end(void* slot, hipStream_t st);
 

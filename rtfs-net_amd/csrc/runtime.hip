@@ -55,10 +55,17 @@ int rtfs_side_stream(hipStream_t owner, int slot, RtfsSide* out) {
             *out = e.side;
             return RTFS_OK;
         }
-    RtfsSide s;
+    RtfsSide s{};
     if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) return RTFS_ERR_LAUNCH;
-    if (hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&s.join, hipEventDisableTiming) != hipSuccess)
+    if (hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) != hipSuccess) {
+        (void)hipStreamDestroy(s.stream);
         return RTFS_ERR_LAUNCH;
+    }
+    if (hipEventCreateWithFlags(&s.join, hipEventDisableTiming) != hipSuccess) {  // nothing half-built is left behind
+        (void)hipEventDestroy(s.fork);
+        (void)hipStreamDestroy(s.stream);
+        return RTFS_ERR_LAUNCH;
+    }
     g_side.push_back({dev, owner, slot, s});
     *out = s;
     return RTFS_OK;

@@ -639,13 +639,16 @@ class AVNet(BaseAVModel):
         vp.record_stream(main)
         Tv = vp.shape[-1]
         out = torch.empty(B, self.n_src, L, device=wav.device, dtype=torch.float32)
-        ws = _lib.workspace(lib.rtfs_separator_workspace_bytes(B, L, Tv), wav.device)
+        # batch split of THIS model's calls (0 = the library's process-wide default, rtfs_set_batch_split / RTFS_SPLIT): a per-call argument
+        # of the C ABI, so two models / threads can run different schedules
+        split = int(getattr(self, "batch_split", 0) or 0)
+        ws = _lib.workspace(lib.rtfs_separator_workspace_bytes_ex(B, L, Tv, split), wav.device)
         packs = [self.encoder.pack(), self.audio_bottleneck.pack(), rm.audio_net.get_block(0).pack(),
                  rm.crossmodal_fusion.get_fusion_block(0).audio_lstm.pack(), self.mask_generator.pack(), self.decoder.pack()]
-        _lib.check(lib.rtfs_separator_forward_f32(_lib.ptr(wav), _lib.ptr(vp), *[_lib.ptr(p) for p in packs], _lib.ptr(out), B, L, Tv,
-                                                  int(self.audio_params["repeats"]), _lib.ptr(ws), ws.numel(), _lib.stream_of(wav),
-                                                  ctypes.c_void_p(ready.cuda_event), rm.audio_net.get_block(0).rnn_kind),
-                   "rtfs_separator_forward_f32")
+        _lib.check(lib.rtfs_separator_forward_ex_f32(_lib.ptr(wav), _lib.ptr(vp), *[_lib.ptr(p) for p in packs], _lib.ptr(out), B, L, Tv,
+                                                     int(self.audio_params["repeats"]), _lib.ptr(ws), ws.numel(), _lib.stream_of(wav),
+                                                     ctypes.c_void_p(ready.cuda_event), rm.audio_net.get_block(0).rnn_kind, split),
+                   "rtfs_separator_forward_ex_f32")
         return out
 
     def _side_stream(self, device):

@@ -80,19 +80,6 @@ def frag_image_ct(img):
     return h16.permute(0, 2, 4, 1, 5, 3, 6).contiguous().view(torch.float32).reshape(-1)
 
 
-def frag_image_gate2(fimg):
-    """frag_image_gate output ([K step][dir 2][gate tile 4][hi|lo][lane][8] halfs) -> split by GEMM pass for k_dualpath16t.hip:
-    [pass 2][K step][dir 2][gate tile of the pass 2][hi|lo][lane][8]; pass 0 = gate tiles 0-1 (candidate, forget), pass 1 = 2-3 (reset, highway)."""
-    h16 = fimg.view(torch.float16).reshape(-1, 2, 2, 2, 2, 64, 8)  # step, dir, pass, m', part, lane, j
-    return h16.permute(2, 0, 1, 3, 4, 5, 6).contiguous().view(torch.float32).reshape(-1)
-
-
-def frag_image_ct2(fimg):
-    """frag_image_ct output ([tap 8][co tile 2][ks 4][hi|lo][lane][8]) -> [tap][k half 2][co tile 2][ks' 2][hi|lo][lane][8] (8 KB per half tap)."""
-    h16 = fimg.view(torch.float16).reshape(8, 2, 2, 2, 2, 64, 8)  # tap, co tile, k half, ks', part, lane, j
-    return h16.permute(0, 2, 1, 3, 4, 5, 6).contiguous().view(torch.float32).reshape(-1)
-
-
 def pack_encoder(sd):
     """STFTEncoder: conv.full_layer.2.weight (256,2,3,3) -> (256,18)."""
     return _cat([sd["conv.full_layer.2.weight"].reshape(256, 18)])
@@ -137,10 +124,6 @@ def _dualpath_parts(sd):
     parts.append(f0)
     parts.append(torch.stack(fl))
     parts.append(fct)
-    # ... and split by GEMM pass (generation-4 sweep kernel, experiment)
-    parts.append(frag_image_gate2(f0))
-    parts.append(torch.stack([frag_image_gate2(frag_image_gate(i)) for i in imgs]))
-    parts.append(frag_image_ct2(fct))
     return parts
 
 

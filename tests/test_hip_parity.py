@@ -169,6 +169,21 @@ def test_generation2_sweep_kernels_still_pass():
     assert pr.returncode == 0, pr.stdout[-3000:]
 
 
+def test_exact_f32_gemm_switch_still_passes():
+    """RTFS_GEMM_F32=1 (read once per process) routes the pointwise / dual-path GEMMs to the exact v_mfma_f32_32x32x2_f32 kernels and the
+    separator to its unfused, contiguous-row sequence - the A/B path for the f16x3 arithmetic and for the padded-row kernels.  Re-run the
+    end-to-end and block cases in a child process."""
+    import subprocess, sys
+    if os.environ.get("RTFS_GEMM_F32"):
+        pytest.skip("already inside the exact-f32 run")
+    env = dict(os.environ, RTFS_GEMM_F32="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pr = subprocess.run([sys.executable, "-m", "pytest", "tests/test_hip_parity.py", "-q", "-x", "-m", "gpu", "-k",
+                         "test_end_to_end_vs_golden or test_rtfs_block or test_audio_bn or test_s3 or test_decoder"],
+                        cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert pr.returncode == 0, pr.stdout[-3000:]
+
+
 def test_dualpath_short_axis_raises():
     m = model()
     with pytest.raises(ValueError):
@@ -410,6 +425,27 @@ def test_batch_split_option_changes_nothing_but_the_schedule():
                 assert rel_err(b[i], a[i]) <= 2e-6 and rel_err(c[i], a[i]) <= 2e-6, (B, i)
     finally:
         R.set_batch_split(0)
+
+
+def test_batch_split_per_call_argument():
+    """rtfs_separator_forward_ex_f32(..., split): the schedule as an argument of the call (AVNet.batch_split) instead of the process-wide
+    setter - consecutive calls of one model with different settings, each mixture as in the single chain."""
+    import rtfs_net_amd as R
+    R.set_batch_split(0)
+    m = model()
+    wav, emb = make_inputs(17, 4096, 7, 411)
+    try:
+        m.batch_split = 1
+        a = host(m(dev(wav), dev(emb)))
+        m.batch_split = 2
+        b = host(m(dev(wav), dev(emb)))
+    finally:
+        m.batch_split = 0
+    for i in range(17):
+        assert rel_err(b[i], a[i]) <= 2e-6, i
+    lib = R._lib.load()
+    assert lib.rtfs_separator_workspace_bytes_ex(32, 4096, 7, 2) > lib.rtfs_separator_workspace_bytes_ex(32, 4096, 7, 1)
+    assert lib.rtfs_separator_workspace_bytes_ex(32, 4096, 7, 9) == 0  # out of range
 
 
 def test_forward_can_be_captured_in_a_hip_graph():

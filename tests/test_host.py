@@ -416,8 +416,9 @@ def test_pack_cache_survives_dot_data_updates_after_invalidate():
 
 
 def test_no_hazardous_packed_f32_instructions_in_the_code_object():
-    """tools/isa_check.py: no `v_pk_{fma,mul,add}_f32` with an op_sel that feeds a HIGH source dword to the LOW lane (the instruction form
-    that was caught producing wrong results on MI355X under load in round 2; the library is built with -fno-slp-vectorize)."""
+    """tools/isa_check.py: no packed VALU instruction (`v_pk_*`, v_pk_mov_b32 included) with an op_sel that feeds a HIGH source half / dword to
+    the LOW lane (the instruction form that was caught producing wrong results on MI355X under load in round 2; its cause was never
+    established, so the guard covers the whole class; the library is built with -fno-slp-vectorize)."""
     import importlib.util
     from rtfs_net_amd import _lib
     spec = importlib.util.spec_from_file_location("isa_check", os.path.join(ROOT, "tools", "isa_check.py"))
@@ -427,6 +428,9 @@ def test_no_hazardous_packed_f32_instructions_in_the_code_object():
     assert not bad, bad[:5]
     assert mod.PAT.search("v_pk_fma_f32 v[72:73], v[168:169], v[76:77], v[72:73] op_sel:[0,1,1]")
     assert not mod.PAT.search("v_pk_fma_f32 v[154:155], v[154:155], v[76:77], v[72:73] op_sel_hi:[1,0,0]")
+    assert mod.PAT.search("v_pk_mov_b32 v[2:3], v[4:5], v[6:7] op_sel:[1,0]")
+    assert mod.PAT.search("v_pk_mul_f16 v1, v2, v3 op_sel:[0,1] op_sel_hi:[1,0]")
+    assert not mod.PAT.search("v_fma_mixhi_f16 v1, v2, 1.0, -v3 op_sel:[0,0,1] op_sel_hi:[0,0,1]")  # not a packed op: one result lane
 
 
 def test_batch_split_setter_and_workspace_layout():

@@ -1,8 +1,10 @@
-"""Static check of the shipped code object: no packed-f32 VALU instruction may select a HIGH source dword for its LOW lane (`op_sel`
-with a 1).  Found in round 2 on MI355X: `v_pk_fma_f32 vD, vA, vS, vT op_sel:[0,1,1]` (emitted by the SLP vectoriser for two adjacent
+"""Static check of the shipped code object: no PACKED VALU instruction (any `v_pk_*`, v_pk_mov_b32 included) may select a HIGH source
+half / dword for its LOW lane (`op_sel:` with a 1; `op_sel_hi` forms - broadcasts of a low half - are not matched).  Found in round 2 on MI355X: `v_pk_fma_f32 vD, vA, vS, vT op_sel:[0,1,1]` (emitted by the SLP vectoriser for two adjacent
 pixels sharing one scale / shift) intermittently computed its low result with a zero product in lanes 48-63 when it followed the VALU
 write of vA.lo - about once per 10^6 executions, only under full-chip load (tools/diag_batch4.py; DESIGN.md "A hardware / toolchain
-hazard").  The library is built with -fno-slp-vectorize; this check keeps the pattern from coming back.
+hazard").  The cause was never established (16 wait states made it 1000x rarer, not gone), so the guard is as wide as the instruction class:
+every packed op with a set op_sel bit, in every kernel of the linked library (k_pwr.o, the one object still built with the SLP vectoriser,
+included).  The library is built with -fno-slp-vectorize; this check keeps the pattern from coming back.
 
     python tools/isa_check.py [path/to/librtfs_amd.so]      exit status 1 and a listing when the pattern is present
 """
@@ -14,7 +16,7 @@ import sys
 import tempfile
 
 LLVM = "/opt/rocm/lib/llvm/bin"
-PAT = re.compile(r"\bv_pk_(fma|mul|add)_f32\b.*\bop_sel:\[[01,]*1[01,]*\]")
+PAT = re.compile(r"\bv_pk_\w+\b.*\bop_sel:\[[01,]*1[01,]*\]")
 
 
 def device_disassembly(so_path):
@@ -46,5 +48,5 @@ if __name__ == "__main__":
     bad = hazardous(so)
     for k, ins in bad:
         print(f"{k}: {ins}")
-    print(f"{len(bad)} hazardous packed-f32 instruction(s) in {so}")
+    print(f"{len(bad)} packed instruction(s) with a set op_sel bit in {so}")
     sys.exit(1 if bad else 0)
