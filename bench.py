@@ -49,15 +49,23 @@ def sweep_bytes(seq_len, n_seq):
 def by_counters(traffic_bytes, avg_launch_ms):
     """What the PMC passes of this round (profiles/r02_pmc/, tools/pmc_mfma.sh, tools/sweep_traffic.py) say about the sweep kernel: real HBM
     traffic per launch against the live launch time, and the matrix-pipe busy fraction (a committed measurement, not re-collected here)."""
-    out = {"hbm_gbs": None, "hbm_frac_of_peak": None, "mfma_busy_frac": None, "bound": None}
+    out = {"hbm_gbs": None, "hbm_frac_of_peak": None, "mfma_busy_frac": None, "bound": None,
+           # provenance: hbm_gbs = STORED traffic figure / LIVE launch time; mfma_busy_frac is a STORED counter reading, not collected in this run
+           "source": {"traffic": "profiles/sweep_traffic.json (stored PMC passes)", "mfma_busy_frac": None, "live": ["avg_launch_ms"]}}
     if traffic_bytes and avg_launch_ms:
         out["hbm_gbs"] = round(traffic_bytes / (avg_launch_ms * 1e-3) / 1e9, 1)
         out["hbm_frac_of_peak"] = round(out["hbm_gbs"] / HBM_PEAK_GBS, 4)
     try:
-        rows = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc", "pmc_mfma_summary.json")))
-        fr = [r["mfma_util_busy"] for r in rows if r["kernel"].startswith("dp16s_kernel") and r.get("mfma_util_busy")]
-        if fr:
-            out["mfma_busy_frac"] = round(sum(fr) / len(fr), 4)
+        for rel in ("profiles/r03_pmc/pmc_mfma_summary.json", "profiles/r02_pmc/pmc_mfma_summary.json"):
+            path = os.path.join(ROOT, rel)
+            if not os.path.exists(path):
+                continue
+            rows = json.load(open(path))
+            fr = [r["mfma_util_busy"] for r in rows if r["kernel"].startswith("dp16s_kernel") and r.get("mfma_util_busy")]
+            if fr:
+                out["mfma_busy_frac"] = round(sum(fr) / len(fr), 4)
+                out["source"]["mfma_busy_frac"] = rel + " (stored; the sweep kernel's source is unchanged since)"
+                break
     except Exception:
         pass
     if out["hbm_frac_of_peak"] is not None and out["mfma_busy_frac"] is not None:
@@ -66,7 +74,7 @@ def by_counters(traffic_bytes, avg_launch_ms):
     return out
 
 
-def cpu_baseline(repeats, workers=None, leg_seconds=12.0):
+def cpu_baseline(repeats, workers=None, leg_seconds=12.0):  # leg_seconds bounds the numpy legs only; the torch legs run the full 3 + 5
     """The CPU oracle (oracle/rtfs_oracle.py, numpy) on this box's host cores: one single-threaded worker process per core
     of the CPU share (16 per GPU), four 2 s mixtures each -> aggregate mixtures/s.  Must run BEFORE this process touches the
     GPU (the workers are child processes)."""
@@ -98,7 +106,7 @@ def cpu_baseline(repeats, workers=None, leg_seconds=12.0):
         rec = json.loads(pr.stdout.strip().splitlines()[-1])
         res["threaded"] = rec
         best = max(rec["legs"], key=lambda l: l["mixtures_per_s"])
-        res["sample"] += (f"; one process on {rec['threads']} threads (3 warm-up + 5 timed forwards, <= {leg_seconds:g} s per leg): best "
+        res["sample"] += (f"; one process on {rec['threads']} threads (torch-ops legs: 3 warm-up + 5 timed forwards; numpy legs <= {leg_seconds:g} s each): best "
                           f"{best['mixtures_per_s']} mixtures/s ({best['impl']}, batch {best['batch']}), all legs under 'threaded'")
         if best["mixtures_per_s"] > res["value"]:
             res["value"] = best["mixtures_per_s"]
@@ -172,6 +180,24 @@ def max_over_ranks(dt, dist, device):
     tt = torch.tensor([dt], device=device, dtype=torch.float64)
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     return float(tt.item())
+
+
+def dist_evidence(dist, world, device=None):
+    """What the job looked like from the inside: the process group's backend, its world size and ONE device identity per rank gathered
+    over that very process group (PCI domain:bus:device + uuid), so a SCALE record shows that RCCL saw N distinct GPUs."""
+    if device is not None and device.type == "cuda":
+        p = torch.cuda.get_device_properties(device)
+        me = {"rank": int(os.environ.get("RANK", "0")), "cuda_index": device.index, "name": p.name,
+              "pci": "%04x:%02x:%02x" % (getattr(p, "pci_domain_id", 0), getattr(p, "pci_bus_id", 0), getattr(p, "pci_device_id", 0)),
+              "uuid": str(getattr(p, "uuid", ""))}
+    else:
+        me = {"rank": int(os.environ.get("RANK", "0")), "cuda_index": None, "name": "cpu (dry run)", "pci": None, "uuid": None, "pid": os.getpid()}
+    if dist is None:
+        return {"backend": None, "world": 1, "devices": [me], "distinct_devices": 1}
+    got = [None] * world
+    dist.all_gather_object(got, me)
+    ids = {(g["pci"], g["uuid"], g.get("pid")) for g in got}
+    return {"backend": dist.get_backend(), "world": dist.get_world_size(), "devices": got, "distinct_devices": len(ids)}
 
 
 def throughput(world, B, steps, dt):
@@ -273,8 +299,9 @@ def dry_run_main(args):
         dist.barrier()
     dt = max_over_ranks(time.perf_counter() - t0 + 0.01 * rank, dist, torch.device("cpu"))
     assert bool(torch.isfinite(chk))
+    ev = dist_evidence(dist, world)
     if rank == 0:
-        print(json.dumps({"metric": "dry run (launcher + rendezvous + timing protocol only; NOT a measurement)", "value": round(throughput(world, B, args.steps, dt), 3),
+        print(json.dumps({"metric": "dry run (launcher + rendezvous + timing protocol only; NOT a measurement)", "dist": ev, "value": round(throughput(world, B, args.steps, dt), 3),
                           "unit": "mixtures/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                           "config": {"workload": "stand-in step on CPU over gloo", "per_gpu_batch": B, "global_batch": B * world}}), flush=True)
@@ -318,6 +345,7 @@ def train_main(args):
     barrier()
     dt = max_over_ranks(time.perf_counter() - t0, dist, dev)
     assert bool(torch.isfinite(last))
+    ev = dist_evidence(dist, world, dev)
     if rank == 0:
         peak_gib = round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)
         extra = {"roofline": train_roofline(dev, B, L)}
@@ -332,7 +360,7 @@ def train_main(args):
                                    + (", SyncBatchNorm" if world > 1 else ""),
                        "per_gpu_batch": B, "global_batch": B * world, "samples": L,
                        "parallelism": f"dp{world} (one flattened gradient all-reduce of {sum(p.numel() for p in model.parameters())} floats per step)"},
-            "peak_memory_gib": peak_gib, **extra}), flush=True)
+            "dist": ev, "peak_memory_gib": peak_gib, **extra}), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -428,6 +456,7 @@ def main():
                   "steps": args.steps, "same_outputs": bool(torch.allclose(out2, out, rtol=0, atol=2e-5 * float(out.abs().max()))),
                   "what": "rtfs_set_batch_split(2): the same step as two half batches on two streams (not the contract measurement)"}
 
+    ev = dist_evidence(dist, world, dev)  # a collective: every rank calls it
     if rank == 0:
         total_bytes = sum(sweep_bytes(ls[i], ns[i]) for i in range(n_ev))
         total_ms = sum(ms[i] for i in range(n_ev))
@@ -457,6 +486,7 @@ def main():
             "config": {"workload": f"RTFS-Net-{args.repeats} forward, batch {B}/GPU, {args.seconds:g} s @16 kHz 2-speaker mixtures "
                                    f"+ dummy lip embeddings (B,512,{Tv}), random-init weights, eval",
                        "per_gpu_batch": B, "global_batch": B * world, "samples": L, "parallelism": f"dp{world} (no data-path collective)"},
+            "dist": ev,
             "roofline": {
                 "kernel": "dp16s_kernel, the fused dual-path sweep (LN + unfold-GEMM + 4x bi-SRU scan + ConvTranspose1d + residual; k_dualpath16s.hip)",
                 # "hbm" is the north_star's DEFINITION of this metric (algorithmic bytes at the reference's op boundary / launch time

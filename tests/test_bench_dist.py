@@ -125,6 +125,10 @@ def test_bench_self_launches_its_ranks():
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["warmup"] == 1 and rec["config"]["global_batch"] == 64
     assert rec["value"] == round(2 * 32 * 3 / (rec["ms_per_step"] * 3e-3), 3) or abs(rec["value"] * rec["ms_per_step"] * 1e-3 - 64) < 0.05
+    # the line carries its own evidence of what the process group saw: backend, world size, one identity per rank gathered over that group
+    d = rec["dist"]
+    assert d["backend"] == "gloo" and d["world"] == 2 and len(d["devices"]) == 2 and d["distinct_devices"] == 2
+    assert sorted(x["rank"] for x in d["devices"]) == [0, 1]
     # the same through torch.distributed.run (the driver's other launch form)
     port = _free_port()
     pr = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
@@ -132,7 +136,7 @@ def test_bench_self_launches_its_ranks():
                         cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
     assert pr.returncode == 0, pr.stderr[-2000:]
     recs = [json.loads(l) for l in pr.stdout.splitlines() if l.startswith("{")]
-    assert len(recs) == 1 and recs[0]["n_gpus"] == 2
+    assert len(recs) == 1 and recs[0]["n_gpus"] == 2 and recs[0]["dist"]["world"] == 2 and recs[0]["dist"]["distinct_devices"] == 2
 
 
 def test_bench_launcher_reports_a_failed_rank():
