@@ -25,7 +25,8 @@ __global__ __launch_bounds__(256) void caf_video_kernel(CafArgs a) {
     }
     // pass 1: statistics of both pre-norm tensors over (channels, Tv)
     double sr = 0, ssr = 0, sa = 0, ssa = 0;
-    for (int t = 0; t < Tv; ++t) {
+#pragma unroll 8
+    for (int t = 0; t < Tv; ++t) {  // (unrolled: the row loads of eight frames in flight - at batch 1 this kernel is on the critical path)
         const float x0 = v0[t], x1 = v1[t];
         const float r = fmaf(wr1, x1, fmaf(wr0, x0, br));
         sr += r;
@@ -60,7 +61,8 @@ __global__ __launch_bounds__(256) void caf_video_kernel(CafArgs a) {
     float* ro = a.r_out + ((size_t)b * 256 + c) * Tv;
     float* ao = a.att_out + ((size_t)b * 256 + c) * Tv;
     float mx = -3.0e38f;
-    for (int t = 0; t < Tv; ++t) {
+#pragma unroll 8
+    for (int t = 0; t < Tv; ++t) {  // (unrolled: the row loads of eight frames in flight - at batch 1 this kernel is on the critical path)
         const float x0 = v0[t], x1 = v1[t];
         ro[t] = fmaf(fmaf(wr1, x1, fmaf(wr0, x0, br)), rsc, rsh);
         float m = 0.f;

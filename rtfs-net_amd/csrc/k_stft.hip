@@ -78,7 +78,9 @@ __global__ __launch_bounds__(256) void enc_conv_kernel(const float* __restrict__
     }
     float s = 0.f, ss = 0.f;
     float* out = a0 + (size_t)b * bs + p0;
-    for (int c = 0; c < C; ++c) {
+    // small batches: the channels are cut into gridDim.z groups (a batch-1 launch was 64 workgroups each walking all 256 channels: 98 us)
+    const int cg = C / gridDim.z, c0 = blockIdx.z * cg;
+    for (int c = c0; c < c0 + cg; ++c) {
         const float* wc = w + c * 18;
         float acc0 = 0.f, acc1 = 0.f;
 #pragma unroll
@@ -166,7 +168,10 @@ int launch_stft(const float* wav, float* spec, int B, int L, int T, hipStream_t 
 
 int launch_enc_conv(const float* spec, const float* w, float* a0, double* stats, int B, int C, int T, int F, size_t cs,
                     size_t bs, hipStream_t st) {
-    hipLaunchKernelGGL(enc_conv_kernel, dim3(cdiv(cdiv(T * F, 2), 256), B), dim3(256), 0, st, spec, w, a0, stats, C, T, F, cs, bs);
+    const int gx = cdiv(cdiv(T * F, 2), 256);
+    int gz = 1;
+    while (gz < 8 && gx * B * gz < 512 && C % (2 * gz) == 0) gz *= 2;
+    hipLaunchKernelGGL(enc_conv_kernel, dim3(gx, B, gz), dim3(256), 0, st, spec, w, a0, stats, C, T, F, cs, bs);
     return rtfs_launch_status();
 }
 

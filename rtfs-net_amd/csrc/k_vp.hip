@@ -9,6 +9,8 @@
 #define VC 64     // hidden channels
 #define VIN 512   // embedding channels
 #define VDEPTH 4
+#define VP_NT 512  // threads per workgroup (one workgroup per sample: at small batches this kernel is the forward's critical path, and
+                    // every stage below is a short loop over at most 64 x Tv items between two barriers - 256 threads took 0.5 ms)
 
 namespace {
 struct Ims {  // InjectionMultiSum parameters: dw conv k3 (no bias) + folded BN for local / global_emb / global_gate
@@ -33,10 +35,10 @@ __device__ __forceinline__ float dw3(const float* x, int n, int t, const float* 
 }
 }  // namespace
 
-__global__ __launch_bounds__(256) void vp_block_kernel(const float* __restrict__ video, const float* __restrict__ pack,
+__global__ __launch_bounds__(VP_NT) void vp_block_kernel(const float* __restrict__ video, const float* __restrict__ pack,
                                                        float* __restrict__ out, int Tv) {
     extern __shared__ float lds[];
-    __shared__ double red[16];
+    __shared__ double red[2 * (VP_NT / 64)];
     __shared__ float stat[2];
     const int tid = threadIdx.x, b = blockIdx.x;
     int len[VDEPTH];
@@ -84,13 +86,14 @@ __global__ __launch_bounds__(256) void vp_block_kernel(const float* __restrict__
 
     // ---- 1. gateway (dw 1x1 + PReLU) + projection 512 -> 64, K chunked by 64 input channels
     {
+        constexpr int NQ = VP_NT / 64, NJ = 128 / NQ;  // time slots tq + NQ j, j < NJ cover Tv <= 120
         const int co = tid & 63, tq = tid >> 6;
-        float acc[32];
+        float acc[NJ];
 #pragma unroll
-        for (int j = 0; j < 32; ++j) acc[j] = 0.f;
+        for (int j = 0; j < NJ; ++j) acc[j] = 0.f;
         for (int c0 = 0; c0 < VIN; c0 += 64) {
             __syncthreads();
-            for (int i = tid; i < 64 * Tv; i += 256) {
+            for (int i = tid; i < 64 * Tv; i += VP_NT) {
                 const int ci = c0 + i / Tv;
                 RS[i] = preluf_(fmaf(vb[(size_t)c0 * Tv + i], gw[ci], gb[ci]), slope);
             }
@@ -102,28 +105,28 @@ __global__ __launch_bounds__(256) void vp_block_kernel(const float* __restrict__
 #pragma unroll
                 for (int k = 0; k < 16; ++k)
 #pragma unroll
-                    for (int j = 0; j < 32; ++j) {
-                        const int t = tq + 4 * j;
+                    for (int j = 0; j < NJ; ++j) {
+                        const int t = tq + NQ * j;
                         if (t < Tv) acc[j] = fmaf(w[k], RS[(k0 + k) * Tv + t], acc[j]);
                     }
             }
         }
 #pragma unroll
-        for (int j = 0; j < 32; ++j) {
-            const int t = tq + 4 * j;
+        for (int j = 0; j < NJ; ++j) {
+            const int t = tq + NQ * j;
             if (t < Tv) XE[co * Tv + t] = acc[j] + proj_b[co];
         }
     }
     __syncthreads();
     // ---- 2. bottom-up pyramid: d0 = BN(dw3 s1 (x_enc)); d_i = BN(dw3 s2 pad1 (d_{i-1}))
-    for (int i = tid; i < VC * Tv; i += 256) {
+    for (int i = tid; i < VC * Tv; i += VP_NT) {
         const int c = i / Tv, t = i - c * Tv;
         D[0][i] = fmaf(dw3(XE + c * Tv, Tv, t, dsw[0] + c * 3), dss[0][c], dsb[0][c]);
     }
     __syncthreads();
     for (int lv = 1; lv < VDEPTH; ++lv) {
         const int n = len[lv - 1], m = len[lv];
-        for (int i = tid; i < VC * m; i += 256) {
+        for (int i = tid; i < VC * m; i += VP_NT) {
             const int c = i / m, t = i - c * m;
             const float* x = D[lv - 1] + c * n;
             const float* w = dsw[lv] + c * 3;
@@ -133,7 +136,7 @@ __global__ __launch_bounds__(256) void vp_block_kernel(const float* __restrict__
         __syncthreads();
     }
     // ---- 3. global features: sum of adaptive average pools to length Lg
-    for (int i = tid; i < VC * Lg; i += 256) {
+    for (int i = tid; i < VC * Lg; i += VP_NT) {
         const int c = i / Lg, t = i - c * Lg;
         float s = 0.f;
         for (int lv = 0; lv < VDEPTH; ++lv) {
@@ -158,7 +161,7 @@ __global__ __launch_bounds__(256) void vp_block_kernel(const float* __restrict__
         for (int c = 0; c < VC; ++c) Y[t * VC + c] = fmaf((G[c * Lg + t] - mu) * rstd, ln1w[c], ln1b[c]) + pe[t * VC + c];
     }
     __syncthreads();
-    for (int i = tid; i < Lg * 192; i += 256) {
+    for (int i = tid; i < Lg * 192; i += VP_NT) {
         const int t = i / 192, o = i - t * 192;
         float a = inb[o];
 #pragma unroll 16
@@ -166,14 +169,14 @@ __global__ __launch_bounds__(256) void vp_block_kernel(const float* __restrict__
         QKV[i] = a;
     }
     __syncthreads();
-    for (int i = tid; i < 8 * Lg * Lg; i += 256) {
+    for (int i = tid; i < 8 * Lg * Lg; i += VP_NT) {
         const int hd = i / (Lg * Lg), r = i - hd * Lg * Lg, ti = r / Lg, tj = r - ti * Lg;
         float a = 0.f;
         for (int d = 0; d < 8; ++d) a = fmaf(QKV[ti * 192 + hd * 8 + d], QKV[tj * 192 + 64 + hd * 8 + d], a);
         SC[(hd * 16 + ti) * 16 + tj] = a * 0.35355339059327373f;  // 1/sqrt(8)
     }
     __syncthreads();
-    for (int i = tid; i < 8 * Lg; i += 256) {
+    for (int i = tid; i < 8 * Lg; i += VP_NT) {
         float* row = SC + (size_t)(i / Lg * 16 + i % Lg) * 16;
         float mx = -3.0e38f;
         for (int j = 0; j < Lg; ++j) mx = fmaxf(mx, row[j]);
@@ -182,14 +185,14 @@ __global__ __launch_bounds__(256) void vp_block_kernel(const float* __restrict__
         for (int j = 0; j < Lg; ++j) row[j] /= s;
     }
     __syncthreads();
-    for (int i = tid; i < Lg * VC; i += 256) {  // attention output, token-major (t, head*8+d)
+    for (int i = tid; i < Lg * VC; i += VP_NT) {  // attention output, token-major (t, head*8+d)
         const int t = i / VC, o = i - t * VC, hd = o >> 3;
         float a = 0.f;
         for (int j = 0; j < Lg; ++j) a = fmaf(SC[(hd * 16 + t) * 16 + j], QKV[j * 192 + 128 + o], a);
         Y2[i] = a;
     }
     __syncthreads();
-    for (int i = tid; i < Lg * VC; i += 256) {  // out_proj + residual (the post-PE tokens)
+    for (int i = tid; i < Lg * VC; i += VP_NT) {  // out_proj + residual (the post-PE tokens)
         const int t = i / VC, o = i - t * VC;
         float a = ob[o];
 #pragma unroll 16
@@ -211,13 +214,13 @@ __global__ __launch_bounds__(256) void vp_block_kernel(const float* __restrict__
     // ---- 5. FFN: 1x1 64->128 (gLN) -> dw3 + bias + ReLU -> 1x1 128->64 (gLN) -> + input
     auto gln_stats = [&](const float* x, int n) {  // leaves (mean, rstd) in stat[]
         float s = 0.f, ss = 0.f;
-        for (int i = tid; i < n; i += 256) { s += x[i]; ss = fmaf(x[i], x[i], ss); }
+        for (int i = tid; i < n; i += VP_NT) { s += x[i]; ss = fmaf(x[i], x[i], ss); }
         const double ds = wave_sum_d((double)s), dss2 = wave_sum_d((double)ss);
         if ((tid & 63) == 0) { red[2 * (tid >> 6)] = ds; red[2 * (tid >> 6) + 1] = dss2; }
         __syncthreads();
         if (tid == 0) {
             double a = 0, c = 0;
-            for (int w = 0; w < 4; ++w) { a += red[2 * w]; c += red[2 * w + 1]; }
+            for (int w = 0; w < VP_NT / 64; ++w) { a += red[2 * w]; c += red[2 * w + 1]; }
             const double mean = a / n;
             double var = c / n - mean * mean;
             var = var < 0 ? 0 : var;
@@ -226,7 +229,7 @@ __global__ __launch_bounds__(256) void vp_block_kernel(const float* __restrict__
         }
         __syncthreads();
     };
-    for (int i = tid; i < 128 * Lg; i += 256) {
+    for (int i = tid; i < 128 * Lg; i += VP_NT) {
         const int o = i / Lg, t = i - o * Lg;
         float a = 0.f;
 #pragma unroll 16
@@ -235,14 +238,14 @@ __global__ __launch_bounds__(256) void vp_block_kernel(const float* __restrict__
     }
     __syncthreads();
     gln_stats(HID, 128 * Lg);
-    for (int i = tid; i < 128 * Lg; i += 256) HID[i] = fmaf((HID[i] - stat[0]) * stat[1], encg[i / Lg], encb[i / Lg]);
+    for (int i = tid; i < 128 * Lg; i += VP_NT) HID[i] = fmaf((HID[i] - stat[0]) * stat[1], encg[i / Lg], encb[i / Lg]);
     __syncthreads();
-    for (int i = tid; i < 128 * Lg; i += 256) {
+    for (int i = tid; i < 128 * Lg; i += VP_NT) {
         const int o = i / Lg, t = i - o * Lg;
         HID2[i] = fmaxf(dw3(HID + o * Lg, Lg, t, refw + o * 3) + refb[o], 0.f);
     }
     __syncthreads();
-    for (int i = tid; i < VC * Lg; i += 256) {
+    for (int i = tid; i < VC * Lg; i += VP_NT) {
         const int o = i / Lg, t = i - o * Lg;
         float a = 0.f;
 #pragma unroll 16
@@ -251,11 +254,11 @@ __global__ __launch_bounds__(256) void vp_block_kernel(const float* __restrict__
     }
     __syncthreads();
     gln_stats(Y, VC * Lg);
-    for (int i = tid; i < VC * Lg; i += 256) G[i] += fmaf((Y[i] - stat[0]) * stat[1], decg[i / Lg], decb[i / Lg]);
+    for (int i = tid; i < VC * Lg; i += VP_NT) G[i] += fmaf((Y[i] - stat[0]) * stat[1], decg[i / Lg], decb[i / Lg]);
     __syncthreads();
     // ---- 6. InjectionMultiSum: out = BN(dw3(local)) * sigmoid(BN(dw3(glob)))^ + BN(dw3(glob))^  (^ = nearest up-sampling)
     auto ims = [&](const Ims& m, const float* loc, int n, const float* glob, int ng, const float* add, float* dst) {
-        for (int i = tid; i < VC * n; i += 256) {
+        for (int i = tid; i < VC * n; i += VP_NT) {
             const int c = i / n, t = i - c * n;
             const int tg = min((t * ng) / n, ng - 1);
             const float l = fmaf(dw3(loc + c * n, n, t, m.lw + c * 3), m.ls[c], m.lb[c]);
@@ -280,12 +283,13 @@ __global__ __launch_bounds__(256) void vp_block_kernel(const float* __restrict__
     // ---- 7. residual_conv 64 -> 512 + bias + gateway(video) (recomputed)
     {
         float* ob_ = out + (size_t)b * VIN * Tv;
-        for (int co = tid; co < VIN; co += 256) {  // one output channel per thread: its 64 weights live in registers
+        constexpr int NTH = VP_NT / VIN > 0 ? VP_NT / VIN : 1;  // threads per output channel (they interleave the frames)
+        for (int co = tid % VIN, th = tid / VIN; co < VIN && th < NTH; co += VIN) {  // one output channel per thread group: its 64 weights live in registers
             float w[VC];
 #pragma unroll
             for (int c = 0; c < VC; ++c) w[c] = res_wt[c * VIN + co];
             const float bias = res_b[co], g0 = gw[co], g1 = gb[co];
-            for (int t = 0; t < Tv; ++t) {
+            for (int t = th; t < Tv; t += NTH) {
                 float a = bias;
 #pragma unroll
                 for (int c = 0; c < VC; ++c) a = fmaf(w[c], cur[c * Tv + t], a);
@@ -311,6 +315,6 @@ int launch_vp_block(const float* video, const float* pack, float* out, int B, in
     if (Tv < 1 || Lg > 16 || Tv > 120) return RTFS_ERR_SHAPE;
     const size_t lds = vp_lds_bytes(Tv);
     if (rtfs_set_max_lds((const void*)vp_block_kernel, lds) != RTFS_OK) return RTFS_ERR_LAUNCH;
-    hipLaunchKernelGGL(vp_block_kernel, dim3(B), dim3(256), lds, st, video, pack, out, Tv);
+    hipLaunchKernelGGL(vp_block_kernel, dim3(B), dim3(VP_NT), lds, st, video, pack, out, Tv);
     return rtfs_launch_status();
 }
