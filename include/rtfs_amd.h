@@ -350,12 +350,15 @@ int rtfs_debug_sweep_stamps(const float* x, const float* pack, float* out, int B
  * all DEVICE pointers, row-major; exact for small integer data. */
 int rtfs_selftest_mfma_f16(const float* A, const float* B, float* D, void* stream);
 
-/* Measurement hook (bench.py roofline leg; no reference counterpart).  While enabled, every launch of the fused
- * dual-path sweep kernel is bracketed by HIP events recorded on the stream it is launched on.  collect() waits for
+/* Measurement hook (bench.py roofline leg; no reference counterpart).  While enabled (on = n > 0), every n-th launch of the fused
+ * dual-path sweep kernel is bracketed by HIP events recorded on the stream it is launched on (on = 0: off).  collect() waits for
  * the recorded launches (host-side, call it outside any timed region / graph capture), writes per-launch
  * milliseconds + sequence length + sequence count (HOST pointers, up to cap entries), clears the log and returns the
  * number of entries (or <0 on error). */
 int rtfs_sweep_timing_enable(int on);
+/* Diagnostics: kernel launches issued by this library in this process so far (every launcher counts; memsets and event records do not).
+ * tests/test_hip_parity.py pins the launches of one small-batch forward with it. */
+unsigned long long rtfs_debug_launch_count(void);
 int rtfs_sweep_timing_collect(float* ms, int* seq_len, int* n_seq, int cap);
 
 /* Evaluation-side loss (the step after the path): PairwiseNegSDR.forward

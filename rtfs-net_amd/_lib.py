@@ -45,6 +45,7 @@ SIGNATURES = {
     "rtfs_istft_decoder_f32": (_i, [_p, _p, _p, _i, _i, _i, _p, _z, _p]),
     "rtfs_separator_workspace_bytes": (_z, [_i, _i, _i]),
     "rtfs_set_batch_split": (_i, [_i]),
+    "rtfs_debug_launch_count": (C.c_ulonglong, []),
     "rtfs_separator_workspace_bytes_ex": (_z, [_i, _i, _i, _i]),
     "rtfs_separator_forward_ex_f32": (_i, [_p] * 9 + [_i, _i, _i, _i, _p, _z, _p, _p, _i, _i]),
     "rtfs_separator_forward_f32": (_i, [_p] * 9 + [_i, _i, _i, _i, _p, _z, _p, _p, _i]),

@@ -15,7 +15,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
+void rtfs_count_launch();  // runtime.hip: process-wide count of kernel launches (rtfs_debug_launch_count; a regression guard for the small-batch path)
 static inline int rtfs_launch_status() {
+    rtfs_count_launch();
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? RTFS_OK : RTFS_ERR_LAUNCH;
 }

@@ -58,8 +58,8 @@ __global__ __launch_bounds__(256) void row_can_kernel(RowCanArgs a) {
         gam[i] = a.gamma[ln_row(i) * AF + lane];
         bet[i] = a.beta[ln_row(i) * AF + lane];
     }
-    const int t0 = blockIdx.x * RCAN_ROWS;
-    const int nrows = min(RCAN_ROWS, T - t0);
+    const int t0 = blockIdx.x * a.rpw;
+    const int nrows = min(a.rpw, T - t0);
     const float* __restrict__ X = a.x + (size_t)b * 64 * T * AF + nt * 32 + r;
     const float* __restrict__ RES = NOUT == 64 ? a.res + ((size_t)b * 64 + wave * 16) * T * AF + lane : nullptr;
     float v[4][8];
@@ -310,14 +310,24 @@ size_t attn_core_lds_bytes(int T) {
     return (size_t)32 * (NK + 4) * sizeof(float);
 }
 
-int launch_row_can_qkv(const RowCanArgs& a, int B, hipStream_t st) {
+// frames per workgroup: RCAN_ROWS when the launch fills the chip anyway, fewer for small batches (batch 1: 125 frames were 16 workgroups)
+static int rcan_rows(int T, int B) {
+    if ((long)T * B >= 3500) return RCAN_ROWS;
+    const int r = (int)((long)T * B / 512);
+    return r < 1 ? 1 : (r > RCAN_ROWS ? RCAN_ROWS : r);
+}
+int launch_row_can_qkv(const RowCanArgs& a_, int B, hipStream_t st) {
+    RowCanArgs a = a_;
+    a.rpw = rcan_rows(a.T, B);
     if (a.ngroups != 12 || a.group_start[8] != 32 || a.group_start[12] != 96) return RTFS_ERR_SHAPE;  // Q_h x4, K_h x4 (4 ch), V_h x4 (16 ch)
-    hipLaunchKernelGGL(row_can_kernel<96>, dim3(cdiv(a.T, RCAN_ROWS), B), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(row_can_kernel<96>, dim3(cdiv(a.T, a.rpw), B), dim3(256), 0, st, a);
     return rtfs_launch_status();
 }
-int launch_row_can_proj(const RowCanArgs& a, int B, hipStream_t st) {
+int launch_row_can_proj(const RowCanArgs& a_, int B, hipStream_t st) {
+    RowCanArgs a = a_;
+    a.rpw = rcan_rows(a.T, B);
     if (a.ngroups != 1) return RTFS_ERR_SHAPE;
-    hipLaunchKernelGGL(row_can_kernel<64>, dim3(cdiv(a.T, RCAN_ROWS), B), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(row_can_kernel<64>, dim3(cdiv(a.T, a.rpw), B), dim3(256), 0, st, a);
     return rtfs_launch_status();
 }
 int launch_attn_core(const AttnArgs& a, int B, hipStream_t st) {

@@ -205,14 +205,16 @@ struct TimingSlot {
 };
 // a process-wide DIAGNOSTIC log (bench.py's roofline object): off by default, guarded by a mutex so concurrent launchers cannot corrupt it
 TimingSlot g_slots[TIMING_CAP];
-int g_nslots = 0, g_nalloc = 0;
+int g_nslots = 0, g_nalloc = 0, g_period = 1, g_seen = 0;
 bool g_timing = false;
 std::mutex g_timing_mu;
 }  // namespace
 
 int dualpath_timing_enable(int on) {
     std::lock_guard<std::mutex> lock(g_timing_mu);
-    g_timing = on != 0;
+    g_timing = on > 0;
+    g_period = on > 0 ? on : 1;  // on = n: every n-th sweep launch is bracketed by events (n = 3 alternates F and T sweeps; an event pair costs
+    g_seen = 0;                  // the stream ~6 us of gap, 16 pairs per forward)
     g_nslots = 0;
     return RTFS_OK;
 }
@@ -236,6 +238,7 @@ int dualpath_timing_collect(float* ms, int* ls, int* nseq, int cap) {
 static TimingSlot* timing_begin(int Ls, int nseq, hipStream_t st) {
     if (!g_timing) return nullptr;  // the product path: one relaxed read, no lock
     std::lock_guard<std::mutex> lock(g_timing_mu);
+    if ((g_seen++ % g_period) != 0) return nullptr;
     if (g_nslots >= TIMING_CAP) return nullptr;
     if (g_nslots >= g_nalloc) {
         if (hipEventCreate(&g_slots[g_nalloc].beg) != hipSuccess || hipEventCreate(&g_slots[g_nalloc].end) != hipSuccess) return nullptr;

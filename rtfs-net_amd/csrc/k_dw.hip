@@ -840,9 +840,9 @@ static int launch_dw_s1_t(const DwArgs& a, int B, hipStream_t st) {
 // Band height for small batches: with 64-row bands a batch-1 launch is 68 workgroups that each walk 64 rows one after the other (13-35 us
 // per kernel, ~15 of them per block).  Below two workgroups per CU the bands are shortened (multiples of the ring depth, >= 8 rows) until the
 // launch has ~768 workgroups; the three halo rows a band re-reads do not matter at that size.  Batches >= 8 keep th.
-static int band_rows(int th, int rows, int gx, int B) {
+static int band_rows(int th, int rows, int gx, int B, int target = 768) {
     if (gx * cdiv(rows, th) * B >= 512) return th;
-    const int want = cdiv(768, gx * B);
+    const int want = cdiv(target, gx * B);
     int t = cdiv(rows, want);
     t = (t + 7) / 8 * 8;
     return t < 8 ? 8 : (t > th ? th : t);
@@ -853,7 +853,8 @@ static int launch_dw1p_t(const DwArgs& a_, int B, hipStream_t st) {
     DwArgs a = a_;
     const int half = (a.W + 1) / 2;
     a.gx = cdiv(cdiv(a.C * half, DW1P_PAIRS), 4);
-    a.TH = band_rows(a.TH, a.H, a.gx, B);
+    // (kernels that end in statistics atomics get fewer, longer workgroups: at batch 1 all of them add onto ONE pair of addresses)
+    a.TH = band_rows(a.TH, a.H, a.gx, B, MODE == 2 ? 768 : 320);
     a.gy = cdiv(a.H, a.TH);
     a.nblk = a.gx * a.gy * B;
     hipLaunchKernelGGL((dw1p_kernel<NCONV, IN_AFFINE, MODE, VAR>), dim3((a.nblk + 7) / 8 * 8), dim3(256), 0, st, a);
@@ -922,7 +923,7 @@ int launch_dw_g3(const DwArgs& conv4, const DwArgs& aff1, int B, hipStream_t st)
         if (!a.cs) a.cs = a.H * a.W;
         if ((size_t)a.C * a.cs * 4 >= ((size_t)1 << 31)) return RTFS_ERR_ARG;
         a.gx = cdiv(cdiv(a.C * ((a.W + 1) / 2), DW1P_PAIRS), 4);
-        a.TH = band_rows(a.TH, a.H, a.gx, 3 * B);  // (three jobs share the launch)
+        a.TH = band_rows(a.TH, a.H, a.gx, 3 * B, 640);  // (three jobs share the launch)
         a.gy = cdiv(a.H, a.TH);
         a.nblk = a.gx * a.gy * B;
         a.blk0 = off;
@@ -938,7 +939,7 @@ int launch_dw_s2_pool(const DwArgs& a_, int B, hipStream_t st) {
     if (!a.cs) a.cs = a.H * a.W;
     if (a.Wg >= 16 && a.W >= 2 && (a.W + 1) / 2 >= a.Wg && (size_t)a.C * a.cs * 4 < ((size_t)1 << 31)) {
         a.gx = cdiv(cdiv(a.C * ((a.W + 1) / 2), DW1P_PAIRS), 4);
-        a.TH = band_rows(a.TH, a.Hg, a.gx, B);
+        a.TH = band_rows(a.TH, a.Hg, a.gx, B, 320);
         a.gy = cdiv(a.Hg, a.TH);
         a.nblk = a.gx * a.gy * B;
         hipLaunchKernelGGL(dw_s2x_kernel, dim3((a.nblk + 7) / 8 * 8), dim3(256), 0, st, a);
@@ -950,12 +951,12 @@ int launch_dw_s2_pool(const DwArgs& a_, int B, hipStream_t st) {
 
 int launch_g_form(const float* p0, const float* c1, const double* st1, double inv_count, const float* gamma,
                   const float* beta, float* g, int B, int C, int HW, hipStream_t st) {
-    hipLaunchKernelGGL(g_form_kernel, dim3(1, C, B), dim3(256), 0, st, p0, c1, st1, inv_count, gamma, beta, g, C, HW);
+    hipLaunchKernelGGL(g_form_kernel, dim3(B * C >= 1024 ? 1 : 4, C, B), dim3(256), 0, st, p0, c1, st1, inv_count, gamma, beta, g, C, HW);
     return rtfs_launch_status();
 }
 
 int launch_g_combine(const GCombineArgs& a, int B, hipStream_t st) {
-    hipLaunchKernelGGL(g_combine_kernel, dim3(1, a.C, B), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(g_combine_kernel, dim3(B * a.C >= 1024 ? 1 : 4, a.C, B), dim3(256), 0, st, a);
     return rtfs_launch_status();
 }
 

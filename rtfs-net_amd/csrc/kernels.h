@@ -174,6 +174,7 @@ struct RowCanArgs {
     int group_start[13] = {0};     // channel range of each LayerNorm group
     unsigned char group_of[96] = {0};
     int T = 0;
+    int rpw = 0;  // frames per workgroup (set by the launcher: 8, fewer for small batches)
     float *q = nullptr, *k = nullptr, *v = nullptr;  // NOUT == 96
     const float* res = nullptr;                       // NOUT == 64: residual
     float* out = nullptr;

@@ -1,8 +1,13 @@
 // Host-side state shared by the launchers: everything here is per device and thread-safe, so the C ABI stays re-entrant
 // (include/rtfs_amd.h: "stateless apart from per-device immutable configuration").
 #include "common.h"
+#include <atomic>
 #include <mutex>
 #include <vector>
+
+static std::atomic<unsigned long long> g_launches{0};
+void rtfs_count_launch() { g_launches.fetch_add(1, std::memory_order_relaxed); }
+extern "C" unsigned long long rtfs_debug_launch_count(void) { return g_launches.load(std::memory_order_relaxed); }
 
 namespace {
 struct LdsEntry {

@@ -448,6 +448,24 @@ def test_batch_split_per_call_argument():
     assert lib.rtfs_separator_workspace_bytes_ex(32, 4096, 7, 9) == 0  # out of range
 
 
+def test_launches_per_small_batch_forward():
+    """A batch-1 forward is a chain of dependent launches at dispatch latency (test.py:51-62, inference.py:55 and infer_any_video.py:86 all run
+    one utterance per step): the library counts its launches, and the count of one RTFS-Net-4 forward must not creep up - 4 blocks x 16
+    + encoder 2 + bottleneck + head + 3 boundaries + tail + S3/taps + decoder + CAF video + VP block."""
+    import rtfs_net_amd as R
+    lib = R._lib.load()
+    m = model()
+    wav, emb = make_inputs(1, 4096, 7, 77)
+    w, e = dev(wav), dev(emb)
+    m(w, e)
+    torch.cuda.synchronize()
+    n0 = lib.rtfs_debug_launch_count()
+    m(w, e)
+    torch.cuda.synchronize()
+    n = lib.rtfs_debug_launch_count() - n0
+    assert 60 <= n <= 82, n
+
+
 def test_forward_can_be_captured_in_a_hip_graph():
     """torch.cuda.graph capture of AVNet.forward (library-internal side streams are forked from / joined into the capturing stream by events,
     the workspace comes from torch's graph pool) and replay on new input values written into the captured tensors."""
