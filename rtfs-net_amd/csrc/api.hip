@@ -970,7 +970,19 @@ int separator_part(const SepPacks& k, const float* wav, const float* video_vp, f
             CHECK(block_body(pk, B, T, NF, w.blk, st, single_chain));
             if (i == 0) CHECK(cafv.join());
             if (i + 1 < repeats) CHECK(block_boundary(pk, w.a1, B, T, NF, w.blk, st, i == 0 ? &ca : nullptr, nctr < 64 ? w.ctr + nctr++ : nullptr));
-            else CHECK(block_tail(pk, cur, B, T, NF, w.blk, st, nctr < 64 ? w.ctr + nctr++ : nullptr));
+            else {
+                // last application: residual conv + S3 mask + complex product + decoder taps in one kernel (k_s3f.hip); `refined` never exists
+                TailS3Args f;
+                f.x = w.blk.expanded; f.res = w.blk.residual; f.a0 = w.a0; f.z = w.z;
+                f.w1_16 = pk.res_w16; f.b1 = pk.res_b; f.w16 = ps.w16; f.bias = ps.bias; f.slope = ps.slope; f.w16b = pd.w16p;
+                f.stats = w.st0; f.inv_count = 1.0 / ((double)CA * P);
+                f.P = P; f.cs = cs; f.cout_live = 18;
+                f.tile_ctr = nctr < 64 ? w.ctr + nctr++ : nullptr;
+                const int rc = launch_tail_s3t(f, B, st);
+                if (rc == RTFS_OK) return launch_dec_istft(w.z, out, B, T, NF, L, (size_t)cs, (size_t)18 * cs, st);
+                if (rc != RTFS_ERR_ARG) return rc;
+                CHECK(block_tail(pk, cur, B, T, NF, w.blk, st, f.tile_ctr));
+            }
         }
     }
     if (!gemm_f32()) {  // S3 + decoder taps in one kernel: the separated spectrum never goes to HBM

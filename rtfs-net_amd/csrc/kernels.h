@@ -73,6 +73,25 @@ int launch_pws_b2b(const B2bArgs& a, int B, hipStream_t st);
 // second generation (k_b2b.hip): padded channel rows (cs % 64 == 0), no CAF; ctr = zeroed tile counter of this launch or null.
 // RTFS_ERR_ARG = call does not qualify, use launch_pws_b2b
 int launch_pws_b2b4(const B2bArgs& a, int B, unsigned* ctr, hipStream_t st);
+// residual conv of the last block application + S3 mask + complex product + decoder taps in one kernel (k_s3f.hip): padded rows only,
+// RTFS_ERR_ARG = call does not qualify, use launch_pws_residual + launch_pwr_s3_taps
+struct TailS3Args {
+    const float* x = nullptr;     // expanded (B,64,cs)
+    const float* res = nullptr;   // residual (B,256,cs)
+    const float* a0 = nullptr;    // encoder output (B,256,cs)
+    float* z = nullptr;           // decoder taps (B,cout_live,cs)
+    const void* w1_16 = nullptr;  // residual_conv f16x3 image [2][hi|lo][256][32]
+    const float* b1 = nullptr;    // (256)
+    const void* w16 = nullptr;    // mask conv f16x3 image [8][hi|lo][256][32]
+    const float* bias = nullptr;  // (256)
+    const float* slope = nullptr; // mask head PReLU (1)
+    const void* w16b = nullptr;   // K-permuted taps image (packing.taps_perm_image)
+    const double* stats = nullptr;  // (B,2) sum / sumsq of a0 (range normalisation of the taps operand), may be null
+    double inv_count = 0;
+    int P = 0, cs = 0, cout_live = 0;
+    unsigned* tile_ctr = nullptr;
+};
+int launch_tail_s3t(const TailS3Args& a, int B, hipStream_t st);
 int launch_pws_head4(const PwArgs& a, int B, hipStream_t st);  // block head on padded rows (k_b2b.hip); RTFS_ERR_ARG = use launch_pws_gateway_proj
 int launch_pws_gateway_proj(const PwArgs& a, int B, hipStream_t st);
 int launch_pws_residual(const PwArgs& a, int B, hipStream_t st);
