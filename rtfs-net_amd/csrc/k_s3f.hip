@@ -43,9 +43,25 @@ __device__ __forceinline__ void mfma_v0(f32x16& c, half8 a, half8 b) {
 __device__ __forceinline__ void mfma_v(f32x16& c, half8 a, half8 b) {
     asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
 }
+// One accumulator register -> VGPR.  Left to the compiler, the first VALU use of an accumulator tile copies all 16 registers of the tile to
+// VGPRs at once - and it hoists the copies of all sixteen tiles (256 registers) to the top of the epilogue.
+__device__ __forceinline__ float acc_rd(float v) {
+    float o;
+    asm("v_accvgpr_read_b32 %0, %1" : "=v"(o) : "a"(v));
+    return o;
+}
 __device__ __forceinline__ void mfma_v_fence(f32x16& c0, f32x16& c1) {
     asm volatile("s_nop 15\n\ts_nop 3" : "+v"(c0), "+v"(c1));
 }
+
+// Diagnostic build only (tools/bench_s3f.hip defines S3F_STAMP and a global s3f_stamps buffer): s_memtime at the phase boundaries of the
+// first tiles of workgroup 0.
+#ifdef S3F_STAMP
+__device__ unsigned s3f_stamps[16 * 32];
+#define STAMP(i) do { __builtin_amdgcn_sched_barrier(0); stamp[i] = (unsigned)__builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
 
 __global__ __launch_bounds__(F_NT) void tail_s3t_kernel(TailS3Args a, int ntiles, int tps) {
     constexpr int L1 = F_L1;
@@ -104,6 +120,10 @@ __global__ __launch_bounds__(F_NT) void tail_s3t_kernel(TailS3Args a, int ntiles
     int it = 0;
     for (int tile = blockIdx.x; tile < ntiles; ++it) {
         if (tid == 0) s_next[it & 1] = (a.tile_ctr ? (int)atomicAdd(a.tile_ctr, 1u) : tile) + (int)gridDim.x;
+#ifdef S3F_STAMP
+        unsigned stamp[32];
+#endif
+        STAMP(0);
         unsigned CS4 = CS4_;
         int nlive = a.cout_live;
         asm volatile("" : "+s"(CS4), "+s"(nlive));  // row offsets are formed where they are used (one s_mul each): hoisted out of the tile loop they cost 300 SGPRs
@@ -141,6 +161,20 @@ __global__ __launch_bounds__(F_NT) void tail_s3t_kernel(TailS3Args a, int ntiles
                 xl[ks][1] = __builtin_bit_cast(half8, *reinterpret_cast<f32x4*>(lo1));
             }
         }
+        const __amdgpu_buffer_rsrc_t es = rsrc_of(a.a0 + (size_t)b * 256 * CS + wp0);
+        // encoder rows of group (m, s2): real rows c = 32m + 4h + (j & 3) + 8 (2 s2 + (j >> 2)), imaginary rows c + 128.  Three groups in flight: the
+        // first three are requested under the last chunk's MFMAs (the residual-conv operand and the residual ring are dead by then)
+        f32x2 E[4][16];
+        auto load_e = [&](int grp, f32x2 (&d)[16]) {
+            const int m = grp >> 1, s2 = grp & 1;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const unsigned ro = (unsigned)(m * 32 + (j & 3) + 8 * (2 * s2 + (j >> 2))) * CS4;
+                d[j] = ld2(es, voffC, ro);
+                d[8 + j] = ld2(es, voffC, ro + 128u * CS4);
+            }
+        };
+        STAMP(1);
         f32x16 acc[8][2];  // mask conv: [output tile][pixel slot]
 #pragma unroll
         for (int m = 0; m < 8; ++m)
@@ -199,6 +233,11 @@ __global__ __launch_bounds__(F_NT) void tail_s3t_kernel(TailS3Args a, int ntiles
             __builtin_amdgcn_sched_barrier(0);
             __syncthreads();  // chunk kc staged (buffer `buf`) and visible; everyone is done reading chunk kc - 1 (the other buffer)
             stage_load((kc + 1) & 7);  // chunk 0 again behind chunk 7: the next tile's first
+            if (kc == 7) {
+                load_e(0, E[0]);
+                load_e(1, E[1]);
+                load_e(2, E[2]);
+            }
             // A fragments in accumulator-register K order: K slot (h, j) of step s is channel 16 s + 4 h + (j & 3) + 8 (j >> 2) of the chunk, i.e.
             // elements 4h .. 4h+3 of piece 2s and of piece 2s + 1
             const unsigned char* wb = Wb + buf * F_BUF + r * F_ROWB + 8 * h;
@@ -233,7 +272,9 @@ __global__ __launch_bounds__(F_NT) void tail_s3t_kernel(TailS3Args a, int ntiles
 #pragma unroll
         for (int kc = 0; kc < 8; kc += 2) {
             chunk(kc, R, 0);
+            STAMP(2 + kc);
             chunk(kc + 1, R, 1);
+            STAMP(3 + kc);
         }
         // ---- mask, complex product with the encoder output, taps GEMM (k_pwr.hip PWR_S3T), eight encoder rows (one K step of the taps GEMM) at a time
         float esc = 1.0f, eisc = WINV;
@@ -245,73 +286,57 @@ __global__ __launch_bounds__(F_NT) void tail_s3t_kernel(TailS3Args a, int ntiles
             esc = __uint_as_float((unsigned)(127 + e) << 23);
             eisc = __uint_as_float((unsigned)(127 - e - 8) << 23);
         }
-        const __amdgpu_buffer_rsrc_t es = rsrc_of(a.a0 + (size_t)b * 256 * CS + wp0);
         f32x16 acc2[2];
 #pragma unroll
         for (int sl = 0; sl < 2; ++sl)
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc2[sl][q] = 0.f;
-        f32x2 E[2][16];  // encoder rows of group (m, s2): real rows c = 32m + 4h + (j & 3) + 8 (2 s2 + (j >> 2)), imaginary rows c + 128; one group ahead
-        auto load_e = [&](int grp, f32x2 (&d)[16]) {
-            const int m = grp >> 1, s2 = grp & 1;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const unsigned ro = (unsigned)(m * 32 + (j & 3) + 8 * (2 * s2 + (j >> 2))) * CS4;
-                d[j] = ld2(es, voffC, ro);
-                d[8 + j] = ld2(es, voffC, ro + 128u * CS4);
-            }
-        };
         auto group = [&](int grp, const f32x2 (&e)[16]) {
             const int m = grp >> 1, s2 = grp & 1;
-            float or0[8], oi0[8], or1[8], oi1[8];
-#pragma unroll
-            for (int g = 0; g < 2; ++g) {
-                const int c4 = m * 32 + 4 * h + 8 * (2 * s2 + g);
-                const f32x4 br = *reinterpret_cast<const f32x4*>(bs + c4), bi = *reinterpret_cast<const f32x4*>(bs + c4 + 128);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int j = 4 * g + i, q = 8 * s2 + j;
-                    const float mr0 = fmaxf(fmaf(acc[m][0][q], WINV, br[i]), 0.f), mi0 = fmaxf(fmaf(acc[m + 4][0][q], WINV, bi[i]), 0.f);
-                    const float mr1 = fmaxf(fmaf(acc[m][1][q], WINV, br[i]), 0.f), mi1 = fmaxf(fmaf(acc[m + 4][1][q], WINV, bi[i]), 0.f);
-                    const float er0 = e[j].x * esc, er1 = e[j].y * esc, ei0 = e[8 + j].x * esc, ei1 = e[8 + j].y * esc;
-                    or0[j] = er0 * mr0 - ei0 * mi0;
-                    oi0[j] = er0 * mi0 + ei0 * mr0;
-                    or1[j] = er1 * mr1 - ei1 * mi1;
-                    oi1[j] = er1 * mi1 + ei1 * mr1;
-                }
-            }
-            unsigned rh0[4], rl0[4], ih0[4], il0[4], rh1[4], rl1[4], ih1[4], il1[4];
-#pragma unroll
-            for (int jp = 0; jp < 4; ++jp) {
-                split2(or0[2 * jp], or0[2 * jp + 1], rh0[jp], rl0[jp]);
-                split2(oi0[2 * jp], oi0[2 * jp + 1], ih0[jp], il0[jp]);
-                split2(or1[2 * jp], or1[2 * jp + 1], rh1[jp], rl1[jp]);
-                split2(oi1[2 * jp], oi1[2 * jp + 1], ih1[jp], il1[jp]);
-            }
             // taps image: [m 4][part 2][s 2][hi|lo][32 taps][16 k] halfs -> 16-byte piece index ((idx*2 + hl)*32 + r)*2 + h
             const int idx_r = (m * 2 + 0) * 2 + s2, idx_i = (m * 2 + 1) * 2 + s2;
             const half8 trh = ld_h8(ts, voffT, (unsigned)(idx_r * 2 + 0) * 1024u), trl = ld_h8(ts, voffT, (unsigned)(idx_r * 2 + 1) * 1024u);
             const half8 tih = ld_h8(ts, voffT, (unsigned)(idx_i * 2 + 0) * 1024u), til = ld_h8(ts, voffT, (unsigned)(idx_i * 2 + 1) * 1024u);
-#define S3F_H8(x) __builtin_bit_cast(half8, *reinterpret_cast<f32x4*>(x))
-            mfma_v(acc2[0], trh, S3F_H8(rh0)); mfma_v(acc2[1], trh, S3F_H8(rh1));
-            mfma_v(acc2[0], trh, S3F_H8(rl0)); mfma_v(acc2[1], trh, S3F_H8(rl1));
-            mfma_v(acc2[0], trl, S3F_H8(rh0)); mfma_v(acc2[1], trl, S3F_H8(rh1));
-            mfma_v(acc2[0], tih, S3F_H8(ih0)); mfma_v(acc2[1], tih, S3F_H8(ih1));
-            mfma_v(acc2[0], tih, S3F_H8(il0)); mfma_v(acc2[1], tih, S3F_H8(il1));
-            mfma_v(acc2[0], til, S3F_H8(ih0)); mfma_v(acc2[1], til, S3F_H8(ih1));
-#undef S3F_H8
-        };
-        load_e(0, E[0]);
 #pragma unroll
-        for (int grp = 0; grp < 8; grp += 2) {
-            load_e(grp + 1, E[1]);
+            for (int sl = 0; sl < 2; ++sl) {  // one pixel slot at a time: half the temporaries (the encoder-row ring needs the registers)
+                float o_r[8], o_i[8];
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    const int c4 = m * 32 + 4 * h + 8 * (2 * s2 + g);
+                    const f32x4 br = *reinterpret_cast<const f32x4*>(bs + c4), bi = *reinterpret_cast<const f32x4*>(bs + c4 + 128);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int j = 4 * g + i, q = 8 * s2 + j;
+                        const float mr = fmaxf(fmaf(acc_rd(acc[m][sl][q]), WINV, br[i]), 0.f), mi = fmaxf(fmaf(acc_rd(acc[m + 4][sl][q]), WINV, bi[i]), 0.f);
+                        const float er = (sl ? e[j].y : e[j].x) * esc, ei = (sl ? e[8 + j].y : e[8 + j].x) * esc;
+                        o_r[j] = er * mr - ei * mi;
+                        o_i[j] = er * mi + ei * mr;
+                    }
+                }
+                unsigned rh[4], rl[4], ih[4], il[4];
+#pragma unroll
+                for (int jp = 0; jp < 4; ++jp) {
+                    split2(o_r[2 * jp], o_r[2 * jp + 1], rh[jp], rl[jp]);
+                    split2(o_i[2 * jp], o_i[2 * jp + 1], ih[jp], il[jp]);
+                }
+#define S3F_H8(x) __builtin_bit_cast(half8, *reinterpret_cast<f32x4*>(x))
+                mfma_v(acc2[sl], trh, S3F_H8(rh));
+                mfma_v(acc2[sl], trh, S3F_H8(rl));
+                mfma_v(acc2[sl], trl, S3F_H8(rh));
+                mfma_v(acc2[sl], tih, S3F_H8(ih));
+                mfma_v(acc2[sl], tih, S3F_H8(il));
+                mfma_v(acc2[sl], til, S3F_H8(ih));
+#undef S3F_H8
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+#pragma unroll
+        for (int grp = 0; grp < 8; ++grp) {
+            if (grp + 3 < 8) load_e(grp + 3, E[(grp + 3) & 3]);
             __builtin_amdgcn_sched_barrier(0);
-            group(grp, E[0]);
+            group(grp, E[grp & 3]);
             __builtin_amdgcn_sched_barrier(0);
-            if (grp + 2 < 8) load_e(grp + 2, E[0]);
-            __builtin_amdgcn_sched_barrier(0);
-            group(grp + 1, E[1]);
-            __builtin_amdgcn_sched_barrier(0);
+            STAMP(10 + grp);
         }
         mfma_v_fence(acc2[0], acc2[1]);
         const __amdgpu_buffer_rsrc_t zs = rsrc_of(a.z + (size_t)b * a.cout_live * CS + wp0);  // z (B, 18, cs)
@@ -320,7 +345,13 @@ __global__ __launch_bounds__(F_NT) void tail_s3t_kernel(TailS3Args a, int ntiles
             const int tap = (q & 3) + 8 * (q >> 2) + 4 * h;
             if (tap < nlive) st2(zs, voffC, (unsigned)((q & 3) + 8 * (q >> 2)) * CS4, f32x2{acc2[0][q] * eisc, acc2[1][q] * eisc});
         }
+        STAMP(18);
         __syncthreads();  // everyone is done with this tile (s_next slot; the weight buffers are ordered by the chunk barriers)
+        STAMP(19);
+#ifdef S3F_STAMP
+        if (blockIdx.x == 0 && tid == 0 && it < 16)
+            for (int i = 0; i < 20; ++i) s3f_stamps[it * 32 + i] = stamp[i];
+#endif
         tile = s_next[it & 1];
     }
 }
