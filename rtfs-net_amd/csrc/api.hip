@@ -935,7 +935,22 @@ int separator_part(const SepPacks& k, const float* wav, const float* video_vp, f
     int nctr = 0;
     CHECK(launch_stft(wav, w.spec, B, L, T, st));
     CHECK(launch_enc_conv(w.spec, pe.w, w.a0, w.st0, B, CA, T, NF, (size_t)cs, (size_t)CA * cs, st));
-    CHECK(audio_bn(pb, w.a0, w.st0, w.a1, B, P, st, cs, w.ctr + nctr++));
+    // audio bottleneck + the first block application's gateway and projection in one kernel (k_bnh.hip) on the fused path
+    bool head_done = false;
+    if (!gemm_f32() && repeats > 1) {
+        BnHeadArgs f;
+        f.x = w.a0; f.a1 = w.a1; f.res = w.blk.residual; f.xenc = w.blk.x_enc;
+        f.stats = w.st0; f.inv_count = 1.0 / ((double)CA * P); f.gamma = pb.gamma; f.beta = pb.beta;
+        f.w16 = pb.w16; f.bias = pb.bias;
+        f.gw = pk.gw; f.gb = pk.gb; f.slope = pk.gslope; f.w2_16 = pk.proj_w16_perm; f.bp = pk.proj_b;
+        f.P = P; f.cs = cs;
+        f.tile_ctr = w.ctr + nctr++;
+        const int rc = launch_bn_head(f, B, st);
+        if (rc == RTFS_OK) head_done = true;
+        else if (rc != RTFS_ERR_ARG) return rc;
+        else --nctr;
+    }
+    if (!head_done) CHECK(audio_bn(pb, w.a0, w.st0, w.a1, B, P, st, cs, w.ctr + nctr++));
     // refinement_module.py:45-62: block(a1); CAF; then (repeats-1) x block(audio + a1), shared weights
     // refinement_module.py:45-62: block(a1); CAF; then (repeats-1) x block(audio + a1), shared weights.
     CafArgs ca = caf_args(pc, w.cur, video_vp, w.nxt, w.r, w.att, T, NF, Tv);
@@ -965,7 +980,7 @@ int separator_part(const SepPacks& k, const float* wav, const float* video_vp, f
         CHECK(cafv.begin(st, 15));
         if (video_ready && hipStreamWaitEvent(cafv.side.stream, (hipEvent_t)video_ready, 0) != hipSuccess) return RTFS_ERR_LAUNCH;
         CHECK(launch_caf_video(ca, B, cafv.side.stream));
-        CHECK(block_head(pk, w.a1, nullptr, B, T, NF, w.blk, st, nullptr, w.ctr + nctr++));
+        if (!head_done) CHECK(block_head(pk, w.a1, nullptr, B, T, NF, w.blk, st, nullptr, w.ctr + nctr++));
         for (int i = 0; i < repeats; ++i) {
             CHECK(block_body(pk, B, T, NF, w.blk, st, single_chain));
             if (i == 0) CHECK(cafv.join());

@@ -73,6 +73,25 @@ int launch_pws_b2b(const B2bArgs& a, int B, hipStream_t st);
 // second generation (k_b2b.hip): padded channel rows (cs % 64 == 0), no CAF; ctr = zeroed tile counter of this launch or null.
 // RTFS_ERR_ARG = call does not qualify, use launch_pws_b2b
 int launch_pws_b2b4(const B2bArgs& a, int B, unsigned* ctr, hipStream_t st);
+// audio bottleneck (gLN -> ReLU -> 1x1 256->256) + first block head (gateway + projection) in one kernel (k_bnh.hip): padded rows only,
+// RTFS_ERR_ARG = call does not qualify, use launch_pwr_audio_bn + launch_pws_head4
+struct BnHeadArgs {
+    const float* x = nullptr;       // encoder output a0 (B,256,cs)
+    float* a1 = nullptr;            // bottleneck output (B,256,cs)
+    float* res = nullptr;           // gateway output (B,256,cs)
+    float* xenc = nullptr;          // projection output (B,64,cs)
+    const double* stats = nullptr;  // (B,2) sum / sumsq of a0
+    double inv_count = 0;
+    const float *gamma = nullptr, *beta = nullptr;  // gLN (256)
+    const void* w16 = nullptr;      // bottleneck f16x3 image [8][hi|lo][256][32]
+    const float* bias = nullptr;    // (256)
+    const float *gw = nullptr, *gb = nullptr, *slope = nullptr;  // gateway dw 1x1 (256), PReLU (1)
+    const void* w2_16 = nullptr;    // projection f16x3 image [8][hi|lo][64][32], K in accumulator order
+    const float* bp = nullptr;      // (64)
+    int P = 0, cs = 0;
+    unsigned* tile_ctr = nullptr;
+};
+int launch_bn_head(const BnHeadArgs& a, int B, hipStream_t st);
 // residual conv of the last block application + S3 mask + complex product + decoder taps in one kernel (k_s3f.hip): padded rows only,
 // RTFS_ERR_ARG = call does not qualify, use launch_pws_residual + launch_pwr_s3_taps
 struct TailS3Args {
