@@ -889,6 +889,7 @@ inline int pitch(int P) { return (P + 63) / 64 * 64; }
 
 struct SepWs {
     float *spec, *a0, *a1, *cur, *nxt, *r, *att, *rt, *attt, *z;
+    float* encimg;  // encoder f16x3 fragment image (32 KB, written by enc_stats_kernel of every call)
     double* st0;
     unsigned* ctr;  // 64 tile counters (one per persistent launch of the call), zeroed together with st0
     int cs;
@@ -904,6 +905,7 @@ struct SepWs {
           rt(a.take<float>((size_t)B * CA * Tv)),
           attt(a.take<float>((size_t)B * CA * Tv)),
           z(a.take<float>((size_t)B * 18 * cs_)),
+          encimg(a.take<float>(8192)),
           st0(a.take<double>(2 * B + 32)),
           ctr(reinterpret_cast<unsigned*>(st0 ? st0 + 2 * B : nullptr)),
           cs(cs_),
@@ -934,21 +936,24 @@ int separator_part(const SepPacks& k, const float* wav, const float* video_vp, f
     if (hipMemsetAsync(w.st0, 0, sizeof(double) * (2 * B + 32), st) != hipSuccess) return RTFS_ERR_LAUNCH;  // + the tile counters
     int nctr = 0;
     CHECK(launch_stft(wav, w.spec, B, L, T, st));
-    CHECK(launch_enc_conv(w.spec, pe.w, w.a0, w.st0, B, CA, T, NF, (size_t)cs, (size_t)CA * cs, st));
-    // audio bottleneck + the first block application's gateway and projection in one kernel (k_bnh.hip) on the fused path
+    // fused path: the encoder output a0 is never written.  Its gLN statistics come from the spectrogram (enc_stats_kernel); the bottleneck + first
+    // block head kernel (k_bnh.hip) and the tail kernel (k_s3f.hip) rebuild the a0 tiles they need on the matrix cores.
     bool head_done = false;
-    if (!gemm_f32() && repeats > 1) {
+    if (!gemm_f32() && repeats > 1 && P >= 64) {
+        CHECK(launch_enc_stats(w.spec, pe.w, w.st0, w.encimg, B, T, NF, st));
         BnHeadArgs f;
-        f.x = w.a0; f.a1 = w.a1; f.res = w.blk.residual; f.xenc = w.blk.x_enc;
+        f.spec = w.spec; f.enc_img = w.encimg; f.T = T; f.F = NF;
+        f.a1 = w.a1; f.res = w.blk.residual; f.xenc = w.blk.x_enc;
         f.stats = w.st0; f.inv_count = 1.0 / ((double)CA * P); f.gamma = pb.gamma; f.beta = pb.beta;
         f.w16 = pb.w16; f.bias = pb.bias;
         f.gw = pk.gw; f.gb = pk.gb; f.slope = pk.gslope; f.w2_16 = pk.proj_w16_perm; f.bp = pk.proj_b;
         f.P = P; f.cs = cs;
         f.tile_ctr = w.ctr + nctr++;
-        const int rc = launch_bn_head(f, B, st);
-        if (rc == RTFS_OK) head_done = true;
-        else if (rc != RTFS_ERR_ARG) return rc;
-        else --nctr;
+        CHECK(launch_bn_head(f, B, st));
+        head_done = true;
+        CHECK(launch_enc_conv(w.spec, pe.w, w.a0, nullptr, B, CA, T, NF, (size_t)cs, (size_t)CA * cs, st));  // TEMP: the tail still reads a0
+    } else {
+        CHECK(launch_enc_conv(w.spec, pe.w, w.a0, w.st0, B, CA, T, NF, (size_t)cs, (size_t)CA * cs, st));
     }
     if (!head_done) CHECK(audio_bn(pb, w.a0, w.st0, w.a1, B, P, st, cs, w.ctr + nctr++));
     // refinement_module.py:45-62: block(a1); CAF; then (repeats-1) x block(audio + a1), shared weights

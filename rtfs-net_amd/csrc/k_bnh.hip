@@ -1,4 +1,5 @@
 // Head of the fused separator in ONE kernel (padded channel rows only; api.hip separator_part routes here):
+//   a0       = Conv2d(2->256, 3x3)(spectrogram)                   TDAVNet/encoder.py:146-157   (rebuilt tile by tile on the matrix cores, never stored)
 //   a1       = conv1x1_256->256(ReLU(gLN(a0))) + bias            TDAVNet/av_model.py audio bottleneck (gLN -> ReLU -> Conv)   (kept: every block adds it)
 //   residual = PReLU(dw1x1(a1))                                   separators/tdanet.py:106  (gateway of the first block application)
 //   x_enc    = conv1x1_256->64(residual) + bias                   separators/tdanet.py:107  (projection)
@@ -8,7 +9,11 @@
 // LDS, double buffered, one barrier per 96 MFMAs) at a time; the epilogue walks the eight 32-channel output tiles: a1 written through, the
 // gateway's PReLU output written through and - split into f16 hi / lo - fed back to the matrix cores as the B operand of the projection
 // (weights resident in LDS with their K axis in accumulator-register order, as in k_b2b.hip).  Two pixels per lane everywhere: 8-byte
-// accesses of whole 128-byte lines.  Per pixel the kernel reads 256 floats and writes 576, where the two kernels read 512 and wrote 576.
+// accesses of whole 128-byte lines.  Per pixel the kernel reads 18 spectrogram taps and writes 576 floats, where the three kernels it
+// replaces (encoder conv, bottleneck, block head) read 530 and wrote 832: it is a pure write stream.  The encoder conv is a K = 18 (padded
+// to 32) GEMM per 32-channel tile - 12 matrix instructions - whose accumulator tile, normalised (the gLN statistics of a0 come from
+// enc_stats_kernel, which does not form a0 either), ReLU'd and split, is the B operand of the bottleneck GEMM as it stands: the bottleneck
+// weights' A fragments are read in accumulator-register K order (two 8-byte reads from adjacent 16-byte pieces, as in k_s3f.hip).
 // The small accumulators (projection: 64 registers) are VGPR-form matrix instructions written by hand: see k_s3f.hip.
 #include "common.h"
 #include "kernels.h"
@@ -17,27 +22,21 @@
 namespace {
 
 constexpr int N_NT = 256;                      // 4 waves, one per SIMD
-constexpr int N_ROWB = 80;                     // bottleneck chunk row: 32 k halfs (64 B) + 16 B pad: 20-bank stride, ds_read_b128 conflict-free
+constexpr int N_ROWB = 72;                     // bottleneck chunk row: 32 k halfs (64 B) + 8 B pad: 18-bank stride, the 8-byte fragment reads are conflict-free
 constexpr int N_PART = 256 * N_ROWB;
 constexpr int N_BUF = 2 * N_PART;
 constexpr int N_L2 = 256 + 8;                  // projection weight row (halfs)
 constexpr size_t N_LDS = (size_t)2 * N_BUF + (size_t)2 * 64 * N_L2 * 2 + (size_t)(5 * 256 + 64) * 4 + 16;
-constexpr int N_RING = 3;                      // chunks of a0 rows in flight
+typedef unsigned long long u64_;
 
-__device__ __forceinline__ void mfma_v0(f32x16& c, half8 a, half8 b) {
-    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "v"(b));
-}
-__device__ __forceinline__ void mfma_v(f32x16& c, half8 a, half8 b) {
-    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
-}
-__device__ __forceinline__ void mfma_v_fence4(f32x16& c0, f32x16& c1, f32x16& c2, f32x16& c3) {
-    asm volatile("s_nop 15\n\ts_nop 3" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3));
-}
-__device__ __forceinline__ float acc_rd(float v) {  // one accumulator register -> VGPR (k_s3f.hip)
-    float o;
-    asm("v_accvgpr_read_b32 %0, %1" : "=v"(o) : "a"(v));
-    return o;
-}
+
+// Diagnostic build only (tools/bench_bnh.hip defines BNH_STAMP): s_memtime at the phase boundaries of workgroup 0's first tiles.
+#ifdef BNH_STAMP
+__device__ unsigned bnh_stamps[16 * 32];
+#define STAMP(i) do { __builtin_amdgcn_sched_barrier(0); stamp[i] = (unsigned)__builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
 
 __global__ __launch_bounds__(N_NT) void bn_head_kernel(BnHeadArgs a, int ntiles, int tps) {
     constexpr int L2 = N_L2;
@@ -46,7 +45,7 @@ __global__ __launch_bounds__(N_NT) void bn_head_kernel(BnHeadArgs a, int ntiles,
     // LDS map: the resident tables first (every constant offset from a lane base fits the 16-bit DS offset field), the chunk buffers last
     _Float16* W2h = reinterpret_cast<_Float16*>(smem);  // [64][L2], K in accumulator order
     _Float16* W2l = W2h + 64 * L2;
-    float* sc = reinterpret_cast<float*>(W2l + 64 * L2);  // gLN fold of the current mixture
+    float* sc = reinterpret_cast<float*>(W2l + 64 * L2);  // gLN fold of the current mixture (scale x the patch normalisation's inverse / 256)
     float* sh = sc + 256;
     float* bb = sh + 256;   // bottleneck bias
     float* gsc = bb + 256;  // gateway scale / bias
@@ -74,16 +73,18 @@ __global__ __launch_bounds__(N_NT) void bn_head_kernel(BnHeadArgs a, int ntiles,
     const int lastw = (cdiv(P, 64) - 1) * 64;
     const __amdgpu_buffer_rsrc_t ws = rsrc_of(reinterpret_cast<const float*>(a.w16));  // bottleneck: [chunk 8][hi|lo][256 co][4 pieces of 8 k]
     const unsigned voffW = (unsigned)tid * 16u;
-    const unsigned voffB = ((unsigned)(8 * h) * CS + 2u * r) * 4u;
+    const __amdgpu_buffer_rsrc_t is = rsrc_of(reinterpret_cast<const float*>(a.enc_img));  // encoder fragments (enc_stats_kernel)
+    const unsigned voffT = (unsigned)(r * 2 + h) * 16u;
+    const int T = a.T, F = a.F;
     const unsigned voffC = ((unsigned)(4 * h) * CS + 2u * r) * 4u;
 
     // lane byte offsets into LDS, opaque to the compiler: every access is one of these + a constant in the instruction's offset field (left
     // alone, it materialises one address register per distinct constant - 150 of them - and spills them before the tile loop)
     unsigned lw2 = (unsigned)(r * L2 + 8 * h) * 2u;                                  // projection fragments
-    unsigned lc8 = OFF_C + 32u * h, lc4 = OFF_C + 16u * h;                           // per-channel constants, B-fragment / accumulator order
-    unsigned lwr0 = OFF_W + (unsigned)(r * N_ROWB + 16 * h), lwr1 = lwr0 + N_BUF;    // bottleneck fragments, buffer 0 / 1
+    unsigned lc4 = OFF_C + 16u * h;                                                  // per-channel constants, accumulator order
+    unsigned lwr0 = OFF_W + (unsigned)(r * N_ROWB + 8 * h), lwr1 = lwr0 + N_BUF;     // bottleneck fragments, buffer 0 / 1
     unsigned lww0 = OFF_W + (unsigned)((tid >> 2) * N_ROWB + (tid & 3) * 16), lww1 = lww0 + N_BUF;  // staging writes
-    asm volatile("" : "+v"(lw2), "+v"(lc8), "+v"(lc4), "+v"(lwr0), "+v"(lwr1), "+v"(lww0), "+v"(lww1));
+    asm volatile("" : "+v"(lw2), "+v"(lc4), "+v"(lwr0), "+v"(lwr1), "+v"(lww0), "+v"(lww1));
     half8 pre[8];
     auto stage_load = [&](int c) {
 #pragma unroll
@@ -92,37 +93,55 @@ __global__ __launch_bounds__(N_NT) void bn_head_kernel(BnHeadArgs a, int ntiles,
     auto stage_write = [&](int buf) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            // piece tid + 256 j: row (tid >> 2) + 64 (j & 3) of part j >> 2
-            *reinterpret_cast<half8*>(smem + (buf ? lww1 : lww0) + (j >> 2) * N_PART + 64 * (j & 3) * N_ROWB) = pre[j];
+            // piece tid + 256 j: row (tid >> 2) + 64 (j & 3) of part j >> 2 (rows are 72 bytes apart: two 8-byte halves)
+            u64_* d = reinterpret_cast<u64_*>(smem + (buf ? lww1 : lww0) + (j >> 2) * N_PART + 64 * (j & 3) * N_ROWB);
+            const u64_* sp = reinterpret_cast<const u64_*>(&pre[j]);
+            d[0] = sp[0];
+            d[1] = sp[1];
         }
     };
     stage_load(0);
     stage_write(0);
 
+    // this lane's nine spectrogram taps (two pixels each) of the tile: carried across tiles, the next tile's are requested BEFORE this tile's
+    // 576 row stores (behind them the first loads of a tile waited 13k cycles of a 97k-cycle tile)
+    f32x2 V[9];
     int cur_b = -1;
     int it = 0;
     for (int tile = blockIdx.x; tile < ntiles; ++it) {
         if (tid == 0) s_next[it & 1] = (a.tile_ctr ? (int)atomicAdd(a.tile_ctr, 1u) : tile) + (int)gridDim.x;
+#ifdef BNH_STAMP
+        unsigned stamp[32];
+#endif
+        STAMP(0);
         unsigned CS4 = CS4_;
         asm volatile("" : "+s"(CS4));  // row offsets are formed where they are used (one s_mul each), not hoisted out of the tile loop
         const int b = tile / tps;
         // a wave segment past the sample's end repeats the last real one (same values to the same addresses): every wave takes part in every barrier
         const int wp0 = min((tile - b * tps) * (N_NT / 64 * 64) + wave * 64, lastw);
-        const __amdgpu_buffer_rsrc_t as = rsrc_of(a.x + (size_t)b * 256 * CS + wp0);
-        // ---- a0 rows of chunk c: channels 32 c + 16 s + 8 h + j (B-fragment order), N_RING chunks ahead
-        f32x2 X[N_RING][16];
-        auto load_x = [&](int c, f32x2 (&d)[16]) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) d[i] = ld2(as, voffB, (unsigned)(c * 32 + (i >> 3) * 16 + (i & 7)) * CS4);
-        };
-#pragma unroll
-        for (int c = 0; c < N_RING; ++c) load_x(c, X[c]);
-        if (b != cur_b) {     // block-uniform: the gLN fold of this mixture
+        const int p0 = wp0 + 2 * r;
+        float esc, eisc;
+        rms_pow2(a.stats + 2 * b, a.inv_count, esc, eisc);
+        if (it == 0) patch_load(spec_rsrc(a.spec + (size_t)b * 2 * P, P), p0, h, P, F, V);  // (later tiles: requested before the previous tile's epilogue)
+        if (b != cur_b) {     // block-uniform: the gLN fold of this mixture; the scale also undoes the patch normalisation and the weights' x 256
             __syncthreads();  // the previous tile's fragments are built
-            gln_fold(a.stats + 2 * b, a.inv_count, a.gamma[tid], a.beta[tid], sc[tid], sh[tid]);
+            float fs, ft;
+            gln_fold(a.stats + 2 * b, a.inv_count, a.gamma[tid], a.beta[tid], fs, ft);
+            sc[tid] = fs * eisc;
+            sh[tid] = ft;
             cur_b = b;
         }
         __syncthreads();  // sc / sh (and, first tile, the resident tables) visible
+        PatchFrag pf;
+        patch_build(V, p0, T, F, P, esc, pf);
+        // encoder A fragments of 32-channel tile c: [K step][hi|lo], one tile ahead (L2-resident 32 KB image)
+        half8 ea[2][4];
+        auto load_ea = [&](int c, half8 (&d)[4]) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) d[i] = ld_h8(is, voffT, (unsigned)(c * 4 + i) * 1024u);
+        };
+        load_ea(0, ea[0]);
+        STAMP(1);
         f32x16 acc[8][2];  // bottleneck conv: [output tile][pixel slot]
 #pragma unroll
         for (int m = 0; m < 8; ++m)
@@ -130,20 +149,34 @@ __global__ __launch_bounds__(N_NT) void bn_head_kernel(BnHeadArgs a, int ntiles,
             for (int sl = 0; sl < 2; ++sl)
 #pragma unroll
                 for (int q = 0; q < 16; ++q) acc[m][sl][q] = 0.f;
-        auto chunk = [&](int kc, f32x2 (&Xb)[16], int buf) {
+        auto chunk = [&](int kc, const half8 (&e)[4], half8 (&en)[4], int buf) {
+            // encoder conv of channels 32 kc .. 32 kc + 31 at this wave's 64 pixels: K = 2 steps, f16x3
+            f32x16 acc1[2];
+#pragma unroll
+            for (int sl = 0; sl < 2; ++sl) {
+                mfma_v0(acc1[sl], e[0], pf.h[0][sl]);
+                mfma_v(acc1[sl], e[0], pf.l[0][sl]);
+                mfma_v(acc1[sl], e[1], pf.h[0][sl]);
+                mfma_v(acc1[sl], e[2], pf.h[1][sl]);
+                mfma_v(acc1[sl], e[2], pf.l[1][sl]);
+                mfma_v(acc1[sl], e[3], pf.h[1][sl]);
+            }
+            mfma_v_fence(acc1[0], acc1[1]);
+            if (kc + 1 < 8) load_ea(kc + 1, en);
+            // gLN + ReLU; split: registers 8s .. 8s+7 of the tile = K step s of this chunk (accumulator order)
             half8 bh[2][2], bl[2][2];  // [K step][pixel slot]
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 float y0[8], y1[8];
 #pragma unroll
                 for (int g = 0; g < 2; ++g) {
-                    const unsigned co = (unsigned)(kc * 32 + 16 * s + 4 * g) * 4u;  // channel kc*32 + 16 s + 8 h + 4 g
-                    const f32x4 ks = *reinterpret_cast<const f32x4*>(smem + lc8 + co), kt = *reinterpret_cast<const f32x4*>(smem + lc8 + 1024 + co);
+                    const unsigned co = (unsigned)(kc * 32 + 8 * (2 * s + g)) * 4u;  // channel kc*32 + 4 h + 8 (2 s + g)
+                    const f32x4 ks = *reinterpret_cast<const f32x4*>(smem + lc4 + co), kt = *reinterpret_cast<const f32x4*>(smem + lc4 + 1024 + co);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        const int j = 4 * g + i;
-                        y0[j] = fmaxf(fmaf(Xb[8 * s + j].x, ks[i], kt[i]), 0.f);
-                        y1[j] = fmaxf(fmaf(Xb[8 * s + j].y, ks[i], kt[i]), 0.f);
+                        const int j = 4 * g + i, q = 8 * s + j;
+                        y0[j] = fmaxf(fmaf(acc1[0][q], ks[i], kt[i]), 0.f);
+                        y1[j] = fmaxf(fmaf(acc1[1][q], ks[i], kt[i]), 0.f);
                     }
                 }
                 unsigned h0[4], l0[4], h1[4], l1[4];
@@ -157,12 +190,15 @@ __global__ __launch_bounds__(N_NT) void bn_head_kernel(BnHeadArgs a, int ntiles,
                 bh[s][1] = __builtin_bit_cast(half8, *reinterpret_cast<f32x4*>(h1));
                 bl[s][1] = __builtin_bit_cast(half8, *reinterpret_cast<f32x4*>(l1));
             }
-            if (kc + N_RING < 8) load_x(kc + N_RING, Xb);  // (uniform) the ring slot is free again
             __builtin_amdgcn_sched_barrier(0);
             __syncthreads();  // chunk kc staged (buffer `buf`) and visible; everyone is done reading chunk kc - 1 (the other buffer)
             stage_load((kc + 1) & 7);  // chunk 0 again behind chunk 7: the next tile's first
+            // A fragments in accumulator-register K order: K slot (h, j) of step s is channel 16 s + 4 h + (j & 3) + 8 (j >> 2) of the chunk, i.e.
+            // elements 4h .. 4h+3 of piece 2s and of piece 2s + 1
             auto afrag = [&](int m, int s, int part) {
-                return *reinterpret_cast<const half8*>(smem + (buf ? lwr1 : lwr0) + part * N_PART + m * 32 * N_ROWB + s * 32);
+                const u64_* pp = reinterpret_cast<const u64_*>(smem + (buf ? lwr1 : lwr0) + part * N_PART + m * 32 * N_ROWB + s * 32);
+                u64_ v[2] = {pp[0], pp[2]};  // +16 bytes: the next piece
+                return __builtin_bit_cast(half8, *reinterpret_cast<f32x4*>(v));
             };
             half8 ah[2][2], al[2][2];  // [buffer][K step]
             ah[0][0] = afrag(0, 0, 0); ah[0][1] = afrag(0, 1, 0);
@@ -188,11 +224,21 @@ __global__ __launch_bounds__(N_NT) void bn_head_kernel(BnHeadArgs a, int ntiles,
             __builtin_amdgcn_sched_barrier(0);
         };
 #pragma unroll
-        for (int kc = 0; kc < 8; ++kc) chunk(kc, X[kc % N_RING], kc & 1);
+        for (int kc = 0; kc < 8; ++kc) {
+            chunk(kc, ea[kc & 1], ea[(kc + 1) & 1], kc & 1);
+            STAMP(2 + kc);
+        }
         // ---- epilogue: a1 and the gateway output written through, projection from the accumulator registers
         const __amdgpu_buffer_rsrc_t a1s = rsrc_of(a.a1 + (size_t)b * 256 * CS + wp0);
         const __amdgpu_buffer_rsrc_t rs = rsrc_of(a.res + (size_t)b * 256 * CS + wp0);
         const __amdgpu_buffer_rsrc_t xes = rsrc_of(a.xenc + (size_t)b * 64 * CS + wp0);
+        const int ntile = s_next[it & 1];  // (written before this tile's first barrier)
+        if (ntile < ntiles) {              // block-uniform
+            const int nb = ntile / tps;
+            const int nwp0 = min((ntile - nb * tps) * (N_NT / 64 * 64) + wave * 64, lastw);
+            patch_load(spec_rsrc(a.spec + (size_t)nb * 2 * P, P), nwp0 + 2 * r, h, P, F, V);
+        }
+        __builtin_amdgcn_sched_barrier(0);
         f32x16 acc2[2][2];  // [projection tile][pixel slot]
 #pragma unroll
         for (int m = 0; m < 8; ++m) {
@@ -242,6 +288,7 @@ __global__ __launch_bounds__(N_NT) void bn_head_kernel(BnHeadArgs a, int ntiles,
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            STAMP(10 + m);
         }
         mfma_v_fence4(acc2[0][0], acc2[0][1], acc2[1][0], acc2[1][1]);
 #pragma unroll
@@ -256,8 +303,14 @@ __global__ __launch_bounds__(N_NT) void bn_head_kernel(BnHeadArgs a, int ntiles,
                 }
             }
         }
+        STAMP(18);
         __syncthreads();  // everyone is done with this tile (s_next slot; sc / sh)
-        tile = s_next[it & 1];
+        STAMP(19);
+#ifdef BNH_STAMP
+        if (blockIdx.x == 0 && tid == 0 && it < 16)
+            for (int i = 0; i < 20; ++i) bnh_stamps[it * 32 + i] = stamp[i];
+#endif
+        tile = ntile;
     }
 }
 
@@ -265,7 +318,7 @@ __global__ __launch_bounds__(N_NT) void bn_head_kernel(BnHeadArgs a, int ntiles,
 
 // RTFS_ERR_ARG = the call does not qualify (contiguous rows, tiny input): the caller runs the two separate kernels
 int launch_bn_head(const BnHeadArgs& a, int B, hipStream_t st) {
-    if (a.cs <= 0 || (a.cs & 63) || a.cs < (a.P + 63) / 64 * 64 || a.P < 64 || !a.w16 || !a.w2_16 || !a.stats) return RTFS_ERR_ARG;
+    if (a.cs <= 0 || (a.cs & 63) || a.cs < (a.P + 63) / 64 * 64 || a.P < 64 || !a.w16 || !a.w2_16 || !a.stats || !a.spec || !a.enc_img || a.T * a.F != a.P) return RTFS_ERR_ARG;
     if ((size_t)256 * a.cs * 4 >= ((size_t)1 << 31)) return RTFS_ERR_ARG;
     if (rtfs_set_max_lds((const void*)bn_head_kernel, N_LDS) != RTFS_OK) return RTFS_ERR_LAUNCH;
     const int tps = cdiv(a.P, N_NT / 64 * 64), ntiles = tps * B;

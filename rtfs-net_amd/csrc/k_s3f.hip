@@ -30,29 +30,7 @@ constexpr size_t F_LDS = (size_t)2 * 256 * F_L1 * 2 + (size_t)2 * F_BUF + 2 * 25
 
 typedef unsigned long long u64_;
 
-// The mask GEMM's 256 accumulator registers fill the AGPR half of the wave's 512 registers.  With a 512-register budget the compiler
-// selects the AGPR form for EVERY matrix instruction of the function, so the small accumulators next to it (the residual conv's 32, the
-// taps GEMM's 32) would have to share those 256 registers: it shuffled them through v_accvgpr moves and spilled 160 registers.  These two
-// GEMMs are therefore written as VGPR-form instructions by hand.  The compiler's hazard recogniser does not look inside inline assembly:
-//   - consecutive instructions on one accumulator (same opcode, same destination = source C) need no wait states (and are interleaved
-//     with the other pixel slot's anyway);
-//   - a VALU read of the result needs 11 wait states behind an 8-pass instruction: mfma_v_fence() (20) closes every sequence.
-__device__ __forceinline__ void mfma_v0(f32x16& c, half8 a, half8 b) {
-    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "v"(b));
-}
-__device__ __forceinline__ void mfma_v(f32x16& c, half8 a, half8 b) {
-    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
-}
-// One accumulator register -> VGPR.  Left to the compiler, the first VALU use of an accumulator tile copies all 16 registers of the tile to
-// VGPRs at once - and it hoists the copies of all sixteen tiles (256 registers) to the top of the epilogue.
-__device__ __forceinline__ float acc_rd(float v) {
-    float o;
-    asm("v_accvgpr_read_b32 %0, %1" : "=v"(o) : "a"(v));
-    return o;
-}
-__device__ __forceinline__ void mfma_v_fence(f32x16& c0, f32x16& c1) {
-    asm volatile("s_nop 15\n\ts_nop 3" : "+v"(c0), "+v"(c1));
-}
+// (the residual conv's and the taps GEMM's small accumulators are VGPR-form matrix instructions written by hand: pipe_helpers.h)
 
 // Diagnostic build only (tools/bench_s3f.hip defines S3F_STAMP and a global s3f_stamps buffer): s_memtime at the phase boundaries of the
 // first tiles of workgroup 0.

@@ -101,6 +101,85 @@ __global__ __launch_bounds__(256) void enc_conv_kernel(const float* __restrict__
     if (stats) block_stats_atomic(s, ss, red, stats + 2 * b);
 }
 
+// The fused separator never materialises the encoder output a0: its two consumers (k_bnh.hip, k_s3f.hip) rebuild the tiles they need on the
+// matrix cores from the spectrogram patches (18 taps per pixel).  What they cannot rebuild is the gLN statistic of a0 - sum and sum of squares
+// over the whole (256, T, F) volume of a mixture - which this kernel computes WITHOUT forming a0:
+//     sum_c a0[c][p]   = wbar . patch(p)                    wbar = sum_c W[c]            (18)
+//     sum_c a0[c][p]^2 = patch(p)^T G patch(p)              G    = sum_c W[c] W[c]^T     (18 x 18, symmetric)
+// 189 f64 FMAs per pixel instead of 4608 f32 ones (the quadratic form cancels: f64).  Every workgroup rebuilds G' (upper triangle, off-diagonal
+// entries doubled) in LDS from the 256 x 18 weights (256 iterations per thread); workgroup (0, 0) also writes the encoder's f16 hi / lo
+// fragment image for the consumers: [tile 8][K step 2][hi|lo][32 rows][h 2][8 halfs], K slot (h, j) of step 0 = tap j of input channel h
+// (re / im), of step 1 = tap 8 of channel h for j = 0 and zero above (weights x 256, as every f16x3 image of this library).
+__global__ __launch_bounds__(256) void enc_stats_kernel(const float* __restrict__ spec, const float* __restrict__ w, double* __restrict__ stats,
+                                                        _Float16* __restrict__ img, int T, int F) {
+    __shared__ double G[171 + 18];  // G' rows i: entries j >= i at i*18 - i(i-1)/2 + (j - i); then wbar
+    __shared__ double red[8];
+    const int tid = threadIdx.x, b = blockIdx.y, P = T * F;
+    if (tid < 171 + 18) {
+        double acc = 0;
+        if (tid < 171) {
+            int i = 0, base = 0;
+            while (tid >= base + 18 - i) { base += 18 - i; ++i; }
+            const int j = i + tid - base;
+            for (int c = 0; c < 256; ++c) acc = fma((double)w[c * 18 + i], (double)w[c * 18 + j], acc);
+            if (j != i) acc *= 2.0;
+        } else {
+            for (int c = 0; c < 256; ++c) acc += (double)w[c * 18 + tid - 171];
+        }
+        G[tid] = acc;
+    }
+    if (img && blockIdx.x == 0 && b == 0) {
+        for (int e = tid; e < 8 * 2 * 32 * 2 * 8; e += 256) {  // (tile, step, row, h, j); hi and lo written together
+            const int j = e & 7, h = (e >> 3) & 1, r = (e >> 4) & 31, s = (e >> 9) & 1, kc = e >> 10;
+            const int c = kc * 32 + r;
+            const float v = s == 0 ? 256.0f * w[c * 18 + h * 9 + j] : (j == 0 ? 256.0f * w[c * 18 + h * 9 + 8] : 0.f);
+            const _Float16 hi = (_Float16)v;
+            const size_t o = ((size_t)((kc * 2 + s) * 2) * 64 + r * 2 + h) * 8 + j;
+            img[o] = hi;
+            img[o + 64 * 8] = (_Float16)(v - (float)hi);
+        }
+    }
+    __syncthreads();
+    const int p = blockIdx.x * 256 + tid;
+    double s1 = 0, s2 = 0;
+    if (p < P) {
+        const int t = p / F, f = p - t * F;
+        double q[18];
+#pragma unroll
+        for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+            for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+                for (int df = 0; df < 3; ++df) {
+                    const int tt = t + dt - 1, ff = f + df - 1;
+                    const bool ok = tt >= 0 && tt < T && ff >= 0 && ff < F;
+                    const int tc = tt < 0 ? 0 : (tt < T ? tt : T - 1), fc = ff < 0 ? 0 : (ff < F ? ff : F - 1);
+                    const float v = spec[((size_t)b * 2 + ci) * P + (size_t)tc * F + fc];  // unconditional, clamped
+                    q[ci * 9 + dt * 3 + df] = ok ? (double)v : 0.0;
+                }
+        int k = 0;
+#pragma unroll
+        for (int i = 0; i < 18; ++i) {
+            double u = 0;
+#pragma unroll
+            for (int j = i; j < 18; ++j) u = fma(G[k++], q[j], u);
+            s2 = fma(q[i], u, s2);
+            s1 = fma(G[171 + i], q[i], s1);
+        }
+    }
+    s1 = wave_sum_d(s1);
+    s2 = wave_sum_d(s2);
+    if ((tid & 63) == 0) {
+        red[2 * (tid >> 6)] = s1;
+        red[2 * (tid >> 6) + 1] = s2;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        atomicAdd(stats + 2 * b, red[0] + red[2] + red[4] + red[6]);
+        atomicAdd(stats + 2 * b + 1, red[1] + red[3] + red[5] + red[7]);
+    }
+}
+
 // Tail of the decoder.  z (B,18,T,F) holds the per-tap pointwise products
 //   z[b][(o*3+dt)*3+df][t][f] = sum_c x[b][c][t][f] * Wdec[c][o][dt][df]
 // ConvTranspose2d(pad 1): y[o][t][f] = sum_{dt,df} z[o,dt,df][t+1-dt][f+1-df].
@@ -172,6 +251,11 @@ int launch_enc_conv(const float* spec, const float* w, float* a0, double* stats,
     int gz = 1;
     while (gz < 8 && gx * B * gz < 512 && C % (2 * gz) == 0) gz *= 2;
     hipLaunchKernelGGL(enc_conv_kernel, dim3(gx, B, gz), dim3(256), 0, st, spec, w, a0, stats, C, T, F, cs, bs);
+    return rtfs_launch_status();
+}
+
+int launch_enc_stats(const float* spec, const float* w, double* stats, void* img, int B, int T, int F, hipStream_t st) {
+    hipLaunchKernelGGL(enc_stats_kernel, dim3(cdiv(T * F, 256), B), dim3(256), 0, st, spec, w, stats, reinterpret_cast<_Float16*>(img), T, F);
     return rtfs_launch_status();
 }
 

@@ -36,6 +36,8 @@ struct PwArgs {
 int launch_stft(const float* wav, float* spec, int B, int L, int T, hipStream_t st);
 int launch_enc_conv(const float* spec, const float* w, float* a0, double* stats, int B, int C, int T, int F, size_t cs,
                     size_t bs, hipStream_t st);
+// gLN statistics of the encoder output computed from the spectrogram (a0 is not formed) + the encoder's f16x3 fragment image (32 KB at img)
+int launch_enc_stats(const float* spec, const float* w, double* stats, void* img, int B, int T, int F, hipStream_t st);
 int launch_dec_istft(const float* z, float* wav, int B, int T, int F, int L, size_t zcs, size_t zbs, hipStream_t st);
 
 int launch_pw_audio_bn(const PwArgs& a, int B, hipStream_t st);
@@ -76,7 +78,9 @@ int launch_pws_b2b4(const B2bArgs& a, int B, unsigned* ctr, hipStream_t st);
 // audio bottleneck (gLN -> ReLU -> 1x1 256->256) + first block head (gateway + projection) in one kernel (k_bnh.hip): padded rows only,
 // RTFS_ERR_ARG = call does not qualify, use launch_pwr_audio_bn + launch_pws_head4
 struct BnHeadArgs {
-    const float* x = nullptr;       // encoder output a0 (B,256,cs)
+    const float* spec = nullptr;    // spectrogram (B,2,T,F): the encoder output a0 is rebuilt on the fly, not read
+    const void* enc_img = nullptr;  // encoder f16x3 fragment image (enc_stats_kernel)
+    int T = 0, F = 0;
     float* a1 = nullptr;            // bottleneck output (B,256,cs)
     float* res = nullptr;           // gateway output (B,256,cs)
     float* xenc = nullptr;          // projection output (B,64,cs)
