@@ -938,9 +938,8 @@ int separator_part(const SepPacks& k, const float* wav, const float* video_vp, f
     CHECK(launch_stft(wav, w.spec, B, L, T, st));
     // fused path: the encoder output a0 is never written.  Its gLN statistics come from the spectrogram (enc_stats_kernel); the bottleneck + first
     // block head kernel (k_bnh.hip) and the tail kernel (k_s3f.hip) rebuild the a0 tiles they need on the matrix cores.
-    bool head_done = false;
-    if (!gemm_f32() && repeats > 1 && P >= 64) {
-        CHECK(launch_enc_stats(w.spec, pe.w, w.st0, w.encimg, B, T, NF, st));
+    bool head_done = false;  // = "a0 does not exist"
+    if (!gemm_f32() && repeats > 1) {
         BnHeadArgs f;
         f.spec = w.spec; f.enc_img = w.encimg; f.T = T; f.F = NF;
         f.a1 = w.a1; f.res = w.blk.residual; f.xenc = w.blk.x_enc;
@@ -948,13 +947,15 @@ int separator_part(const SepPacks& k, const float* wav, const float* video_vp, f
         f.w16 = pb.w16; f.bias = pb.bias;
         f.gw = pk.gw; f.gb = pk.gb; f.slope = pk.gslope; f.w2_16 = pk.proj_w16_perm; f.bp = pk.proj_b;
         f.P = P; f.cs = cs;
-        f.tile_ctr = w.ctr + nctr++;
-        CHECK(launch_bn_head(f, B, st));
-        head_done = true;
-        CHECK(launch_enc_conv(w.spec, pe.w, w.a0, nullptr, B, CA, T, NF, (size_t)cs, (size_t)CA * cs, st));  // TEMP: the tail still reads a0
-    } else {
-        CHECK(launch_enc_conv(w.spec, pe.w, w.a0, w.st0, B, CA, T, NF, (size_t)cs, (size_t)CA * cs, st));
+        f.tile_ctr = w.ctr + nctr;
+        if (launch_bn_head_qualifies(f)) {
+            CHECK(launch_enc_stats(w.spec, pe.w, w.st0, w.encimg, B, T, NF, st));
+            CHECK(launch_bn_head(f, B, st));
+            ++nctr;
+            head_done = true;
+        }
     }
+    if (!head_done) CHECK(launch_enc_conv(w.spec, pe.w, w.a0, w.st0, B, CA, T, NF, (size_t)cs, (size_t)CA * cs, st));
     if (!head_done) CHECK(audio_bn(pb, w.a0, w.st0, w.a1, B, P, st, cs, w.ctr + nctr++));
     // refinement_module.py:45-62: block(a1); CAF; then (repeats-1) x block(audio + a1), shared weights
     // refinement_module.py:45-62: block(a1); CAF; then (repeats-1) x block(audio + a1), shared weights.
@@ -993,14 +994,15 @@ int separator_part(const SepPacks& k, const float* wav, const float* video_vp, f
             else {
                 // last application: residual conv + S3 mask + complex product + decoder taps in one kernel (k_s3f.hip); `refined` never exists
                 TailS3Args f;
-                f.x = w.blk.expanded; f.res = w.blk.residual; f.a0 = w.a0; f.z = w.z;
+                f.x = w.blk.expanded; f.res = w.blk.residual; f.spec = w.spec; f.enc_img = w.encimg; f.T = T; f.F = NF; f.z = w.z;
                 f.w1_16 = pk.res_w16; f.b1 = pk.res_b; f.w16 = ps.w16; f.bias = ps.bias; f.slope = ps.slope; f.w16b = pd.w16p;
                 f.stats = w.st0; f.inv_count = 1.0 / ((double)CA * P);
                 f.P = P; f.cs = cs; f.cout_live = 18;
                 f.tile_ctr = nctr < 64 ? w.ctr + nctr++ : nullptr;
-                const int rc = launch_tail_s3t(f, B, st);
-                if (rc == RTFS_OK) return launch_dec_istft(w.z, out, B, T, NF, L, (size_t)cs, (size_t)18 * cs, st);
-                if (rc != RTFS_ERR_ARG) return rc;
+                if (head_done) {  // (the two launches qualify together: same P, same pitch)
+                    CHECK(launch_tail_s3t(f, B, st));
+                    return launch_dec_istft(w.z, out, B, T, NF, L, (size_t)cs, (size_t)18 * cs, st);
+                }
                 CHECK(block_tail(pk, cur, B, T, NF, w.blk, st, f.tile_ctr));
             }
         }

@@ -316,10 +316,14 @@ __global__ __launch_bounds__(N_NT) void bn_head_kernel(BnHeadArgs a, int ntiles,
 
 }  // namespace
 
-// RTFS_ERR_ARG = the call does not qualify (contiguous rows, tiny input): the caller runs the two separate kernels
+bool launch_bn_head_qualifies(const BnHeadArgs& a) {
+    if (a.cs <= 0 || (a.cs & 63) || a.cs < (a.P + 63) / 64 * 64 || a.P < 64 || !a.w16 || !a.w2_16 || !a.stats || !a.spec || !a.enc_img || a.T * a.F != a.P) return false;
+    return (size_t)256 * a.cs * 4 < ((size_t)1 << 31);
+}
+
+// RTFS_ERR_ARG = the call does not qualify (contiguous rows, tiny input): the caller runs the separate kernels
 int launch_bn_head(const BnHeadArgs& a, int B, hipStream_t st) {
-    if (a.cs <= 0 || (a.cs & 63) || a.cs < (a.P + 63) / 64 * 64 || a.P < 64 || !a.w16 || !a.w2_16 || !a.stats || !a.spec || !a.enc_img || a.T * a.F != a.P) return RTFS_ERR_ARG;
-    if ((size_t)256 * a.cs * 4 >= ((size_t)1 << 31)) return RTFS_ERR_ARG;
+    if (!launch_bn_head_qualifies(a)) return RTFS_ERR_ARG;
     if (rtfs_set_max_lds((const void*)bn_head_kernel, N_LDS) != RTFS_OK) return RTFS_ERR_LAUNCH;
     const int tps = cdiv(a.P, N_NT / 64 * 64), ntiles = tps * B;
     const int grid = ntiles < 256 ? ntiles : 256;  // one resident workgroup per CU

@@ -1,7 +1,7 @@
 // Tail of the fused separator in ONE kernel (padded channel rows only; api.hip separator_part routes here):
 //   refined = residual_conv(expanded) + residual                       separators/tdanet.py:129   (last block application)
 //   mask    = ReLU(conv1x1_256->256(PReLU(refined)) + bias)            TDAVNet/mask_generator.py:67-88
-//   sep     = mask (x) a0  (complex product with the encoder output)   TDAVNet/mask_generator.py:89-99
+//   sep     = mask (x) a0  (complex product with the encoder output)   TDAVNet/mask_generator.py:89-99   (a0 rebuilt from the spectrogram, not read)
 //   z       = the decoder's 18 per-tap 1x1 maps of sep                 TDAVNet/decoder.py:110-117 (ConvTranspose2d as taps + shift-sum)
 // Until round 3 this was two launches (pws_res2_kernel 0.44 ms + pwr_kernel<S3T> 0.78 ms) with the 1 GB `refined` tensor written and read back
 // in between, and the second one bound by the texture addresser (one pixel per lane: 512 dword accesses per 32 pixels).  Here `refined` never
@@ -9,7 +9,7 @@
 // registers, and the tile - bias, residual, PReLU, f16 hi / lo split - is the B operand of the mask GEMM as it stands.  The mask GEMM is
 // K-streaming: its whole 256 x 64-pixel output tile lives in 256 accumulator registers (AGPRs; 4 waves x 512 registers, one wave per SIMD),
 // the K axis advances one residual-conv tile (32 channels = one weight chunk) at a time.  Two pixels per lane everywhere: 8-byte accesses of
-// whole 128-byte lines.  Per pixel the kernel reads 64 + 256 + 256 floats and writes 18, where the two kernels read 832 and wrote 274.
+// whole 128-byte lines.  Per pixel the kernel reads 64 + 256 floats (+ 18 spectrogram taps) and writes 18, where the two kernels read 832 and wrote 274.
 //   weights: residual conv resident in LDS (72 KB); mask conv streamed through LDS one 32-channel chunk (32 KB) at a time, double buffered,
 //            one barrier per chunk (= per 120 MFMAs); the chunk's A fragments are read in ACCUMULATOR-REGISTER K order (two 8-byte reads
 //            from two adjacent 16-byte pieces), so no permuted copy of the weight image is needed;
@@ -70,6 +70,7 @@ __global__ __launch_bounds__(F_NT) void tail_s3t_kernel(TailS3Args a, int ntiles
     // address per piece alive across the tile loop: 40 register pairs, spilled)
     const __amdgpu_buffer_rsrc_t ws = rsrc_of(reinterpret_cast<const float*>(a.w16));   // mask conv: [chunk 8][hi|lo][256 co][4 pieces of 8 k]
     const __amdgpu_buffer_rsrc_t ts = rsrc_of(reinterpret_cast<const float*>(a.w16b));  // taps: [m 4][part 2][s 2][hi|lo][32 taps][16 k]
+    const __amdgpu_buffer_rsrc_t is = rsrc_of(reinterpret_cast<const float*>(a.enc_img));  // encoder fragments (enc_stats_kernel)
     const unsigned voffW = (unsigned)tid * 16u, voffT = (unsigned)(r * 2 + h) * 16u;
     const unsigned voffB = ((unsigned)(8 * h) * CS + 2u * r) * 4u;
     const unsigned voffC = ((unsigned)(4 * h) * CS + 2u * r) * 4u;
@@ -139,17 +140,15 @@ __global__ __launch_bounds__(F_NT) void tail_s3t_kernel(TailS3Args a, int ntiles
                 xl[ks][1] = __builtin_bit_cast(half8, *reinterpret_cast<f32x4*>(lo1));
             }
         }
-        const __amdgpu_buffer_rsrc_t es = rsrc_of(a.a0 + (size_t)b * 256 * CS + wp0);
-        // encoder rows of group (m, s2): real rows c = 32m + 4h + (j & 3) + 8 (2 s2 + (j >> 2)), imaginary rows c + 128.  Three groups in flight: the
-        // first three are requested under the last chunk's MFMAs (the residual-conv operand and the residual ring are dead by then)
-        f32x2 E[4][16];
-        auto load_e = [&](int grp, f32x2 (&d)[16]) {
-            const int m = grp >> 1, s2 = grp & 1;
+        // The encoder output a0 (the complex product's other factor) is not read: its tiles are rebuilt on the matrix cores from this lane's
+        // nine spectrogram taps (pipe_helpers.h), requested under the last chunk's MFMAs together with the first tiles' encoder fragments
+        f32x2 V[9];
+        half8 ea[8];  // encoder A fragments of tiles m (real part) and m + 4 (imaginary part): [tile][K step][hi|lo]
+        auto load_ea = [&](int m) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const unsigned ro = (unsigned)(m * 32 + (j & 3) + 8 * (2 * s2 + (j >> 2))) * CS4;
-                d[j] = ld2(es, voffC, ro);
-                d[8 + j] = ld2(es, voffC, ro + 128u * CS4);
+            for (int i = 0; i < 4; ++i) {
+                ea[i] = ld_h8(is, voffT, (unsigned)(m * 4 + i) * 1024u);
+                ea[4 + i] = ld_h8(is, voffT, (unsigned)((m + 4) * 4 + i) * 1024u);
             }
         };
         STAMP(1);
@@ -212,9 +211,8 @@ __global__ __launch_bounds__(F_NT) void tail_s3t_kernel(TailS3Args a, int ntiles
             __syncthreads();  // chunk kc staged (buffer `buf`) and visible; everyone is done reading chunk kc - 1 (the other buffer)
             stage_load((kc + 1) & 7);  // chunk 0 again behind chunk 7: the next tile's first
             if (kc == 7) {
-                load_e(0, E[0]);
-                load_e(1, E[1]);
-                load_e(2, E[2]);
+                patch_load(spec_rsrc(a.spec + (size_t)b * 2 * P, P), wp0 + 2 * r, h, P, a.F, V);
+                load_ea(0);
             }
             // A fragments in accumulator-register K order: K slot (h, j) of step s is channel 16 s + 4 h + (j & 3) + 8 (j >> 2) of the chunk, i.e.
             // elements 4h .. 4h+3 of piece 2s and of piece 2s + 1
@@ -256,20 +254,16 @@ __global__ __launch_bounds__(F_NT) void tail_s3t_kernel(TailS3Args a, int ntiles
         }
         // ---- mask, complex product with the encoder output, taps GEMM (k_pwr.hip PWR_S3T), eight encoder rows (one K step of the taps GEMM) at a time
         float esc = 1.0f, eisc = WINV;
-        if (a.stats) {  // power of two nearest 1 / rms(a0) of this mixture (exponent arithmetic on the bits, wave-uniform)
-            const float ms = (float)(a.stats[2 * b + 1] * a.inv_count);
-            const int eb = (int)((__float_as_uint(ms) >> 23) & 0xFF) - 127;
-            int e = -(eb >> 1);
-            e = e < -40 ? -40 : (e > 40 ? 40 : e);
-            esc = __uint_as_float((unsigned)(127 + e) << 23);
-            eisc = __uint_as_float((unsigned)(127 - e - 8) << 23);
-        }
+        if (a.stats) rms_pow2(a.stats + 2 * b, a.inv_count, esc, eisc);  // power of two nearest 1 / rms(a0) of this mixture (wave-uniform)
+        PatchFrag pf;
+        patch_build(V, wp0 + 2 * r, a.T, a.F, P, esc, pf);
         f32x16 acc2[2];
 #pragma unroll
         for (int sl = 0; sl < 2; ++sl)
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc2[sl][q] = 0.f;
-        auto group = [&](int grp, const f32x2 (&e)[16]) {
+        f32x16 eR[2], eI[2];  // a0 x esc x 256 of tiles m / m + 4, per pixel slot
+        auto group = [&](int grp) {
             const int m = grp >> 1, s2 = grp & 1;
             // taps image: [m 4][part 2][s 2][hi|lo][32 taps][16 k] halfs -> 16-byte piece index ((idx*2 + hl)*32 + r)*2 + h
             const int idx_r = (m * 2 + 0) * 2 + s2, idx_i = (m * 2 + 1) * 2 + s2;
@@ -286,7 +280,7 @@ __global__ __launch_bounds__(F_NT) void tail_s3t_kernel(TailS3Args a, int ntiles
                     for (int i = 0; i < 4; ++i) {
                         const int j = 4 * g + i, q = 8 * s2 + j;
                         const float mr = fmaxf(fmaf(acc_rd(acc[m][sl][q]), WINV, br[i]), 0.f), mi = fmaxf(fmaf(acc_rd(acc[m + 4][sl][q]), WINV, bi[i]), 0.f);
-                        const float er = (sl ? e[j].y : e[j].x) * esc, ei = (sl ? e[8 + j].y : e[8 + j].x) * esc;
+                        const float er = eR[sl][q] * WINV, ei = eI[sl][q] * WINV;  // (already normalised: the patches carry esc)
                         o_r[j] = er * mr - ei * mi;
                         o_i[j] = er * mi + ei * mr;
                     }
@@ -309,12 +303,31 @@ __global__ __launch_bounds__(F_NT) void tail_s3t_kernel(TailS3Args a, int ntiles
             }
         };
 #pragma unroll
-        for (int grp = 0; grp < 8; ++grp) {
-            if (grp + 3 < 8) load_e(grp + 3, E[(grp + 3) & 3]);
+        for (int m = 0; m < 4; ++m) {
+            // encoder conv of channels 32 m .. (real) and 128 + 32 m .. (imaginary) at this wave's 64 pixels: K = 2 steps, f16x3
+#pragma unroll
+            for (int sl = 0; sl < 2; ++sl) {
+                mfma_v0(eR[sl], ea[0], pf.h[0][sl]);
+                mfma_v0(eI[sl], ea[4], pf.h[0][sl]);
+                mfma_v(eR[sl], ea[0], pf.l[0][sl]);
+                mfma_v(eI[sl], ea[4], pf.l[0][sl]);
+                mfma_v(eR[sl], ea[1], pf.h[0][sl]);
+                mfma_v(eI[sl], ea[5], pf.h[0][sl]);
+                mfma_v(eR[sl], ea[2], pf.h[1][sl]);
+                mfma_v(eI[sl], ea[6], pf.h[1][sl]);
+                mfma_v(eR[sl], ea[2], pf.l[1][sl]);
+                mfma_v(eI[sl], ea[6], pf.l[1][sl]);
+                mfma_v(eR[sl], ea[3], pf.h[1][sl]);
+                mfma_v(eI[sl], ea[7], pf.h[1][sl]);
+            }
+            mfma_v_fence4(eR[0], eR[1], eI[0], eI[1]);
+            if (m + 1 < 4) load_ea(m + 1);  // (the fragments are free again; they land under the two groups below)
             __builtin_amdgcn_sched_barrier(0);
-            group(grp, E[grp & 3]);
+            group(2 * m);
+            STAMP(10 + 2 * m);
+            group(2 * m + 1);
             __builtin_amdgcn_sched_barrier(0);
-            STAMP(10 + grp);
+            STAMP(11 + 2 * m);
         }
         mfma_v_fence(acc2[0], acc2[1]);
         const __amdgpu_buffer_rsrc_t zs = rsrc_of(a.z + (size_t)b * a.cout_live * CS + wp0);  // z (B, 18, cs)
@@ -338,7 +351,7 @@ __global__ __launch_bounds__(F_NT) void tail_s3t_kernel(TailS3Args a, int ntiles
 
 // RTFS_ERR_ARG = the call does not qualify (contiguous rows, tiny input): the caller runs the two separate kernels
 int launch_tail_s3t(const TailS3Args& a, int B, hipStream_t st) {
-    if (a.cs <= 0 || (a.cs & 63) || a.cs < (a.P + 63) / 64 * 64 || a.P < 64 || !a.w16b || a.cout_live > 24) return RTFS_ERR_ARG;
+    if (a.cs <= 0 || (a.cs & 63) || a.cs < (a.P + 63) / 64 * 64 || a.P < 64 || !a.w16b || a.cout_live > 24 || !a.spec || !a.enc_img || a.T * a.F != a.P) return RTFS_ERR_ARG;
     if ((size_t)256 * a.cs * 4 >= ((size_t)1 << 31)) return RTFS_ERR_ARG;
     if (rtfs_set_max_lds((const void*)tail_s3t_kernel, F_LDS) != RTFS_OK) return RTFS_ERR_LAUNCH;
     const int tps = cdiv(a.P, F_NT / 64 * 64), ntiles = tps * B;

@@ -95,13 +95,16 @@ struct BnHeadArgs {
     int P = 0, cs = 0;
     unsigned* tile_ctr = nullptr;
 };
+bool launch_bn_head_qualifies(const BnHeadArgs& a);  // same conditions as launch_tail_s3t (same P, same pitch)
 int launch_bn_head(const BnHeadArgs& a, int B, hipStream_t st);
 // residual conv of the last block application + S3 mask + complex product + decoder taps in one kernel (k_s3f.hip): padded rows only,
 // RTFS_ERR_ARG = call does not qualify, use launch_pws_residual + launch_pwr_s3_taps
 struct TailS3Args {
     const float* x = nullptr;     // expanded (B,64,cs)
     const float* res = nullptr;   // residual (B,256,cs)
-    const float* a0 = nullptr;    // encoder output (B,256,cs)
+    const float* spec = nullptr;  // spectrogram (B,2,T,F): the encoder output a0 is rebuilt on the fly, not read
+    const void* enc_img = nullptr;  // encoder f16x3 fragment image (enc_stats_kernel)
+    int T = 0, F = 0;
     float* z = nullptr;           // decoder taps (B,cout_live,cs)
     const void* w1_16 = nullptr;  // residual_conv f16x3 image [2][hi|lo][256][32]
     const float* b1 = nullptr;    // (256)
