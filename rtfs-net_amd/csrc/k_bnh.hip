@@ -162,6 +162,7 @@ __global__ __launch_bounds__(N_NT) void bn_head_kernel(BnHeadArgs a, int ntiles,
                 mfma_v(acc1[sl], e[3], pf.h[1][sl]);
             }
             mfma_v_fence(acc1[0], acc1[1]);
+            if (kc == 3) STAMP(20);
             if (kc + 1 < 8) load_ea(kc + 1, en);
             // gLN + ReLU; split: registers 8s .. 8s+7 of the tile = K step s of this chunk (accumulator order)
             half8 bh[2][2], bl[2][2];  // [K step][pixel slot]
@@ -190,8 +191,10 @@ __global__ __launch_bounds__(N_NT) void bn_head_kernel(BnHeadArgs a, int ntiles,
                 bh[s][1] = __builtin_bit_cast(half8, *reinterpret_cast<f32x4*>(h1));
                 bl[s][1] = __builtin_bit_cast(half8, *reinterpret_cast<f32x4*>(l1));
             }
+            if (kc == 3) STAMP(21);
             __builtin_amdgcn_sched_barrier(0);
             __syncthreads();  // chunk kc staged (buffer `buf`) and visible; everyone is done reading chunk kc - 1 (the other buffer)
+            if (kc == 3) STAMP(22);
             stage_load((kc + 1) & 7);  // chunk 0 again behind chunk 7: the next tile's first
             // A fragments in accumulator-register K order: K slot (h, j) of step s is channel 16 s + 4 h + (j & 3) + 8 (j >> 2) of the chunk, i.e.
             // elements 4h .. 4h+3 of piece 2s and of piece 2s + 1
@@ -220,6 +223,7 @@ __global__ __launch_bounds__(N_NT) void bn_head_kernel(BnHeadArgs a, int ntiles,
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if (kc == 3) STAMP(23);
             stage_write(buf ^ 1);
             __builtin_amdgcn_sched_barrier(0);
         };
@@ -308,7 +312,7 @@ __global__ __launch_bounds__(N_NT) void bn_head_kernel(BnHeadArgs a, int ntiles,
         STAMP(19);
 #ifdef BNH_STAMP
         if (blockIdx.x == 0 && tid == 0 && it < 16)
-            for (int i = 0; i < 20; ++i) bnh_stamps[it * 32 + i] = stamp[i];
+            for (int i = 0; i < 24; ++i) bnh_stamps[it * 32 + i] = stamp[i];
 #endif
         tile = ntile;
     }

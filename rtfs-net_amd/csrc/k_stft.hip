@@ -111,20 +111,25 @@ __global__ __launch_bounds__(256) void enc_conv_kernel(const float* __restrict__
 // fragment image for the consumers: [tile 8][K step 2][hi|lo][32 rows][h 2][8 halfs], K slot (h, j) of step 0 = tap j of input channel h
 // (re / im), of step 1 = tap 8 of channel h for j = 0 and zero above (weights x 256, as every f16x3 image of this library).
 __global__ __launch_bounds__(256) void enc_stats_kernel(const float* __restrict__ spec, const float* __restrict__ w, double* __restrict__ stats,
-                                                        _Float16* __restrict__ img, int T, int F) {
+                                                        _Float16* __restrict__ img, int T, int F, int ppt) {
+    __shared__ float W[256 * 18];
     __shared__ double G[171 + 18];  // G' rows i: entries j >= i at i*18 - i(i-1)/2 + (j - i); then wbar
     __shared__ double red[8];
     const int tid = threadIdx.x, b = blockIdx.y, P = T * F;
+    for (int i = tid; i < 256 * 18; i += 256) W[i] = w[i];
+    __syncthreads();
     if (tid < 171 + 18) {
         double acc = 0;
         if (tid < 171) {
             int i = 0, base = 0;
             while (tid >= base + 18 - i) { base += 18 - i; ++i; }
             const int j = i + tid - base;
-            for (int c = 0; c < 256; ++c) acc = fma((double)w[c * 18 + i], (double)w[c * 18 + j], acc);
+#pragma unroll 8
+            for (int c = 0; c < 256; ++c) acc = fma((double)W[c * 18 + i], (double)W[c * 18 + j], acc);
             if (j != i) acc *= 2.0;
         } else {
-            for (int c = 0; c < 256; ++c) acc += (double)w[c * 18 + tid - 171];
+#pragma unroll 8
+            for (int c = 0; c < 256; ++c) acc += (double)W[c * 18 + tid - 171];
         }
         G[tid] = acc;
     }
@@ -132,7 +137,7 @@ __global__ __launch_bounds__(256) void enc_stats_kernel(const float* __restrict_
         for (int e = tid; e < 8 * 2 * 32 * 2 * 8; e += 256) {  // (tile, step, row, h, j); hi and lo written together
             const int j = e & 7, h = (e >> 3) & 1, r = (e >> 4) & 31, s = (e >> 9) & 1, kc = e >> 10;
             const int c = kc * 32 + r;
-            const float v = s == 0 ? 256.0f * w[c * 18 + h * 9 + j] : (j == 0 ? 256.0f * w[c * 18 + h * 9 + 8] : 0.f);
+            const float v = s == 0 ? 256.0f * W[c * 18 + h * 9 + j] : (j == 0 ? 256.0f * W[c * 18 + h * 9 + 8] : 0.f);
             const _Float16 hi = (_Float16)v;
             const size_t o = ((size_t)((kc * 2 + s) * 2) * 64 + r * 2 + h) * 8 + j;
             img[o] = hi;
@@ -140,9 +145,10 @@ __global__ __launch_bounds__(256) void enc_stats_kernel(const float* __restrict_
         }
     }
     __syncthreads();
-    const int p = blockIdx.x * 256 + tid;
     double s1 = 0, s2 = 0;
-    if (p < P) {
+    for (int it = 0; it < ppt; ++it) {  // (ppt pixels per thread: the prologue above is per workgroup)
+        const int p = (blockIdx.x * ppt + it) * 256 + tid;
+        if (p >= P) break;
         const int t = p / F, f = p - t * F;
         double q[18];
 #pragma unroll
@@ -255,7 +261,8 @@ int launch_enc_conv(const float* spec, const float* w, float* a0, double* stats,
 }
 
 int launch_enc_stats(const float* spec, const float* w, double* stats, void* img, int B, int T, int F, hipStream_t st) {
-    hipLaunchKernelGGL(enc_stats_kernel, dim3(cdiv(T * F, 256), B), dim3(256), 0, st, spec, w, stats, reinterpret_cast<_Float16*>(img), T, F);
+    const int ppt = B * cdiv(T * F, 256) >= 2048 ? 4 : 1;
+    hipLaunchKernelGGL(enc_stats_kernel, dim3(cdiv(T * F, 256 * ppt), B), dim3(256), 0, st, spec, w, stats, reinterpret_cast<_Float16*>(img), T, F, ppt);
     return rtfs_launch_status();
 }
 

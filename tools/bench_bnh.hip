@@ -1,6 +1,7 @@
 // Diagnostic harness (not part of the product): the fused bottleneck + block head kernel of rtfs-net_amd/csrc/k_bnh.hip alone at the bench
 // shape (B=32, P=32379, padded rows), timed, and - built with -DBNH_STAMP - with s_memtime stamps at the phase boundaries of workgroup 0's first tiles.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize [-DBNH_STAMP] -Irtfs-net_amd/csrc -o tools/_bbnh tools/bench_bnh.hip rtfs-net_amd/csrc/runtime.hip
+#include "../rtfs-net_amd/csrc/k_stft.hip"
 #include "../rtfs-net_amd/csrc/k_bnh.hip"
 #include <cstdio>
 #include <vector>
@@ -8,21 +9,24 @@
 int main(int argc, char** argv) {
     const int B = argc > 1 ? atoi(argv[1]) : 32;
     const int P = 32379, cs = (P + 63) / 64 * 64;
-    float *a0, *a1, *res, *xe, *par;
+    const int T = 251, F = 129;
+    float *a0, *a1, *res, *xe, *par, *wenc;
+    void* encimg;
     double* st;
     unsigned* ctr;
-    CK(hipMalloc(&a0, (size_t)B * 256 * cs * 4)); CK(hipMalloc(&a1, (size_t)B * 256 * cs * 4)); CK(hipMalloc(&res, (size_t)B * 256 * cs * 4));
+    CK(hipMalloc(&a0, (size_t)B * 2 * P * 4 + 64)); CK(hipMalloc(&wenc, 256 * 18 * 4)); CK(hipMalloc(&encimg, 32768)); CK(hipMalloc(&a1, (size_t)B * 256 * cs * 4)); CK(hipMalloc(&res, (size_t)B * 256 * cs * 4));
     CK(hipMalloc(&xe, (size_t)B * 64 * cs * 4)); CK(hipMalloc(&par, 1 << 20)); CK(hipMalloc(&st, B * 16)); CK(hipMalloc(&ctr, 256));
     {
         std::vector<float> h((size_t)64 * cs);
         for (size_t i = 0; i < h.size(); ++i) h[i] = (float)((i * 2654435761u) >> 8 & 0xffff) / 65536.f - 0.5f;
-        for (int i = 0; i < B * 4; ++i) CK(hipMemcpy(a0 + (size_t)i * 64 * cs, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+        for (int i = 0; i < B; ++i) CK(hipMemcpy(a0 + (size_t)i * 2 * P, h.data(), (size_t)2 * P * 4, hipMemcpyHostToDevice));
+        CK(hipMemcpy(wenc, h.data(), 256 * 18 * 4, hipMemcpyHostToDevice));
         CK(hipMemset(par, 0, 1 << 20));  // all-zero weight images: the timing does not depend on the values
-        std::vector<double> hs(2 * B, 1e6);
-        CK(hipMemcpy(st, hs.data(), B * 16, hipMemcpyHostToDevice));
+        CK(hipMemset(st, 0, B * 16));
+        if (launch_enc_stats(a0, wenc, st, encimg, B, T, F, 0)) return 1;
     }
     BnHeadArgs a;
-    a.x = a0; a.a1 = a1; a.res = res; a.xenc = xe;
+    a.spec = a0; a.enc_img = encimg; a.T = T; a.F = F; a.a1 = a1; a.res = res; a.xenc = xe;
     a.stats = st; a.inv_count = 1.0 / (256.0 * P); a.gamma = par + 16384; a.beta = par + 16384;
     a.w16 = par + 32768; a.bias = par + 16384; a.gw = par + 16384; a.gb = par + 16384; a.slope = par + 16384; a.w2_16 = par; a.bp = par + 16384;
     a.P = P; a.cs = cs; a.tile_ctr = ctr;
@@ -39,7 +43,7 @@ int main(int argc, char** argv) {
         float ms; (void)hipEventElapsedTime(&ms, e0, e1);
         if (i >= 3) { sum += ms; best = ms < best ? ms : best; }
     }
-    const double bytes = (double)B * (256 + 256 + 256 + 64) * cs * 4;
+    const double bytes = (double)B * (256 + 256 + 64) * cs * 4;
     printf("B=%d bn_head  avg %.1f us  best %.1f us  %.2f TB/s (avg)\n", B, sum / R * 1e3, best * 1e3, bytes / (sum / R * 1e-3) / 1e12);
 #ifdef BNH_STAMP
     unsigned h[16 * 32];
@@ -51,7 +55,8 @@ int main(int argc, char** argv) {
         for (int k = 0; k < 8; ++k) printf(" %5u", s[2 + k] - s[1 + k]);
         printf(" |");
         for (int g = 0; g < 8; ++g) printf(" %5u", s[10 + g] - s[9 + g]);
-        printf(" | st %5u | bar %5u | total %6u\n", s[18] - s[17], s[19] - s[18], s[19] - s[0]);
+        printf(" | st %5u | bar %5u | total %6u", s[18] - s[17], s[19] - s[18], s[19] - s[0]);
+        printf(" || chunk 3: gemm1 %u valu %u barrier %u mfma %u stage-write %u\n", s[20] - s[4], s[21] - s[20], s[22] - s[21], s[23] - s[22], s[5] - s[23]);
     }
 #endif
     return 0;
