@@ -110,8 +110,9 @@ __global__ __launch_bounds__(256) void enc_conv_kernel(const float* __restrict__
 // entries doubled) in LDS from the 256 x 18 weights (256 iterations per thread); workgroup (0, 0) also writes the encoder's f16 hi / lo
 // fragment image for the consumers: [tile 8][K step 2][hi|lo][32 rows][h 2][8 halfs], K slot (h, j) of step 0 = tap j of input channel h
 // (re / im), of step 1 = tap 8 of channel h for j = 0 and zero above (weights x 256, as every f16x3 image of this library).
+template <int PPT>  // pixels per thread, processed TOGETHER: every G' entry read from LDS (a broadcast read still moves 512 bytes) serves PPT pixels
 __global__ __launch_bounds__(256) void enc_stats_kernel(const float* __restrict__ spec, const float* __restrict__ w, double* __restrict__ stats,
-                                                        _Float16* __restrict__ img, int T, int F, int ppt) {
+                                                        _Float16* __restrict__ img, int T, int F) {
     __shared__ float W[256 * 18];
     __shared__ double G[171 + 18];  // G' rows i: entries j >= i at i*18 - i(i-1)/2 + (j - i); then wbar
     __shared__ double red[8];
@@ -146,31 +147,44 @@ __global__ __launch_bounds__(256) void enc_stats_kernel(const float* __restrict_
     }
     __syncthreads();
     double s1 = 0, s2 = 0;
-    for (int it = 0; it < ppt; ++it) {  // (ppt pixels per thread: the prologue above is per workgroup)
-        const int p = (blockIdx.x * ppt + it) * 256 + tid;
-        if (p >= P) break;
-        const int t = p / F, f = p - t * F;
-        double q[18];
+    {
+        double q[PPT][18];
 #pragma unroll
-        for (int ci = 0; ci < 2; ++ci)
+        for (int it = 0; it < PPT; ++it) {
+            const int p = (blockIdx.x * PPT + it) * 256 + tid;
+            const bool live = p < P;
+            const int t = live ? p / F : 0, f = live ? p - t * F : 0;
 #pragma unroll
-            for (int dt = 0; dt < 3; ++dt)
+            for (int ci = 0; ci < 2; ++ci)
 #pragma unroll
-                for (int df = 0; df < 3; ++df) {
-                    const int tt = t + dt - 1, ff = f + df - 1;
-                    const bool ok = tt >= 0 && tt < T && ff >= 0 && ff < F;
-                    const int tc = tt < 0 ? 0 : (tt < T ? tt : T - 1), fc = ff < 0 ? 0 : (ff < F ? ff : F - 1);
-                    const float v = spec[((size_t)b * 2 + ci) * P + (size_t)tc * F + fc];  // unconditional, clamped
-                    q[ci * 9 + dt * 3 + df] = ok ? (double)v : 0.0;
-                }
+                for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+                    for (int df = 0; df < 3; ++df) {
+                        const int tt = t + dt - 1, ff = f + df - 1;
+                        const bool ok = live && tt >= 0 && tt < T && ff >= 0 && ff < F;
+                        const int tc = tt < 0 ? 0 : (tt < T ? tt : T - 1), fc = ff < 0 ? 0 : (ff < F ? ff : F - 1);
+                        const float v = spec[((size_t)b * 2 + ci) * P + (size_t)tc * F + fc];  // unconditional, clamped
+                        q[it][ci * 9 + dt * 3 + df] = ok ? (double)v : 0.0;
+                    }
+        }
         int k = 0;
 #pragma unroll
         for (int i = 0; i < 18; ++i) {
-            double u = 0;
+            double u[PPT];
 #pragma unroll
-            for (int j = i; j < 18; ++j) u = fma(G[k++], q[j], u);
-            s2 = fma(q[i], u, s2);
-            s1 = fma(G[171 + i], q[i], s1);
+            for (int it = 0; it < PPT; ++it) u[it] = 0;
+#pragma unroll
+            for (int j = i; j < 18; ++j) {
+                const double g = G[k++];
+#pragma unroll
+                for (int it = 0; it < PPT; ++it) u[it] = fma(g, q[it][j], u[it]);
+            }
+            const double wb = G[171 + i];
+#pragma unroll
+            for (int it = 0; it < PPT; ++it) {
+                s2 = fma(q[it][i], u[it], s2);
+                s1 = fma(wb, q[it][i], s1);
+            }
         }
     }
     s1 = wave_sum_d(s1);
@@ -261,8 +275,10 @@ int launch_enc_conv(const float* spec, const float* w, float* a0, double* stats,
 }
 
 int launch_enc_stats(const float* spec, const float* w, double* stats, void* img, int B, int T, int F, hipStream_t st) {
-    const int ppt = B * cdiv(T * F, 256) >= 2048 ? 4 : 1;
-    hipLaunchKernelGGL(enc_stats_kernel, dim3(cdiv(T * F, 256 * ppt), B), dim3(256), 0, st, spec, w, stats, reinterpret_cast<_Float16*>(img), T, F, ppt);
+    if (B * cdiv(T * F, 256) >= 2048)
+        hipLaunchKernelGGL(enc_stats_kernel<4>, dim3(cdiv(T * F, 256 * 4), B), dim3(256), 0, st, spec, w, stats, reinterpret_cast<_Float16*>(img), T, F);
+    else
+        hipLaunchKernelGGL(enc_stats_kernel<1>, dim3(cdiv(T * F, 256), B), dim3(256), 0, st, spec, w, stats, reinterpret_cast<_Float16*>(img), T, F);
     return rtfs_launch_status();
 }
 
