@@ -949,7 +949,7 @@ int separator_part(const SepPacks& k, const float* wav, const float* video_vp, f
         f.P = P; f.cs = cs;
         f.tile_ctr = w.ctr + nctr;
         if (launch_bn_head_qualifies(f)) {
-            CHECK(launch_enc_stats(w.spec, pe.w, w.st0, w.encimg, B, T, NF, st));
+            CHECK(launch_enc_stats(w.spec, pe.w, w.st0, w.encimg, EncPadJobs(), B, T, NF, st));
             CHECK(launch_bn_head(f, B, st));
             ++nctr;
             head_done = true;

@@ -86,22 +86,29 @@ __global__ __launch_bounds__(N_NT) void bn_head_kernel(BnHeadArgs a, int ntiles,
     unsigned lww0 = OFF_W + (unsigned)((tid >> 2) * N_ROWB + (tid & 3) * 16), lww1 = lww0 + N_BUF;  // staging writes
     asm volatile("" : "+v"(lw2), "+v"(lc4), "+v"(lwr0), "+v"(lwr1), "+v"(lww0), "+v"(lww1));
     half8 pre[8];
+    auto stage_load_piece = [&](int c, int j) { pre[j] = ld_h8(ws, voffW, (unsigned)(c * 2048 + 256 * j) * 16u); };
     auto stage_load = [&](int c) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) pre[j] = ld_h8(ws, voffW, (unsigned)(c * 2048 + 256 * j) * 16u);
+        for (int j = 0; j < 8; ++j) stage_load_piece(c, j);
+    };
+    auto stage_write_piece = [&](int buf, int j) {
+        // piece tid + 256 j: row (tid >> 2) + 64 (j & 3) of part j >> 2 (rows are 72 bytes apart: two 8-byte halves)
+        u64_* d = reinterpret_cast<u64_*>(smem + (buf ? lww1 : lww0) + (j >> 2) * N_PART + 64 * (j & 3) * N_ROWB);
+        const u64_* sp = reinterpret_cast<const u64_*>(&pre[j]);
+        d[0] = sp[0];
+        d[1] = sp[1];
     };
     auto stage_write = [&](int buf) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            // piece tid + 256 j: row (tid >> 2) + 64 (j & 3) of part j >> 2 (rows are 72 bytes apart: two 8-byte halves)
-            u64_* d = reinterpret_cast<u64_*>(smem + (buf ? lww1 : lww0) + (j >> 2) * N_PART + 64 * (j & 3) * N_ROWB);
-            const u64_* sp = reinterpret_cast<const u64_*>(&pre[j]);
-            d[0] = sp[0];
-            d[1] = sp[1];
-        }
+        for (int j = 0; j < 8; ++j) stage_write_piece(buf, j);
     };
     stage_load(0);
     stage_write(0);
+    // Phase stagger: every workgroup does the same work per tile, so without it all 256 CUs write their tiles' 576 rows at the same time and
+    // then leave the memory system idle through the next K loop (the first output tile of an epilogue took 8-13 k cycles, the others 3 k).
+    // Workgroups start a quarter of a tile apart in four groups; the tile counter keeps them apart.
+    if (a.stagger)
+        for (int i = 0; i < (int)((blockIdx.x >> 3) & 3) * a.stagger; ++i) __builtin_amdgcn_s_sleep(127);
 
     // this lane's nine spectrogram taps (two pixels each) of the tile: carried across tiles, the next tile's are requested BEFORE this tile's
     // 576 row stores (behind them the first loads of a tile waited 13k cycles of a 97k-cycle tile)
@@ -134,13 +141,14 @@ __global__ __launch_bounds__(N_NT) void bn_head_kernel(BnHeadArgs a, int ntiles,
         __syncthreads();  // sc / sh (and, first tile, the resident tables) visible
         PatchFrag pf;
         patch_build(V, p0, T, F, P, esc, pf);
-        // encoder A fragments of 32-channel tile c: [K step][hi|lo], one tile ahead (L2-resident 32 KB image)
-        half8 ea[2][4];
-        auto load_ea = [&](int c, half8 (&d)[4]) {
+        // encoder A fragments of 32-channel tile c: [K step][hi|lo] (L2-resident 32 KB image), requested one chunk before their use
+        half8 ea[4];
+        auto load_ea_piece = [&](int c, int i) { ea[i] = ld_h8(is, voffT, (unsigned)(c * 4 + i) * 1024u); };
+        auto load_ea = [&](int c) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) d[i] = ld_h8(is, voffT, (unsigned)(c * 4 + i) * 1024u);
+            for (int i = 0; i < 4; ++i) load_ea_piece(c, i);
         };
-        load_ea(0, ea[0]);
+        load_ea(0);
         STAMP(1);
         f32x16 acc[8][2];  // bottleneck conv: [output tile][pixel slot]
 #pragma unroll
@@ -149,53 +157,74 @@ __global__ __launch_bounds__(N_NT) void bn_head_kernel(BnHeadArgs a, int ntiles,
             for (int sl = 0; sl < 2; ++sl)
 #pragma unroll
                 for (int q = 0; q < 16; ++q) acc[m][sl][q] = 0.f;
-        auto chunk = [&](int kc, const half8 (&e)[4], half8 (&en)[4], int buf) {
-            // encoder conv of channels 32 kc .. 32 kc + 31 at this wave's 64 pixels: K = 2 steps, f16x3
-            f32x16 acc1[2];
+        // ---- software pipeline over the eight K chunks: while the 96 matrix instructions of chunk kc issue, chunk kc + 1 is prepared in their
+        // shadow - its encoder tile (12 matrix instructions, at the head of the phase), then gLN + ReLU + f16 split in slices of 4-6 VALU
+        // instructions, one slice per gap between two matrix instructions (one wave per SIMD: nothing else would fill the gaps), then the
+        // staging writes of the next weight chunk.  A chunk cost 5.5 k cycles with the phases in sequence (0.5 k encoder GEMM, 0.9 k VALU,
+        // 3.5 k matrix instructions, 0.5 k staging writes).
+        half8 bh[2][2][2], bl[2][2][2];  // [chunk parity][K step][pixel slot]
+        f32x16 acc1[2];
+        float y0[8], y1[8];
+        f32x4 kk[2][2];  // gLN scale / shift of four channels, [group parity][scale | shift]: read one group ahead (a wait for them also waits
+                         // for the fragment reads queued in front: 4 x ~250 exposed cycles per chunk when they were read at their use)
+        unsigned h0[4], l0[4], h1[4], l1[4];
+        auto gemm1 = [&]() {  // encoder conv of the tile whose fragments are in ea: K = 2 steps, f16x3
 #pragma unroll
             for (int sl = 0; sl < 2; ++sl) {
-                mfma_v0(acc1[sl], e[0], pf.h[0][sl]);
-                mfma_v(acc1[sl], e[0], pf.l[0][sl]);
-                mfma_v(acc1[sl], e[1], pf.h[0][sl]);
-                mfma_v(acc1[sl], e[2], pf.h[1][sl]);
-                mfma_v(acc1[sl], e[2], pf.l[1][sl]);
-                mfma_v(acc1[sl], e[3], pf.h[1][sl]);
+                mfma_v0(acc1[sl], ea[0], pf.h[0][sl]);
+                mfma_v(acc1[sl], ea[0], pf.l[0][sl]);
+                mfma_v(acc1[sl], ea[1], pf.h[0][sl]);
+                mfma_v(acc1[sl], ea[2], pf.h[1][sl]);
+                mfma_v(acc1[sl], ea[2], pf.l[1][sl]);
+                mfma_v(acc1[sl], ea[3], pf.h[1][sl]);
             }
-            mfma_v_fence(acc1[0], acc1[1]);
-            if (kc == 3) STAMP(20);
-            if (kc + 1 < 8) load_ea(kc + 1, en);
-            // gLN + ReLU; split: registers 8s .. 8s+7 of the tile = K step s of this chunk (accumulator order)
-            half8 bh[2][2], bl[2][2];  // [K step][pixel slot]
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                float y0[8], y1[8];
-#pragma unroll
-                for (int g = 0; g < 2; ++g) {
-                    const unsigned co = (unsigned)(kc * 32 + 8 * (2 * s + g)) * 4u;  // channel kc*32 + 4 h + 8 (2 s + g)
-                    const f32x4 ks = *reinterpret_cast<const f32x4*>(smem + lc4 + co), kt = *reinterpret_cast<const f32x4*>(smem + lc4 + 1024 + co);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int j = 4 * g + i, q = 8 * s + j;
-                        y0[j] = fmaxf(fmaf(acc1[0][q], ks[i], kt[i]), 0.f);
-                        y1[j] = fmaxf(fmaf(acc1[1][q], ks[i], kt[i]), 0.f);
-                    }
+        };
+        auto side_consts = [&](int c, int gi) {  // channels c*32 + 4 h + 8 gi ..
+            const unsigned co = (unsigned)(c * 32 + 8 * gi) * 4u;
+            kk[gi & 1][0] = *reinterpret_cast<const f32x4*>(smem + lc4 + co);
+            kk[gi & 1][1] = *reinterpret_cast<const f32x4*>(smem + lc4 + 1024 + co);
+        };
+        // slice `step` (0 .. 31) of chunk c's gLN + ReLU + split: registers 8s .. 8s+7 of the encoder tile = K step s of the chunk (accumulator
+        // order).  A slice is 3-4 VALU instructions: what fits beside one matrix instruction without delaying the next
+        auto side = [&](int c, int step) {
+            const int s = step >> 4, u = step & 15;
+            if (u < 8) {
+                const int g = u >> 2, i = u & 3, j = 4 * g + i, q = 8 * s + j, gi = 2 * s + g;
+                if (i == 0 && gi < 3) side_consts(c, gi + 1);
+                y0[j] = fmaxf(fmaf(acc1[0][q], kk[gi & 1][0][i], kk[gi & 1][1][i]), 0.f);
+                y1[j] = fmaxf(fmaf(acc1[1][q], kk[gi & 1][0][i], kk[gi & 1][1][i]), 0.f);
+            } else {
+                const int jp = (u - 8) >> 1;
+                if (u & 1) split2(y1[2 * jp], y1[2 * jp + 1], h1[jp], l1[jp]);
+                else split2(y0[2 * jp], y0[2 * jp + 1], h0[jp], l0[jp]);
+                if (u == 15) {
+                    bh[c & 1][s][0] = __builtin_bit_cast(half8, *reinterpret_cast<f32x4*>(h0));
+                    bl[c & 1][s][0] = __builtin_bit_cast(half8, *reinterpret_cast<f32x4*>(l0));
+                    bh[c & 1][s][1] = __builtin_bit_cast(half8, *reinterpret_cast<f32x4*>(h1));
+                    bl[c & 1][s][1] = __builtin_bit_cast(half8, *reinterpret_cast<f32x4*>(l1));
                 }
-                unsigned h0[4], l0[4], h1[4], l1[4];
-#pragma unroll
-                for (int jp = 0; jp < 4; ++jp) {
-                    split2(y0[2 * jp], y0[2 * jp + 1], h0[jp], l0[jp]);
-                    split2(y1[2 * jp], y1[2 * jp + 1], h1[jp], l1[jp]);
-                }
-                bh[s][0] = __builtin_bit_cast(half8, *reinterpret_cast<f32x4*>(h0));
-                bl[s][0] = __builtin_bit_cast(half8, *reinterpret_cast<f32x4*>(l0));
-                bh[s][1] = __builtin_bit_cast(half8, *reinterpret_cast<f32x4*>(h1));
-                bl[s][1] = __builtin_bit_cast(half8, *reinterpret_cast<f32x4*>(l1));
             }
-            if (kc == 3) STAMP(21);
+        };
+        gemm1();
+        side_consts(0, 0);
+        mfma_v_fence(acc1[0], acc1[1]);
+        load_ea(1);
+#pragma unroll
+        for (int step = 0; step < 32; ++step) side(0, step);
+        gemm1();  // chunk 1's encoder tile (its slices run in the shadow of chunk 0's matrix instructions)
+        side_consts(1, 0);
+        // (two chunks per trip - the buffer parity is static - and four trips: fully unrolled the kernel was 80 KB of code, more than the
+        // instruction cache two CUs share; the work for "chunk 8" behind the last one is done on wrapped indices and dropped: no branches)
+#pragma unroll 2
+        for (int kc = 0; kc < 8; ++kc) {
+            const int buf = kc & 1;
             __builtin_amdgcn_sched_barrier(0);
             __syncthreads();  // chunk kc staged (buffer `buf`) and visible; everyone is done reading chunk kc - 1 (the other buffer)
-            if (kc == 3) STAMP(22);
-            stage_load((kc + 1) & 7);  // chunk 0 again behind chunk 7: the next tile's first
+            // (the 12 loads of a chunk - next weight chunk, next encoder fragments - are spread over the matrix-instruction gaps below: issued
+            // together behind the barrier by all four waves they queued on the CU's one address unit for ~800 cycles, a fifth of a chunk)
+#ifdef BNH_STAMP
+            if (kc == 2) STAMP(20);
+#endif
             // A fragments in accumulator-register K order: K slot (h, j) of step s is channel 16 s + 4 h + (j & 3) + 8 (j >> 2) of the chunk, i.e.
             // elements 4h .. 4h+3 of piece 2s and of piece 2s + 1
             auto afrag = [&](int m, int s, int part) {
@@ -213,23 +242,23 @@ __global__ __launch_bounds__(N_NT) void bn_head_kernel(BnHeadArgs a, int ntiles,
                     al[(m + 1) & 1][0] = afrag(m + 1, 0, 1); al[(m + 1) & 1][1] = afrag(m + 1, 1, 1);
                 }
 #pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m & 1][s], bh[s][0], acc[m][0], 0, 0, 0);
-                    acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m & 1][s], bh[s][1], acc[m][1], 0, 0, 0);
-                    acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m & 1][s], bl[s][0], acc[m][0], 0, 0, 0);
-                    acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m & 1][s], bl[s][1], acc[m][1], 0, 0, 0);
-                    acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m & 1][s], bh[s][0], acc[m][0], 0, 0, 0);
-                    acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m & 1][s], bh[s][1], acc[m][1], 0, 0, 0);
+                for (int t = 0; t < 12; ++t) {
+                    const int s = t / 6, sl = t & 1, v = (t % 6) >> 1;  // products hi*hi, hi*lo, lo*hi of K step s, the two pixel slots alternating
+                    acc[m][sl] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v == 2 ? al[m & 1][s] : ah[m & 1][s], v == 1 ? bl[buf][s][sl] : bh[buf][s][sl], acc[m][sl], 0, 0, 0);
+                    if (m >= 1 && (m - 1) * 12 + t < 32) side((kc + 1) & 7, (m - 1) * 12 + t);
+                    if ((m == 0 || m == 4) && t % 3 == 0) stage_load_piece((kc + 1) & 7, (m >> 2) * 4 + t / 3);  // chunk 0 again behind chunk 7: the next tile's first
+                    if (m == 3 && t >= 8) load_ea_piece((kc + 2) & 7, t - 8);
+                    if ((m == 5 || m == 7) && t < 4) stage_write_piece(buf ^ 1, (m == 5 ? 0 : 4) + t);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                __builtin_amdgcn_sched_barrier(0);
+#ifdef BNH_STAMP
+                if (kc == 2 && m < 7) STAMP(21 + m);
+#endif
             }
-            if (kc == 3) STAMP(23);
-            stage_write(buf ^ 1);
-            __builtin_amdgcn_sched_barrier(0);
-        };
-#pragma unroll
-        for (int kc = 0; kc < 8; ++kc) {
-            chunk(kc, ea[kc & 1], ea[(kc + 1) & 1], kc & 1);
+            // chunk kc + 2's encoder tile, issued BEFORE the barrier: the matrix pipe works on it while the four waves meet.  Its first reader
+            // is a slice 12+ matrix instructions behind the barrier (no wait states needed); chunk kc + 1's slices are through with acc1.
+            gemm1();
+            side_consts((kc + 2) & 7, 0);
             STAMP(2 + kc);
         }
         // ---- epilogue: a1 and the gateway output written through, projection from the accumulator registers
@@ -312,7 +341,7 @@ __global__ __launch_bounds__(N_NT) void bn_head_kernel(BnHeadArgs a, int ntiles,
         STAMP(19);
 #ifdef BNH_STAMP
         if (blockIdx.x == 0 && tid == 0 && it < 16)
-            for (int i = 0; i < 24; ++i) bnh_stamps[it * 32 + i] = stamp[i];
+            for (int i = 0; i < 28; ++i) bnh_stamps[it * 32 + i] = stamp[i];
 #endif
         tile = ntile;
     }

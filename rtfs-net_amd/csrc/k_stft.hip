@@ -112,7 +112,20 @@ __global__ __launch_bounds__(256) void enc_conv_kernel(const float* __restrict__
 // (re / im), of step 1 = tap 8 of channel h for j = 0 and zero above (weights x 256, as every f16x3 image of this library).
 template <int PPT>  // pixels per thread, processed TOGETHER: every G' entry read from LDS (a broadcast read still moves 512 bytes) serves PPT pixels
 __global__ __launch_bounds__(256) void enc_stats_kernel(const float* __restrict__ spec, const float* __restrict__ w, double* __restrict__ stats,
-                                                        _Float16* __restrict__ img, int T, int F) {
+                                                        _Float16* __restrict__ img, int T, int F, EncPadJobs pad, int B) {
+    if ((int)blockIdx.y == B) {  // extra block row: the head / tail kernels' padded weight images (see EncPadJobs)
+        typedef unsigned long long u64;
+        for (int job = 0; job < 2; ++job) {
+            const u64* src = reinterpret_cast<const u64*>(pad.src[job]);
+            u64* dst = reinterpret_cast<u64*>(pad.dst[job]);
+            if (!src || !dst) continue;
+            for (int i = blockIdx.x * 256 + threadIdx.x; i < 4096 * 9; i += gridDim.x * 256) {
+                const int row = i / 9, c = i - row * 9;
+                dst[i] = c < 8 ? src[row * 8 + c] : 0ull;
+            }
+        }
+        return;
+    }
     __shared__ float W[256 * 18];
     __shared__ double G[171 + 18];  // G' rows i: entries j >= i at i*18 - i(i-1)/2 + (j - i); then wbar
     __shared__ double red[8];
@@ -274,11 +287,12 @@ int launch_enc_conv(const float* spec, const float* w, float* a0, double* stats,
     return rtfs_launch_status();
 }
 
-int launch_enc_stats(const float* spec, const float* w, double* stats, void* img, int B, int T, int F, hipStream_t st) {
+int launch_enc_stats(const float* spec, const float* w, double* stats, void* img, const EncPadJobs& pad, int B, int T, int F, hipStream_t st) {
+    const int gy = B + ((pad.src[0] && pad.dst[0]) || (pad.src[1] && pad.dst[1]) ? 1 : 0);
     if (B * cdiv(T * F, 256) >= 2048)
-        hipLaunchKernelGGL(enc_stats_kernel<4>, dim3(cdiv(T * F, 256 * 4), B), dim3(256), 0, st, spec, w, stats, reinterpret_cast<_Float16*>(img), T, F);
+        hipLaunchKernelGGL(enc_stats_kernel<4>, dim3(cdiv(T * F, 256 * 4), gy), dim3(256), 0, st, spec, w, stats, reinterpret_cast<_Float16*>(img), T, F, pad, B);
     else
-        hipLaunchKernelGGL(enc_stats_kernel<1>, dim3(cdiv(T * F, 256), B), dim3(256), 0, st, spec, w, stats, reinterpret_cast<_Float16*>(img), T, F);
+        hipLaunchKernelGGL(enc_stats_kernel<1>, dim3(cdiv(T * F, 256), gy), dim3(256), 0, st, spec, w, stats, reinterpret_cast<_Float16*>(img), T, F, pad, B);
     return rtfs_launch_status();
 }
 

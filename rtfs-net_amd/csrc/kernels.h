@@ -37,7 +37,14 @@ int launch_stft(const float* wav, float* spec, int B, int L, int T, hipStream_t 
 int launch_enc_conv(const float* spec, const float* w, float* a0, double* stats, int B, int C, int T, int F, size_t cs,
                     size_t bs, hipStream_t st);
 // gLN statistics of the encoder output computed from the spectrogram (a0 is not formed) + the encoder's f16x3 fragment image (32 KB at img)
-int launch_enc_stats(const float* spec, const float* w, double* stats, void* img, int B, int T, int F, hipStream_t st);
+// + (one extra row of workgroups) up to two 256 -> 256 f16x3 weight images [8 chunks][hi|lo][256 rows][64 B] copied with their rows padded to
+// 72 bytes (294912 B each): the LDS image of the head / tail kernels, which they fetch by LDS-DMA - a DMA writes LDS linearly, so the
+// conflict-free row padding has to exist in memory
+struct EncPadJobs {
+    const void* src[2] = {nullptr, nullptr};
+    void* dst[2] = {nullptr, nullptr};
+};
+int launch_enc_stats(const float* spec, const float* w, double* stats, void* img, const EncPadJobs& pad, int B, int T, int F, hipStream_t st);
 int launch_dec_istft(const float* z, float* wav, int B, int T, int F, int L, size_t zcs, size_t zbs, hipStream_t st);
 
 int launch_pw_audio_bn(const PwArgs& a, int B, hipStream_t st);
@@ -93,6 +100,7 @@ struct BnHeadArgs {
     const void* w2_16 = nullptr;    // projection f16x3 image [8][hi|lo][64][32], K in accumulator order
     const float* bp = nullptr;      // (64)
     int P = 0, cs = 0;
+    int stagger = 2;                // start offset between the four workgroup groups, in units of 8128 cycles (s_sleep 127); 0 = none
     unsigned* tile_ctr = nullptr;
 };
 bool launch_bn_head_qualifies(const BnHeadArgs& a);  // same conditions as launch_tail_s3t (same P, same pitch)

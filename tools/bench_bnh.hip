@@ -23,13 +23,14 @@ int main(int argc, char** argv) {
         CK(hipMemcpy(wenc, h.data(), 256 * 18 * 4, hipMemcpyHostToDevice));
         CK(hipMemset(par, 0, 1 << 20));  // all-zero weight images: the timing does not depend on the values
         CK(hipMemset(st, 0, B * 16));
-        if (launch_enc_stats(a0, wenc, st, encimg, B, T, F, 0)) return 1;
+        if (launch_enc_stats(a0, wenc, st, encimg, EncPadJobs(), B, T, F, 0)) return 1;
     }
     BnHeadArgs a;
     a.spec = a0; a.enc_img = encimg; a.T = T; a.F = F; a.a1 = a1; a.res = res; a.xenc = xe;
     a.stats = st; a.inv_count = 1.0 / (256.0 * P); a.gamma = par + 16384; a.beta = par + 16384;
     a.w16 = par + 32768; a.bias = par + 16384; a.gw = par + 16384; a.gb = par + 16384; a.slope = par + 16384; a.w2_16 = par; a.bp = par + 16384;
     a.P = P; a.cs = cs; a.tile_ctr = ctr;
+    if (argc > 2) a.stagger = atoi(argv[2]);
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     float best = 1e9f, sum = 0;
@@ -56,7 +57,9 @@ int main(int argc, char** argv) {
         printf(" |");
         for (int g = 0; g < 8; ++g) printf(" %5u", s[10 + g] - s[9 + g]);
         printf(" | st %5u | bar %5u | total %6u", s[18] - s[17], s[19] - s[18], s[19] - s[0]);
-        printf(" || chunk 3: gemm1 %u valu %u barrier %u mfma %u stage-write %u\n", s[20] - s[4], s[21] - s[20], s[22] - s[21], s[23] - s[22], s[5] - s[23]);
+        printf(" || chunk 2: barrier+gemm1 %u | m0..7:", s[20] - s[3]);
+        for (int m = 0; m < 7; ++m) printf(" %u", s[21 + m] - s[20 + m]);
+        printf(" %u\n", s[4] - s[27]);
     }
 #endif
     return 0;

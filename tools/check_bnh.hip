@@ -41,7 +41,7 @@ int main(int argc, char** argv) {
     CK(hipMemset(zero, 0, 1 << 18)); CK(hipMemset(st, 0, 512)); CK(hipMemset(st2, 0, 512));
     CK(hipMemset(a0, 0, (size_t)B * 256 * cs * 4));
     if (launch_enc_conv(dspec, dwenc, a0, st, B, 256, T, F, cs, (size_t)256 * cs, 0)) return 1;
-    if (launch_enc_stats(dspec, dwenc, st2, encimg, B, T, F, 0)) return 1;
+    if (launch_enc_stats(dspec, dwenc, st2, encimg, EncPadJobs(), B, T, F, 0)) return 1;
     if (argc > 3) {  // unit statistics, unit gamma, zero beta / bias: a1 = ReLU(a0)
         double fake[4] = {0, 256.0 * P, 0, 256.0 * P};
         CK(hipMemcpy(st, fake, 32, hipMemcpyHostToDevice)); CK(hipMemcpy(st2, fake, 32, hipMemcpyHostToDevice));
