@@ -78,20 +78,22 @@ __global__ __launch_bounds__(F_NT) void tail_s3t_kernel(TailS3Args a, int ntiles
     // mask-conv weight chunk c -> registers -> LDS buffer (2048 16-byte pieces, 8 per thread, contiguous in the image; rows are 72 bytes
     // apart, so a piece is written as two 8-byte halves)
     half8 pre[8];
+    auto stage_load_piece = [&](int c, int j) { pre[j] = ld_h8(ws, voffW, (unsigned)(c * 2048 + 256 * j) * 16u); };
     auto stage_load = [&](int c) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) pre[j] = ld_h8(ws, voffW, (unsigned)(c * 2048 + 256 * j) * 16u);
+        for (int j = 0; j < 8; ++j) stage_load_piece(c, j);
+    };
+    auto stage_write_piece = [&](int buf, int j) {
+        const int i = tid + 256 * j;
+        const int kq = i & 3, co = (i >> 2) & 255, part = i >> 10;
+        u64_* d = reinterpret_cast<u64_*>(Wb + buf * F_BUF + part * F_PART + co * F_ROWB + kq * 16);
+        const u64_* sp = reinterpret_cast<const u64_*>(&pre[j]);
+        d[0] = sp[0];
+        d[1] = sp[1];
     };
     auto stage_write = [&](int buf) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int i = tid + 256 * j;
-            const int kq = i & 3, co = (i >> 2) & 255, part = i >> 10;
-            u64_* d = reinterpret_cast<u64_*>(Wb + buf * F_BUF + part * F_PART + co * F_ROWB + kq * 16);
-            const u64_* sp = reinterpret_cast<const u64_*>(&pre[j]);
-            d[0] = sp[0];
-            d[1] = sp[1];
-        }
+        for (int j = 0; j < 8; ++j) stage_write_piece(buf, j);
     };
     stage_load(0);
     stage_write(0);
@@ -179,6 +181,7 @@ __global__ __launch_bounds__(F_NT) void tail_s3t_kernel(TailS3Args a, int ntiles
                 mfma_v(acc1[1], al, xh[ks][1]);
             }
             mfma_v_fence(acc1[0], acc1[1]);
+            if (kc == 3) STAMP(20);
             // refined = conv + bias + residual; the mask head's PReLU; split: registers 8s .. 8s+7 of the tile = K step s of this chunk
             half8 bh[2][2], bl[2][2];  // [K step][pixel slot]
             const int cob = kc * 32 + 4 * h;
@@ -207,9 +210,12 @@ __global__ __launch_bounds__(F_NT) void tail_s3t_kernel(TailS3Args a, int ntiles
                 bl[s][1] = __builtin_bit_cast(half8, *reinterpret_cast<f32x4*>(l1));
             }
             if (kc + 1 < 8) load_res(kc + 1, Rb);  // (uniform) the next tile's residual rows fly under this chunk's 96 MFMAs
+            if (kc == 3) STAMP(21);
             __builtin_amdgcn_sched_barrier(0);
-            __syncthreads();  // chunk kc staged (buffer `buf`) and visible; everyone is done reading chunk kc - 1 (the other buffer)
-            stage_load((kc + 1) & 7);  // chunk 0 again behind chunk 7: the next tile's first
+            __syncthreads();
+            if (kc == 3) STAMP(22);  // chunk kc staged (buffer `buf`) and visible; everyone is done reading chunk kc - 1 (the other buffer)
+            // (the next weight chunk - chunk 0 again behind chunk 7: the next tile's first - is requested two pieces per output tile below: all
+            // eight behind the barrier, from all four waves at once, queued on the CU's one address unit for ~800 cycles; k_bnh.hip)
             if (kc == 7) {
                 patch_load(spec_rsrc(a.spec + (size_t)b * 2 * P, P), wp0 + 2 * r, h, P, a.F, V);
                 load_ea(0);
@@ -239,10 +245,11 @@ __global__ __launch_bounds__(F_NT) void tail_s3t_kernel(TailS3Args a, int ntiles
                     acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m & 1][s], bl[s][1], acc[m][1], 0, 0, 0);
                     acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m & 1][s], bh[s][0], acc[m][0], 0, 0, 0);
                     acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m & 1][s], bh[s][1], acc[m][1], 0, 0, 0);
+                    if (m < 4) stage_load_piece((kc + 1) & 7, 2 * m + s);
+                    else stage_write_piece(buf ^ 1, 2 * (m - 4) + s);  // (its load is four output tiles = 1.5 k cycles old)
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            stage_write(buf ^ 1);
             __builtin_amdgcn_sched_barrier(0);
         };
 #pragma unroll
@@ -341,7 +348,7 @@ __global__ __launch_bounds__(F_NT) void tail_s3t_kernel(TailS3Args a, int ntiles
         STAMP(19);
 #ifdef S3F_STAMP
         if (blockIdx.x == 0 && tid == 0 && it < 16)
-            for (int i = 0; i < 20; ++i) s3f_stamps[it * 32 + i] = stamp[i];
+            for (int i = 0; i < 24; ++i) s3f_stamps[it * 32 + i] = stamp[i];
 #endif
         tile = s_next[it & 1];
     }

@@ -58,7 +58,7 @@ int main(int argc, char** argv) {
         for (int k = 0; k < 8; ++k) printf(" %5u", s[2 + k] - s[1 + k]);
         printf(" |");
         for (int g = 0; g < 8; ++g) printf(" %5u", s[10 + g] - s[9 + g]);
-        printf(" | st %5u | bar %5u | total %6u\n", s[18] - s[17], s[19] - s[18], s[19] - s[0]);
+        printf(" | st %5u | bar %5u | total %6u || chunk 3: gemm1 %u valu+R %u barrier %u mfma %u\n", s[18] - s[17], s[19] - s[18], s[19] - s[0], s[20] - s[4], s[21] - s[20], s[22] - s[21], s[5] - s[22]);
     }
 #endif
     return 0;
