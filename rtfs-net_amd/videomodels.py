@@ -15,56 +15,82 @@ from . import _lib, packing
 
 
 # The trunk holds no arithmetic here (the fused front-end call does it all): it is a tree of parameter holders whose
-# state_dict keys, order, shapes and default initialisation are those a reference checkpoint carries (resnet.py:23-118).
-# One row per residual stage: (stage name, input width, width, stride of its first unit); two units per stage.
-_TRUNK_STAGES = (("layer1", 64, 64, 1), ("layer2", 64, 128, 2), ("layer3", 128, 256, 2), ("layer4", 256, 512, 2))
-_UNITS_PER_STAGE = 2
+# state_dict keys, order, shapes, construction order (= consumption of the random stream) and final initialisation pass are
+# those of the reference's ResNet (resnet.py:5-121), under the reference's public names.
+def conv3x3(in_planes: int, out_planes: int, stride: int = 1) -> nn.Conv2d:
+    """resnet.py:5-6."""
+    return nn.Conv2d(in_planes, out_planes, kernel_size=3, stride=stride, padding=1, bias=False)
 
 
-def _unit_entries(cin: int, width: int, stride: int):
-    """(key, kind, dims) of one residual unit, in checkpoint order.  kind: 'c' conv (cout, cin, k, stride), 'n' batch norm
-    (channels), 'a' per-channel PReLU slope (channels)."""
-    rows = [("conv1", "c", (width, cin, 3, stride)), ("bn1", "n", (width,)), ("relu1", "a", (width,)), ("relu2", "a", (width,)),
-            ("conv2", "c", (width, width, 3, 1)), ("bn2", "n", (width,))]
-    if stride != 1 or cin != width:  # the 1x1 projection on the skip path where the shape changes
-        rows.append(("downsample", "s", (("0", "c", (width, cin, 1, stride)), ("1", "n", (width,)))))
-    return rows
+def downsample_basic_block(inplanes: int, outplanes: int, stride: int) -> nn.Sequential:
+    """The 1x1 projection + batch norm on a skip path whose shape changes (resnet.py:9-13)."""
+    return nn.Sequential(nn.Conv2d(inplanes, outplanes, kernel_size=1, stride=stride, bias=False), nn.BatchNorm2d(outplanes))
 
 
-def _holder(kind: str, dims) -> nn.Module:
-    if kind == "c":
-        cout, cin, k, stride = dims
-        m = nn.Conv2d(cin, cout, k, stride, k // 2, bias=False)
-        nn.init.normal_(m.weight, 0.0, math.sqrt(2.0 / (k * k * cout)))  # resnet.py:90-94
-        return m
-    if kind == "n":
-        return nn.BatchNorm2d(*dims)  # weight 1, bias 0 (resnet.py:95-97 == torch's default)
-    if kind == "a":
-        return nn.PReLU(num_parameters=dims[0])
-    seq = nn.Sequential()
-    for key, k2, d2 in dims:
-        seq.add_module(key, _holder(k2, d2))
-    return seq
+class BasicBlock(nn.Module):
+    """Parameter holder of one residual unit (resnet.py:24-50): conv1, bn1, relu1, relu2, conv2, bn2 in checkpoint order, then
+    ``downsample`` (None where the skip path is the identity) and ``stride``.  Only the PReLU variant is on the MI355X path."""
+    expansion = 1
 
-
-class _Holders(nn.Module):
-    """A module that only owns named children built from a table."""
-
-    def __init__(self, rows):
+    def __init__(self, inplanes, planes, stride=1, downsample=None, relu_type="prelu"):
         super().__init__()
-        for key, kind, dims in rows:
-            self.add_module(key, _holder(kind, dims))
+        if relu_type != "prelu":
+            raise ValueError("MI355X video trunk: relu_type='prelu' only")
+        self.conv1 = conv3x3(inplanes, planes, stride)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.relu1 = nn.PReLU(num_parameters=planes)
+        self.relu2 = nn.PReLU(num_parameters=planes)
+        self.conv2 = conv3x3(planes, planes)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        raise RuntimeError("the MI355X video trunk runs inside rtfs_video_frontend_f32 (FRCNNVideoModel.forward), not unit by unit")
+
+
+class ResNet(nn.Module):
+    """ResNet-18 trunk as the reference builds it (resnet.py:68-121): four stages of two BasicBlocks, widths 64 .. 512, the first
+    unit of stages 2-4 strided with a projected skip path; convolutions re-drawn N(0, sqrt(2 / (k*k*cout))) and batch norms reset
+    in ONE pass over modules() after construction (so a seed gives the reference's initial weights); ``gamma_zero`` zeroes each
+    unit's last batch-norm scale.  Configurations the fused front-end kernel does not implement are rejected here."""
+
+    def __init__(self, block=BasicBlock, layers=(2, 2, 2, 2), num_classes=1000, relu_type="prelu", gamma_zero=False, avg_pool_downsample=False):
+        super().__init__()
+        if list(layers) != [2, 2, 2, 2] or block is not BasicBlock:
+            raise ValueError("MI355X video trunk: ResNet-18 (BasicBlock, layers [2, 2, 2, 2]) only")
+        if avg_pool_downsample:
+            raise ValueError("MI355X video trunk: avg_pool_downsample is not implemented (the RTFS-Net recipes do not use it)")
+        self.inplanes, self.relu_type, self.gamma_zero = 64, relu_type, gamma_zero
+        self.downsample_block = downsample_basic_block
+        for i, (planes, stride) in enumerate(((64, 1), (128, 2), (256, 2), (512, 2))):
+            setattr(self, f"layer{i + 1}", self._make_layer(block, planes, layers[i], stride))
+        self.avgpool = nn.AdaptiveAvgPool2d(1)
+        for m in self.modules():  # resnet.py:90-97
+            if isinstance(m, nn.Conv2d):
+                nn.init.normal_(m.weight, 0.0, math.sqrt(2.0 / (m.kernel_size[0] * m.kernel_size[1] * m.out_channels)))
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.ones_(m.weight)
+                nn.init.zeros_(m.bias)
+        if gamma_zero:  # resnet.py:99-104
+            for m in self.modules():
+                if isinstance(m, BasicBlock):
+                    nn.init.zeros_(m.bn2.weight)
+
+    def _make_layer(self, block, planes, blocks, stride=1):
+        # the projection is built BEFORE its unit (resnet.py:106-121): the order in which default initialisers draw from the random stream
+        skip = self.downsample_block(self.inplanes, planes * block.expansion, stride) if stride != 1 or self.inplanes != planes * block.expansion else None
+        units = [block(self.inplanes, planes, stride, skip, relu_type=self.relu_type)]
+        self.inplanes = planes * block.expansion
+        units += [block(self.inplanes, planes, relu_type=self.relu_type) for _ in range(1, blocks)]
+        return nn.Sequential(*units)
+
+    def forward(self, x):
+        raise RuntimeError("the MI355X video trunk runs inside rtfs_video_frontend_f32 (FRCNNVideoModel.forward)")
 
 
 def _trunk(gamma_zero: bool = False) -> nn.Module:
-    trunk = nn.Module()
-    for name, cin, width, stride in _TRUNK_STAGES:
-        units = [_Holders(_unit_entries(cin if u == 0 else width, width, stride if u == 0 else 1)) for u in range(_UNITS_PER_STAGE)]
-        if gamma_zero:
-            for u in units:
-                nn.init.zeros_(u.bn2.weight)
-        trunk.add_module(name, nn.Sequential(*units))
-    return trunk
+    return ResNet(BasicBlock, [2, 2, 2, 2], relu_type="prelu", gamma_zero=gamma_zero)
 
 
 class FRCNNVideoModel(nn.Module):
