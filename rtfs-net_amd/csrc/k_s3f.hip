@@ -71,32 +71,24 @@ __global__ __launch_bounds__(F_NT) void tail_s3t_kernel(TailS3Args a, int ntiles
     const __amdgpu_buffer_rsrc_t ws = rsrc_of(reinterpret_cast<const float*>(a.w16));   // mask conv: [chunk 8][hi|lo][256 co][4 pieces of 8 k]
     const __amdgpu_buffer_rsrc_t ts = rsrc_of(reinterpret_cast<const float*>(a.w16b));  // taps: [m 4][part 2][s 2][hi|lo][32 taps][16 k]
     const __amdgpu_buffer_rsrc_t is = rsrc_of(reinterpret_cast<const float*>(a.enc_img));  // encoder fragments (enc_stats_kernel)
-    const unsigned voffW = (unsigned)tid * 16u, voffT = (unsigned)(r * 2 + h) * 16u;
+    const unsigned voffT = (unsigned)(r * 2 + h) * 16u;
     const unsigned voffB = ((unsigned)(8 * h) * CS + 2u * r) * 4u;
     const unsigned voffC = ((unsigned)(4 * h) * CS + 2u * r) * 4u;
 
-    // mask-conv weight chunk c -> registers -> LDS buffer (2048 16-byte pieces, 8 per thread, contiguous in the image; rows are 72 bytes
-    // apart, so a piece is written as two 8-byte halves)
-    half8 pre[8];
-    auto stage_load_piece = [&](int c, int j) { pre[j] = ld_h8(ws, voffW, (unsigned)(c * 2048 + 256 * j) * 16u); };
-    auto stage_load = [&](int c) {
+    // mask-conv weight chunk c -> LDS buffer by LDS-DMA (`buffer_load_dwordx4 ... lds`: no staging registers, no ds_write pass).  A DMA
+    // instruction writes 1 KB of LDS linearly (lane x 16 bytes), so the image in memory already has the LDS image's 72-byte rows
+    // (enc_stats_kernel's extra block row pads the pack's 64-byte rows, kernels.h EncPadJobs): a chunk is 36 KB = 36 pieces, 9 per wave.
+    // The pieces count on vmcnt like loads; `__syncthreads()` waits for them (the compiler knows an LDS write is pending).
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    const unsigned voffL = (unsigned)lane * 16u;
+    int wave1k = wave * 1024;  // (laundered per tile below: the 72 piece offsets of a tile are loop invariants, and hoisted they spill 120 SGPRs)
+    auto stage_dma_piece = [&](int c, int buf, int j) {
+        const int po = j * 4096 + wave1k;  // uniform: piece j * 4 + wave
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ws, (lds_ptr)(Wb + buf * F_BUF + po), 16, voffL, c * F_BUF + po, 0, 0);
+    };
 #pragma unroll
-        for (int j = 0; j < 8; ++j) stage_load_piece(c, j);
-    };
-    auto stage_write_piece = [&](int buf, int j) {
-        const int i = tid + 256 * j;
-        const int kq = i & 3, co = (i >> 2) & 255, part = i >> 10;
-        u64_* d = reinterpret_cast<u64_*>(Wb + buf * F_BUF + part * F_PART + co * F_ROWB + kq * 16);
-        const u64_* sp = reinterpret_cast<const u64_*>(&pre[j]);
-        d[0] = sp[0];
-        d[1] = sp[1];
-    };
-    auto stage_write = [&](int buf) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) stage_write_piece(buf, j);
-    };
-    stage_load(0);
-    stage_write(0);
+    for (int j = 0; j < 9; ++j) stage_dma_piece(0, 0, j);
+
 
     int it = 0;
     for (int tile = blockIdx.x; tile < ntiles; ++it) {
@@ -107,7 +99,7 @@ __global__ __launch_bounds__(F_NT) void tail_s3t_kernel(TailS3Args a, int ntiles
         STAMP(0);
         unsigned CS4 = CS4_;
         int nlive = a.cout_live;
-        asm volatile("" : "+s"(CS4), "+s"(nlive));  // row offsets are formed where they are used (one s_mul each): hoisted out of the tile loop they cost 300 SGPRs
+        asm volatile("" : "+s"(CS4), "+s"(nlive), "+s"(wave1k));  // row offsets are formed where they are used (one s_mul each): hoisted out of the tile loop they cost 300 SGPRs
         const int b = tile / tps;
         // a wave segment past the sample's end repeats the last real one (same values to the same addresses): every wave takes part in every barrier
         const int wp0 = min((tile - b * tps) * (F_NT / 64 * 64) + wave * 64, lastw);
@@ -209,13 +201,13 @@ __global__ __launch_bounds__(F_NT) void tail_s3t_kernel(TailS3Args a, int ntiles
                 bh[s][1] = __builtin_bit_cast(half8, *reinterpret_cast<f32x4*>(h1));
                 bl[s][1] = __builtin_bit_cast(half8, *reinterpret_cast<f32x4*>(l1));
             }
-            if (kc + 1 < 8) load_res(kc + 1, Rb);  // (uniform) the next tile's residual rows fly under this chunk's 96 MFMAs
             if (kc == 3) STAMP(21);
             __builtin_amdgcn_sched_barrier(0);
             __syncthreads();
             if (kc == 3) STAMP(22);  // chunk kc staged (buffer `buf`) and visible; everyone is done reading chunk kc - 1 (the other buffer)
-            // (the next weight chunk - chunk 0 again behind chunk 7: the next tile's first - is requested two pieces per output tile below: all
-            // eight behind the barrier, from all four waves at once, queued on the CU's one address unit for ~800 cycles; k_bnh.hip)
+            // the next chunk's residual rows: requested BEHIND the barrier (in front of it the barrier's wait for the weight DMA would also wait
+            // for them); the next weight chunk - chunk 0 again behind chunk 7: the next tile's first - follows piece by piece in the matrix phase
+            if (kc + 1 < 8) load_res(kc + 1, Rb);
             if (kc == 7) {
                 patch_load(spec_rsrc(a.spec + (size_t)b * 2 * P, P), wp0 + 2 * r, h, P, a.F, V);
                 load_ea(0);
@@ -245,8 +237,7 @@ __global__ __launch_bounds__(F_NT) void tail_s3t_kernel(TailS3Args a, int ntiles
                     acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m & 1][s], bl[s][1], acc[m][1], 0, 0, 0);
                     acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m & 1][s], bh[s][0], acc[m][0], 0, 0, 0);
                     acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m & 1][s], bh[s][1], acc[m][1], 0, 0, 0);
-                    if (m < 4) stage_load_piece((kc + 1) & 7, 2 * m + s);
-                    else stage_write_piece(buf ^ 1, 2 * (m - 4) + s);  // (its load is four output tiles = 1.5 k cycles old)
+                    if (2 * m + s < 9) stage_dma_piece((kc + 1) & 7, buf ^ 1, 2 * m + s);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }

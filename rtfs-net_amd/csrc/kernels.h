@@ -116,7 +116,7 @@ struct TailS3Args {
     float* z = nullptr;           // decoder taps (B,cout_live,cs)
     const void* w1_16 = nullptr;  // residual_conv f16x3 image [2][hi|lo][256][32]
     const float* b1 = nullptr;    // (256)
-    const void* w16 = nullptr;    // mask conv f16x3 image [8][hi|lo][256][32]
+    const void* w16 = nullptr;    // mask conv f16x3 image [8][hi|lo][256 rows of 72 bytes: 32 halfs + 8 bytes of padding] (EncPadJobs)
     const float* bias = nullptr;  // (256)
     const float* slope = nullptr; // mask head PReLU (1)
     const void* w16b = nullptr;   // K-permuted taps image (packing.taps_perm_image)
