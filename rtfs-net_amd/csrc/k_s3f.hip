@@ -78,7 +78,8 @@ __global__ __launch_bounds__(F_NT) void tail_s3t_kernel(TailS3Args a, int ntiles
     // mask-conv weight chunk c -> LDS buffer by LDS-DMA (`buffer_load_dwordx4 ... lds`: no staging registers, no ds_write pass).  A DMA
     // instruction writes 1 KB of LDS linearly (lane x 16 bytes), so the image in memory already has the LDS image's 72-byte rows
     // (enc_stats_kernel's extra block row pads the pack's 64-byte rows, kernels.h EncPadJobs): a chunk is 36 KB = 36 pieces, 9 per wave.
-    // The pieces count on vmcnt like loads; `__syncthreads()` waits for them (the compiler knows an LDS write is pending).
+    // The pieces count on vmcnt like loads; the barrier that publishes a chunk is preceded by an explicit `s_waitcnt vmcnt(0)` (the compiler's
+    // own wait for a pending LDS write is missing at a loop header, see below).
     typedef __attribute__((address_space(3))) void* lds_ptr;
     const unsigned voffL = (unsigned)lane * 16u;
     int wave1k = wave * 1024;  // (laundered per tile below: the 72 piece offsets of a tile are loop invariants, and hoisted they spill 120 SGPRs)
@@ -104,7 +105,8 @@ __global__ __launch_bounds__(F_NT) void tail_s3t_kernel(TailS3Args a, int ntiles
         // a wave segment past the sample's end repeats the last real one (same values to the same addresses): every wave takes part in every barrier
         const int wp0 = min((tile - b * tps) * (F_NT / 64 * 64) + wave * 64, lastw);
         const __amdgpu_buffer_rsrc_t xs = rsrc_of(a.x + (size_t)b * 64 * CS + wp0);
-        const __amdgpu_buffer_rsrc_t rs = rsrc_of(a.res + (size_t)b * 256 * CS + wp0);
+        // (exact size: the pipeline below requests the rows of "chunks 8 and 9" behind the last one - out of range, they return 0 without a memory access)
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.res + (size_t)b * 256 * CS + wp0), 0, (int)((256u * CS - (unsigned)wp0) * 4u), 0x00020000);
         // ---- residual rows of 32-channel tile m, one tile ahead
         f32x2 R[16];
         auto load_res = [&](int m, f32x2 (&Rb)[16]) {
@@ -153,13 +155,24 @@ __global__ __launch_bounds__(F_NT) void tail_s3t_kernel(TailS3Args a, int ntiles
             for (int sl = 0; sl < 2; ++sl)
 #pragma unroll
                 for (int q = 0; q < 16; ++q) acc[m][sl][q] = 0.f;
-        // one K chunk: residual-conv tile kc -> refined tile -> PReLU -> B fragments -> 96 MFMAs of the mask conv
-        auto chunk = [&](int kc, f32x2 (&Rb)[16], int buf) {
-            f32x16 acc1[2];
+        // ---- software pipeline over the eight K chunks (the recipe of k_bnh.hip): while the 96 matrix instructions of chunk kc issue, chunk
+        // kc + 1 is prepared in their shadow.  Its residual-conv tile was computed in FRONT of the previous barrier (24 matrix instructions the
+        // pipe works on while the four waves meet); bias + residual + PReLU + f16 split run in 48 slices of 3-4 VALU instructions, one per gap
+        // between two matrix instructions, writing a second set of B fragments; every residual row is re-requested (two chunks ahead) by the
+        // slice that consumed it; the weight chunk's nine DMA pieces sit in gaps too.  A chunk cost 6.4 k cycles with the phases in sequence
+        // (1.0 k residual GEMM, 1.5 k VALU, 3.7 k matrix phase).
+        half8 bh[2][2][2], bl[2][2][2];  // [chunk parity][K step][pixel slot]
+        f32x16 acc1[2];
+        float y[4];
+        f32x4 kk[2];  // residual-conv bias of four channels, read one group ahead
+        unsigned hh[2][4], ll[2][4];
+        const float pc1 = 0.5f * (1.0f + slope), pc2 = 0.5f * (1.0f - slope);  // PReLU(x) = pc1 x + pc2 |x| (two instructions, any slope)
+        auto gemm1 = [&](int c) {  // residual conv of channels 32 c .. (weights resident in LDS): K = 64, f16x3
+            const int row = ((c & 7) * 32 + r) * L1 + 8 * h;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const half8 ah = *reinterpret_cast<const half8*>(W1h + (kc * 32 + r) * L1 + ks * 16 + 8 * h);
-                const half8 al = *reinterpret_cast<const half8*>(W1l + (kc * 32 + r) * L1 + ks * 16 + 8 * h);
+                const half8 ah = *reinterpret_cast<const half8*>(W1h + row + ks * 16);
+                const half8 al = *reinterpret_cast<const half8*>(W1l + row + ks * 16);
                 if (ks == 0) {
                     mfma_v0(acc1[0], ah, xh[0][0]);
                     mfma_v0(acc1[1], ah, xh[0][1]);
@@ -172,46 +185,46 @@ __global__ __launch_bounds__(F_NT) void tail_s3t_kernel(TailS3Args a, int ntiles
                 mfma_v(acc1[0], al, xh[ks][0]);
                 mfma_v(acc1[1], al, xh[ks][1]);
             }
-            mfma_v_fence(acc1[0], acc1[1]);
-            if (kc == 3) STAMP(20);
-            // refined = conv + bias + residual; the mask head's PReLU; split: registers 8s .. 8s+7 of the tile = K step s of this chunk
-            half8 bh[2][2], bl[2][2];  // [K step][pixel slot]
-            const int cob = kc * 32 + 4 * h;
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                float y0[8], y1[8];
-#pragma unroll
-                for (int g = 0; g < 2; ++g) {
-                    const f32x4 kb = *reinterpret_cast<const f32x4*>(b1 + cob + 8 * (2 * s + g));
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int j = 4 * g + i, q = 8 * s + j;
-                        y0[j] = preluf_(fmaf(acc1[0][q], WINV, kb[i]) + Rb[q].x, slope);
-                        y1[j] = preluf_(fmaf(acc1[1][q], WINV, kb[i]) + Rb[q].y, slope);
-                    }
+        };
+        auto side_consts = [&](int c, int gi) {  // channels 32 c + 4 h + 8 gi ..
+            kk[gi & 1] = *reinterpret_cast<const f32x4*>(b1 + (c & 7) * 32 + 4 * h + 8 * gi);
+        };
+        // slice `step` (0 .. 47) of chunk c.  Per group of four channels gi = 2 s + g (12 slices; the group's bias is live in kk[gi & 1] for all of
+        // them, the next group's is requested by the first): pixel slot 0's four values, its two splits, slot 1's four values (each re-requests
+        // its residual row for chunk `creload` once both slots have read it), its two splits
+        auto side = [&](int c, int step, int creload) {
+            const int gi = step / 12, s = gi >> 1, g = gi & 1, u = step % 12, sl = u / 6, v = u % 6;
+            if (v < 4) {
+                const int q = 8 * s + 4 * g + v;
+                if (u == 0 && gi < 3) side_consts(c, gi + 1);
+                const float x = fmaf(acc1[sl][q], WINV, kk[gi & 1][v]) + (sl ? R[q].y : R[q].x);
+                y[v] = fmaf(pc2, __builtin_fabsf(x), pc1 * x);
+                if (sl == 1) R[q] = ld2(rs, voffC, (unsigned)(creload * 32 + (q & 3) + 8 * (q >> 2)) * CS4);
+            } else {
+                const int jl = v - 4, jp = 2 * g + jl;  // pair (4 g + 2 jl, 4 g + 2 jl + 1) of K step s
+                split2(y[2 * jl], y[2 * jl + 1], hh[sl][jp], ll[sl][jp]);
+                if (g == 1 && jl == 1) {
+                    bh[c & 1][s][sl] = __builtin_bit_cast(half8, *reinterpret_cast<f32x4*>(hh[sl]));
+                    bl[c & 1][s][sl] = __builtin_bit_cast(half8, *reinterpret_cast<f32x4*>(ll[sl]));
                 }
-                unsigned h0[4], l0[4], h1[4], l1[4];
-#pragma unroll
-                for (int jp = 0; jp < 4; ++jp) {
-                    split2(y0[2 * jp], y0[2 * jp + 1], h0[jp], l0[jp]);
-                    split2(y1[2 * jp], y1[2 * jp + 1], h1[jp], l1[jp]);
-                }
-                bh[s][0] = __builtin_bit_cast(half8, *reinterpret_cast<f32x4*>(h0));
-                bl[s][0] = __builtin_bit_cast(half8, *reinterpret_cast<f32x4*>(l0));
-                bh[s][1] = __builtin_bit_cast(half8, *reinterpret_cast<f32x4*>(h1));
-                bl[s][1] = __builtin_bit_cast(half8, *reinterpret_cast<f32x4*>(l1));
             }
-            if (kc == 3) STAMP(21);
+        };
+        gemm1(0);
+        side_consts(0, 0);
+        mfma_v_fence(acc1[0], acc1[1]);
+#pragma unroll
+        for (int step = 0; step < 48; ++step) side(0, step, 1);
+        gemm1(1);
+        side_consts(1, 0);
+#pragma unroll 2
+        for (int kc = 0; kc < 8; ++kc) {
+            const int buf = kc & 1;
             __builtin_amdgcn_sched_barrier(0);
-            __syncthreads();
-            if (kc == 3) STAMP(22);  // chunk kc staged (buffer `buf`) and visible; everyone is done reading chunk kc - 1 (the other buffer)
-            // the next chunk's residual rows: requested BEHIND the barrier (in front of it the barrier's wait for the weight DMA would also wait
-            // for them); the next weight chunk - chunk 0 again behind chunk 7: the next tile's first - follows piece by piece in the matrix phase
-            if (kc + 1 < 8) load_res(kc + 1, Rb);
-            if (kc == 7) {
-                patch_load(spec_rsrc(a.spec + (size_t)b * 2 * P, P), wp0 + 2 * r, h, P, a.F, V);
-                load_ea(0);
-            }
+            // chunk kc's DMA pieces must have landed before the barrier publishes them.  The compiler inserts this wait only where it sees the
+            // DMA on a straight path: at the loop header - pieces issued on the back edge - it emitted none, and one run in three a mixture
+            // came out different from its batch-1 run.  (It also drains the residual rows requested three output tiles ago: they are due anyway.)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();  // chunk kc staged (buffer `buf`) and visible; everyone is done reading chunk kc - 1 (the other buffer)
             // A fragments in accumulator-register K order: K slot (h, j) of step s is channel 16 s + 4 h + (j & 3) + 8 (j >> 2) of the chunk, i.e.
             // elements 4h .. 4h+3 of piece 2s and of piece 2s + 1
             const unsigned char* wb = Wb + buf * F_BUF + r * F_ROWB + 8 * h;
@@ -225,31 +238,28 @@ __global__ __launch_bounds__(F_NT) void tail_s3t_kernel(TailS3Args a, int ntiles
             al[0][0] = afrag(0, 0, 1); al[0][1] = afrag(0, 1, 1);
 #pragma unroll
             for (int m = 0; m < 8; ++m) {
-                if (m + 1 < 8) {  // tile m + 1's fragments are requested before tile m's twelve MFMAs; nothing moves across a tile
+                if (m + 1 < 8) {  // tile m + 1's fragments are requested before tile m's twelve MFMAs
                     ah[(m + 1) & 1][0] = afrag(m + 1, 0, 0); ah[(m + 1) & 1][1] = afrag(m + 1, 1, 0);
                     al[(m + 1) & 1][0] = afrag(m + 1, 0, 1); al[(m + 1) & 1][1] = afrag(m + 1, 1, 1);
                 }
 #pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m & 1][s], bh[s][0], acc[m][0], 0, 0, 0);
-                    acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m & 1][s], bh[s][1], acc[m][1], 0, 0, 0);
-                    acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m & 1][s], bl[s][0], acc[m][0], 0, 0, 0);
-                    acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m & 1][s], bl[s][1], acc[m][1], 0, 0, 0);
-                    acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m & 1][s], bh[s][0], acc[m][0], 0, 0, 0);
-                    acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m & 1][s], bh[s][1], acc[m][1], 0, 0, 0);
-                    if (2 * m + s < 9) stage_dma_piece((kc + 1) & 7, buf ^ 1, 2 * m + s);
+                for (int t = 0; t < 12; ++t) {
+                    const int s = t / 6, sl = t & 1, v = (t % 6) >> 1;  // products hi*hi, hi*lo, lo*hi of K step s, the two pixel slots alternating
+                    acc[m][sl] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v == 2 ? al[m & 1][s] : ah[m & 1][s], v == 1 ? bl[buf][s][sl] : bh[buf][s][sl], acc[m][sl], 0, 0, 0);
+                    if (m >= 1 && m <= 4) side(kc + 1, (m - 1) * 12 + t, kc + 2);  // (chunk 8's slices work on chunk 0's constants and are dropped)
+                    if ((m == 0 || m == 5) && t % 3 == 0) stage_dma_piece((kc + 1) & 7, buf ^ 1, (m == 0 ? 0 : 4) + t / 3);
+                    if (m == 6 && t == 0) stage_dma_piece((kc + 1) & 7, buf ^ 1, 8);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
-        };
-#pragma unroll
-        for (int kc = 0; kc < 8; kc += 2) {
-            chunk(kc, R, 0);
+            // chunk kc + 2's residual-conv tile, issued BEFORE the barrier; its first reader is a slice 12+ matrix instructions behind the barrier
+            gemm1(kc + 2);
+            side_consts(kc + 2, 0);
             STAMP(2 + kc);
-            chunk(kc + 1, R, 1);
-            STAMP(3 + kc);
         }
+        // the epilogue's spectrogram taps and first encoder fragments (the residual-conv operand is dead now: their registers)
+        patch_load(spec_rsrc(a.spec + (size_t)b * 2 * P, P), wp0 + 2 * r, h, P, a.F, V);
+        load_ea(0);
         // ---- mask, complex product with the encoder output, taps GEMM (k_pwr.hip PWR_S3T), eight encoder rows (one K step of the taps GEMM) at a time
         float esc = 1.0f, eisc = WINV;
         if (a.stats) rms_pow2(a.stats + 2 * b, a.inv_count, esc, eisc);  // power of two nearest 1 / rms(a0) of this mixture (wave-uniform)
