@@ -6,6 +6,7 @@
 //   row_can_kernel<64>   attn_concat_proj ConvActNorm + residual (attention.py:182-184)
 #include "common.h"
 #include "kernels.h"
+#include "pipe_helpers.h"
 
 #define AF 64  // n_freqs: LayerNormalization4D gamma/beta are (1,C,1,64), so F' is tied to 64
 
@@ -18,7 +19,7 @@
 #define RCAN_ROWS 8
 #define RCAN_LD 72  // Ys row stride: D-layout writes (rows +4 on the upper half-wave) land in the other 32 banks
 template <int NOUT>
-__global__ __launch_bounds__(256) void row_can_kernel(RowCanArgs a) {
+__global__ __launch_bounds__(256, 2) void row_can_kernel(RowCanArgs a) {
     constexpr int MT = NOUT / 32, MTW = (MT + 1) / 2;
     constexpr int NR = NOUT / 4;  // LayerNorm rows per wave: 96 -> Q_w (4) + K_w (4) + V_w (16); 64 -> 16 of the one group
     constexpr float WSC = 256.f, WINV = 1.f / 256.f;
@@ -52,11 +53,12 @@ __global__ __launch_bounds__(256) void row_can_kernel(RowCanArgs a) {
         if (NOUT == 64) return wave * 16 + i;
         return i < 4 ? 4 * wave + i : i < 8 ? 16 + 4 * wave + (i - 4) : 32 + 16 * wave + (i - 8);
     };
-    float gam[NR], bet[NR];
-#pragma unroll
-    for (int i = 0; i < NR; ++i) {
-        gam[i] = a.gamma[ln_row(i) * AF + lane];
-        bet[i] = a.beta[ln_row(i) * AF + lane];
+    // the LayerNorm affine of this wave's rows lives in LDS (48 registers when it was held per lane: with them the kernel needed 319 registers,
+    // one workgroup per CU, and every latency of its serial per-frame phases - GEMM, two reductions, stores - was exposed)
+    __shared__ float gam_s[NOUT][AF], bet_s[NOUT][AF];
+    for (int i = tid; i < NOUT * AF; i += 256) {
+        gam_s[0][i] = a.gamma[i];
+        bet_s[0][i] = a.beta[i];
     }
     const int t0 = blockIdx.x * a.rpw;
     const int nrows = min(a.rpw, T - t0);
@@ -76,13 +78,13 @@ __global__ __launch_bounds__(256) void row_can_kernel(RowCanArgs a) {
         const int t = t0 + rr;
         half8 bh[4], bl[4];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
+        for (int ks = 0; ks < 4; ++ks) {
+            unsigned hi[4], lo[4];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const _Float16 hi = (_Float16)v[ks][j];
-                bh[ks][j] = hi;
-                bl[ks][j] = (_Float16)(v[ks][j] - (float)hi);
-            }
+            for (int jp = 0; jp < 4; ++jp) split2(v[ks][2 * jp], v[ks][2 * jp + 1], hi[jp], lo[jp]);  // 3 instructions per pair (pipe_helpers.h)
+            bh[ks] = __builtin_bit_cast(half8, *reinterpret_cast<f32x4*>(hi));
+            bl[ks] = __builtin_bit_cast(half8, *reinterpret_cast<f32x4*>(lo));
+        }
         if (NOUT == 64) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) rs[i] = RES[((size_t)i * T + t) * AF];
@@ -130,7 +132,7 @@ __global__ __launch_bounds__(256) void row_can_kernel(RowCanArgs a) {
                 const float rstd = 1.0f / sqrtf(wave_sum(vv) / (float)(gs * AF) + RTFS_EPS);
                 float* __restrict__ dst = (g == 0 ? a.q : g == 1 ? a.k : a.v) + (((size_t)b * 4 + wave) * T + t) * (gs * AF) + lane;
 #pragma unroll
-                for (int i = 0; i < gs; ++i) dst[i * AF] = fmaf(y[i0 + i] * rstd, gam[i0 + i], bet[i0 + i]);
+                for (int i = 0; i < gs; ++i) dst[i * AF] = fmaf(y[i0 + i] * rstd, gam_s[ln_row(i0 + i)][lane], bet_s[ln_row(i0 + i)][lane]);
             }
         } else {
             // one LayerNorm group over all (64, F): 16 channels per wave, partial sums exchanged through LDS
@@ -153,7 +155,7 @@ __global__ __launch_bounds__(256) void row_can_kernel(RowCanArgs a) {
             const float rstd = 1.0f / sqrtf((red[4] + red[5] + red[6] + red[7]) / (float)(64 * AF) + RTFS_EPS);
             float* __restrict__ O = a.out + ((size_t)b * 64 + wave * 16) * T * AF + lane;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) O[((size_t)i * T + t) * AF] = fmaf(y[i] * rstd, gam[i], bet[i]) + rs[i];
+            for (int i = 0; i < 16; ++i) O[((size_t)i * T + t) * AF] = fmaf(y[i] * rstd, gam_s[ln_row(i)][lane], bet_s[ln_row(i)][lane]) + rs[i];
         }
         __syncthreads();  // Ys / red are rewritten by the next row
     }
