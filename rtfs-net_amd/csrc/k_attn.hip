@@ -167,13 +167,11 @@ __global__ __launch_bounds__(256, 2) void row_can_kernel(RowCanArgs a) {
 // in LDS (softmax rows, then the A operand of P V).
 #define ATT_PSC 4096.f  // P in [0,1] is scaled so its low half stays above the f16 flush threshold
 __device__ __forceinline__ void split8(const float (&v)[8], float sc, half8& hi, half8& lo) {
+    unsigned h[4], l[4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const float x = v[j] * sc;
-        const _Float16 t = (_Float16)x;
-        hi[j] = t;
-        lo[j] = (_Float16)(x - (float)t);
-    }
+    for (int jp = 0; jp < 4; ++jp) split2(v[2 * jp] * sc, v[2 * jp + 1] * sc, h[jp], l[jp]);  // 3 instructions per pair (pipe_helpers.h)
+    hi = __builtin_bit_cast(half8, *reinterpret_cast<f32x4*>(h));
+    lo = __builtin_bit_cast(half8, *reinterpret_cast<f32x4*>(l));
 }
 __global__ __launch_bounds__(256) void attn_core_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float S[];  // [32][ldp]
@@ -260,18 +258,17 @@ __global__ __launch_bounds__(256) void attn_core_kernel(AttnArgs a) {
         for (int n = 0; n < 4; ++n)
 #pragma unroll
             for (int q = 0; q < 16; ++q) o[n][q] = 0.f;
-        const int nt0 = wave * 8 + grp * 4;
-        const float* __restrict__ vp = V + nt0 * 32 + r;
-        float vv[2][4][8];
-        auto load_v = [&](int ks, float (&dst)[4][8]) {
+        // the group's four column tiles interleaved: tile n holds columns 128 (2 wave + grp) + 4 r + n, so that a lane's four B-operand values
+        // of a key are ONE 16-byte load (and its four outputs of a query one 16-byte store).  With tile-contiguous columns these were four
+        // dword accesses each: 512 load instructions per wave, ~30 % of the kernel on the CU's address unit.
+        const int col0 = (wave * 8 + grp * 4) * 32 + 4 * r;
+        const float* __restrict__ vp = V + col0;
+        f32x4 vv[2][8];
+        auto load_v = [&](int ks, f32x4 (&dst)[8]) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const size_t ro = (size_t)min(ks * 16 + 8 * h + j, T - 1) * 1024;  // P is 0 on the padded keys
-#pragma unroll
-                for (int n = 0; n < 4; ++n) dst[n][j] = vp[ro + n * 32];
-            }
+            for (int j = 0; j < 8; ++j) dst[j] = *reinterpret_cast<const f32x4*>(vp + (size_t)min(ks * 16 + 8 * h + j, T - 1) * 1024);  // P is 0 on the padded keys
         };
-        auto step = [&](int ks, const float (&src)[4][8]) {
+        auto step = [&](int ks, const f32x4 (&src)[8]) {
             float pv[8];
             *reinterpret_cast<f32x4*>(pv) = *reinterpret_cast<const f32x4*>(S + r * ldp + ks * 16 + 8 * h);
             *reinterpret_cast<f32x4*>(pv + 4) = *reinterpret_cast<const f32x4*>(S + r * ldp + ks * 16 + 8 * h + 4);
@@ -279,8 +276,11 @@ __global__ __launch_bounds__(256) void attn_core_kernel(AttnArgs a) {
             split8(pv, ATT_PSC, ph, pl);
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
+                float t8[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) t8[j] = src[j][n];
                 half8 vh, vl;
-                split8(src[n], 1.f, vh, vl);
+                split8(t8, 1.f, vh, vl);
                 o[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vh, o[n], 0, 0, 0);
                 o[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vl, o[n], 0, 0, 0);
                 o[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pl, vh, o[n], 0, 0, 0);
@@ -294,14 +294,14 @@ __global__ __launch_bounds__(256) void attn_core_kernel(AttnArgs a) {
             load_v(min(ks + 2, nks - 1), vv[0]);
             step(ks + 1, vv[1]);
         }
-#pragma unroll
-        for (int n = 0; n < 4; ++n) {
-            const int col = (nt0 + n) * 32 + r;
-            const int c = col >> 6, f = col & 63;
+        {
+            const int c = col0 >> 6, f = col0 & 63;  // four adjacent columns: one channel, f .. f + 3
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const int qq = q0 + (q & 3) + 8 * (q >> 2) + 4 * h;
-                if (qq < T) a.out[(((size_t)b * 64 + hd * 16 + c) * T + qq) * AF + f] = o[n][q] * (1.f / ATT_PSC);
+                if (qq < T)
+                    *reinterpret_cast<f32x4*>(a.out + (((size_t)b * 64 + hd * 16 + c) * T + qq) * AF + f) =
+                        f32x4{o[0][q], o[1][q], o[2][q], o[3][q]} * (1.f / ATT_PSC);
             }
         }
     }
