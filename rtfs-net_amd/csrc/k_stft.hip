@@ -1,47 +1,127 @@
 // STFT encoder / iSTFT decoder kernels (gfx950).
-//   stft_kernel        reference TDAVNet/encoder.py:164-172  (torch.stft + stack(re,im).transpose)
+//   stft_mfma_kernel   reference TDAVNet/encoder.py:164-172  (torch.stft + stack(re,im).transpose)
 //   enc_conv_kernel    reference TDAVNet/encoder.py:146-157,173 (Conv2d 2->C 3x3 'same', no bias) + gLN stats of its output
-//   dec_shift_sum_istft reference TDAVNet/decoder.py:117-128   (tail of ConvTranspose2d + torch.istft)
+//   enc_stats_kernel   the gLN statistics of that conv's output without the conv (fused separator path)
+//   istft_mfma_kernel  reference TDAVNet/decoder.py:117-128   (tail of ConvTranspose2d + torch.istft)
 #include "common.h"
 #include "kernels.h"
+#include "pipe_helpers.h"
 
 #define NFFT 256
 #define HOP 128
 #define NBIN 129
 
-// One workgroup per (frame t, batch b): 256 threads.  Direct 256-point real DFT with an exact
-// table of cos/sin(2*pi*k/256) built in LDS (angle index reduced mod 256 in integers, so the
-// bin indexing is exact).  Output spec (B,2,T,F): [b][0][t][f] = Re, [b][1][t][f] = Im.
-__global__ __launch_bounds__(256) void stft_kernel(const float* __restrict__ wav, float* __restrict__ spec, int L, int T) {
-    __shared__ float xw[NFFT];
-    __shared__ float ct[NFFT];
-    __shared__ float st[NFFT];
-    const int t = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+// STFT on the matrix cores (round 3; rounds 1-2 had one workgroup per frame, a direct 256-point DFT over an exact cos / sin table in LDS:
+// 2 x 256 table reads per output, LDS-bound with bank conflicts on the gather, 105 us).  Output spec (B,2,T,F): [b][0][t][f] = Re, [b][1][t][f] = Im.
+// The 256-point real DFT of 32 frames is a (320 x 256) x (256 x 32) GEMM - rows = 129 real
+// + 129 imaginary outputs (each padded to 160 = 5 tiles), K = sample index, columns = frames - in the f16 hi / lo split form of the rest of
+// the library (3 matrix instructions per product, 2^-22 relative).  One workgroup per (32 frames, mixture), 4 waves:
+//   1. the windowed samples of the 32 frames become the B fragments (lane = frame, 8 consecutive samples per K step and lane half), built once
+//      and shared through LDS.  Each frame is scaled by the power of two that brings its largest sample to [1, 2) - the split keeps its low
+//      half only for values >= 2^-3 or so, and a recording at amplitude 1e-5 would otherwise vanish in f16 - and the column is scaled back
+//      at the store: exact;
+//   2. a wave owns output tiles {w, w + 4, w + 8}; the twiddle A fragment of (tile, K step) is GATHERED from the exact 256-entry cos / sin
+//      table in LDS (angle index f n reduced mod 256 in integers: exact bin indexing) and split on the fly - used once, so no 288 KB image
+//      is needed.  105 -> 26 us.
+#define STFT_FT 32
+__global__ __launch_bounds__(256) void stft_mfma_kernel(const float* __restrict__ wav, float* __restrict__ spec, int L, int T) {
+    __shared__ float ct[NFFT], st[NFFT], hann[NFFT];  // 256 cos, -256 sin, window
+    __shared__ __attribute__((aligned(16))) half8 Bh[16][64], Bl[16][64];
+    __shared__ float pmax[4][STFT_FT];
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int t0 = blockIdx.x * STFT_FT, b = blockIdx.y;
     {
-        float s, c;
-        sincospif((float)tid * (1.0f / 128.0f), &s, &c);
-        ct[tid] = c;
-        st[tid] = s;
-        int n = t * HOP + tid - NFFT / 2;  // index into the un-padded signal
-        if (n < 0) n = -n;                 // reflect (no edge repeat)
-        if (n >= L) n = 2 * (L - 1) - n;
-        n = n < 0 ? 0 : n;
-        const float w = 0.5f - 0.5f * cospif((float)tid * (1.0f / 128.0f));  // periodic Hann
-        xw[tid] = wav[(size_t)b * L + n] * w;
+        float sn, cs;
+        sincospif((float)tid * (1.0f / 128.0f), &sn, &cs);
+        ct[tid] = 256.0f * cs;
+        st[tid] = -256.0f * sn;
+        hann[tid] = 0.5f - 0.5f * cospif((float)tid * (1.0f / 128.0f));  // periodic Hann
     }
     __syncthreads();
-    if (tid < NBIN) {
-        float re = 0.f, im = 0.f;
-#pragma unroll 8
-        for (int n = 0; n < NFFT; ++n) {
-            const int k = (tid * n) & (NFFT - 1);
-            const float x = xw[n];
-            re = fmaf(x, ct[k], re);
-            im = fmaf(-x, st[k], im);
+    // ---- B fragments: wave w builds K steps 4 w .. 4 w + 3 (samples 64 w .. 64 w + 63) of every frame
+    const int t = min(t0 + r, T - 1);  // (frames past the end repeat the last one; their columns are not stored)
+    float x[4][8];
+    float mx = 0.f;
+#pragma unroll
+    for (int k4 = 0; k4 < 4; ++k4)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int n = (wave * 4 + k4) * 16 + 8 * h + j;
+            int i = t * HOP + n - NFFT / 2;  // index into the un-padded signal
+            if (i < 0) i = -i;               // reflect (no edge repeat)
+            if (i >= L) i = 2 * (L - 1) - i;
+            i = i < 0 ? 0 : i;
+            x[k4][j] = wav[(size_t)b * L + i] * hann[n];
+            mx = fmaxf(mx, fabsf(x[k4][j]));
         }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));  // the two lane halves of a frame
+    if (h == 0) pmax[wave][r] = mx;
+    __syncthreads();
+    const float fm = fmaxf(fmaxf(pmax[0][r], pmax[1][r]), fmaxf(pmax[2][r], pmax[3][r]));
+    // 2^-floor(log2(fm)) on the exponent bits (fm = 0 or denormal: 1)
+    const unsigned eb = (__float_as_uint(fm) >> 23) & 0xFF;
+    const float sc = (eb > 1 && eb < 253) ? __uint_as_float((254u - eb) << 23) : 1.0f;
+    const float isc = (eb > 1 && eb < 253) ? __uint_as_float(eb << 23) * (1.0f / 256.0f) : (1.0f / 256.0f);  // undoes the scale and the table's x 256
+#pragma unroll
+    for (int k4 = 0; k4 < 4; ++k4) {
+        unsigned hi[4], lo[4];
+#pragma unroll
+        for (int jp = 0; jp < 4; ++jp) split2(x[k4][2 * jp] * sc, x[k4][2 * jp + 1] * sc, hi[jp], lo[jp]);
+        Bh[wave * 4 + k4][lane] = __builtin_bit_cast(half8, *reinterpret_cast<f32x4*>(hi));
+        Bl[wave * 4 + k4][lane] = __builtin_bit_cast(half8, *reinterpret_cast<f32x4*>(lo));
+    }
+    __syncthreads();
+    // ---- GEMM: output tiles mt = wave, wave + 4, wave + 8 (< 10); tile mt: rows f2 = 32 mt + r -> part (mt >= 5), bin f = f2 - 160 part
+    f32x16 acc[3];
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[m][q] = 0.f;
+#pragma unroll 2
+    for (int ks = 0; ks < 16; ++ks) {
+        const half8 bh = Bh[ks][lane], bl = Bl[ks][lane];
+        const int n0 = ks * 16 + 8 * h;
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+            const int mt = wave + 4 * m;
+            if (mt < 10) {  // wave-uniform
+                const int part = mt >= 5, f = mt * 32 + r - 160 * part;
+                const float* __restrict__ tab = part ? st : ct;
+                const bool live = f < NBIN;
+                float tw[8];
+                int k = f * n0;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    tw[j] = live ? tab[k & (NFFT - 1)] : 0.f;
+                    k += f;
+                }
+                unsigned hi[4], lo[4];
+#pragma unroll
+                for (int jp = 0; jp < 4; ++jp) split2(tw[2 * jp], tw[2 * jp + 1], hi[jp], lo[jp]);
+                const half8 ah = __builtin_bit_cast(half8, *reinterpret_cast<f32x4*>(hi)), al = __builtin_bit_cast(half8, *reinterpret_cast<f32x4*>(lo));
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[m], 0, 0, 0);
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[m], 0, 0, 0);
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[m], 0, 0, 0);
+            }
+        }
+    }
+    // ---- store: accumulator register q of tile mt = row f2 = 32 mt + (q & 3) + 8 (q >> 2) + 4 h, column = frame t0 + r
+    if (t0 + r < T) {
         const size_t plane = (size_t)T * NBIN;
-        spec[((size_t)b * 2 + 0) * plane + (size_t)t * NBIN + tid] = re;
-        spec[((size_t)b * 2 + 1) * plane + (size_t)t * NBIN + tid] = im;
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+            const int mt = wave + 4 * m;
+            if (mt < 10) {
+                const int part = mt >= 5;
+                float* __restrict__ o = spec + ((size_t)b * 2 + part) * plane + (size_t)(t0 + r) * NBIN;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int f = mt * 32 + (q & 3) + 8 * (q >> 2) + 4 * h - 160 * part;
+                    if (f < NBIN) o[f] = acc[m][q] * isc;
+                }
+            }
+        }
     }
 }
 
@@ -213,68 +293,136 @@ __global__ __launch_bounds__(256) void enc_stats_kernel(const float* __restrict_
     }
 }
 
-// Tail of the decoder.  z (B,18,T,F) holds the per-tap pointwise products
-//   z[b][(o*3+dt)*3+df][t][f] = sum_c x[b][c][t][f] * Wdec[c][o][dt][df]
-// ConvTranspose2d(pad 1): y[o][t][f] = sum_{dt,df} z[o,dt,df][t+1-dt][f+1-df].
-// Then torch.istft: frame-wise irfft(256) * hann, overlap-add, / sum(w^2), drop 128, keep L.
-// One workgroup per hop-block s of 128 output samples: the two frames that overlap it are
-// t0 = s (second half, m = 128 + n) and t1 = s + 1 (first half, m = n).
-__global__ __launch_bounds__(128) void dec_shift_sum_istft_kernel(const float* __restrict__ z, float* __restrict__ wav,
-                                                                  int T, int F, int L, size_t zcs, size_t zbs) {
-    __shared__ float re[2][NBIN];
-    __shared__ float im[2][NBIN];
-    __shared__ float ct[NFFT];
-    __shared__ float st[NFFT];
-    const int s = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-    for (int k = tid; k < NFFT; k += 128) {
+// Tail of the decoder on the matrix cores (round 3; rounds 1-2: one workgroup per hop block, direct sums over the table, 119 us -> 43).
+// z (B,18,T,F) holds the per-tap pointwise products z[b][(o*3+dt)*3+df][t][f] = sum_c x[b][c][t][f] * Wdec[c][o][dt][df];
+// ConvTranspose2d(pad 1): y[o][t][f] = sum_{dt,df} z[o,dt,df][t+1-dt][f+1-df]; then torch.istft: frame-wise irfft(256) * hann, overlap-add,
+// / sum(w^2), drop 128, keep L.  The 256 samples of a frame are a (256 x 256) x (256 x frames) GEMM over K = the 129 real and 127 contributing imaginary bins:
+//     y[m] = (1/256) (re_0 + (-1)^m re_128 + 2 sum_{f=1..127} re_f cos(2 pi f m / 256) - im_f sin(2 pi f m / 256))
+// K order: k = 0 .. 127 -> re_k, k = 128 .. 254 -> im_{k-127}, k = 255 -> re_128.  One workgroup per (31 hop blocks, mixture) = 32 frames
+// (block s overlap-adds the second half of frame s and the first half of frame s + 1, so consecutive workgroups share one frame):
+//   1. the shift-sum of the decoder's 18 tap maps (ConvTranspose2d pad 1, decoder.py:117-121) for 32 frames x 258 values goes to LDS;
+//   2. B fragments (lane = frame) from there, each frame scaled by the power of two that brings its largest value to [1, 2) (the separated
+//      spectrum scales with the recording's amplitude; the f16 split wants O(1)), shared through LDS;
+//   3. wave w owns sample tiles w and w + 4 - rows m and m + 128, exactly the two halves that meet in the overlap-add; twiddle A
+//      fragments gathered from the exact cos / sin table (index f m mod 256 in integers) and split on the fly;
+//   4. epilogue: column r + 1's first half comes over by one lane shift, Hann window, envelope, store.
+#define ISTFT_FT 32
+__global__ __launch_bounds__(256) void istft_mfma_kernel(const float* __restrict__ z, float* __restrict__ wav, int T, int F, int L, size_t zcs,
+                                                         size_t zbs) {
+    __shared__ float ct[NFFT], st[NFFT], hann[NFFT];          // 256 cos, -256 sin, window
+    __shared__ float S[2][NBIN][ISTFT_FT + 1];                 // [re | im][bin][frame]
+    __shared__ __attribute__((aligned(16))) half8 Bh[16][64], Bl[16][64];
+    __shared__ float pmax[4][ISTFT_FT];
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int t0 = blockIdx.x * (ISTFT_FT - 1), b = blockIdx.y;
+    {
         float sn, cs;
-        sincospif((float)k * (1.0f / 128.0f), &sn, &cs);
-        ct[k] = cs;
-        st[k] = sn;
+        sincospif((float)tid * (1.0f / 128.0f), &sn, &cs);
+        ct[tid] = 256.0f * cs;
+        st[tid] = -256.0f * sn;
+        hann[tid] = 0.5f - 0.5f * cospif((float)tid * (1.0f / 128.0f));
     }
-    for (int idx = tid; idx < 2 * 2 * NBIN; idx += 128) {
-        const int fr = idx / (2 * NBIN), o = (idx / NBIN) & 1, f = idx % NBIN;
-        const int t = s + fr;
+    // ---- 1. shift-sum: S[o][f][tt] = sum_{dt,df} z[(o*3+dt)*3+df][t+1-dt][f+1-df], frames past the end = 0
+    const float* __restrict__ zb = z + (size_t)b * zbs;
+    // (unconditional, clamped loads + selects: a branch per load costs a full wait each; four items = 36 loads in flight per thread)
+#pragma unroll 4
+    for (int it = 0; it < (2 * ISTFT_FT * NBIN + 255) / 256; ++it) {
+        const int idx = min(tid + 256 * it, 2 * ISTFT_FT * NBIN - 1);  // (the last trip's surplus threads redo the last item)
+        const int f = idx % NBIN, tt_ = (idx / NBIN) % ISTFT_FT, o = idx / (NBIN * ISTFT_FT);
+        const int t = t0 + tt_;
         float acc = 0.f;
-        if (t < T) {
 #pragma unroll
-            for (int dt = 0; dt < 3; ++dt)
+        for (int dt = 0; dt < 3; ++dt)
 #pragma unroll
-                for (int df = 0; df < 3; ++df) {
-                    const int tt = t + 1 - dt, ff = f + 1 - df;
-                    if (tt >= 0 && tt < T && ff >= 0 && ff < F)
-                        acc += z[(size_t)b * zbs + (size_t)((o * 3 + dt) * 3 + df) * zcs + (size_t)tt * F + ff];
-                }
-        }
-        (o == 0 ? re : im)[fr][f] = acc;
+            for (int df = 0; df < 3; ++df) {
+                const int tt = t + 1 - dt, ff = f + 1 - df;
+                const bool ok = t < T && tt >= 0 && tt < T && ff >= 0 && ff < F;
+                const int tc = min(max(tt, 0), T - 1), fc = min(max(ff, 0), F - 1);
+                const float v = zb[(size_t)((o * 3 + dt) * 3 + df) * zcs + (size_t)tc * F + fc];
+                acc += ok ? v : 0.f;
+            }
+        S[o][f][tt_] = acc;
     }
     __syncthreads();
-    const int n = s * HOP + tid;  // output sample
-    if (n >= L) return;
-    float num = 0.f, env = 0.f;
+    // ---- 2. B fragments: wave w builds K steps 4 w .. 4 w + 3; K slot k -> (part, bin)
+    auto sval = [&](int k) { return k < 128 ? S[0][k][r] : (k < 255 ? S[1][k - 127][r] : S[0][128][r]); };
+    float x[4][8];
+    float mx = 0.f;
 #pragma unroll
-    for (int fr = 0; fr < 2; ++fr) {
-        const int t = s + fr;
-        if (t >= T) continue;
-        const int m = fr == 0 ? tid + HOP : tid;  // sample index inside the frame
-        // irfft: bins 0 and 128 contribute their real part only
-        float acc = re[fr][0] + ((m & 1) ? -re[fr][128] : re[fr][128]);
-        float a2 = 0.f;
-        for (int f = 1; f < 128; ++f) {
-            const int k = (f * m) & (NFFT - 1);
-            a2 = fmaf(re[fr][f], ct[k], a2);
-            a2 = fmaf(-im[fr][f], st[k], a2);
+    for (int k4 = 0; k4 < 4; ++k4)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            x[k4][j] = sval((wave * 4 + k4) * 16 + 8 * h + j);
+            mx = fmaxf(mx, fabsf(x[k4][j]));
         }
-        acc = (acc + 2.f * a2) * (1.0f / NFFT);
-        const float w = 0.5f - 0.5f * cospif((float)m * (1.0f / 128.0f));
-        num = fmaf(acc, w, num);
-        env = fmaf(w, w, env);
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    if (h == 0) pmax[wave][r] = mx;
+    __syncthreads();
+    const float fm = fmaxf(fmaxf(pmax[0][r], pmax[1][r]), fmaxf(pmax[2][r], pmax[3][r]));
+    const unsigned eb = (__float_as_uint(fm) >> 23) & 0xFF;
+    const bool scaled = eb > 1 && eb < 253;
+    const float sc = scaled ? __uint_as_float((254u - eb) << 23) : 1.0f;
+    // undoes the frame scale, the table's x 256 and the transform's 1 / 256 (the factor 2 of bins 1 .. 127 is in the fragments)
+    const float isc = (scaled ? __uint_as_float(eb << 23) : 1.0f) * (1.0f / 65536.0f);
+#pragma unroll
+    for (int k4 = 0; k4 < 4; ++k4) {
+        unsigned hi[4], lo[4];
+#pragma unroll
+        for (int jp = 0; jp < 4; ++jp) split2(x[k4][2 * jp] * sc, x[k4][2 * jp + 1] * sc, hi[jp], lo[jp]);
+        Bh[wave * 4 + k4][lane] = __builtin_bit_cast(half8, *reinterpret_cast<f32x4*>(hi));
+        Bl[wave * 4 + k4][lane] = __builtin_bit_cast(half8, *reinterpret_cast<f32x4*>(lo));
     }
-    wav[(size_t)b * L + n] = num / env;
+    __syncthreads();
+    // ---- 3. GEMM: sample tiles wave and wave + 4; row m = 32 mt + r; coefficient of K slot k: re_f -> c_f cos(2 pi f m / 256) (c = 1 for f = 0, 128,
+    //         else 2), im_f -> -2 sin(2 pi f m / 256)
+    f32x16 acc[2];
+#pragma unroll
+    for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[m2][q] = 0.f;
+#pragma unroll 2
+    for (int ks = 0; ks < 16; ++ks) {
+        const half8 bh = Bh[ks][lane], bl = Bl[ks][lane];
+#pragma unroll
+        for (int m2 = 0; m2 < 2; ++m2) {
+            const int m = (wave + 4 * m2) * 32 + r;
+            float tw[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = ks * 16 + 8 * h + j;
+                const int f = k < 128 ? k : (k < 255 ? k - 127 : 128);
+                const float v = (k >= 128 && k < 255 ? st : ct)[(f * m) & (NFFT - 1)];
+                tw[j] = (f == 0 || f == 128) ? v : 2.0f * v;
+            }
+            unsigned hi[4], lo[4];
+#pragma unroll
+            for (int jp = 0; jp < 4; ++jp) split2(tw[2 * jp], tw[2 * jp + 1], hi[jp], lo[jp]);
+            const half8 ah = __builtin_bit_cast(half8, *reinterpret_cast<f32x4*>(hi)), al = __builtin_bit_cast(half8, *reinterpret_cast<f32x4*>(lo));
+            acc[m2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[m2], 0, 0, 0);
+            acc[m2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[m2], 0, 0, 0);
+            acc[m2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[m2], 0, 0, 0);
+        }
+    }
+    // ---- 4. overlap-add: hop block s = t0 + r takes samples m = 128 + j of frame s (tile wave + 4, this lane) and m = j of frame s + 1 (tile wave,
+    //         the next lane's column); j = 32 wave + (q & 3) + 8 (q >> 2) + 4 h.  Lane 31's block belongs to the next workgroup.
+    const int sblk = t0 + r;
+    const bool f0 = sblk < T, f1 = sblk + 1 < T;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int j = wave * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+        const float y1 = __shfl_down(acc[0][q] * isc, 1);  // frame s + 1, sample j (every lane takes part in the shuffle)
+        const float y0 = acc[1][q] * isc;                   // frame s, sample 128 + j
+        const float w0 = hann[HOP + j], w1 = hann[j];
+        const float num = (f0 ? y0 * w0 : 0.f) + (f1 ? y1 * w1 : 0.f);
+        const float env = (f0 ? w0 * w0 : 0.f) + (f1 ? w1 * w1 : 0.f);
+        const int n = sblk * HOP + j;
+        if (r < ISTFT_FT - 1 && n < L && (f0 || f1)) wav[(size_t)b * L + n] = num / env;
+    }
 }
 
 int launch_stft(const float* wav, float* spec, int B, int L, int T, hipStream_t st) {
-    hipLaunchKernelGGL(stft_kernel, dim3(T, B), dim3(256), 0, st, wav, spec, L, T);
+    hipLaunchKernelGGL(stft_mfma_kernel, dim3(cdiv(T, STFT_FT), B), dim3(256), 0, st, wav, spec, L, T);
     return rtfs_launch_status();
 }
 
@@ -297,6 +445,7 @@ int launch_enc_stats(const float* spec, const float* w, double* stats, void* img
 }
 
 int launch_dec_istft(const float* z, float* wav, int B, int T, int F, int L, size_t zcs, size_t zbs, hipStream_t st) {
-    hipLaunchKernelGGL(dec_shift_sum_istft_kernel, dim3(cdiv(L, HOP), B), dim3(128), 0, st, z, wav, T, F, L, zcs, zbs);
+    if (F != NBIN) return RTFS_ERR_SHAPE;
+    hipLaunchKernelGGL(istft_mfma_kernel, dim3(cdiv(cdiv(L, HOP), ISTFT_FT - 1), B), dim3(256), 0, st, z, wav, T, F, L, zcs, zbs);
     return rtfs_launch_status();
 }
