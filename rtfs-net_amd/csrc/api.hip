@@ -536,7 +536,10 @@ int block_forward(const BlockPack& p, const float* x, const float* x_res, float*
 }
 
 // block boundary of the fused separator: residual_conv(i) + [CAF] + a1 + gateway + projection(i+1) in one kernel
-int block_boundary(const BlockPack& p, const float* a1, int B, int T, int F, BlockWs& w, hipStream_t st, const CafArgs* caf, unsigned* ctr = nullptr) {
+// res_has_a1 (in / out): whether w.residual currently holds residual + a1.  A boundary that has to read a1 anyway also adds it to the residual
+// it writes (unless it is the last one: the tail wants the plain residual), and the boundary after it then does not read a1 at all.
+int block_boundary(const BlockPack& p, const float* a1, int B, int T, int F, BlockWs& w, hipStream_t st, const CafArgs* caf, unsigned* ctr = nullptr,
+                   bool* res_has_a1 = nullptr, bool last = true) {
     B2bArgs a;
     a.x = w.expanded;
     a.res = w.residual;
@@ -557,7 +560,11 @@ int block_boundary(const BlockPack& p, const float* a1, int B, int T, int F, Blo
         a.caf_w_key = caf->w_key; a.caf_bn_key = caf->bn_key; a.caf_w_val = caf->w_val; a.caf_bn_val = caf->bn_val;
         a.caf_T = caf->T; a.caf_F = caf->F; a.caf_Tv = caf->Tv;
     }
-    const int rc = launch_pws_b2b4(a, B, ctr, st);  // padded rows, no CAF: the pipelined kernel (k_b2b.hip)
+    if (res_has_a1 && launch_pws_b2b4_qualifies(a)) {
+        a.a1_mode = *res_has_a1 ? 0 : (last ? 1 : 3);
+        *res_has_a1 = a.a1_mode == 3;
+    }
+    const int rc = launch_pws_b2b4(a, B, ctr, st);  // padded rows: the pipelined kernel (k_b2b.hip)
     return rc == RTFS_ERR_ARG ? launch_pws_b2b(a, B, st) : rc;
 }
 
@@ -991,10 +998,11 @@ int separator_part(const SepPacks& k, const float* wav, const float* video_vp, f
         if (video_ready && hipStreamWaitEvent(cafv.side.stream, (hipEvent_t)video_ready, 0) != hipSuccess) return RTFS_ERR_LAUNCH;
         CHECK(launch_caf_video(ca, B, cafv.side.stream));
         if (!head_done) CHECK(block_head(pk, w.a1, nullptr, B, T, NF, w.blk, st, nullptr, w.ctr + nctr++));
+        bool res_has_a1 = false;
         for (int i = 0; i < repeats; ++i) {
             CHECK(block_body(pk, B, T, NF, w.blk, st, single_chain));
             if (i == 0) CHECK(cafv.join());
-            if (i + 1 < repeats) CHECK(block_boundary(pk, w.a1, B, T, NF, w.blk, st, i == 0 ? &ca : nullptr, nctr < 64 ? w.ctr + nctr++ : nullptr));
+            if (i + 1 < repeats) CHECK(block_boundary(pk, w.a1, B, T, NF, w.blk, st, i == 0 ? &ca : nullptr, nctr < 64 ? w.ctr + nctr++ : nullptr, &res_has_a1, i + 2 == repeats));
             else {
                 // last application: residual conv + S3 mask + complex product + decoder taps in one kernel (k_s3f.hip); `refined` never exists
                 TailS3Args f;

@@ -30,7 +30,9 @@ constexpr size_t B4_LDS = (size_t)2 * 256 * B4_L1 * 2 + (size_t)2 * 64 * B4_L2 *
 // CAF: the block input is CAF(out_0, video) + a1 (TDAVNet/fusion.py:204-212 after the first block): out <- ReLU(key(out)) * r[tv] + att[tv] * value(out)
 // with key / value = dw 1x1 . eval BatchNorm (layers/fusion.py:205-226, folded to one FMA each) and r / att the video-side terms of
 // caf_video_kernel, read from their (B, Tv, 256) transposed copies: four consecutive channels of one video frame are one 16-byte load.
-template <bool CAF>
+// AM: bit 0 = the residual read does not contain a1 yet: read a1 and add it (the block input is out + a1); bit 1 = write the new residual WITH
+// a1 added (the next boundary then runs with bit 0 clear and does not read a1 at all: one boundary in two saves 256 of its 576 row reads).
+template <bool CAF, int AM>
 __global__ __launch_bounds__(B4_NT) void pws_b2b4_kernel(B2bArgs a, int ntiles, int tiles_per_sample, unsigned* __restrict__ ctr) {
     constexpr int L1 = B4_L1, L2 = B4_L2;
     constexpr float WINV = 1.0f / 256.0f;
@@ -119,7 +121,7 @@ __global__ __launch_bounds__(B4_NT) void pws_b2b4_kernel(B2bArgs a, int ntiles, 
                 for (int q = 0; q < 16; ++q) {
                     const unsigned ro = (unsigned)(m * 32 + (q & 3) + 8 * (q >> 2)) * CS4;  // uniform
                     Rb[q] = ld2(ress, voffC, ro);
-                    Ab[q] = ld2(a1s, voffC, ro);
+                    if (AM & 1) Ab[q] = ld2(a1s, voffC, ro);
                 }
             };
             // ---- B fragments of GEMM 1 (expanded_i: 64 channels of this lane's two pixels)
@@ -208,13 +210,13 @@ __global__ __launch_bounds__(B4_NT) void pws_b2b4_kernel(B2bArgs a, int ntiles, 
                                 t0 = fmaf(o0 + Ab[q].x, kB[i], kC[i]);
                                 t1 = fmaf(o1 + Ab[q].y, kB[i], kC[i]);
                             } else {
-                                const f32x2 ra = Rb[q] + Ab[q];
+                                const f32x2 ra = (AM & 1) ? Rb[q] + Ab[q] : Rb[q];
                                 t0 = fmaf(acc1[0][q], kA[i], fmaf(ra.x, kB[i], kC[i]));
                                 t1 = fmaf(acc1[1][q], kA[i], fmaf(ra.y, kB[i], kC[i]));
                             }
                             y0[j] = preluf_(t0, slope);
                             y1[j] = preluf_(t1, slope);
-                            st2(ress, voffC, (unsigned)(m * 32 + (q & 3) + 8 * (q >> 2)) * CS4, f32x2{y0[j], y1[j]});
+                            st2(ress, voffC, (unsigned)(m * 32 + (q & 3) + 8 * (q >> 2)) * CS4, (AM & 2) ? f32x2{y0[j], y1[j]} + Ab[q] : f32x2{y0[j], y1[j]});
                         }
                     }
                     unsigned h0[4], l0[4], h1[4], l1[4];
@@ -394,18 +396,32 @@ __global__ __launch_bounds__(256, 2) void pws_head4_kernel(PwArgs a, int ntiles,
 
 // cs must be a multiple of 64 floats covering every wave segment (api.hip pitch()); ctr: one zeroed counter word for this launch, or null
 // (static stride).  Returns RTFS_ERR_ARG when the call does not qualify (the caller then uses the first-generation kernel).
+bool launch_pws_b2b4_qualifies(const B2bArgs& a) {
+    if ((a.caf_r && !(a.caf_rt && a.caf_attt)) || a.cs <= 0 || (a.cs & 63) || a.cs < (a.P + 63) / 64 * 64 || a.P < 2) return false;
+    return (size_t)256 * a.cs * 4 < ((size_t)1 << 31);  // buffer offsets inside one sample: 31 bits
+}
 int launch_pws_b2b4(const B2bArgs& a, int B, unsigned* ctr, hipStream_t st) {
-    if ((a.caf_r && !(a.caf_rt && a.caf_attt)) || a.cs <= 0 || (a.cs & 63) || a.cs < (a.P + 63) / 64 * 64 || a.P < 2) return RTFS_ERR_ARG;
-    if ((size_t)256 * a.cs * 4 >= ((size_t)1 << 31)) return RTFS_ERR_ARG;  // buffer offsets inside one sample: 31 bits
+    if (!launch_pws_b2b4_qualifies(a)) return RTFS_ERR_ARG;
     const int tps = cdiv(a.P, B4_NT / 64 * 64), ntiles = tps * B;
     const int grid = ntiles < 256 ? ntiles : 256;  // one resident workgroup per CU
+    const int am = a.a1_mode;
+    if ((am != 0 && am != 1 && am != 3) || (a.caf_r && !(am & 1))) return RTFS_ERR_ARG;
+#define B4_LAUNCH(CAF_, AM_)                                                                                                  \
+    do {                                                                                                                      \
+        if (rtfs_set_max_lds((const void*)pws_b2b4_kernel<CAF_, AM_>, B4_LDS) != RTFS_OK) return RTFS_ERR_LAUNCH;             \
+        hipLaunchKernelGGL((pws_b2b4_kernel<CAF_, AM_>), dim3(grid), dim3(B4_NT), B4_LDS, st, a, ntiles, tps, ctr);           \
+    } while (0)
     if (a.caf_r) {
-        if (rtfs_set_max_lds((const void*)pws_b2b4_kernel<true>, B4_LDS) != RTFS_OK) return RTFS_ERR_LAUNCH;
-        hipLaunchKernelGGL(pws_b2b4_kernel<true>, dim3(grid), dim3(B4_NT), B4_LDS, st, a, ntiles, tps, ctr);
+        if (am == 3) B4_LAUNCH(true, 3);
+        else B4_LAUNCH(true, 1);
+    } else if (am == 3) {
+        B4_LAUNCH(false, 3);
+    } else if (am == 1) {
+        B4_LAUNCH(false, 1);
     } else {
-        if (rtfs_set_max_lds((const void*)pws_b2b4_kernel<false>, B4_LDS) != RTFS_OK) return RTFS_ERR_LAUNCH;
-        hipLaunchKernelGGL(pws_b2b4_kernel<false>, dim3(grid), dim3(B4_NT), B4_LDS, st, a, ntiles, tps, ctr);
+        B4_LAUNCH(false, 0);
     }
+#undef B4_LAUNCH
     return rtfs_launch_status();
 }
 

@@ -77,8 +77,12 @@ struct B2bArgs {
     const float *caf_r = nullptr, *caf_att = nullptr, *caf_w_key = nullptr, *caf_bn_key = nullptr, *caf_w_val = nullptr, *caf_bn_val = nullptr;
     const float *caf_rt = nullptr, *caf_attt = nullptr;  // (B, Tv, 256) transposed copies of caf_r / caf_att (k_b2b.hip)
     int caf_T = 0, caf_F = 0, caf_Tv = 0;
+    // k_b2b.hip only: bit 0 = `res` does not contain a1 yet (read a1, add it to the block input); bit 1 = write the new residual WITH a1 added, so
+    // that the next boundary runs with bit 0 clear and never reads a1.  1 = the reference sequence as written (launch_pws_b2b knows no other).
+    int a1_mode = 1;
 };
 int launch_pws_b2b(const B2bArgs& a, int B, hipStream_t st);
+bool launch_pws_b2b4_qualifies(const B2bArgs& a);
 // second generation (k_b2b.hip): padded channel rows (cs % 64 == 0), no CAF; ctr = zeroed tile counter of this launch or null.
 // RTFS_ERR_ARG = call does not qualify, use launch_pws_b2b
 int launch_pws_b2b4(const B2bArgs& a, int B, unsigned* ctr, hipStream_t st);
