@@ -897,7 +897,7 @@ inline int pitch(int P) { return (P + 63) / 64 * 64; }
 struct SepWs {
     float *spec, *a0, *a1, *cur, *nxt, *r, *att, *rt, *attt, *z;
     float* encimg;  // encoder f16x3 fragment image (32 KB, written by enc_stats_kernel of every call)
-    float* wpad[2];  // bottleneck / mask-conv weight images with 72-byte rows (LDS-DMA source of the head / tail kernels; written by the same kernel)
+    float* wpad;    // mask-conv weight image with 72-byte rows (LDS-DMA source of the tail kernel, 288 KB; written by the same kernel)
     double* st0;
     unsigned* ctr;  // 64 tile counters (one per persistent launch of the call), zeroed together with st0
     int cs;
@@ -914,7 +914,7 @@ struct SepWs {
           attt(a.take<float>((size_t)B * CA * Tv)),
           z(a.take<float>((size_t)B * 18 * cs_)),
           encimg(a.take<float>(8192)),
-          wpad{a.take<float>(73728), a.take<float>(73728)},
+          wpad(a.take<float>(73728)),
           st0(a.take<double>(2 * B + 32)),
           ctr(reinterpret_cast<unsigned*>(st0 ? st0 + 2 * B : nullptr)),
           cs(cs_),
@@ -959,7 +959,7 @@ int separator_part(const SepPacks& k, const float* wav, const float* video_vp, f
         f.tile_ctr = w.ctr + nctr;
         if (launch_bn_head_qualifies(f)) {
             EncPadJobs pad;
-            pad.src[1] = ps.w16; pad.dst[1] = w.wpad[1];  // mask conv: the tail kernel's LDS-DMA source
+            pad.src[1] = ps.w16; pad.dst[1] = w.wpad;  // mask conv: the tail kernel's LDS-DMA source
             CHECK(launch_enc_stats(w.spec, pe.w, w.st0, w.encimg, pad, B, T, NF, st));
             CHECK(launch_bn_head(f, B, st));
             ++nctr;
@@ -1007,7 +1007,7 @@ int separator_part(const SepPacks& k, const float* wav, const float* video_vp, f
                 // last application: residual conv + S3 mask + complex product + decoder taps in one kernel (k_s3f.hip); `refined` never exists
                 TailS3Args f;
                 f.x = w.blk.expanded; f.res = w.blk.residual; f.spec = w.spec; f.enc_img = w.encimg; f.T = T; f.F = NF; f.z = w.z;
-                f.w1_16 = pk.res_w16; f.b1 = pk.res_b; f.w16 = head_done ? (const void*)w.wpad[1] : (const void*)ps.w16; f.bias = ps.bias; f.slope = ps.slope; f.w16b = pd.w16p;
+                f.w1_16 = pk.res_w16; f.b1 = pk.res_b; f.w16 = head_done ? (const void*)w.wpad : (const void*)ps.w16; f.bias = ps.bias; f.slope = ps.slope; f.w16b = pd.w16p;
                 f.stats = w.st0; f.inv_count = 1.0 / ((double)CA * P);
                 f.P = P; f.cs = cs; f.cout_live = 18;
                 f.tile_ctr = nctr < 64 ? w.ctr + nctr++ : nullptr;
