@@ -32,7 +32,9 @@ __device__ __forceinline__ void split2(float v0, float v1, unsigned& hi, unsigne
     hi = __builtin_bit_cast(unsigned, h);
     unsigned l;
     asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(l) : "v"(v0), "v"(hi));
-    asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(v1), "v"(hi));
+    // (s_nop 1: `lo` usually feeds a matrix instruction, which must not read a VGPR fewer than 2 wait states behind its VALU write; the compiler
+    // pads its own VALU instructions but does not look at an inline-asm producer - tools/isa_check.py found seven such pairs in the library)
+    asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\ts_nop 1" : "+v"(l) : "v"(v1), "v"(hi));
     lo = l;
 }
 

@@ -426,6 +426,8 @@ def test_no_hazardous_packed_f32_instructions_in_the_code_object():
     spec.loader.exec_module(mod)
     bad = mod.hazardous(_lib.LIB_PATH)
     assert not bad, bad[:5]
+    bad = mod.mfma_read_hazards(_lib.LIB_PATH)  # VALU write -> matrix-instruction read needs 2 wait states; inline asm is not padded by the compiler
+    assert not bad, bad[:5]
     assert mod.PAT.search("v_pk_fma_f32 v[72:73], v[168:169], v[76:77], v[72:73] op_sel:[0,1,1]")
     assert not mod.PAT.search("v_pk_fma_f32 v[154:155], v[154:155], v[76:77], v[72:73] op_sel_hi:[1,0,0]")
     assert mod.PAT.search("v_pk_mov_b32 v[2:3], v[4:5], v[6:7] op_sel:[1,0]")

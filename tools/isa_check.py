@@ -43,10 +43,63 @@ def hazardous(so_path):
     return [(k, ins) for k, ins in device_disassembly(so_path) if PAT.search(ins)]
 
 
+# ---- second check (round 3): a matrix instruction must not read a VGPR that a VALU instruction wrote fewer than MFMA_WAIT wait states earlier.
+# The compiler inserts these wait states for the VALU instructions it knows; it does not look inside inline assembly - neither at a hand-written
+# `v_mfma` (pipe_helpers.h: every one carries its own `s_nop 1`) nor at an inline-asm PRODUCER such as split2()'s v_fma_mixlo / mixhi in front
+# of a compiler-generated `v_mfma`.  Found as stale fragment registers (zeros at random pixels, NOTES.md); the check reads the linked code.
+MFMA_WAIT = 2
+_VREG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
+
+
+def _vregs(tok):
+    out = set()
+    for m in _VREG.finditer(tok):
+        if m.group(1) is not None:
+            out.add(int(m.group(1)))
+        else:
+            out.update(range(int(m.group(2)), int(m.group(3)) + 1))
+    return out
+
+
+def mfma_read_hazards(so_path):
+    """(kernel, producer, consumer, wait states) for every v_mfma whose A / B / C source VGPR was last written by a VALU instruction fewer
+    than MFMA_WAIT wait states before it (an intervening instruction counts as one wait state, `s_nop N` as N + 1; a label ends the window)."""
+    bad, window, kernel = [], [], None  # window: [(text, dest vregs or None), ...] most recent last
+    for k, ins in device_disassembly(so_path):
+        if k != kernel:
+            kernel, window = k, []
+        op = ins.split()[0] if ins.split() else ""
+        if op.startswith("v_mfma"):
+            ops = [t.strip() for t in ins.split(None, 1)[1].split(",")]
+            src = set()
+            for t in ops[1:4]:
+                src |= _vregs(t)
+            ws = 0
+            for text, dst in reversed(window):
+                if ws >= MFMA_WAIT:
+                    break
+                if dst and (dst & src):
+                    bad.append((k, text, ins, ws))
+                    break
+                m = re.match(r"s_nop\s+(\d+)", text)
+                ws += int(m.group(1)) + 1 if m else 1
+        dst = None
+        if op.startswith("v_") and not op.startswith(("v_mfma", "v_cmp", "v_accvgpr_write")) and len(ins.split(None, 1)) > 1:
+            dst = _vregs(ins.split(None, 1)[1].split(",")[0])  # (v_readlane / v_readfirstlane write SGPRs: no v-register in the first operand)
+        window.append((ins, dst))
+        if len(window) > 8:
+            window.pop(0)
+    return bad
+
+
 if __name__ == "__main__":
     so = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rtfs-net_amd", "librtfs_amd.so")
     bad = hazardous(so)
     for k, ins in bad:
         print(f"{k}: {ins}")
     print(f"{len(bad)} packed instruction(s) with a set op_sel bit in {so}")
-    sys.exit(1 if bad else 0)
+    bad2 = mfma_read_hazards(so)
+    for k, prod, cons, ws in bad2[:40]:
+        print(f"{k}: {prod}  ->  {cons}   ({ws} wait state(s))")
+    print(f"{len(bad2)} matrix instruction(s) reading a VGPR fewer than {MFMA_WAIT} wait states behind its VALU write in {so}")
+    sys.exit(1 if bad or bad2 else 0)
