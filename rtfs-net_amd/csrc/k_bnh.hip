@@ -261,6 +261,7 @@ __global__ __launch_bounds__(N_NT) void bn_head_kernel(BnHeadArgs a, int ntiles,
             side_consts((kc + 2) & 7, 0);
             STAMP(2 + kc);
         }
+        mfma_v_fence(acc1[0], acc1[1]);  // the dropped encoder tile of "chunk 9" is still being written: nothing may move into its registers yet (tools/isa_check.py)
         // ---- epilogue: a1 and the gateway output written through, projection from the accumulator registers
         const __amdgpu_buffer_rsrc_t a1s = rsrc_of(a.a1 + (size_t)b * 256 * CS + wp0);
         const __amdgpu_buffer_rsrc_t rs = rsrc_of(a.res + (size_t)b * 256 * CS + wp0);

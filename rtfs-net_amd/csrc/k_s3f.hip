@@ -257,6 +257,7 @@ __global__ __launch_bounds__(F_NT) void tail_s3t_kernel(TailS3Args a, int ntiles
             side_consts(kc + 2, 0);
             STAMP(2 + kc);
         }
+        mfma_v_fence(acc1[0], acc1[1]);  // the dropped tile of "chunk 9" is still being written: nothing may move into its registers yet (tools/isa_check.py)
         // the epilogue's spectrogram taps and first encoder fragments (the residual-conv operand is dead now: their registers)
         patch_load(spec_rsrc(a.spec + (size_t)b * 2 * P, P), wp0 + 2 * r, h, P, a.F, V);
         load_ea(0);

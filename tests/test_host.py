@@ -428,11 +428,41 @@ def test_no_hazardous_packed_f32_instructions_in_the_code_object():
     assert not bad, bad[:5]
     bad = mod.mfma_read_hazards(_lib.LIB_PATH)  # VALU write -> matrix-instruction read needs 2 wait states; inline asm is not padded by the compiler
     assert not bad, bad[:5]
+    bad = mod.mfma_result_hazards(_lib.LIB_PATH)  # matrix-instruction VGPR result -> any access needs 11 (hand-written instructions: fences)
+    assert not bad, bad[:5]
     assert mod.PAT.search("v_pk_fma_f32 v[72:73], v[168:169], v[76:77], v[72:73] op_sel:[0,1,1]")
     assert not mod.PAT.search("v_pk_fma_f32 v[154:155], v[154:155], v[76:77], v[72:73] op_sel_hi:[1,0,0]")
     assert mod.PAT.search("v_pk_mov_b32 v[2:3], v[4:5], v[6:7] op_sel:[1,0]")
     assert mod.PAT.search("v_pk_mul_f16 v1, v2, v3 op_sel:[0,1] op_sel_hi:[1,0]")
     assert not mod.PAT.search("v_fma_mixhi_f16 v1, v2, 1.0, -v3 op_sel:[0,0,1] op_sel_hi:[0,0,1]")  # not a packed op: one result lane
+
+
+def test_isa_check_wait_state_rules_on_synthetic_streams(monkeypatch):
+    """The two wait-state checks of tools/isa_check.py on hand-made instruction streams (the shipped library itself is checked above)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("isa_check2", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "isa_check.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+
+    def run(fn, stream):
+        monkeypatch.setattr(mod, "device_disassembly", lambda so: [("k", i) for i in stream])
+        return fn("unused.so")
+
+    mf = "v_mfma_f32_32x32x16_f16 a[0:15], v[64:67], v[8:11], a[0:15]"
+    # VALU write of a source register directly / one instruction / two wait states in front of the matrix instruction
+    assert len(run(mod.mfma_read_hazards, ["v_mov_b32_e32 v66, v65", mf])) == 1
+    assert len(run(mod.mfma_read_hazards, ["v_mov_b32_e32 v66, v65", "s_nop 0", mf])) == 1
+    assert not run(mod.mfma_read_hazards, ["v_mov_b32_e32 v66, v65", "s_nop 1", mf])
+    assert not run(mod.mfma_read_hazards, ["v_mov_b32_e32 v66, v65", "s_waitcnt vmcnt(0)", "s_nop 0", mf])
+    assert not run(mod.mfma_read_hazards, ["v_mov_b32_e32 v70, v65", mf])  # not a source
+    # a hand-written (VGPR-form) matrix instruction's result: read or overwritten too early, or behind a fence
+    mv = "v_mfma_f32_32x32x16_f16 v[0:15], v[134:137], v[88:91], v[0:15]"
+    assert len(run(mod.mfma_result_hazards, [mv] + ["s_mov_b32 s1, s2"] * 9 + ["v_lshlrev_b32_e32 v0, 1, v202"])) == 1   # overwritten
+    assert len(run(mod.mfma_result_hazards, [mv, "s_nop 7", "v_add_f32_e32 v20, v3, v3"])) == 1                            # read
+    assert len(run(mod.mfma_result_hazards, [mv, "s_nop 7", "buffer_store_dword v3, v9, s[0:3], 0 offen"])) == 1           # stored
+    assert not run(mod.mfma_result_hazards, [mv, "s_nop 15", "s_nop 3", "v_add_f32_e32 v20, v3, v3"])
+    assert not run(mod.mfma_result_hazards, [mv] + [mf] * 12 + ["v_add_f32_e32 v20, v3, v3"])   # a dozen matrix instructions in between
+    assert not run(mod.mfma_result_hazards, [mf, "v_accvgpr_read_b32 v1, a15"])                  # AGPR results are the compiler's business
 
 
 def test_batch_split_setter_and_workspace_layout():

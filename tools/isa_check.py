@@ -92,6 +92,55 @@ def mfma_read_hazards(so_path):
     return bad
 
 
+# ---- third check: the VGPR result of an 8-pass matrix instruction must not be read OR OVERWRITTEN by a VALU / memory instruction fewer than
+# MFMA_RESULT_WAIT wait states behind it.  The compiler pads its own pairs (it gives a VGPR-form builtin 12); pipe_helpers.h's hand-written
+# sequences end in mfma_v_fence() (s_nop 15 + s_nop 3) or put a dozen matrix instructions in between - but a hand-written instruction whose
+# result is DEAD (the pipelines' work for the non-existent chunk behind the last) is followed by whatever the compiler puts into the freed
+# registers: found by this check in tail_s3t_kernel (a `v_lshlrev_b32 v0` nine wait states behind a `v_mfma ... v[0:15]`: the late result
+# write would have landed on the new value).  AGPR results are left to the compiler (no hand-written instruction has one).  Counted as the
+# compiler counts: one wait state per instruction, N + 1 per `s_nop N`.
+MFMA_RESULT_WAIT = 11
+_AVREG = re.compile(r"\b([av])(\d+)\b|\b([av])\[(\d+):(\d+)\]")
+
+
+def _regs(tok):
+    out = set()
+    for m in _AVREG.finditer(tok):
+        if m.group(1) is not None:
+            out.add((m.group(1), int(m.group(2))))
+        else:
+            out.update((m.group(3), i) for i in range(int(m.group(4)), int(m.group(5)) + 1))
+    return out
+
+
+def mfma_result_hazards(so_path):
+    bad, kernel, pending = [], None, {}  # pending: register -> (wait states since the matrix instruction that wrote it, its text)
+    for k, ins in device_disassembly(so_path):
+        if k != kernel:
+            kernel, pending = k, {}
+        parts = ins.split(None, 1)
+        op = parts[0] if parts else ""
+        m = re.match(r"s_nop\s+(\d+)", ins)
+        step = int(m.group(1)) + 1 if m else 1
+        if op.startswith(("v_", "ds_", "buffer_", "global_", "flat_", "scratch_")) and not op.startswith("v_mfma") and len(parts) > 1:
+            ops = [t.strip() for t in parts[1].split(",")]
+            for r in set().union(*[_regs(t) for t in ops]):
+                if r in pending and pending[r][0] < MFMA_RESULT_WAIT:
+                    bad.append((k, pending[r][1], ins, pending[r][0]))
+                    break
+        for r in list(pending):
+            w, text = pending[r]
+            if w + step >= 64:
+                del pending[r]
+            else:
+                pending[r] = (w + step, text)
+        if op.startswith("v_mfma") and len(parts) > 1:
+            for r in _regs(parts[1].split(",")[0]):
+                if r[0] == "v":
+                    pending[r] = (0, ins)
+    return bad
+
+
 if __name__ == "__main__":
     so = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rtfs-net_amd", "librtfs_amd.so")
     bad = hazardous(so)
@@ -102,4 +151,8 @@ if __name__ == "__main__":
     for k, prod, cons, ws in bad2[:40]:
         print(f"{k}: {prod}  ->  {cons}   ({ws} wait state(s))")
     print(f"{len(bad2)} matrix instruction(s) reading a VGPR fewer than {MFMA_WAIT} wait states behind its VALU write in {so}")
-    sys.exit(1 if bad or bad2 else 0)
+    bad3 = mfma_result_hazards(so)
+    for k, prod, cons, ws in bad3[:40]:
+        print(f"{k}: {prod}  ->  {cons}   ({ws} wait state(s))")
+    print(f"{len(bad3)} VALU access(es) to a matrix instruction's VGPR result fewer than {MFMA_RESULT_WAIT} wait states behind it in {so}")
+    sys.exit(1 if bad or bad2 or bad3 else 0)
