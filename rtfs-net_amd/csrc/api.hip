@@ -898,6 +898,7 @@ struct SepWs {
     float *spec, *a0, *a1, *cur, *nxt, *r, *att, *rt, *attt, *z;
     float* encimg;  // encoder f16x3 fragment image (32 KB, written by enc_stats_kernel of every call)
     float* wpad;    // mask-conv weight image with 72-byte rows (LDS-DMA source of the tail kernel, 288 KB; written by the same kernel)
+    float* wpad0;   // the same for the bottleneck weights (head kernel)
     double* st0;
     unsigned* ctr;  // 64 tile counters (one per persistent launch of the call), zeroed together with st0
     int cs;
@@ -915,6 +916,7 @@ struct SepWs {
           z(a.take<float>((size_t)B * 18 * cs_)),
           encimg(a.take<float>(8192)),
           wpad(a.take<float>(73728)),
+          wpad0(a.take<float>(73728)),
           st0(a.take<double>(2 * B + 32)),
           ctr(reinterpret_cast<unsigned*>(st0 ? st0 + 2 * B : nullptr)),
           cs(cs_),
@@ -953,13 +955,14 @@ int separator_part(const SepPacks& k, const float* wav, const float* video_vp, f
         f.spec = w.spec; f.enc_img = w.encimg; f.T = T; f.F = NF;
         f.a1 = w.a1; f.res = w.blk.residual; f.xenc = w.blk.x_enc;
         f.stats = w.st0; f.inv_count = 1.0 / ((double)CA * P); f.gamma = pb.gamma; f.beta = pb.beta;
-        f.w16 = pb.w16; f.bias = pb.bias;
+        f.w16 = w.wpad0; f.bias = pb.bias;
         f.gw = pk.gw; f.gb = pk.gb; f.slope = pk.gslope; f.w2_16 = pk.proj_w16_perm; f.bp = pk.proj_b;
         f.P = P; f.cs = cs;
         f.tile_ctr = w.ctr + nctr;
         if (launch_bn_head_qualifies(f)) {
             EncPadJobs pad;
-            pad.src[1] = ps.w16; pad.dst[1] = w.wpad;  // mask conv: the tail kernel's LDS-DMA source
+            pad.src[0] = pb.w16; pad.dst[0] = w.wpad0;  // bottleneck: the head kernel's LDS-DMA source
+            pad.src[1] = ps.w16; pad.dst[1] = w.wpad;   // mask conv: the tail kernel's
             CHECK(launch_enc_stats(w.spec, pe.w, w.st0, w.encimg, pad, B, T, NF, st));
             CHECK(launch_bn_head(f, B, st));
             ++nctr;

@@ -72,7 +72,6 @@ __global__ __launch_bounds__(N_NT) void bn_head_kernel(BnHeadArgs a, int ntiles,
     const unsigned CS = (unsigned)a.cs, CS4_ = CS * 4u;
     const int lastw = (cdiv(P, 64) - 1) * 64;
     const __amdgpu_buffer_rsrc_t ws = rsrc_of(reinterpret_cast<const float*>(a.w16));  // bottleneck: [chunk 8][hi|lo][256 co][4 pieces of 8 k]
-    const unsigned voffW = (unsigned)tid * 16u;
     const __amdgpu_buffer_rsrc_t is = rsrc_of(reinterpret_cast<const float*>(a.enc_img));  // encoder fragments (enc_stats_kernel)
     const unsigned voffT = (unsigned)(r * 2 + h) * 16u;
     const int T = a.T, F = a.F;
@@ -83,27 +82,19 @@ __global__ __launch_bounds__(N_NT) void bn_head_kernel(BnHeadArgs a, int ntiles,
     unsigned lw2 = (unsigned)(r * L2 + 8 * h) * 2u;                                  // projection fragments
     unsigned lc4 = OFF_C + 16u * h;                                                  // per-channel constants, accumulator order
     unsigned lwr0 = OFF_W + (unsigned)(r * N_ROWB + 8 * h), lwr1 = lwr0 + N_BUF;     // bottleneck fragments, buffer 0 / 1
-    unsigned lww0 = OFF_W + (unsigned)((tid >> 2) * N_ROWB + (tid & 3) * 16), lww1 = lww0 + N_BUF;  // staging writes
-    asm volatile("" : "+v"(lw2), "+v"(lc4), "+v"(lwr0), "+v"(lwr1), "+v"(lww0), "+v"(lww1));
-    half8 pre[8];
-    auto stage_load_piece = [&](int c, int j) { pre[j] = ld_h8(ws, voffW, (unsigned)(c * 2048 + 256 * j) * 16u); };
-    auto stage_load = [&](int c) {
+    asm volatile("" : "+v"(lw2), "+v"(lc4), "+v"(lwr0), "+v"(lwr1));
+    // bottleneck weight chunk c -> LDS buffer by LDS-DMA (`buffer_load_dwordx4 ... lds`; k_s3f.hip has the details): the image in memory already
+    // has the 72-byte rows (enc_stats_kernel's extra block row writes it); a chunk is 36 pieces of 1 KB, 9 per wave; the barrier that publishes
+    // a chunk is preceded by an explicit wait (the compiler's own is missing at a loop header)
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    const unsigned voffL = (unsigned)lane * 16u;
+    int wave1k = wave * 1024;  // (laundered per tile: the piece offsets are loop invariants and spill as SGPRs when hoisted)
+    auto stage_dma_piece = [&](int c, int buf, int j) {
+        const int po = j * 4096 + wave1k;  // uniform: piece j * 4 + wave
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ws, (lds_ptr)(smem + OFF_W + buf * N_BUF + po), 16, voffL, c * N_BUF + po, 0, 0);
+    };
 #pragma unroll
-        for (int j = 0; j < 8; ++j) stage_load_piece(c, j);
-    };
-    auto stage_write_piece = [&](int buf, int j) {
-        // piece tid + 256 j: row (tid >> 2) + 64 (j & 3) of part j >> 2 (rows are 72 bytes apart: two 8-byte halves)
-        u64_* d = reinterpret_cast<u64_*>(smem + (buf ? lww1 : lww0) + (j >> 2) * N_PART + 64 * (j & 3) * N_ROWB);
-        const u64_* sp = reinterpret_cast<const u64_*>(&pre[j]);
-        d[0] = sp[0];
-        d[1] = sp[1];
-    };
-    auto stage_write = [&](int buf) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) stage_write_piece(buf, j);
-    };
-    stage_load(0);
-    stage_write(0);
+    for (int j = 0; j < 9; ++j) stage_dma_piece(0, 0, j);
     // Phase stagger: every workgroup does the same work per tile, so without it all 256 CUs write their tiles' 576 rows at the same time and
     // then leave the memory system idle through the next K loop (the first output tile of an epilogue took 8-13 k cycles, the others 3 k).
     // Workgroups start a quarter of a tile apart in four groups; the tile counter keeps them apart.
@@ -122,7 +113,7 @@ __global__ __launch_bounds__(N_NT) void bn_head_kernel(BnHeadArgs a, int ntiles,
 #endif
         STAMP(0);
         unsigned CS4 = CS4_;
-        asm volatile("" : "+s"(CS4));  // row offsets are formed where they are used (one s_mul each), not hoisted out of the tile loop
+        asm volatile("" : "+s"(CS4), "+s"(wave1k));  // row offsets are formed where they are used (one s_mul each), not hoisted out of the tile loop
         const int b = tile / tps;
         // a wave segment past the sample's end repeats the last real one (same values to the same addresses): every wave takes part in every barrier
         const int wp0 = min((tile - b * tps) * (N_NT / 64 * 64) + wave * 64, lastw);
@@ -219,6 +210,7 @@ __global__ __launch_bounds__(N_NT) void bn_head_kernel(BnHeadArgs a, int ntiles,
         for (int kc = 0; kc < 8; ++kc) {
             const int buf = kc & 1;
             __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces of chunk kc have landed
             __syncthreads();  // chunk kc staged (buffer `buf`) and visible; everyone is done reading chunk kc - 1 (the other buffer)
             // (the 12 loads of a chunk - next weight chunk, next encoder fragments - are spread over the matrix-instruction gaps below: issued
             // together behind the barrier by all four waves they queued on the CU's one address unit for ~800 cycles, a fifth of a chunk)
@@ -246,9 +238,9 @@ __global__ __launch_bounds__(N_NT) void bn_head_kernel(BnHeadArgs a, int ntiles,
                     const int s = t / 6, sl = t & 1, v = (t % 6) >> 1;  // products hi*hi, hi*lo, lo*hi of K step s, the two pixel slots alternating
                     acc[m][sl] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v == 2 ? al[m & 1][s] : ah[m & 1][s], v == 1 ? bl[buf][s][sl] : bh[buf][s][sl], acc[m][sl], 0, 0, 0);
                     if (m >= 1 && (m - 1) * 12 + t < 32) side((kc + 1) & 7, (m - 1) * 12 + t);
-                    if ((m == 0 || m == 4) && t % 3 == 0) stage_load_piece((kc + 1) & 7, (m >> 2) * 4 + t / 3);  // chunk 0 again behind chunk 7: the next tile's first
+                    if ((m == 0 || m == 4) && t % 3 == 0) stage_dma_piece((kc + 1) & 7, buf ^ 1, (m >> 2) * 4 + t / 3);  // chunk 0 again behind chunk 7: the next tile's first
+                    if (m == 5 && t == 0) stage_dma_piece((kc + 1) & 7, buf ^ 1, 8);
                     if (m == 3 && t >= 8) load_ea_piece((kc + 2) & 7, t - 8);
-                    if ((m == 5 || m == 7) && t < 4) stage_write_piece(buf ^ 1, (m == 5 ? 0 : 4) + t);
                     __builtin_amdgcn_sched_barrier(0);
                 }
 #ifdef BNH_STAMP

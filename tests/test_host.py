@@ -479,6 +479,6 @@ def test_batch_split_setter_and_workspace_layout():
         two = [lib.rtfs_separator_workspace_bytes(B, 4096, 7) for B in (32, 17, 15, 9)]
         assert two[0] != one[0] and two[1] != one[1]      # 16 + 16, 8 + 9: two arenas, different padding
         assert two[2] == one[2] and two[3] == one[3]      # 15 and 9 mixtures are not split (a part would be < 8)
-        assert all(0 <= t - o < 384 * 1024 for t, o in zip(two, one))  # per part: padding + the 32 KB encoder fragment image + the 288 KB padded mask-conv image
+        assert all(0 <= t - o < 704 * 1024 for t, o in zip(two, one))  # per part: padding + the 32 KB encoder fragment image + two 288 KB padded weight images
     finally:
         R.set_batch_split(0)

@@ -29,13 +29,17 @@ int main(int argc, char** argv) {
                 img[((size_t)(c * 2 + 0) * 256 + co) * 32 + k] = hi;
                 img[((size_t)(c * 2 + 1) * 256 + co) * 32 + k] = (_Float16)(v - (float)hi);
             }
+    // the head kernel fetches its weight chunks by LDS-DMA from an image whose rows are padded to 72 bytes
+    std::vector<_Float16> imgp((size_t)8 * 2 * 256 * 36, (_Float16)0.f);
+    for (size_t row = 0; row < (size_t)8 * 2 * 256; ++row)
+        for (int k = 0; k < 32; ++k) imgp[row * 36 + k] = img[row * 32 + k];
     float *dspec, *dwenc, *dvec, *a0, *a1r, *a1, *res, *xe, *zero;
-    void *dimg, *encimg;
+    void *dimg, *dimgp, *encimg;
     double *st, *st2;
     CK(hipMalloc(&dspec, spec.size() * 4)); CK(hipMalloc(&dwenc, wenc.size() * 4)); CK(hipMalloc(&dvec, vec.size() * 4));
     CK(hipMalloc(&a0, (size_t)B * 256 * cs * 4)); CK(hipMalloc(&a1r, (size_t)B * 256 * cs * 4)); CK(hipMalloc(&a1, (size_t)B * 256 * cs * 4));
     CK(hipMalloc(&res, (size_t)B * 256 * cs * 4)); CK(hipMalloc(&xe, (size_t)B * 64 * cs * 4)); CK(hipMalloc(&zero, 1 << 18));
-    CK(hipMalloc(&dimg, img.size() * 2)); CK(hipMalloc(&encimg, 32768)); CK(hipMalloc(&st, 64 * 8)); CK(hipMalloc(&st2, 64 * 8));
+    CK(hipMalloc(&dimg, img.size() * 2)); CK(hipMalloc(&dimgp, imgp.size() * 2)); CK(hipMemcpy(dimgp, imgp.data(), imgp.size() * 2, hipMemcpyHostToDevice)); CK(hipMalloc(&encimg, 32768)); CK(hipMalloc(&st, 64 * 8)); CK(hipMalloc(&st2, 64 * 8));
     CK(hipMemcpy(dspec, spec.data(), spec.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dwenc, wenc.data(), wenc.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(dvec, vec.data(), vec.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dimg, img.data(), img.size() * 2, hipMemcpyHostToDevice));
     CK(hipMemset(zero, 0, 1 << 18)); CK(hipMemset(st, 0, 512)); CK(hipMemset(st2, 0, 512));
@@ -53,7 +57,7 @@ int main(int argc, char** argv) {
     if (launch_pwr_audio_bn(pa, B, 0)) return 1;
     BnHeadArgs f;
     f.spec = dspec; f.enc_img = encimg; f.T = T; f.F = F; f.a1 = a1; f.res = res; f.xenc = xe; f.stats = st2; f.inv_count = pa.inv_count;
-    f.gamma = dvec + 256; f.beta = dvec + 512; f.w16 = dimg; f.bias = dvec; f.gw = dvec + 768; f.gb = dvec + 1024; f.slope = dvec + 1280; f.w2_16 = zero; f.bp = zero;
+    f.gamma = dvec + 256; f.beta = dvec + 512; f.w16 = dimgp; f.bias = dvec; f.gw = dvec + 768; f.gb = dvec + 1024; f.slope = dvec + 1280; f.w2_16 = zero; f.bp = zero;
     f.P = P; f.cs = cs;
     if (launch_bn_head(f, B, 0)) { printf("bn_head does not qualify\n"); return 1; }
     CK(hipDeviceSynchronize());
