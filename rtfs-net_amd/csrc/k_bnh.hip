@@ -68,6 +68,7 @@ __global__ __launch_bounds__(N_NT) void bn_head_kernel(BnHeadArgs a, int ntiles,
         if (tid < 64) bp[tid] = a.bp[tid];
     }
     const float slope = a.slope[0];
+    const float pc1 = 0.5f * (1.0f + slope), pc2 = 0.5f * (1.0f - slope);
     const int P = a.P;
     const unsigned CS = (unsigned)a.cs, CS4_ = CS * 4u;
     const int lastw = (cdiv(P, 64) - 1) * 64;
@@ -282,8 +283,9 @@ __global__ __launch_bounds__(N_NT) void bn_head_kernel(BnHeadArgs a, int ntiles,
                         const unsigned ro = (unsigned)(m * 32 + (q & 3) + 8 * (q >> 2)) * CS4;
                         const float v0 = fmaf(acc_rd(acc[m][0][q]), WINV, kb[i]), v1 = fmaf(acc_rd(acc[m][1][q]), WINV, kb[i]);
                         st2(a1s, voffC, ro, f32x2{v0, v1});
-                        y0[j] = preluf_(fmaf(v0, kg[i], kh[i]), slope);
-                        y1[j] = preluf_(fmaf(v1, kg[i], kh[i]), slope);
+                        const float t0 = fmaf(v0, kg[i], kh[i]), t1 = fmaf(v1, kg[i], kh[i]);
+                        y0[j] = fmaf(pc2, __builtin_fabsf(t0), pc1 * t0);  // PReLU(t) = pc1 t + pc2 |t| (one instruction fewer than compare + select)
+                        y1[j] = fmaf(pc2, __builtin_fabsf(t1), pc1 * t1);
                         st2(rs, voffC, ro, f32x2{y0[j], y1[j]});
                     }
                 }
