@@ -539,7 +539,7 @@ int block_forward(const BlockPack& p, const float* x, const float* x_res, float*
 // res_has_a1 (in / out): whether w.residual currently holds residual + a1.  A boundary that has to read a1 anyway also adds it to the residual
 // it writes (unless it is the last one: the tail wants the plain residual), and the boundary after it then does not read a1 at all.
 int block_boundary(const BlockPack& p, const float* a1, int B, int T, int F, BlockWs& w, hipStream_t st, const CafArgs* caf, unsigned* ctr = nullptr,
-                   bool* res_has_a1 = nullptr, bool last = true) {
+                   bool* res_has_a1 = nullptr, bool last = true, bool res_from_a1 = false) {
     B2bArgs a;
     a.x = w.expanded;
     a.res = w.residual;
@@ -563,6 +563,9 @@ int block_boundary(const BlockPack& p, const float* a1, int B, int T, int F, Blo
     if (res_has_a1 && launch_pws_b2b4_qualifies(a)) {
         a.a1_mode = *res_has_a1 ? 0 : (last ? 1 : 3);
         *res_has_a1 = a.a1_mode == 3;
+        if (res_from_a1 && caf) a.a1_mode |= 4;  // residual_0 was not written by the head: it is the gateway of a1
+    } else if (res_from_a1) {
+        return RTFS_ERR_ARG;  // (cannot happen: the head kernel that skipped the residual qualifies on the same conditions)
     }
     const int rc = launch_pws_b2b4(a, B, ctr, st);  // padded rows: the pipelined kernel (k_b2b.hip)
     return rc == RTFS_ERR_ARG ? launch_pws_b2b(a, B, st) : rc;
@@ -953,7 +956,7 @@ int separator_part(const SepPacks& k, const float* wav, const float* video_vp, f
     if (!gemm_f32() && repeats > 1) {
         BnHeadArgs f;
         f.spec = w.spec; f.enc_img = w.encimg; f.T = T; f.F = NF;
-        f.a1 = w.a1; f.res = w.blk.residual; f.xenc = w.blk.x_enc;
+        f.a1 = w.a1; f.res = nullptr; f.xenc = w.blk.x_enc;  // residual_0 is formed by the first boundary from a1 (B2bArgs::a1_mode bit 2)
         f.stats = w.st0; f.inv_count = 1.0 / ((double)CA * P); f.gamma = pb.gamma; f.beta = pb.beta;
         f.w16 = w.wpad0; f.bias = pb.bias;
         f.gw = pk.gw; f.gb = pk.gb; f.slope = pk.gslope; f.w2_16 = pk.proj_w16_perm; f.bp = pk.proj_b;
@@ -1005,7 +1008,7 @@ int separator_part(const SepPacks& k, const float* wav, const float* video_vp, f
         for (int i = 0; i < repeats; ++i) {
             CHECK(block_body(pk, B, T, NF, w.blk, st, single_chain));
             if (i == 0) CHECK(cafv.join());
-            if (i + 1 < repeats) CHECK(block_boundary(pk, w.a1, B, T, NF, w.blk, st, i == 0 ? &ca : nullptr, nctr < 64 ? w.ctr + nctr++ : nullptr, &res_has_a1, i + 2 == repeats));
+            if (i + 1 < repeats) CHECK(block_boundary(pk, w.a1, B, T, NF, w.blk, st, i == 0 ? &ca : nullptr, nctr < 64 ? w.ctr + nctr++ : nullptr, &res_has_a1, i + 2 == repeats, head_done && i == 0));
             else {
                 // last application: residual conv + S3 mask + complex product + decoder taps in one kernel (k_s3f.hip); `refined` never exists
                 TailS3Args f;

@@ -31,7 +31,10 @@ constexpr size_t B4_LDS = (size_t)2 * 256 * B4_L1 * 2 + (size_t)2 * 64 * B4_L2 *
 // with key / value = dw 1x1 . eval BatchNorm (layers/fusion.py:205-226, folded to one FMA each) and r / att the video-side terms of
 // caf_video_kernel, read from their (B, Tv, 256) transposed copies: four consecutive channels of one video frame are one 16-byte load.
 // AM: bit 0 = the residual read does not contain a1 yet: read a1 and add it (the block input is out + a1); bit 1 = write the new residual WITH
-// a1 added (the next boundary then runs with bit 0 clear and does not read a1 at all: one boundary in two saves 256 of its 576 row reads).
+// a1 added (the next boundary then runs with bit 0 clear and does not read a1 at all: one boundary in two saves 256 of its 576 row reads);
+// bit 2 (first boundary only, CAF): residual_0 is not read either - it is the gateway of a1, PReLU(gw a1 + gb) with the block's own gateway
+// weights (tdanet.py:106 applied to the bottleneck output), three instructions per value from the a1 rows that are loaded anyway; the head
+// kernel then does not write it.
 template <bool CAF, int AM>
 __global__ __launch_bounds__(B4_NT) void pws_b2b4_kernel(B2bArgs a, int ntiles, int tiles_per_sample, unsigned* __restrict__ ctr) {
     constexpr int L1 = B4_L1, L2 = B4_L2;
@@ -120,7 +123,7 @@ __global__ __launch_bounds__(B4_NT) void pws_b2b4_kernel(B2bArgs a, int ntiles, 
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {
                     const unsigned ro = (unsigned)(m * 32 + (q & 3) + 8 * (q >> 2)) * CS4;  // uniform
-                    Rb[q] = ld2(ress, voffC, ro);
+                    if (!(AM & 4)) Rb[q] = ld2(ress, voffC, ro);
                     if (AM & 1) Ab[q] = ld2(a1s, voffC, ro);
                 }
             };
@@ -204,7 +207,10 @@ __global__ __launch_bounds__(B4_NT) void pws_b2b4_kernel(B2bArgs a, int ntiles, 
                             const int j = 4 * g + i, q = 8 * s + j;
                             float t0, t1;
                             if (CAF) {
-                                float o0 = fmaf(acc1[0][q], WINV, kA[i]) + Rb[q].x, o1 = fmaf(acc1[1][q], WINV, kA[i]) + Rb[q].y;  // out_0
+                                // out_0 = residual_conv(expanded_0) + residual_0 (CAF constants: kB = gateway scale, kC = gateway bias)
+                                const float r0_ = (AM & 4) ? preluf_(fmaf(Ab[q].x, kB[i], kC[i]), slope) : Rb[q].x;
+                                const float r1_ = (AM & 4) ? preluf_(fmaf(Ab[q].y, kB[i], kC[i]), slope) : Rb[q].y;
+                                float o0 = fmaf(acc1[0][q], WINV, kA[i]) + r0_, o1 = fmaf(acc1[1][q], WINV, kA[i]) + r1_;
                                 o0 = fmaf(fmaxf(fmaf(o0, kks[i], kkb[i]), 0.f), vr0[2 * s + g][i], va0[2 * s + g][i] * fmaf(o0, kvs[i], kvb[i]));
                                 o1 = fmaf(fmaxf(fmaf(o1, kks[i], kkb[i]), 0.f), vr1[2 * s + g][i], va1[2 * s + g][i] * fmaf(o1, kvs[i], kvb[i]));
                                 t0 = fmaf(o0 + Ab[q].x, kB[i], kC[i]);
@@ -405,14 +411,16 @@ int launch_pws_b2b4(const B2bArgs& a, int B, unsigned* ctr, hipStream_t st) {
     const int tps = cdiv(a.P, B4_NT / 64 * 64), ntiles = tps * B;
     const int grid = ntiles < 256 ? ntiles : 256;  // one resident workgroup per CU
     const int am = a.a1_mode;
-    if ((am != 0 && am != 1 && am != 3) || (a.caf_r && !(am & 1))) return RTFS_ERR_ARG;
+    if ((am != 0 && am != 1 && am != 3 && am != 5 && am != 7) || (a.caf_r && !(am & 1)) || ((am & 4) && !a.caf_r)) return RTFS_ERR_ARG;
 #define B4_LAUNCH(CAF_, AM_)                                                                                                  \
     do {                                                                                                                      \
         if (rtfs_set_max_lds((const void*)pws_b2b4_kernel<CAF_, AM_>, B4_LDS) != RTFS_OK) return RTFS_ERR_LAUNCH;             \
         hipLaunchKernelGGL((pws_b2b4_kernel<CAF_, AM_>), dim3(grid), dim3(B4_NT), B4_LDS, st, a, ntiles, tps, ctr);           \
     } while (0)
     if (a.caf_r) {
-        if (am == 3) B4_LAUNCH(true, 3);
+        if (am == 7) B4_LAUNCH(true, 7);
+        else if (am == 5) B4_LAUNCH(true, 5);
+        else if (am == 3) B4_LAUNCH(true, 3);
         else B4_LAUNCH(true, 1);
     } else if (am == 3) {
         B4_LAUNCH(false, 3);

@@ -38,6 +38,7 @@ __device__ unsigned bnh_stamps[16 * 32];
 #define STAMP(i) do { } while (0)
 #endif
 
+template <bool WRES>  // write the gateway output (false: the first block boundary forms it from a1, k_b2b.hip AM bit 2)
 __global__ __launch_bounds__(N_NT) void bn_head_kernel(BnHeadArgs a, int ntiles, int tps) {
     constexpr int L2 = N_L2;
     constexpr float WINV = 1.0f / 256.0f;
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(N_NT) void bn_head_kernel(BnHeadArgs a, int ntiles,
         mfma_v_fence(acc1[0], acc1[1]);  // the dropped encoder tile of "chunk 9" is still being written: nothing may move into its registers yet (tools/isa_check.py)
         // ---- epilogue: a1 and the gateway output written through, projection from the accumulator registers
         const __amdgpu_buffer_rsrc_t a1s = rsrc_of(a.a1 + (size_t)b * 256 * CS + wp0);
-        const __amdgpu_buffer_rsrc_t rs = rsrc_of(a.res + (size_t)b * 256 * CS + wp0);
+        const __amdgpu_buffer_rsrc_t rs = rsrc_of((WRES ? a.res : a.a1) + (size_t)b * 256 * CS + wp0);
         const __amdgpu_buffer_rsrc_t xes = rsrc_of(a.xenc + (size_t)b * 64 * CS + wp0);
         const int ntile = s_next[it & 1];  // (written before this tile's first barrier)
         if (ntile < ntiles) {              // block-uniform
@@ -286,7 +287,7 @@ __global__ __launch_bounds__(N_NT) void bn_head_kernel(BnHeadArgs a, int ntiles,
                         const float t0 = fmaf(v0, kg[i], kh[i]), t1 = fmaf(v1, kg[i], kh[i]);
                         y0[j] = fmaf(pc2, __builtin_fabsf(t0), pc1 * t0);  // PReLU(t) = pc1 t + pc2 |t| (one instruction fewer than compare + select)
                         y1[j] = fmaf(pc2, __builtin_fabsf(t1), pc1 * t1);
-                        st2(rs, voffC, ro, f32x2{y0[j], y1[j]});
+                        if (WRES) st2(rs, voffC, ro, f32x2{y0[j], y1[j]});
                     }
                 }
                 unsigned h0[4], l0[4], h1[4], l1[4];
@@ -352,9 +353,14 @@ bool launch_bn_head_qualifies(const BnHeadArgs& a) {
 // RTFS_ERR_ARG = the call does not qualify (contiguous rows, tiny input): the caller runs the separate kernels
 int launch_bn_head(const BnHeadArgs& a, int B, hipStream_t st) {
     if (!launch_bn_head_qualifies(a)) return RTFS_ERR_ARG;
-    if (rtfs_set_max_lds((const void*)bn_head_kernel, N_LDS) != RTFS_OK) return RTFS_ERR_LAUNCH;
     const int tps = cdiv(a.P, N_NT / 64 * 64), ntiles = tps * B;
     const int grid = ntiles < 256 ? ntiles : 256;  // one resident workgroup per CU
-    hipLaunchKernelGGL(bn_head_kernel, dim3(grid), dim3(N_NT), N_LDS, st, a, ntiles, tps);
+    if (a.res) {
+        if (rtfs_set_max_lds((const void*)bn_head_kernel<true>, N_LDS) != RTFS_OK) return RTFS_ERR_LAUNCH;
+        hipLaunchKernelGGL(bn_head_kernel<true>, dim3(grid), dim3(N_NT), N_LDS, st, a, ntiles, tps);
+    } else {
+        if (rtfs_set_max_lds((const void*)bn_head_kernel<false>, N_LDS) != RTFS_OK) return RTFS_ERR_LAUNCH;
+        hipLaunchKernelGGL(bn_head_kernel<false>, dim3(grid), dim3(N_NT), N_LDS, st, a, ntiles, tps);
+    }
     return rtfs_launch_status();
 }

@@ -79,6 +79,8 @@ struct B2bArgs {
     int caf_T = 0, caf_F = 0, caf_Tv = 0;
     // k_b2b.hip only: bit 0 = `res` does not contain a1 yet (read a1, add it to the block input); bit 1 = write the new residual WITH a1 added, so
     // that the next boundary runs with bit 0 clear and never reads a1.  1 = the reference sequence as written (launch_pws_b2b knows no other).
+    // bit 2 (with a CAF, i.e. the first boundary): `res` is not read - residual_0 = PReLU(gw a1 + gb) is formed from the a1 rows (the head kernel
+    // then need not write it).
     int a1_mode = 1;
 };
 int launch_pws_b2b(const B2bArgs& a, int B, hipStream_t st);
@@ -93,7 +95,7 @@ struct BnHeadArgs {
     const void* enc_img = nullptr;  // encoder f16x3 fragment image (enc_stats_kernel)
     int T = 0, F = 0;
     float* a1 = nullptr;            // bottleneck output (B,256,cs)
-    float* res = nullptr;           // gateway output (B,256,cs)
+    float* res = nullptr;           // gateway output (B,256,cs); null = not written (the first boundary forms it from a1: B2bArgs::a1_mode bit 2)
     float* xenc = nullptr;          // projection output (B,64,cs)
     const double* stats = nullptr;  // (B,2) sum / sumsq of a0
     double inv_count = 0;
