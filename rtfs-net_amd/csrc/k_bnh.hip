@@ -268,56 +268,65 @@ __global__ __launch_bounds__(N_NT) void bn_head_kernel(BnHeadArgs a, int ntiles,
         }
         __builtin_amdgcn_sched_barrier(0);
         f32x16 acc2[2][2];  // [projection tile][pixel slot]
-#pragma unroll
-        for (int m = 0; m < 8; ++m) {
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {  // accumulator registers 8s .. 8s+7 = K step 2m + s of the projection
-                float y0[8], y1[8];
-#pragma unroll
-                for (int g = 0; g < 2; ++g) {
-                    const unsigned co = (unsigned)(m * 32 + 8 * (2 * s + g)) * 4u;  // channel m*32 + 4 h + 8 (2 s + g)
-                    const f32x4 kb = *reinterpret_cast<const f32x4*>(smem + lc4 + 2048 + co);
-                    const f32x4 kg = *reinterpret_cast<const f32x4*>(smem + lc4 + 3072 + co), kh = *reinterpret_cast<const f32x4*>(smem + lc4 + 4096 + co);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int j = 4 * g + i, q = 8 * s + j;
-                        const unsigned ro = (unsigned)(m * 32 + (q & 3) + 8 * (q >> 2)) * CS4;
-                        const float v0 = fmaf(acc_rd(acc[m][0][q]), WINV, kb[i]), v1 = fmaf(acc_rd(acc[m][1][q]), WINV, kb[i]);
-                        st2(a1s, voffC, ro, f32x2{v0, v1});
-                        const float t0 = fmaf(v0, kg[i], kh[i]), t1 = fmaf(v1, kg[i], kh[i]);
-                        y0[j] = fmaf(pc2, __builtin_fabsf(t0), pc1 * t0);  // PReLU(t) = pc1 t + pc2 |t| (one instruction fewer than compare + select)
-                        y1[j] = fmaf(pc2, __builtin_fabsf(t1), pc1 * t1);
-                        if (WRES) st2(rs, voffC, ro, f32x2{y0[j], y1[j]});
-                    }
+        // The epilogue is a software pipeline too: block k = (output tile m, K step s of the projection) = 16 accumulator values per pixel
+        // slot.  While the 12 projection matrix instructions of block k issue, block k + 1 is built in their gaps: eight value slices (a1 =
+        // acc / 256 + bias written through, gateway, PReLU) and four split slices, one per gap; the per-channel constants of a group of four
+        // channels are read one group ahead.  In sequence the 192 matrix instructions of a tile added 6 k cycles to 20 k of VALU and stores.
+        half8 pbh[2][2], pbl[2][2];  // [block parity][pixel slot]
+        float ey0[8], ey1[8];
+        f32x4 ek[2][3];  // [group parity][bottleneck bias | gateway scale | gateway bias]
+        unsigned eh0[4], el0[4], eh1[4], el1[4];
+        auto econsts = [&](int gg) {  // group gg = 2 k + g: channels 32 (gg >> 2) + 4 h + 8 (gg & 3) ..
+            const unsigned co = (unsigned)((gg >> 2) * 32 + 8 * (gg & 3)) * 4u;
+            ek[gg & 1][0] = *reinterpret_cast<const f32x4*>(smem + lc4 + 2048 + co);
+            ek[gg & 1][1] = *reinterpret_cast<const f32x4*>(smem + lc4 + 3072 + co);
+            ek[gg & 1][2] = *reinterpret_cast<const f32x4*>(smem + lc4 + 4096 + co);
+        };
+        auto ebuild = [&](int k, int step) {
+            const int m = k >> 1, sq = k & 1;
+            if (step < 8) {
+                const int g = step >> 2, i = step & 3, j = 4 * g + i, q = 8 * sq + j, gg = 2 * k + g;
+                if (i == 1 && gg + 1 < 32) econsts(gg + 1);
+                const unsigned ro = (unsigned)(m * 32 + (q & 3) + 8 * (q >> 2)) * CS4;
+                const float v0 = fmaf(acc_rd(acc[m][0][q]), WINV, ek[gg & 1][0][i]), v1 = fmaf(acc_rd(acc[m][1][q]), WINV, ek[gg & 1][0][i]);
+                st2(a1s, voffC, ro, f32x2{v0, v1});
+                const float t0 = fmaf(v0, ek[gg & 1][1][i], ek[gg & 1][2][i]), t1 = fmaf(v1, ek[gg & 1][1][i], ek[gg & 1][2][i]);
+                ey0[j] = fmaf(pc2, __builtin_fabsf(t0), pc1 * t0);  // PReLU(t) = pc1 t + pc2 |t| (one instruction fewer than compare + select)
+                ey1[j] = fmaf(pc2, __builtin_fabsf(t1), pc1 * t1);
+                if (WRES) st2(rs, voffC, ro, f32x2{ey0[j], ey1[j]});
+            } else {
+                const int jp = step - 8;
+                split2(ey0[2 * jp], ey0[2 * jp + 1], eh0[jp], el0[jp]);
+                split2(ey1[2 * jp], ey1[2 * jp + 1], eh1[jp], el1[jp]);
+                if (jp == 3) {
+                    pbh[k & 1][0] = __builtin_bit_cast(half8, *reinterpret_cast<f32x4*>(eh0));
+                    pbl[k & 1][0] = __builtin_bit_cast(half8, *reinterpret_cast<f32x4*>(el0));
+                    pbh[k & 1][1] = __builtin_bit_cast(half8, *reinterpret_cast<f32x4*>(eh1));
+                    pbl[k & 1][1] = __builtin_bit_cast(half8, *reinterpret_cast<f32x4*>(el1));
                 }
-                unsigned h0[4], l0[4], h1[4], l1[4];
+            }
+        };
+        econsts(0);
 #pragma unroll
-                for (int jp = 0; jp < 4; ++jp) {
-                    split2(y0[2 * jp], y0[2 * jp + 1], h0[jp], l0[jp]);
-                    split2(y1[2 * jp], y1[2 * jp + 1], h1[jp], l1[jp]);
-                }
-                const half8 bh0 = __builtin_bit_cast(half8, *reinterpret_cast<f32x4*>(h0)), bl0 = __builtin_bit_cast(half8, *reinterpret_cast<f32x4*>(l0));
-                const half8 bh1 = __builtin_bit_cast(half8, *reinterpret_cast<f32x4*>(h1)), bl1 = __builtin_bit_cast(half8, *reinterpret_cast<f32x4*>(l1));
+        for (int step = 0; step < 12; ++step) ebuild(0, step);
 #pragma unroll
-                for (int m2 = 0; m2 < 2; ++m2) {
-                    const unsigned wo = (unsigned)(m2 * 32 * L2 + (2 * m + s) * 16) * 2u;
-                    const half8 ph = *reinterpret_cast<const half8*>(smem + lw2 + wo);
-                    const half8 pl = *reinterpret_cast<const half8*>(smem + lw2 + 64 * L2 * 2 + wo);
-                    if (m == 0 && s == 0) {
-                        mfma_v0(acc2[m2][0], ph, bh0);
-                        mfma_v0(acc2[m2][1], ph, bh1);
-                    } else {
-                        mfma_v(acc2[m2][0], ph, bh0);
-                        mfma_v(acc2[m2][1], ph, bh1);
-                    }
-                    mfma_v(acc2[m2][0], ph, bl0);
-                    mfma_v(acc2[m2][1], ph, bl1);
-                    mfma_v(acc2[m2][0], pl, bh0);
-                    mfma_v(acc2[m2][1], pl, bh1);
+        for (int k = 0; k < 16; ++k) {
+            half8 ph, pl;
+#pragma unroll
+            for (int t = 0; t < 12; ++t) {
+                const int m2 = t / 6, v = (t % 6) >> 1, sl = t & 1;  // products hi*hi, hi*lo, lo*hi of projection tile m2, the two pixel slots alternating
+                if (t % 6 == 0) {
+                    const unsigned wo = (unsigned)(m2 * 32 * L2 + k * 16) * 2u;  // K step 2 m + s = k
+                    ph = *reinterpret_cast<const half8*>(smem + lw2 + wo);
+                    pl = *reinterpret_cast<const half8*>(smem + lw2 + 64 * L2 * 2 + wo);
                 }
+                const half8 af = v == 2 ? pl : ph, bf = v == 1 ? pbl[k & 1][sl] : pbh[k & 1][sl];
+                if (k == 0 && v == 0) mfma_v0(acc2[m2][sl], af, bf);
+                else mfma_v(acc2[m2][sl], af, bf);
+                if (k + 1 < 16) ebuild(k + 1, t);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            STAMP(10 + m);
+            if (k & 1) STAMP(10 + (k >> 1));
         }
         mfma_v_fence4(acc2[0][0], acc2[0][1], acc2[1][0], acc2[1][1]);
 #pragma unroll
