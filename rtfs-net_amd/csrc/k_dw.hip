@@ -145,7 +145,10 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 struct DwBlk { int x, y, z; bool ok; };
 __device__ __forceinline__ DwBlk dw_block(const DwArgs& a) {
     int id = blockIdx.x;
-    if (DW_XCD) id = (id & 7) * (int)(gridDim.x >> 3) + (id >> 3);
+    if (DW_XCD) {
+        const int n8 = (int)(gridDim.x >> 3), q = id >> 3;
+        id = (id & 7) * n8 + (a.rev ? n8 - 1 - q : q);  // rev: every XCD walks its eighth back to front
+    }
     id -= a.blk0;
     DwBlk k;
     k.ok = id >= 0 && id < a.nblk;

@@ -153,6 +153,8 @@ struct DwArgs {
     int cs = 0;  // channel stride (floats) of the (B, C, H, W) tensors x / out[] / addend; 0 = H * W.  gate / emb (Hg x Wg) stay contiguous
     int in_combine = 0;  // lane-exchange kernels, MODE 0: the input is the same-size TFAR combination gLN(x) * sigmoid(gLN(gate)) + gLN(emb) of three
                          // pre-norm tensors (folds: loc_* / gate_* / emb_*, all with g_inv_count), formed at load time (fusion.py:62-67)
+    int rev = 0;  // lane-exchange kernels: walk the tensor back to front (a consumer that starts where its producer stopped finds that end in the
+                  // memory-side cache: tools/bench_mall.hip)
     int gx = 0, gy = 0, nblk = 0, blk0 = 0;  // set by the launchers of the lane-exchange kernels: logical grid (gx, gy, B) behind a 1-D launch
                                               // (XCD order); blk0 = first block of this job when several jobs share one launch
     // MODE 2 (TFAR apply) / stride-2 kernel: the low-resolution side
