@@ -367,6 +367,11 @@ int block_body(const BlockPack& p, int B, int T, int F, const BlockWs& w, hipStr
     const int P = T * F, Pg = Tp * Fp;
     const double icF = 1.0 / ((double)CH * P), icG = 1.0 / ((double)CH * Pg);
     typedef BlockWs W;
+    // Band heights (rows a workgroup walks).  The read + write passes at full resolution take 24-row bands: 64-row bands are 2176 workgroups for
+    // 1024 resident ones, i.e. a third round of 128 workgroups on an otherwise idle chip (same-box A/B: step 2 162 -> 153 us, 15 172 -> 162,
+    // 17 213 -> 204, stride-2 pass 118 -> 103 with 12 output rows; 10.51 -> 10.35 ms per forward).  The statistics passes (one pair of f64 atomics
+    // per workgroup) and the low-resolution launches are better off with 64 (measured: 62 -> 65 / 70 us and 122 -> 131 us with shorter bands).
+    constexpr int TH_A = 24, TH_B = 24, TH_C = 12, TH_G = 64, TH_S = 64;
     if (hipMemsetAsync(w.stats, 0, sizeof(double) * W::NSTAT * w.Bfull * 2, st) != hipSuccess) return RTFS_ERR_LAUNCH;
     {  // 2. downsample[0]: dw 4x4 s1 + bias -> c0 (pre-gLN) + stats                         tdanet.py:110
         DwArgs a;
@@ -375,7 +380,7 @@ int block_body(const BlockPack& p, int B, int T, int F, const BlockWs& w, hipStr
         a.bias[0] = p.ds0_b;
         a.out[0] = w.c0;
         a.stats_out[0] = w.st(W::S_C0, B);
-        a.C = CH; a.H = T; a.W = F; a.TH = 64; a.cs = w.cs;
+        a.C = CH; a.H = T; a.W = F; a.TH = TH_A; a.cs = w.cs;
         CHECK(launch_dw_s1(a, 1, false, 0, B, st));
     }
     // Step 14 (statistics of fusion 0's local conv on d0: one full-resolution read, HBM-bound) needs only c0 and its statistics; steps 3-13 are
@@ -403,7 +408,7 @@ int block_body(const BlockPack& p, int B, int T, int F, const BlockWs& w, hipStr
         a.out[0] = w.c1;
         a.out[1] = w.p0;
         a.stats_out[0] = w.st(W::S_C1, B);
-        a.C = CH; a.H = T; a.W = F; a.Hg = Tp; a.Wg = Fp; a.TH = 64; a.cs = w.cs;
+        a.C = CH; a.H = T; a.W = F; a.Hg = Tp; a.Wg = Fp; a.TH = TH_C; a.cs = w.cs;
         // Traversal order against the memory-side cache (256 MB; a 64-channel tensor is 265 MB at batch 32): step 2 wrote c0 front to back, so
         // its END is what is still on the die - this pass walks back to front (tools/bench_mall.hip: a read-only consumer of a 265 MB tensor
         // 59 -> 44 us; here 125 -> 112 us).  Likewise step 16 after 15 (79 -> 62 us) and step 17 after 16.  10.39 -> 10.17 ms per forward.
@@ -425,14 +430,14 @@ int block_body(const BlockPack& p, int B, int T, int F, const BlockWs& w, hipStr
         a.out[0] = w.E0; a.out[1] = w.G0; a.out[2] = w.E1; a.out[3] = w.G1;
         a.stats_out[0] = w.st(W::S_E0, B); a.stats_out[1] = w.st(W::S_G0, B);
         a.stats_out[2] = w.st(W::S_E1, B); a.stats_out[3] = w.st(W::S_G1, B);
-        a.C = CH; a.H = Tp; a.W = Fp; a.TH = 64;
+        a.C = CH; a.H = Tp; a.W = Fp; a.TH = TH_G;
         DwArgs l;
         l.x = w.c1;
         l.in_stats = w.st(W::S_C1, B); l.in_inv_count = icG; l.in_gamma = p.ds1_g; l.in_beta = p.ds1_be;
         l.w[0] = p.fus1.loc_w;
         l.out[0] = w.L1;
         l.stats_out[0] = w.st(W::S_L1, B);
-        l.C = CH; l.H = Tp; l.W = Fp; l.TH = 64;
+        l.C = CH; l.H = Tp; l.W = Fp; l.TH = TH_G;
         const int rc = launch_dw_g3(a, l, B, st);
         if (rc == RTFS_ERR_ARG) {
             CHECK(launch_dw_s1(a, 4, false, 0, B, st));
@@ -454,7 +459,7 @@ int block_body(const BlockPack& p, int B, int T, int F, const BlockWs& w, hipStr
         a.w[0] = p.cat0.emb_w; a.w[1] = p.cat0.gate_w;
         a.out[0] = w.E2; a.out[1] = w.G2;
         a.stats_out[0] = w.st(W::S_E2, B); a.stats_out[1] = w.st(W::S_G2, B);
-        a.C = CH; a.H = Tp; a.W = Fp; a.TH = 64;
+        a.C = CH; a.H = Tp; a.W = Fp; a.TH = TH_G;
         if (Fp >= 16) {
             CHECK(launch_dw_s1(a, 2, false, 0, B, st));
         } else {  // (narrow inputs run the scalar kernels: separate combination pass)
@@ -490,6 +495,7 @@ int block_body(const BlockPack& p, int B, int T, int F, const BlockWs& w, hipStr
         a.emb = w.E0; a.emb_stats = w.st(W::S_E0, B); a.emb_gamma = p.fus0.emb_g; a.emb_beta = p.fus0.emb_b;
         a.g_inv_count = icG;
         a.out[0] = w.xf0;
+        a.TH = TH_B;
         CHECK(launch_dw_s1(a, 1, true, 2, B, st));
     }
     DwArgs xin;  // common: read xf0
@@ -500,6 +506,7 @@ int block_body(const BlockPack& p, int B, int T, int F, const BlockWs& w, hipStr
         a.w[0] = p.cat0.loc_w;
         a.stats_out[0] = w.st(W::S_L2, B);
         a.rev = 1;  // xf0 was just written front to back by step 15 (see step 3)
+        a.TH = TH_S;
         CHECK(launch_dw_s1(a, 1, false, 1, B, st));
     }
     {  // 17. expanded = InjectionMultiSum(xf0, xf1) + d0                                     tdanet.py:125
@@ -512,6 +519,7 @@ int block_body(const BlockPack& p, int B, int T, int F, const BlockWs& w, hipStr
         a.addend = w.c0; a.add_stats = w.st(W::S_C0, B); a.add_inv_count = icF; a.add_gamma = p.ds0_g; a.add_beta = p.ds0_be;
         a.out[0] = w.expanded;
         a.rev = 1;
+        a.TH = TH_B;
         CHECK(launch_dw_s1(a, 1, false, 2, B, st));
     }
     return RTFS_OK;
