@@ -191,6 +191,9 @@ __device__ __forceinline__ float from_prev_lane(float v) {
 __device__ __forceinline__ float from_next_lane(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, false));  // wave_shl:1
 }
+// wave-uniform copies of a float (bit patterns: the builtins are integer ones)
+__device__ __forceinline__ float first_lane_f(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+__device__ __forceinline__ float lane0_f(float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)); }
 // raw-buffer accesses: address = descriptor base (wave-uniform) + lane byte offset (VGPR) + row byte offset (SGPR)
 typedef __amdgpu_buffer_rsrc_t BufRsrc;
 typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
@@ -219,6 +222,16 @@ __device__ __forceinline__ void dw1p_body(const DwArgs& a, const float* __restri
                                           float* __restrict__ OUT1, float* __restrict__ OUT2, float* __restrict__ OUT3) {
     static_assert(NCONV == 1 || (MODE == 0 && !IN_AFFINE), "multi-conv: plain write + stats only");
     __shared__ double red[8];
+    // ROW (VAR bit 3; W == 129, the width every configuration of this model has): a wave is exactly ONE channel row - 64 lanes x 2 columns plus
+    // column 128 as an extra value every lane carries (only lane 63's copy is ever stored) - so there are no halo lanes (the zero a DPP wave
+    // shift delivers at the wave's ends IS the zero padding) and, the point of it, a wave's output over its band is ONE contiguous byte range of
+    // the channel plane (516-byte rows).  Rows are appended to a per-wave LDS ring at their byte position and leave as 512-byte-ALIGNED chunks:
+    // every store instruction writes four whole 128-byte lines.  Row-by-row stores at 516-byte pitch start and end inside a line every time;
+    // tools/bench_rows.hip: the same read + write walk 3.8 TB/s with row stores, 4.7 staged, 5.1 with 512-byte rows.
+    constexpr bool ROW = (VAR & 8) != 0;
+    static_assert(!ROW || (NCONV == 1 && (MODE == 0 || MODE == 2) && !(VAR & 4)), "row variant: single conv, write or TFAR apply");
+    constexpr int RING = 2048;
+    __shared__ __attribute__((aligned(16))) unsigned char ring_all[ROW ? 4 : 1][ROW ? RING : 16];
     constexpr bool gshare = MODE == 2 && (VAR & 2);  // the launcher checks 2 Wg <= W
     constexpr bool HAS_ADD = MODE == 2 && (VAR & 1);
     constexpr bool COMBINE = MODE == 0 && (VAR & 4);  // input = TFAR combination of x / gate / emb, formed at load time (DwArgs.in_combine)
@@ -230,10 +243,10 @@ __device__ __forceinline__ void dw1p_body(const DwArgs& a, const float* __restri
     const int lane = threadIdx.x & 63;
     // flattened (channel, pair) index: wave-slot ws covers [62 ws - 1, 62 ws + 62]; lanes 0 and 63 are halo lanes
     const int ws = blk.x * 4 + (threadIdx.x >> 6);
-    const int gi = ws * DW1P_PAIRS - 1 + lane;
-    const bool live = lane >= 1 && lane <= DW1P_PAIRS && gi < C * NP;  // gi >= 0 follows from lane >= 1
+    const int gi = ROW ? ws * NP + lane : ws * DW1P_PAIRS - 1 + lane;
+    const bool live = ROW || (lane >= 1 && lane <= DW1P_PAIRS && gi < C * NP);  // gi >= 0 follows from lane >= 1
     const int gc = gi < 0 ? 0 : (gi < C * NP ? gi : C * NP - 1);      // halo / dead lanes still load real, finite data
-    const int c = gc / NP, p = gc - c * NP;
+    const int c = ROW ? ws : gc / NP, p = ROW ? lane : gc - c * NP;  // (ROW: the launcher checks C % 4 == 0)
     const int x0 = 2 * p, x1 = 2 * p + 1;
     const bool liveb = live && x1 < W;
     const int r0 = blk.y * a.TH, r1 = min(r0 + a.TH, H);
@@ -256,6 +269,7 @@ __device__ __forceinline__ void dw1p_body(const DwArgs& a, const float* __restri
     // lane's s0: one load per lane and row, the neighbour's by DPP.
     unsigned fga = 0, fgb = 0;
     bool gnext = false;
+    const unsigned vex = pa + 4u * (unsigned)(W - 1);  // ROW: column 128 of this wave's channel (one address for the whole wave)
     const size_t gsample = MODE == 2 ? (size_t)b * C * a.Hg * a.Wg : 0;
     const BufRsrc gs = buf_rsrc(MODE == 2 ? GATE + gsample : (COMBINE ? GATE + sample : X)), es = buf_rsrc(MODE == 2 ? EMB + gsample : (COMBINE ? EMB + sample : X));
     const BufRsrc as_ = buf_rsrc(HAS_ADD ? ADD_ + sample : X);
@@ -267,6 +281,9 @@ __device__ __forceinline__ void dw1p_body(const DwArgs& a, const float* __restri
         fga = gpa + 4u * s0;
         fgb = gpa + 4u * s1;
         gnext = s1 != s0;
+        // ROW: lane 0's two columns and lane 1's first share source column 0 (the launcher checks it), so lane 0 takes its value from lane 1 and
+        // spends its own gather on the source column of column W - 1 instead - read back from lane 0 where it is needed
+        if (ROW && lane == 0) fga = gpa + 4u * min((unsigned)(W - 1) * (unsigned)a.Wg / (unsigned)W, (unsigned)a.Wg - 1u);
     }
     const bool border = r0 == 0 || r1 + 3 > H;  // block-uniform: only these bands ever see an out-of-image row
     // MODE 2: low-resolution source row floor(t Hg / H) as an incremental quotient / remainder, advanced in LOAD order
@@ -277,7 +294,7 @@ __device__ __forceinline__ void dw1p_body(const DwArgs& a, const float* __restri
     }
     // A row in flight: own pair (raw, as loaded - the odd row end's select is applied by the consumer: a use next to the load would pull the
     // wait there) and, for MODE 2, the epilogue operands of OUTPUT row t - 2 (gate / embedding gathers, addend)
-    struct Raw { f32x2 pr, ar, gr, er; float g0, g1, m0, m1; };
+    struct Raw { f32x2 pr, ar, gr, er; float g0, g1, m0, m1, xe, ae; };  // xe, ae: column 128 (ROW)
     auto load_raw = [&](int t) {  // window row t, and the epilogue operands of OUTPUT row t - 2
         const int tc = t < 0 ? 0 : (t < H ? t : H - 1);
         Raw r;
@@ -288,6 +305,8 @@ __device__ __forceinline__ void dw1p_body(const DwArgs& a, const float* __restri
             r.er = buf_ld2(es, vld, (unsigned)tc * W4);
         }
         r.g0 = r.g1 = r.m0 = r.m1 = 0.f;
+        r.xe = r.ae = 0.f;
+        if (ROW) r.xe = buf_ld1(xs, vex, (unsigned)tc * W4);
         if (MODE == 2) {
             const int to = min(max(t - 2, r0), H - 1);  // output row served (clamped: the extra rows of the last trip are dropped)
             const int tg = tgq < a.Hg - 1 ? tgq : a.Hg - 1;
@@ -306,12 +325,13 @@ __device__ __forceinline__ void dw1p_body(const DwArgs& a, const float* __restri
                 r.m1 = buf_ld1(es, fgb, grow);
             }
             if (HAS_ADD) r.ar = buf_ld2(as_, vld, (unsigned)to * W4);
+            if (ROW && HAS_ADD) r.ae = buf_ld1(as_, vex, (unsigned)to * W4);
         }
         return r;
     };
     float lsc = 1.f, lsh = 0.f, gsc = 1.f, gsh = 0.f, esc = 1.f, esh = 0.f, asc = 1.f, ash = 0.f;  // set below, before the first complete()
     // a window row as the four operand pairs of its taps
-    struct Row { f32x2 p[4]; };
+    struct Row { f32x2 p[4]; float xe; };  // xe (ROW): column 128; output column 128 meets it and column 127 = p[1].y of lane 63
     auto complete = [&](int t, const Raw& r) {
         float v1 = whole ? r.pr.x : r.pr.y, v2 = r.pr.y;  // x1 == W: v2 only ever meets zero weights
         if (COMBINE) {
@@ -319,8 +339,10 @@ __device__ __forceinline__ void dw1p_body(const DwArgs& a, const float* __restri
             v1 = fmaf(fmaf(v1, lsc, lsh), sigmoidf_(fmaf(g1_, gsc, gsh)), fmaf(e1_, esc, esh));
             v2 = fmaf(fmaf(v2, lsc, lsh), sigmoidf_(fmaf(r.gr.y, gsc, gsh)), fmaf(r.er.y, esc, esh));
         }
-        const float v0 = from_prev_lane(v2), v3 = from_next_lane(v1), v4 = from_next_lane(v2);
+        float v0 = from_prev_lane(v2), v3 = from_next_lane(v1), v4 = from_next_lane(v2);
+        if (ROW) v3 = lane == 63 ? r.xe : v3;  // the last pair's right neighbour is column 128
         Row w;
+        w.xe = r.xe;
         w.p[0] = f32x2{v0, v1};
         w.p[1] = f32x2{v1, v2};
         w.p[2] = f32x2{v2, v3};
@@ -328,6 +350,7 @@ __device__ __forceinline__ void dw1p_body(const DwArgs& a, const float* __restri
         if (border && (t < 0 || t >= H)) {  // uniform
 #pragma unroll
             for (int j = 0; j < 4; ++j) w.p[j] = f32x2{0.f, 0.f};
+            w.xe = 0.f;
         }
         return w;
     };
@@ -352,6 +375,11 @@ __device__ __forceinline__ void dw1p_body(const DwArgs& a, const float* __restri
         gln_fold(a.gate_stats + 2 * b, a.g_inv_count, a.gate_gamma[c], a.gate_beta[c], gsc, gsh);
         gln_fold(a.emb_stats + 2 * b, a.g_inv_count, a.emb_gamma[c], a.emb_beta[c], esc, esh);
         if (HAS_ADD) gln_fold(a.add_stats + 2 * b, a.add_inv_count, a.add_gamma[c], a.add_beta[c], asc, ash);
+        if (ROW) {  // one channel per wave: the folds that only meet plain FMAs live in scalar registers
+            gsc = first_lane_f(gsc); gsh = first_lane_f(gsh);
+            esc = first_lane_f(esc); esh = first_lane_f(esh);
+            asc = first_lane_f(asc); ash = first_lane_f(ash);
+        }
     }
     // weight pairs: tap (i, j) of output x0 meets column x0 - 1 + j, of output x1 column x1 - 1 + j; a weight whose tap column is outside the
     // image - or whose output does not exist (halo lane, lane past the end, x1 == W) - is 0
@@ -378,6 +406,42 @@ __device__ __forceinline__ void dw1p_body(const DwArgs& a, const float* __restri
         const float bv = a.bias[n] ? a.bias[n][c] : 0.f;
         bias[n] = f32x2{live ? bv : 0.f, liveb ? bv : 0.f};
     }
+    // ROW: output column W - 1 = 128 meets columns 127 and 128 only (taps 0 and 1 of every window row)
+    // (its channel is the whole wave's: weights as scalars)
+    float we0[4], we1[4], rse[4], bias_e = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        we0[i] = ROW ? first_lane_f(wraw[0][i][0]) : 0.f;
+        we1[i] = ROW ? first_lane_f(wraw[0][i][1]) : 0.f;
+        rse[i] = we0[i] + we1[i];
+    }
+    if (ROW) bias_e = a.bias[0] ? first_lane_f(a.bias[0][c]) : 0.f;
+    const float wve_full = (rse[0] + rse[1]) + (rse[2] + rse[3]);
+    // ROW: the staged store (see the head of this function).  Byte positions are relative to the channel plane; s0 / s1 = this band's range
+    unsigned char* const ring = ring_all[ROW ? (threadIdx.x >> 6) : 0];
+    const unsigned s0 = (unsigned)r0 * W4, s1 = (unsigned)r1 * W4;
+    unsigned chunk = s0 >> 9;  // next 512-byte chunk to leave
+    auto flush = [&](unsigned cidx) {
+        const unsigned cb = cidx << 9, b0 = cb + 8u * (unsigned)lane;
+        const f32x2 v = *reinterpret_cast<const f32x2*>(ring + (cb & (RING - 1)) + 8u * (unsigned)lane);
+        if (cb >= s0 && cb + 512u <= s1) {  // uniform: the whole chunk is this band's
+            buf_st2(os[0], pa + 8u * (unsigned)lane, cb, v);
+        } else {  // a band's first / last chunk: the other bytes belong to the neighbouring band's wave
+            if (b0 >= s0 && b0 + 4u <= s1) buf_st1(os[0], pa + 8u * (unsigned)lane, cb, v.x);
+            if (b0 + 4u >= s0 && b0 + 8u <= s1) buf_st1(os[0], pa + 8u * (unsigned)lane + 4u, cb, v.y);
+        }
+    };
+    auto stage = [&](int t, f32x2 y, float ye) {
+        const unsigned pos = (unsigned)t * W4 + 8u * (unsigned)lane;
+        *reinterpret_cast<float*>(ring + (pos & (RING - 1))) = y.x;
+        *reinterpret_cast<float*>(ring + ((pos + 4u) & (RING - 1))) = y.y;
+        if (lane == 63) *reinterpret_cast<float*>(ring + ((pos + 8u) & (RING - 1))) = ye;  // column 128 follows lane 63's pair
+        const unsigned end = (unsigned)(t + 1) * W4;
+        while (((chunk + 1u) << 9) <= end) {  // uniform
+            flush(chunk);
+            ++chunk;
+        }
+    };
     Row win[3];
     win[0] = complete(r0 - 1, st0);
     win[1] = complete(r0, st1);
@@ -404,35 +468,64 @@ __device__ __forceinline__ void dw1p_body(const DwArgs& a, const float* __restri
                 accB = w3.p[j] * wp[n][12 + j] + accB;
             }
             f32x2 acc = accA + accB;
+            float acce = 0.f;
+            if (ROW) {  // two chains, as above (every lane computes it, lane 63's is the one that counts)
+                float ea = fmaf(w0.xe, we1[0], w0.p[1].y * we0[0]), eb = fmaf(w2.xe, we1[2], w2.p[1].y * we0[2]);
+                ea = fmaf(w1.xe, we1[1], fmaf(w1.p[1].y, we0[1], ea));
+                eb = fmaf(w3.xe, we1[3], fmaf(w3.p[1].y, we0[3], eb));
+                acce = ea + eb;
+            }
             if (IN_AFFINE) {  // conv(pad0(s x + b)) = s conv(pad0(x)) + b * (sum of the weights whose tap is inside the image)
                 f32x2 wv = wv_full;
+                float wve = wve_full;
                 if (border) {
-                    if (t - 1 < 0) wv -= rowsum[0];
-                    if (t + 1 >= H) wv -= rowsum[2];
-                    if (t + 2 >= H) wv -= rowsum[3];
+                    if (t - 1 < 0) { wv -= rowsum[0]; wve -= rse[0]; }
+                    if (t + 1 >= H) { wv -= rowsum[2]; wve -= rse[2]; }
+                    if (t + 2 >= H) { wv -= rowsum[3]; wve -= rse[3]; }
                 }
                 acc = acc * isc + wv * ish;
+                if (ROW) acce = fmaf(acce, isc, wve * ish);
             }
             acc += bias[n];
+            if (ROW) acce += bias_e;
             if (MODE == 0) {
-                if (liveb) buf_st2(os[n], vst, orow, acc);
+                if (ROW) stage(t, acc, acce);
+                else if (liveb) buf_st2(os[n], vst, orow, acc);
                 else if (live) buf_st1(os[n], vst, orow, acc.x);
             }
             if (MODE != 2) {
                 s2[n] += acc;  // dead outputs are exactly 0
                 ss2[n] = acc * acc + ss2[n];
-            } else {
-                float g1 = e.g1, m1 = e.m1;
-                if (gshare) {
-                    const float gn = from_next_lane(e.g0), mn = from_next_lane(e.m0);
-                    g1 = gnext ? gn : e.g0;
-                    m1 = gnext ? mn : e.m0;
+                if (ROW) {
+                    const float em = lane == 63 ? acce : 0.f;
+                    s2[n].x += em;
+                    ss2[n].x = fmaf(em, em, ss2[n].x);
                 }
-                const f32x2 gate = {sigmoidf_(fmaf(e.g0, gsc, gsh)), sigmoidf_(fmaf(g1, gsc, gsh))};
-                const f32x2 emb = {fmaf(e.m0, esc, esh), fmaf(m1, esc, esh)};
+            } else {
+                float g0 = e.g0, m0 = e.m0, g1 = e.g1, m1 = e.m1;
+                float ge = 0.f, me = 0.f;
+                if (gshare) {
+                    float gn = from_next_lane(e.g0), mn = from_next_lane(e.m0);
+                    if (ROW) {
+                        ge = lane0_f(e.g0);  // column 128's source column, gathered by lane 0 (see fga)
+                        me = lane0_f(e.m0);
+                        g0 = lane == 0 ? gn : g0;  // lane 0's own source column is lane 1's
+                        m0 = lane == 0 ? mn : m0;
+                        gn = lane == 63 ? ge : gn;  // the last pair's second source column is column 128's (the launcher checks both)
+                        mn = lane == 63 ? me : mn;
+                    }
+                    g1 = gnext ? gn : g0;
+                    m1 = gnext ? mn : m0;
+                }
+                const f32x2 gate = {sigmoidf_(fmaf(g0, gsc, gsh)), sigmoidf_(fmaf(g1, gsc, gsh))};
+                const f32x2 emb = {fmaf(m0, esc, esh), fmaf(m1, esc, esh)};
                 f32x2 y = (acc * lsc + lsh) * gate + emb;
                 if (HAS_ADD) y += f32x2{fmaf(whole ? e.ar.x : e.ar.y, asc, ash), fmaf(e.ar.y, asc, ash)};
-                if (liveb) buf_st2(os[0], vst, orow, y);
+                if (ROW) {
+                    float ye = fmaf(fmaf(acce, lsc, lsh), sigmoidf_(fmaf(ge, gsc, gsh)), fmaf(me, esc, esh));
+                    if (HAS_ADD) ye += fmaf(e.ae, asc, ash);
+                    stage(t, y, ye);
+                } else if (liveb) buf_st2(os[0], vst, orow, y);
                 else if (live) buf_st1(os[0], vst, orow, y.x);
             }
         }
@@ -454,6 +547,7 @@ __device__ __forceinline__ void dw1p_body(const DwArgs& a, const float* __restri
             win[2] = n;
         }
     }
+    if (ROW && (chunk << 9) < s1) flush(chunk);  // the band's last, partial chunk
     if (MODE != 2) {
 #pragma unroll
         for (int n = 0; n < NCONV; ++n) {
@@ -855,7 +949,7 @@ template <int NCONV, bool IN_AFFINE, int MODE, int VAR = 0>
 static int launch_dw1p_t(const DwArgs& a_, int B, hipStream_t st) {
     DwArgs a = a_;
     const int half = (a.W + 1) / 2;
-    a.gx = cdiv(cdiv(a.C * half, DW1P_PAIRS), 4);
+    a.gx = (VAR & 8) ? a.C / 4 : cdiv(cdiv(a.C * half, DW1P_PAIRS), 4);  // (row variant: a wave per channel)
     // (kernels that end in statistics atomics get fewer, longer workgroups: at batch 1 all of them add onto ONE pair of addresses)
     a.TH = band_rows(a.TH, a.H, a.gx, B, MODE == 2 ? 768 : 320);
     a.gy = cdiv(a.H, a.TH);
@@ -870,6 +964,15 @@ int launch_dw_s1(const DwArgs& a_, int nconv, bool in_affine, int mode, int B, h
     if (!a.cs) a.cs = a.H * a.W;
     if ((size_t)a.C * a.cs * 4 >= ((size_t)1 << 31)) return RTFS_ERR_SHAPE;  // 32-bit lane offsets
     if (a.W >= 16) {  // packed two-column variant (v_pk_fma_f32); the scalar kernel below only serves very narrow inputs
+        // row variant (a wave = one 129-column channel row, stores leave as aligned 512-byte chunks: dw1p_body): the three full-resolution
+        // read + write passes of a block
+        static const bool row_off = getenv("RTFS_NOROW") != nullptr;  // TEMP
+        const bool row_ok = !row_off && nconv == 1 && a.W == 129 && a.C % 4 == 0 && a.cs % 32 == 0 && a.out[0] && ((size_t)a.out[0] & 127) == 0;
+        if (row_ok && mode == 0 && !in_affine) return launch_dw1p_t<1, false, 0, 8>(a, B, st);
+        if (row_ok && mode == 2 && 2 * a.Wg <= a.W && (a.W - 1) * a.Wg / a.W == (a.W - 2) * a.Wg / a.W && 2 * a.Wg / a.W == 0) {
+            if (in_affine && !a.addend) return launch_dw1p_t<1, true, 2, 10>(a, B, st);
+            if (!in_affine && a.addend) return launch_dw1p_t<1, false, 2, 11>(a, B, st);
+        }
         if (nconv == 1) {
             if (mode == 0) return in_affine ? launch_dw1p_t<1, true, 0>(a, B, st) : launch_dw1p_t<1, false, 0>(a, B, st);
             if (mode == 1) return in_affine ? launch_dw1p_t<1, true, 1>(a, B, st) : launch_dw1p_t<1, false, 1>(a, B, st);
