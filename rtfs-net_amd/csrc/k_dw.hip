@@ -966,8 +966,7 @@ int launch_dw_s1(const DwArgs& a_, int nconv, bool in_affine, int mode, int B, h
     if (a.W >= 16) {  // packed two-column variant (v_pk_fma_f32); the scalar kernel below only serves very narrow inputs
         // row variant (a wave = one 129-column channel row, stores leave as aligned 512-byte chunks: dw1p_body): the three full-resolution
         // read + write passes of a block
-        static const bool row_off = getenv("RTFS_NOROW") != nullptr;  // TEMP
-        const bool row_ok = !row_off && nconv == 1 && a.W == 129 && a.C % 4 == 0 && a.cs % 32 == 0 && a.out[0] && ((size_t)a.out[0] & 127) == 0;
+        const bool row_ok = nconv == 1 && a.W == 129 && a.C % 4 == 0 && a.cs % 32 == 0 && a.out[0] && ((size_t)a.out[0] & 127) == 0;
         if (row_ok && mode == 0 && !in_affine) return launch_dw1p_t<1, false, 0, 8>(a, B, st);
         if (row_ok && mode == 2 && 2 * a.Wg <= a.W && (a.W - 1) * a.Wg / a.W == (a.W - 2) * a.Wg / a.W && 2 * a.Wg / a.W == 0) {
             if (in_affine && !a.addend) return launch_dw1p_t<1, true, 2, 10>(a, B, st);
