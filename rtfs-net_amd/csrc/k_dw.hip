@@ -230,6 +230,11 @@ __device__ __forceinline__ void dw1p_body(const DwArgs& a, const float* __restri
     // tools/bench_rows.hip: the same read + write walk 3.8 TB/s with row stores, 4.7 staged, 5.1 with 512-byte rows.
     constexpr bool ROW = (VAR & 8) != 0;
     static_assert(!ROW || (NCONV == 1 && (MODE == 0 || MODE == 2) && !(VAR & 4)), "row variant: single conv, write or TFAR apply");
+    // NOHALO (VAR bit 4; rows whose pair count divides 64, i.e. the 64-column low-resolution planes): a wave = 64 pairs = whole channel rows and
+    // no halo lanes (a neighbour across a wave boundary is a neighbour across a channel boundary: its weight is 0 anyway), so every store
+    // writes whole 256-byte rows instead of 496 bytes that begin and end inside a line.
+    constexpr bool NOHALO = (VAR & 16) != 0;
+    static_assert(!(ROW && NOHALO), "one mapping");
     constexpr int RING = 2048;
     __shared__ __attribute__((aligned(16))) unsigned char ring_all[ROW ? 4 : 1][ROW ? RING : 16];
     constexpr bool gshare = MODE == 2 && (VAR & 2);  // the launcher checks 2 Wg <= W
@@ -243,8 +248,8 @@ __device__ __forceinline__ void dw1p_body(const DwArgs& a, const float* __restri
     const int lane = threadIdx.x & 63;
     // flattened (channel, pair) index: wave-slot ws covers [62 ws - 1, 62 ws + 62]; lanes 0 and 63 are halo lanes
     const int ws = blk.x * 4 + (threadIdx.x >> 6);
-    const int gi = ROW ? ws * NP + lane : ws * DW1P_PAIRS - 1 + lane;
-    const bool live = ROW || (lane >= 1 && lane <= DW1P_PAIRS && gi < C * NP);  // gi >= 0 follows from lane >= 1
+    const int gi = ROW ? ws * NP + lane : NOHALO ? ws * 64 + lane : ws * DW1P_PAIRS - 1 + lane;
+    const bool live = ROW || (NOHALO ? gi < C * NP : lane >= 1 && lane <= DW1P_PAIRS && gi < C * NP);  // gi >= 0 follows from lane >= 1
     const int gc = gi < 0 ? 0 : (gi < C * NP ? gi : C * NP - 1);      // halo / dead lanes still load real, finite data
     const int c = ROW ? ws : gc / NP, p = ROW ? lane : gc - c * NP;  // (ROW: the launcher checks C % 4 == 0)
     const int x0 = 2 * p, x1 = 2 * p + 1;
@@ -564,12 +569,13 @@ __global__ __launch_bounds__(256, NCONV == 1 && MODE != 2 ? 4 : 2) void dw1p_ker
 }
 
 // three jobs in one launch (launch_dw_g3): block-uniform dispatch on the permuted block id
+template <int V>
 __global__ __launch_bounds__(256, 2) void dw_g3_kernel(DwArgs a0, DwArgs a1, DwArgs a2) {
     int id = blockIdx.x;
     if (DW_XCD) id = (id & 7) * (int)(gridDim.x >> 3) + (id >> 3);
-    if (id < a1.blk0) dw1p_body<2, false, 0>(a0, a0.x, a0.gate, a0.emb, a0.addend, a0.out[0], a0.out[1], a0.out[2], a0.out[3]);
-    else if (id < a2.blk0) dw1p_body<2, false, 0>(a1, a1.x, a1.gate, a1.emb, a1.addend, a1.out[0], a1.out[1], a1.out[2], a1.out[3]);
-    else dw1p_body<1, true, 0>(a2, a2.x, a2.gate, a2.emb, a2.addend, a2.out[0], a2.out[1], a2.out[2], a2.out[3]);
+    if (id < a1.blk0) dw1p_body<2, false, 0, V>(a0, a0.x, a0.gate, a0.emb, a0.addend, a0.out[0], a0.out[1], a0.out[2], a0.out[3]);
+    else if (id < a2.blk0) dw1p_body<2, false, 0, V>(a1, a1.x, a1.gate, a1.emb, a1.addend, a1.out[0], a1.out[1], a1.out[2], a1.out[3]);
+    else dw1p_body<1, true, 0, V>(a2, a2.x, a2.gate, a2.emb, a2.addend, a2.out[0], a2.out[1], a2.out[2], a2.out[3]);
 }
 
 // ---------------------------------------------------------------- stride-2 pad-1 4x4 + adaptive average pool
@@ -949,7 +955,7 @@ template <int NCONV, bool IN_AFFINE, int MODE, int VAR = 0>
 static int launch_dw1p_t(const DwArgs& a_, int B, hipStream_t st) {
     DwArgs a = a_;
     const int half = (a.W + 1) / 2;
-    a.gx = (VAR & 8) ? a.C / 4 : cdiv(cdiv(a.C * half, DW1P_PAIRS), 4);  // (row variant: a wave per channel)
+    a.gx = (VAR & 8) ? a.C / 4 : cdiv(cdiv(a.C * half, (VAR & 16) ? 64 : DW1P_PAIRS), 4);  // (row variant: a wave per channel)
     // (kernels that end in statistics atomics get fewer, longer workgroups: at batch 1 all of them add onto ONE pair of addresses)
     a.TH = band_rows(a.TH, a.H, a.gx, B, MODE == 2 ? 768 : 320);
     a.gy = cdiv(a.H, a.TH);
@@ -993,6 +999,7 @@ int launch_dw_s1(const DwArgs& a_, int nconv, bool in_affine, int mode, int B, h
                 }
             }
         } else if (mode == 0 && !in_affine) {
+            if (nconv == 2 && a.in_combine && 64 % ((a.W + 1) / 2) == 0) return launch_dw1p_t<2, false, 0, 4 | 16>(a, B, st);
             if (nconv == 2) return a.in_combine ? launch_dw1p_t<2, false, 0, 4>(a, B, st) : launch_dw1p_t<2, false, 0>(a, B, st);
             if (nconv == 4) {  // two 2-conv launches: the 4-conv kernel needs 256 VGPRs and runs slower than both together
                 DwArgs b = a;
@@ -1018,6 +1025,7 @@ int launch_dw_s1(const DwArgs& a_, int nconv, bool in_affine, int mode, int B, h
 
 int launch_dw_g3(const DwArgs& conv4, const DwArgs& aff1, int B, hipStream_t st) {
     DwArgs j[3] = {conv4, conv4, aff1};
+    const bool nohalo = 64 % ((conv4.W + 1) / 2) == 0 && conv4.W == aff1.W;  // whole rows per wave (dw1p_body NOHALO)
     for (int i = 0; i < 2; ++i) {
         j[1].w[i] = conv4.w[2 + i]; j[1].bias[i] = conv4.bias[2 + i]; j[1].out[i] = conv4.out[2 + i]; j[1].stats_out[i] = conv4.stats_out[2 + i];
     }
@@ -1027,14 +1035,15 @@ int launch_dw_g3(const DwArgs& conv4, const DwArgs& aff1, int B, hipStream_t st)
         if (a.W < 16 || (a.cs && a.cs < a.H * a.W)) return RTFS_ERR_ARG;  // the caller falls back to separate launches
         if (!a.cs) a.cs = a.H * a.W;
         if ((size_t)a.C * a.cs * 4 >= ((size_t)1 << 31)) return RTFS_ERR_ARG;
-        a.gx = cdiv(cdiv(a.C * ((a.W + 1) / 2), DW1P_PAIRS), 4);
+        a.gx = cdiv(cdiv(a.C * ((a.W + 1) / 2), nohalo ? 64 : DW1P_PAIRS), 4);
         a.TH = band_rows(a.TH, a.H, a.gx, 3 * B, 640);  // (three jobs share the launch)
         a.gy = cdiv(a.H, a.TH);
         a.nblk = a.gx * a.gy * B;
         a.blk0 = off;
         off += a.nblk;
     }
-    hipLaunchKernelGGL(dw_g3_kernel, dim3((off + 7) / 8 * 8), dim3(256), 0, st, j[0], j[1], j[2]);
+    if (nohalo) hipLaunchKernelGGL(dw_g3_kernel<16>, dim3((off + 7) / 8 * 8), dim3(256), 0, st, j[0], j[1], j[2]);
+    else hipLaunchKernelGGL(dw_g3_kernel<0>, dim3((off + 7) / 8 * 8), dim3(256), 0, st, j[0], j[1], j[2]);
     return rtfs_launch_status();
 }
 
