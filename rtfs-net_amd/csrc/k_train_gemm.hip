@@ -142,6 +142,105 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ C = A . Bt^T, 16x16x32 form
+// The same product on v_mfma_f32_16x16x32_bf16 (MODE 0 / 1, K % 32 == 0).  Why a second form: with the 32x32x16 fragment a lane owns 8
+// consecutive k of ONE of 32 rows, so a 16-byte load instruction touches 32 rows' lines for 32 bytes each - the kernel above is bound by the
+// texture path's line look-ups as much as by HBM (0.36-0.43 of the HBM rate its traffic would allow).  In the 16x16x32 fragment four lanes
+// (l >> 4 = 0 .. 3) own 4 x 8 consecutive k of one row: a load instruction touches 16 rows for a whole 128-byte line each - half the
+// look-ups per byte - and the matrix pipe loses nothing (48 x 16 cycles per 32 k instead of 24 x 32).  Measured: training step 66.6 -> 66.0 ms
+// at batch 16 (two A/B pairs on one box) - a small part of what holds these GEMMs back; the LDS-staged, pre-split-operand form is still open.
+typedef float f32x4_ __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void mfma3_16(f32x4_& acc, const Frag& a, const Frag& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.lo, b.hi, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.hi, b.lo, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.hi, b.hi, acc, 0, 0, 0);
+}
+template <int MODE>
+__global__ __launch_bounds__(256) void gemm_nt16_kernel(GemmArgs g) {
+    g.A += (size_t)blockIdx.y * g.sA;
+    g.B += (size_t)blockIdx.y * g.sB;
+    g.C += (size_t)blockIdx.y * g.sC;
+    const int id = blockIdx.x;
+    const int rowblk = (id / (8 * g.ncb)) * 8 + (id & 7), colblk = (id >> 3) % g.ncb;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, kg = lane >> 4;
+    const int m0 = rowblk * 256 + wave * 64, n0 = colblk * 64;
+    if (m0 >= g.M) return;
+    const float *pa[4], *pb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = min(m0 + 16 * i + r, g.M - 1);
+        pa[i] = g.A + (size_t)row * g.lda + 8 * kg;
+        pb[i] = g.B + (size_t)(n0 + 16 * i + r) * g.ldb + 8 * kg;
+    }
+    f32x4_ acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_{0.f, 0.f, 0.f, 0.f};
+    f32x4 ra[4][2], rb[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        ra[i][0] = *(const f32x4*)(pa[i]);
+        ra[i][1] = *(const f32x4*)(pa[i] + 4);
+        rb[i][0] = *(const f32x4*)(pb[i]);
+        rb[i][1] = *(const f32x4*)(pb[i] + 4);
+    }
+    for (int k0 = 0; k0 < g.K; k0 += 32) {
+        const int kn = min(k0 + 32, g.K - 32);
+        f32x4 na[4][2], nb[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            na[i][0] = *(const f32x4*)(pa[i] + kn);
+            na[i][1] = *(const f32x4*)(pa[i] + kn + 4);
+            nb[i][0] = *(const f32x4*)(pb[i] + kn);
+            nb[i][1] = *(const f32x4*)(pb[i] + kn + 4);
+        }
+        Frag fa[4], fb[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            fa[i] = split_bf16(ra[i][0], ra[i][1]);
+            fb[i] = split_bf16(rb[i][0], rb[i][1]);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mfma3_16(acc[i][j], fa[i], fb[j]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int x = 0; x < 2; ++x) {
+                ra[i][x] = na[i][x];
+                rb[i][x] = nb[i][x];
+            }
+    }
+    // epilogue through LDS, 32 rows at a time (see gemm_nt_kernel): accumulator register q of tile (i, j) is row 16 i + 4 kg + q, column 16 j + r
+    __shared__ float tile[4][32][68];
+    float (*t)[68] = tile[wave];
+    const int cq = (lane & 15) * 4, r4 = lane >> 4;
+    f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+    if (g.bias) b4 = *(const f32x4*)(g.bias + n0 + cq);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) t[16 * ii + 4 * kg + q][16 * j + r] = acc[2 * half + ii][j][q];
+        // a wave only reads what it wrote itself: no workgroup barrier (LDS operations of a wave complete in order)
+#pragma unroll
+        for (int p8 = 0; p8 < 8; ++p8) {
+            const int lr = r4 + 4 * p8, row = m0 + 32 * half + lr;
+            if (row < g.M) {
+                f32x4 v = *(const f32x4*)&t[lr][cq] + b4;
+                f32x4* p = (f32x4*)(g.C + (size_t)row * g.ldc + n0 + cq);
+                if (MODE == 1) v += *p;
+                *p = v;
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ C += A^T . B (split K)
 // A (K, M), B (K, N), both with K as the slow axis; C (M, N) must hold the running sum (zeroed by the caller).
 // M % 64 == 0, N % 64 == 0, any K.  One wave = one 64 x 64 tile of C over one K chunk; the four waves of a workgroup take four
@@ -225,8 +324,11 @@ int launch_gemm_nt(const float* A, int lda, const float* Bt, int ldb, float* C, 
     g.nrb = cdiv(M, 256);
     const long grid = (long)cdiv(g.nrb, 8) * 8 * g.ncb;
     if (grid > 0x7fffffffL) return RTFS_ERR_SHAPE;
+    const bool f16 = mode != 2 && (K & 31) == 0;  // the 16x16x32 form (fewer line look-ups per byte of A / Bt)
     if (mode == 2) hipLaunchKernelGGL(gemm_nt_kernel<2>, dim3((unsigned)grid, batch), dim3(256), 0, st, g);
+    else if (mode == 1 && f16) hipLaunchKernelGGL(gemm_nt16_kernel<1>, dim3((unsigned)grid, batch), dim3(256), 0, st, g);
     else if (mode == 1) hipLaunchKernelGGL(gemm_nt_kernel<1>, dim3((unsigned)grid, batch), dim3(256), 0, st, g);
+    else if (f16) hipLaunchKernelGGL(gemm_nt16_kernel<0>, dim3((unsigned)grid, batch), dim3(256), 0, st, g);
     else hipLaunchKernelGGL(gemm_nt_kernel<0>, dim3((unsigned)grid, batch), dim3(256), 0, st, g);
     return rtfs_launch_status();
 }
