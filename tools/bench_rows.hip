@@ -57,8 +57,8 @@ __global__ __launch_bounds__(256, 4) void walk(const float* __restrict__ x, floa
 // The same walk with a wave = one whole 129-column row (64 lanes x 2 columns + column 128 as an extra dword of lane 63) and the OUTPUT staged
 // through a per-wave LDS ring: rows are appended at their byte position in the plane (516 bytes each), and every completed 512-byte-ALIGNED
 // chunk is stored with one 8-byte-per-lane instruction - every store instruction writes four whole 128-byte lines.
-template <int RQ>
-__global__ __launch_bounds__(256, 4) void walk_staged(const float* __restrict__ x, float* __restrict__ y, int H, int PS, int TH, int nbands, int nblk) {
+template <int RQ, int FEAT = 0>
+__global__ __launch_bounds__(256, 4) void walk_staged(const float* __restrict__ x, float* __restrict__ y, int H, int PS, int TH, int nbands, int nblk, const float* __restrict__ wts = nullptr, double* __restrict__ stats = nullptr) {
     constexpr int W = 129, RING = 2048;
     __shared__ __attribute__((aligned(16))) unsigned char ring_all[4][RING];
     int id = blockIdx.x;
@@ -77,10 +77,27 @@ __global__ __launch_bounds__(256, 4) void walk_staged(const float* __restrict__ 
     char* yb = reinterpret_cast<char*>(y + (size_t)plane * PS);
     f32x2u q[RQ];
     float qe[RQ];
-    auto ld = [&](int t) { return *reinterpret_cast<const f32x2u*>(xp + (size_t)min(t, H - 1) * W); };
-    auto lde = [&](int t) { return xe[(size_t)min(t, H - 1) * W]; };
+    auto ld = [&](int t) { return *reinterpret_cast<const f32x2u*>(xp + (size_t)min(max(t, 0), H - 1) * W); };
+    auto lde = [&](int t) { return xe[(size_t)min(max(t, 0), H - 1) * W]; };
+    f32x2u hsum = {0.f, 0.f};
+    if (FEAT & 1) {  // the three halo rows a 4x4 window needs around the band
+        const f32x2u h0 = ld(r0 - 1), h1 = ld(r1), h2 = ld(r1 + 1);
+        hsum = h0 + h1 + h2;
+    }
 #pragma unroll
     for (int k = 0; k < RQ; ++k) { q[k] = ld(r0 + k); qe[k] = lde(r0 + k); }
+    float wsum = 0.f;
+    if (FEAT & 4) {  // per-workgroup set-up: weight loads + ~100 dependent instructions
+        const int c = plane & 63;
+        float w[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) w[i] = wts[c * 16 + i];
+#pragma unroll
+        for (int rep = 0; rep < 6; ++rep)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) wsum = fmaf(w[i], wsum + (float)lane, w[(i + rep) & 15]);
+    }
+    float st = 0.f;
     const unsigned s0 = (unsigned)r0 * 516u, s1 = (unsigned)r1 * 516u;
     unsigned chunk = s0 >> 9;  // next 512-byte chunk to flush
     auto flush = [&](unsigned c) {  // chunk c is complete in the ring (or is the band's last, partial one)
@@ -104,7 +121,10 @@ __global__ __launch_bounds__(256, 4) void walk_staged(const float* __restrict__ 
             f32x2u o = v * 1.5f + 1.0f;
             float oe = ve * 1.5f + 1.0f;
 #pragma unroll
-            for (int j = 0; j < 12; ++j) o = o * 1.0001f + 0.5f;
+            for (int j = 0; j < ((FEAT & 2) ? 56 : 12); ++j) o = o * 1.0001f + 0.5f;
+            if (FEAT & 1) o += hsum * 1e-30f;
+            if (FEAT & 4) o += wsum * 1e-30f;
+            if (FEAT & 8) st += o.x + o.y;
             if (t + k < r1) {
                 const unsigned pos = (unsigned)(t + k) * 516u;
                 *reinterpret_cast<float*>(ring + ((pos + 8u * lane) & (RING - 1))) = o.x;
@@ -115,9 +135,21 @@ __global__ __launch_bounds__(256, 4) void walk_staged(const float* __restrict__ 
         }
     }
     if ((chunk << 9) < s1) flush(chunk);
+    if (FEAT & 8) {  // per-workgroup statistics: LDS fold + two f64 atomics onto the sample's pair
+        __shared__ double red[8];
+        double d = (double)st;
+        for (int o = 32; o; o >>= 1) d += __shfl_xor(d, o);
+        if (lane == 0) red[wave] = d;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            atomicAdd(stats + 2 * (plane >> 6), red[0] + red[1] + red[2] + red[3]);
+            atomicAdd(stats + 2 * (plane >> 6) + 1, red[0] * red[1]);
+        }
+    }
 }
 
-int run_staged(const float* x, float* y, int NP, int H, int PS, int TH) {
+template <int FEAT>
+int run_staged(const float* x, float* y, int NP, int H, int PS, int TH, const float* wts, double* stats) {
     const int nbands = (H + TH - 1) / TH, nblk = NP / 4 * nbands;
     const unsigned grid = (unsigned)((nblk + 7) / 8 * 8);
     hipEvent_t e0, e1;
@@ -125,13 +157,13 @@ int run_staged(const float* x, float* y, int NP, int H, int PS, int TH) {
     CK(hipEventCreate(&e1));
     for (int rep = 0; rep < 2; ++rep) {
         CK(hipEventRecord(e0));
-        for (int it = 0; it < 20; ++it) hipLaunchKernelGGL((walk_staged<8>), dim3(grid), dim3(256), 0, 0, (it & 1) ? y : x, (it & 1) ? const_cast<float*>(x) : y, H, PS, TH, nbands, nblk);
+        for (int it = 0; it < 20; ++it) hipLaunchKernelGGL((walk_staged<8, FEAT>), dim3(grid), dim3(256), 0, 0, (it & 1) ? y : x, (it & 1) ? const_cast<float*>(x) : y, H, PS, TH, nbands, nblk, wts, stats);
         CK(hipEventRecord(e1));
         CK(hipEventSynchronize(e1));
         float ms;
         CK(hipEventElapsedTime(&ms, e0, e1));
         const double bytes = (double)NP * H * 516 * 2;
-        if (rep) printf("%-28s TH %3d: %.1f us = %.2f TB/s\n", "rw  staged aligned stores", TH, ms * 50, bytes / (ms / 20 * 1e-3) / 1e12);
+        if (rep) printf("rw  staged, features %2d      TH %3d: %.1f us = %.2f TB/s\n", FEAT, TH, ms * 50, bytes / (ms / 20 * 1e-3) / 1e12);
     }
     return 0;
 }
@@ -186,7 +218,20 @@ int main(int argc, char** argv) {
             }
         printf("staged store check: %zu mismatches\n", bad);
         CK(hipMemset(x, 0, (size_t)NP * PS * 4));
-        for (int th : {24, 64}) if (run_staged(x, y, NP, H, PS, th)) return 1;
+        float* wts;
+        double* stats;
+        CK(hipMalloc(&wts, 64 * 16 * 4));
+        CK(hipMemset(wts, 0, 64 * 16 * 4));
+        CK(hipMalloc(&stats, 64 * 16));
+        CK(hipMemset(stats, 0, 64 * 16));
+        // which of the product kernel's extras costs what (bit 0 halo rows, 1 heavy arithmetic, 2 per-workgroup set-up, 3 statistics atomics)
+        if (run_staged<0>(x, y, NP, H, PS, 24, wts, stats)) return 1;
+        if (run_staged<1>(x, y, NP, H, PS, 24, wts, stats)) return 1;
+        if (run_staged<2>(x, y, NP, H, PS, 24, wts, stats)) return 1;
+        if (run_staged<4>(x, y, NP, H, PS, 24, wts, stats)) return 1;
+        if (run_staged<8>(x, y, NP, H, PS, 24, wts, stats)) return 1;
+        if (run_staged<15>(x, y, NP, H, PS, 24, wts, stats)) return 1;
+        if (run_staged<0>(x, y, NP, H, PS, 24, wts, stats)) return 1;
     }
     for (int TH : {24}) {
         if (run<8, 1, true>("rw  RQ 8  one row per trip", x, y, NP, H, W, PS, TH, sink)) return 1;
