@@ -362,7 +362,7 @@ int block_head(const BlockPack& p, const float* x, const float* x_res, int B, in
 }
 
 // steps 2-17: everything between the projection (x_enc, residual in the workspace) and `expanded`
-int block_body(const BlockPack& p, int B, int T, int F, const BlockWs& w, hipStream_t st, bool side_pass = true) {
+int block_body(const BlockPack& p, int B, int T, int F, const BlockWs& w, hipStream_t st, bool side_pass = true, bool zero_stats = true) {
     const int Tp = T / 2, Fp = F / 2;
     const int P = T * F, Pg = Tp * Fp;
     const double icF = 1.0 / ((double)CH * P), icG = 1.0 / ((double)CH * Pg);
@@ -372,7 +372,9 @@ int block_body(const BlockPack& p, int B, int T, int F, const BlockWs& w, hipStr
     // 17 213 -> 204, stride-2 pass 118 -> 103 with 12 output rows; 10.51 -> 10.35 ms per forward).  The statistics passes (one pair of f64 atomics
     // per workgroup) and the low-resolution launches are better off with 64 (measured: 62 -> 65 / 70 us and 122 -> 131 us with shorter bands).
     constexpr int TH_A = 24, TH_B = 24, TH_C = 12, TH_G = 64, TH_S = 64;
-    if (hipMemsetAsync(w.stats, 0, sizeof(double) * W::NSTAT * w.Bfull * 2, st) != hipSuccess) return RTFS_ERR_LAUNCH;
+    // (the separator gives every block application its own, already zeroed slots: one memset per call instead of one per block - 6 us each on
+    // the chain, 1 % of a batch-1 forward)
+    if (zero_stats && hipMemsetAsync(w.stats, 0, sizeof(double) * W::NSTAT * w.Bfull * 2, st) != hipSuccess) return RTFS_ERR_LAUNCH;
     {  // 2. downsample[0]: dw 4x4 s1 + bias -> c0 (pre-gLN) + stats                         tdanet.py:110
         DwArgs a;
         a.x = w.x_enc;
@@ -919,6 +921,9 @@ struct SepWs {
     float* wpad0;   // the same for the bottleneck weights (head kernel)
     double* st0;
     unsigned* ctr;  // 64 tile counters (one per persistent launch of the call), zeroed together with st0
+    double* bstats;  // statistic slots of up to STAT_APPS block applications (BlockWs::NSTAT x (B, 2) each), zeroed together with st0
+    static constexpr int STAT_APPS = 16;
+    int B_ = 0;
     int cs;
     BlockWs blk;
     SepWs(Arena& a, int B, int T, int Tv, int cs_)
@@ -937,6 +942,8 @@ struct SepWs {
           wpad0(a.take<float>(73728)),
           st0(a.take<double>(2 * B + 32)),
           ctr(reinterpret_cast<unsigned*>(st0 ? st0 + 2 * B : nullptr)),
+          bstats(a.take<double>((size_t)STAT_APPS * BlockWs::NSTAT * B * 2)),
+          B_(B),
           cs(cs_),
           blk(a, B, T, NF, cs_) {}
 };
@@ -962,7 +969,10 @@ int separator_part(const SepPacks& k, const float* wav, const float* video_vp, f
     const S3Pack& ps = k.ps;
     const DecPack& pd = k.pd;
     const int P = T * NF, cs = w.cs;
-    if (hipMemsetAsync(w.st0, 0, sizeof(double) * (2 * B + 32), st) != hipSuccess) return RTFS_ERR_LAUNCH;  // + the tile counters
+    // one memset per call: the bottleneck statistics, the tile counters and the statistic slots of every block application (SepWs::bstats)
+    const size_t app_stats = (size_t)BlockWs::NSTAT * B * 2;
+    const size_t zero_bytes = (size_t)(reinterpret_cast<char*>(w.bstats + SepWs::STAT_APPS * app_stats) - reinterpret_cast<char*>(w.st0));
+    if (hipMemsetAsync(w.st0, 0, zero_bytes, st) != hipSuccess) return RTFS_ERR_LAUNCH;
     int nctr = 0;
     CHECK(launch_stft(wav, w.spec, B, L, T, st));
     // fused path: the encoder output a0 is never written.  Its gLN statistics come from the spectrogram (enc_stats_kernel); the bottleneck + first
@@ -1020,8 +1030,10 @@ int separator_part(const SepPacks& k, const float* wav, const float* video_vp, f
         CHECK(launch_caf_video(ca, B, cafv.side.stream));
         if (!head_done) CHECK(block_head(pk, w.a1, nullptr, B, T, NF, w.blk, st, nullptr, w.ctr + nctr++));
         bool res_has_a1 = false;
+        const bool own_slots = repeats <= SepWs::STAT_APPS;  // (more applications than slots: every block zeroes and reuses the first)
         for (int i = 0; i < repeats; ++i) {
-            CHECK(block_body(pk, B, T, NF, w.blk, st, single_chain));
+            if (own_slots) w.blk.stats = w.bstats + (size_t)i * app_stats;
+            CHECK(block_body(pk, B, T, NF, w.blk, st, single_chain, !own_slots));
             if (i == 0) CHECK(cafv.join());
             if (i + 1 < repeats) CHECK(block_boundary(pk, w.a1, B, T, NF, w.blk, st, i == 0 ? &ca : nullptr, nctr < 64 ? w.ctr + nctr++ : nullptr, &res_has_a1, i + 2 == repeats, head_done && i == 0));
             else {
