@@ -118,10 +118,17 @@ __global__ __launch_bounds__(256, 4) void walk_staged(const float* __restrict__ 
             const float ve = qe[k];
             q[k] = ld(t + RQ + k);
             qe[k] = lde(t + RQ + k);
-            f32x2u o = v * 1.5f + 1.0f;
-            float oe = ve * 1.5f + 1.0f;
+            f32x2u o = (FEAT & 16) ? v : v * 1.5f + 1.0f;
+            float oe = (FEAT & 16) ? ve : ve * 1.5f + 1.0f;
+            if (FEAT & 16) {  // values preserved (random data stays random over the ping-pong); the same number of dependent operations
+                f32x2u tt = o;
 #pragma unroll
-            for (int j = 0; j < ((FEAT & 2) ? 56 : 12); ++j) o = o * 1.0001f + 0.5f;
+                for (int j = 0; j < 12; ++j) tt = tt * 1.0001f + 0.5f;
+                if (tt.x == 123.456f) o.x = tt.y;
+            } else {
+#pragma unroll
+                for (int j = 0; j < ((FEAT & 2) ? 56 : 12); ++j) o = o * 1.0001f + 0.5f;
+            }
             if (FEAT & 1) o += hsum * 1e-30f;
             if (FEAT & 4) o += wsum * 1e-30f;
             if (FEAT & 8) st += o.x + o.y;
@@ -225,6 +232,13 @@ int main(int argc, char** argv) {
         CK(hipMalloc(&stats, 64 * 16));
         CK(hipMemset(stats, 0, 64 * 16));
         // which of the product kernel's extras costs what (bit 0 halo rows, 1 heavy arithmetic, 2 per-workgroup set-up, 3 statistics atomics)
+        if (run_staged<16>(x, y, NP, H, PS, 24, wts, stats)) return 1;  // copy of zeros
+        CK(hipMemcpy(x, hx.data(), hx.size() * 4, hipMemcpyHostToDevice));
+        for (size_t i = 0; i < hx.size(); ++i) hx[i] = (float)((i * 40503u + 12345u) % 65521u) * 3.1e-5f - 1.0f;
+        CK(hipMemcpy(y, hx.data(), hx.size() * 4, hipMemcpyHostToDevice));
+        if (run_staged<16>(x, y, NP, H, PS, 24, wts, stats)) return 1;  // copy of random data
+        CK(hipMemset(x, 0, (size_t)NP * PS * 4));
+        CK(hipMemset(y, 0, (size_t)NP * PS * 4));
         if (run_staged<0>(x, y, NP, H, PS, 24, wts, stats)) return 1;
         if (run_staged<1>(x, y, NP, H, PS, 24, wts, stats)) return 1;
         if (run_staged<2>(x, y, NP, H, PS, 24, wts, stats)) return 1;
