@@ -385,37 +385,47 @@ int block_body(const BlockPack& p, int B, int T, int F, const BlockWs& w, hipStr
         a.C = CH; a.H = T; a.W = F; a.TH = TH_A; a.cs = w.cs;
         CHECK(launch_dw_s1(a, 1, false, 0, B, st));
     }
-    // Step 14 (statistics of fusion 0's local conv on d0: one full-resolution read, HBM-bound) needs only c0 and its statistics; steps 3-13 are
-    // the low-resolution chain (sweeps, attention: latency-bound, HBM at < 10 %): it runs on a side stream beside them (14.43 -> 14.25 ms per
-    // forward, sweep launch times unchanged).  Not when the batch is split into parts (the other part already fills those gaps: 13.5 -> 14.5).
-    const bool overlap = side_pass;
+    // Step 14 (statistics of fusion 0's local conv on d0: one full-resolution read, HBM-bound) needs only c0 and its statistics.  Round 2 ran it
+    // on a side stream beside steps 3-13 (14.43 -> 14.25 ms per forward); since round 3 it shares step 3's launch (below), the side-stream form
+    // remains for the shapes that launch does not take.
+    bool overlap = side_pass;
     Fork side14;  // joined before step 15, or by its destructor on an early return
-    if (overlap) {
-        CHECK(side14.begin(st, 0));
-        DwArgs a;
-        a.x = w.c0;
-        a.in_stats = w.st(W::S_C0, B); a.in_inv_count = icF; a.in_gamma = p.ds0_g; a.in_beta = p.ds0_be;
-        a.C = CH; a.H = T; a.W = F; a.TH = 64; a.Hg = Tp; a.Wg = Fp; a.cs = w.cs;
-        a.w[0] = p.fus0.loc_w;
-        a.stats_out[0] = w.st(W::S_L0, B);
-        a.rev = 1;  // (as step 3, which it runs beside)
-        CHECK(launch_dw_s1(a, 1, true, 1, B, side14.side.stream));
+    DwArgs s14;   // step 14: statistics of fusion 0's local conv on d0
+    s14.x = w.c0;
+    s14.in_stats = w.st(W::S_C0, B); s14.in_inv_count = icF; s14.in_gamma = p.ds0_g; s14.in_beta = p.ds0_be;
+    s14.C = CH; s14.H = T; s14.W = F; s14.TH = 64; s14.Hg = Tp; s14.Wg = Fp; s14.cs = w.cs;
+    s14.w[0] = p.fus0.loc_w;
+    s14.stats_out[0] = w.st(W::S_L0, B);
+    s14.rev = 1;  // (as step 3, which it runs beside)
+    DwArgs s3;  // 3. downsample[1] on d0 = gLN(c0): dw 4x4 s2 -> c1 + stats; p0 = adaptive_avg_pool2d(d0)   tdanet.py:111-116
+    s3.x = w.c0;
+    s3.in_stats = w.st(W::S_C0, B); s3.in_inv_count = icF; s3.in_gamma = p.ds0_g; s3.in_beta = p.ds0_be;
+    s3.w[0] = p.ds1_w;
+    s3.bias[0] = p.ds1_b;
+    s3.out[0] = w.c1;
+    s3.out[1] = w.p0;
+    s3.stats_out[0] = w.st(W::S_C1, B);
+    s3.C = CH; s3.H = T; s3.W = F; s3.Hg = Tp; s3.Wg = Fp; s3.TH = TH_C; s3.cs = w.cs;
+    // Traversal order against the memory-side cache (256 MB; a 64-channel tensor is 265 MB at batch 32): step 2 wrote c0 front to back, so
+    // its END is what is still on the die - this pass walks back to front (tools/bench_mall.hip: a read-only consumer of a 265 MB tensor
+    // 59 -> 44 us; here 125 -> 112 us).  Likewise step 16 after 15 (79 -> 62 us) and step 17 after 16.  10.39 -> 10.17 ms per forward.
+    s3.rev = 1;
+    // Steps 3 and 14 read the same tensor: one launch, the two jobs interleaved per sample (launch_dw_s2_stats).  Shapes it does not take run
+    // as before: the statistics pass on a side stream beside steps 3-13 when this call is one chain, in line before step 15 otherwise.
+    // (same-box A/B against the side-stream form: batch 32 9.81 -> 9.74 ms with the F sweep 295 -> 289 us - nothing runs beside it any more -
+    // and `g_form` 66 -> 33 us; batch 1 1.46 -> 1.42 ms, two event pairs per block fewer)
+    bool merged = false;
+    {
+        const int rc = launch_dw_s2_stats(s3, s14, B, st);
+        if (rc == RTFS_OK) merged = true;
+        else if (rc != RTFS_ERR_ARG) return rc;
     }
-    {  // 3. downsample[1] on d0 = gLN(c0): dw 4x4 s2 -> c1 + stats; p0 = adaptive_avg_pool2d(d0)   tdanet.py:111-116
-        DwArgs a;
-        a.x = w.c0;
-        a.in_stats = w.st(W::S_C0, B); a.in_inv_count = icF; a.in_gamma = p.ds0_g; a.in_beta = p.ds0_be;
-        a.w[0] = p.ds1_w;
-        a.bias[0] = p.ds1_b;
-        a.out[0] = w.c1;
-        a.out[1] = w.p0;
-        a.stats_out[0] = w.st(W::S_C1, B);
-        a.C = CH; a.H = T; a.W = F; a.Hg = Tp; a.Wg = Fp; a.TH = TH_C; a.cs = w.cs;
-        // Traversal order against the memory-side cache (256 MB; a 64-channel tensor is 265 MB at batch 32): step 2 wrote c0 front to back, so
-        // its END is what is still on the die - this pass walks back to front (tools/bench_mall.hip: a read-only consumer of a 265 MB tensor
-        // 59 -> 44 us; here 125 -> 112 us).  Likewise step 16 after 15 (79 -> 62 us) and step 17 after 16.  10.39 -> 10.17 ms per forward.
-        a.rev = 1;
-        CHECK(launch_dw_s2_pool(a, B, st));
+    if (!merged) {
+        if (overlap) {
+            CHECK(side14.begin(st, 0));
+            CHECK(launch_dw_s1(s14, 1, true, 1, B, side14.side.stream));
+        }
+        CHECK(launch_dw_s2_pool(s3, B, st));
     }
     // 4. g = pool(d0) + d1
     CHECK(launch_g_form(w.p0, w.c1, w.st(W::S_C1, B), icG, p.ds1_g, p.ds1_be, w.g, B, CH, Pg, st));
@@ -481,7 +491,8 @@ int block_body(const BlockPack& p, int B, int T, int F, const BlockWs& w, hipStr
     d0in.x = w.c0;
     d0in.in_stats = w.st(W::S_C0, B); d0in.in_inv_count = icF; d0in.in_gamma = p.ds0_g; d0in.in_beta = p.ds0_be;
     d0in.C = CH; d0in.H = T; d0in.W = F; d0in.TH = 64; d0in.Hg = Tp; d0in.Wg = Fp; d0in.cs = w.cs;
-    if (overlap) {
+    if (merged) {
+    } else if (overlap) {
         CHECK(side14.join());
     } else {  // 14. fusion 0 local_embedding conv on d0: statistics only
         DwArgs a = d0in;

@@ -149,8 +149,17 @@ __device__ __forceinline__ DwBlk dw_block(const DwArgs& a) {
         const int n8 = (int)(gridDim.x >> 3), q = id >> 3;
         id = (id & 7) * n8 + (a.rev ? n8 - 1 - q : q);  // rev: every XCD walks its eighth back to front
     }
-    id -= a.blk0;
     DwBlk k;
+    if (a.job_stride) {  // two jobs per sample: [job 0's blocks | job 1's blocks] of sample 0, then of sample 1, ...
+        const int z = id / a.job_stride, r = id - z * a.job_stride - a.job_off;
+        k.ok = r >= 0 && r < a.gx * a.gy && z * a.gx * a.gy < a.nblk;
+        const int rr = k.ok ? r : 0;
+        k.x = rr % a.gx;
+        k.y = rr / a.gx;
+        k.z = k.ok ? z : 0;
+        return k;
+    }
+    id -= a.blk0;
     k.ok = id >= 0 && id < a.nblk;
     id = k.ok ? id : 0;
     k.x = id % a.gx;
@@ -812,6 +821,20 @@ __device__ __forceinline__ void dw_s2x_body(const DwArgs& a, const float* __rest
 }
 __global__ __launch_bounds__(256) void dw_s2x_kernel(DwArgs a) { dw_s2x_body(a, a.x, a.out[0], a.out[1]); }
 
+// The stride-2 + pool pass (step 3) and the statistics pass of fusion 0's local convolution (step 14) read the same tensor, d0 = gLN(c0): one
+// launch, the two jobs' workgroups interleaved per sample, so that the second job finds the sample's rows where the first one just left them
+// (same XCD, memory-side cache) - and no side stream, no fork / join events, nothing left running beside the F sweep.
+__global__ __launch_bounds__(256, 4) void dw_s2_stats_kernel(DwArgs a0, DwArgs a1) {
+    int id = blockIdx.x;
+    if (DW_XCD) {
+        const int n8 = (int)(gridDim.x >> 3), q = id >> 3;
+        id = (id & 7) * n8 + (a0.rev ? n8 - 1 - q : q);
+    }
+    const int r = id % a0.job_stride;  // block-uniform
+    if (r < a1.job_off) dw_s2x_body(a0, a0.x, a0.out[0], a0.out[1]);
+    else dw1p_body<1, true, 1>(a1, a1.x, a1.gate, a1.emb, a1.addend, a1.out[0], a1.out[1], a1.out[2], a1.out[3]);
+}
+
 // ---------------------------------------------------------------- G-level elementwise glue
 // g = p0 + gLN(c1)           (global pooling sum, tdanet.py:116)
 __global__ __launch_bounds__(256) void g_form_kernel(const float* __restrict__ p0, const float* __restrict__ c1,
@@ -1044,6 +1067,28 @@ int launch_dw_g3(const DwArgs& conv4, const DwArgs& aff1, int B, hipStream_t st)
     }
     if (nohalo) hipLaunchKernelGGL(dw_g3_kernel<16>, dim3((off + 7) / 8 * 8), dim3(256), 0, st, j[0], j[1], j[2]);
     else hipLaunchKernelGGL(dw_g3_kernel<0>, dim3((off + 7) / 8 * 8), dim3(256), 0, st, j[0], j[1], j[2]);
+    return rtfs_launch_status();
+}
+
+int launch_dw_s2_stats(const DwArgs& s2_, const DwArgs& st_, int B, hipStream_t st) {
+    DwArgs a = s2_, b = st_;
+    if ((a.cs && a.cs < a.H * a.W) || a.x != b.x || a.cs != b.cs || a.H != b.H || a.W != b.W || a.C != b.C) return RTFS_ERR_ARG;
+    if (!a.cs) a.cs = b.cs = a.H * a.W;
+    if (!(a.Wg >= 16 && a.W >= 16 && (a.W + 1) / 2 >= a.Wg && (size_t)a.C * a.cs * 4 < ((size_t)1 << 31))) return RTFS_ERR_ARG;
+    a.gx = b.gx = cdiv(cdiv(a.C * ((a.W + 1) / 2), DW1P_PAIRS), 4);
+    a.TH = band_rows(a.TH, a.Hg, a.gx, B, 320);
+    a.gy = cdiv(a.Hg, a.TH);
+    b.TH = band_rows(b.TH, b.H, b.gx, B, 320);
+    b.gy = cdiv(b.H, b.TH);
+    const int ca = a.gx * a.gy, cb = b.gx * b.gy;
+    a.nblk = ca * B;
+    b.nblk = cb * B;
+    a.job_stride = b.job_stride = ca + cb;
+    a.job_off = 0;
+    b.job_off = ca;
+    b.rev = a.rev;
+    const long total = (long)(ca + cb) * B;
+    hipLaunchKernelGGL(dw_s2_stats_kernel, dim3((unsigned)((total + 7) / 8 * 8)), dim3(256), 0, st, a, b);
     return rtfs_launch_status();
 }
 

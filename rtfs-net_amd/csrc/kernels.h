@@ -155,6 +155,8 @@ struct DwArgs {
                          // pre-norm tensors (folds: loc_* / gate_* / emb_*, all with g_inv_count), formed at load time (fusion.py:62-67)
     int rev = 0;  // lane-exchange kernels: walk the tensor back to front (a consumer that starts where its producer stopped finds that end in the
                   // memory-side cache: tools/bench_mall.hip)
+    int job_stride = 0, job_off = 0;  // two jobs interleaved per sample in one launch (launch_dw_s2_stats): logical block id -> sample id / job_stride,
+                                      // this job's block (id % job_stride) - job_off if that lies in [0, gx * gy); 0 = one job (id -> x, y, z)
     int gx = 0, gy = 0, nblk = 0, blk0 = 0;  // set by the launchers of the lane-exchange kernels: logical grid (gx, gy, B) behind a 1-D launch
                                               // (XCD order); blk0 = first block of this job when several jobs share one launch
     // MODE 2 (TFAR apply) / stride-2 kernel: the low-resolution side
@@ -193,6 +195,8 @@ int launch_dw_s1(const DwArgs& a, int nconv, bool in_affine, int mode, int B, hi
 // jobs + one conv on a gLN-folded input): each alone is 576 workgroups, too few to fill the chip
 int launch_dw_g3(const DwArgs& conv4, const DwArgs& aff1, int B, hipStream_t st);
 int launch_dw_s2_pool(const DwArgs& a, int B, hipStream_t st);
+// the stride-2 + pool pass and a statistics-only pass (MODE 1, input fold) over the SAME input in one launch; RTFS_ERR_ARG = not eligible
+int launch_dw_s2_stats(const DwArgs& s2, const DwArgs& stats, int B, hipStream_t st);
 int launch_g_form(const float* p0, const float* c1, const double* st1, double inv_count, const float* gamma,
                   const float* beta, float* g, int B, int C, int HW, hipStream_t st);
 int launch_g_combine(const GCombineArgs& a, int B, hipStream_t st);
