@@ -17,7 +17,7 @@
  *     allocate, never call back; workspace contents are scratch
  *   - return 0 on success; <0 on error: -1 bad shape, -2 workspace too small, -3 launch failure, -4 bad argument
  *   - eval-mode semantics (BatchNorm running statistics, no dropout); re-entrant: the only host-side state is a mutex-guarded cache
- *     of per-(device, kernel) launch attributes, the per-(device, caller stream) internal side streams of rtfs_block_f32 /
+ *     of per-(device, kernel) launch attributes, the per-(device, caller stream) internal side streams of
  *     rtfs_separator_forward_f32 (forked from `stream` by an event and joined back into it inside the call: from outside all work of a call
  *     is ordered on `stream`), the process-wide DEFAULT of the batch split (rtfs_set_batch_split; the _ex entry points take it per call) and
  *     the diagnostic sweep-timing log (off by default), so the

@@ -362,7 +362,7 @@ int block_head(const BlockPack& p, const float* x, const float* x_res, int B, in
 }
 
 // steps 2-17: everything between the projection (x_enc, residual in the workspace) and `expanded`
-int block_body(const BlockPack& p, int B, int T, int F, const BlockWs& w, hipStream_t st, bool side_pass = true, bool zero_stats = true) {
+int block_body(const BlockPack& p, int B, int T, int F, const BlockWs& w, hipStream_t st, bool zero_stats = true) {
     const int Tp = T / 2, Fp = F / 2;
     const int P = T * F, Pg = Tp * Fp;
     const double icF = 1.0 / ((double)CH * P), icG = 1.0 / ((double)CH * Pg);
@@ -386,10 +386,7 @@ int block_body(const BlockPack& p, int B, int T, int F, const BlockWs& w, hipStr
         CHECK(launch_dw_s1(a, 1, false, 0, B, st));
     }
     // Step 14 (statistics of fusion 0's local conv on d0: one full-resolution read, HBM-bound) needs only c0 and its statistics.  Round 2 ran it
-    // on a side stream beside steps 3-13 (14.43 -> 14.25 ms per forward); since round 3 it shares step 3's launch (below), the side-stream form
-    // remains for the shapes that launch does not take.
-    bool overlap = side_pass;
-    Fork side14;  // joined before step 15, or by its destructor on an early return
+    // on a side stream beside steps 3-13 (14.43 -> 14.25 ms per forward); since round 3 it shares step 3's launch (below).
     DwArgs s14;   // step 14: statistics of fusion 0's local conv on d0
     s14.x = w.c0;
     s14.in_stats = w.st(W::S_C0, B); s14.in_inv_count = icF; s14.in_gamma = p.ds0_g; s14.in_beta = p.ds0_be;
@@ -410,22 +407,13 @@ int block_body(const BlockPack& p, int B, int T, int F, const BlockWs& w, hipStr
     // its END is what is still on the die - this pass walks back to front (tools/bench_mall.hip: a read-only consumer of a 265 MB tensor
     // 59 -> 44 us; here 125 -> 112 us).  Likewise step 16 after 15 (79 -> 62 us) and step 17 after 16.  10.39 -> 10.17 ms per forward.
     s3.rev = 1;
-    // Steps 3 and 14 read the same tensor: one launch, the two jobs interleaved per sample (launch_dw_s2_stats).  Shapes it does not take run
-    // as before: the statistics pass on a side stream beside steps 3-13 when this call is one chain, in line before step 15 otherwise.
+    // Steps 3 and 14 read the same tensor: one launch, the two jobs interleaved per sample (launch_dw_s2_stats; the block's frequency axis is
+    // tied to 2 x 64 by the attention's LayerNorm, so the launcher's width conditions always hold here).
     // (same-box A/B against the side-stream form: batch 32 9.81 -> 9.74 ms with the F sweep 295 -> 289 us - nothing runs beside it any more -
     // and `g_form` 66 -> 33 us; batch 1 1.46 -> 1.42 ms, two event pairs per block fewer)
-    bool merged = false;
     {
         const int rc = launch_dw_s2_stats(s3, s14, B, st);
-        if (rc == RTFS_OK) merged = true;
-        else if (rc != RTFS_ERR_ARG) return rc;
-    }
-    if (!merged) {
-        if (overlap) {
-            CHECK(side14.begin(st, 0));
-            CHECK(launch_dw_s1(s14, 1, true, 1, B, side14.side.stream));
-        }
-        CHECK(launch_dw_s2_pool(s3, B, st));
+        if (rc != RTFS_OK) return rc == RTFS_ERR_ARG ? RTFS_ERR_SHAPE : rc;
     }
     // 4. g = pool(d0) + d1
     CHECK(launch_g_form(w.p0, w.c1, w.st(W::S_C1, B), icG, p.ds1_g, p.ds1_be, w.g, B, CH, Pg, st));
@@ -491,15 +479,6 @@ int block_body(const BlockPack& p, int B, int T, int F, const BlockWs& w, hipStr
     d0in.x = w.c0;
     d0in.in_stats = w.st(W::S_C0, B); d0in.in_inv_count = icF; d0in.in_gamma = p.ds0_g; d0in.in_beta = p.ds0_be;
     d0in.C = CH; d0in.H = T; d0in.W = F; d0in.TH = 64; d0in.Hg = Tp; d0in.Wg = Fp; d0in.cs = w.cs;
-    if (merged) {
-    } else if (overlap) {
-        CHECK(side14.join());
-    } else {  // 14. fusion 0 local_embedding conv on d0: statistics only
-        DwArgs a = d0in;
-        a.w[0] = p.fus0.loc_w;
-        a.stats_out[0] = w.st(W::S_L0, B);
-        CHECK(launch_dw_s1(a, 1, true, 1, B, st));
-    }
     {  // 15. xf0 = gLN(conv(d0)) * sigmoid(gLN(G0))^ + gLN(E0)^                              fusion.py:58-67
         DwArgs a = d0in;
         a.w[0] = p.fus0.loc_w;
@@ -972,7 +951,7 @@ struct SepPacks {
 
 // the whole chain for mixtures [first, first + B) of the call: wav / video_vp / out already point at mixture `first`
 int separator_part(const SepPacks& k, const float* wav, const float* video_vp, float* out, int B, int L, int T, int Tv, int repeats, SepWs& w,
-                   hipStream_t st, void* video_ready, bool single_chain) {
+                   hipStream_t st, void* video_ready) {
     const EncPack& pe = k.pe;
     const BnPack& pb = k.pb;
     const BlockPack& pk = k.pk;
@@ -1044,7 +1023,7 @@ int separator_part(const SepPacks& k, const float* wav, const float* video_vp, f
         const bool own_slots = repeats <= SepWs::STAT_APPS;  // (more applications than slots: every block zeroes and reuses the first)
         for (int i = 0; i < repeats; ++i) {
             if (own_slots) w.blk.stats = w.bstats + (size_t)i * app_stats;
-            CHECK(block_body(pk, B, T, NF, w.blk, st, single_chain, !own_slots));
+            CHECK(block_body(pk, B, T, NF, w.blk, st, !own_slots));
             if (i == 0) CHECK(cafv.join());
             if (i + 1 < repeats) CHECK(block_boundary(pk, w.a1, B, T, NF, w.blk, st, i == 0 ? &ca : nullptr, nctr < 64 ? w.ctr + nctr++ : nullptr, &res_has_a1, i + 2 == repeats, head_done && i == 0));
             else {
@@ -1135,7 +1114,7 @@ int rtfs_separator_forward_ex_f32(const float* wav, const float* video_vp, const
     hipStream_t st = S(stream);
     Cursor ce(pack_enc), cb(pack_bn), ck(pack_block), cc(pack_caf), cs(pack_s3), cd(pack_dec);
     const SepPacks k{EncPack(ce), BnPack(cb), BlockPack::make(ck, rnn_kind), CafPack(cc), S3Pack(cs), DecPack(cd)};
-    if (np == 1) return separator_part(k, wav, video_vp, out, B, L, T, Tv, repeats, parts[0], st, video_ready, true);
+    if (np == 1) return separator_part(k, wav, video_vp, out, B, L, T, Tv, repeats, parts[0], st, video_ready);
     // part 0 on the caller's stream, parts 1.. on side streams forked from it and joined back into it
     std::vector<RtfsSide> side(np);
     for (int i = 1; i < np; ++i) {
@@ -1146,7 +1125,7 @@ int rtfs_separator_forward_ex_f32(const float* wav, const float* video_vp, const
     for (int i = 0; i < np && rc == RTFS_OK; ++i) {
         const int first = (B * i) / np, nb = (B * (i + 1)) / np - first;
         rc = separator_part(k, wav + (size_t)first * L, video_vp + (size_t)first * 512 * Tv, out + (size_t)first * L, nb, L, T, Tv, repeats, parts[i],
-                            i == 0 ? st : side[i].stream, video_ready, false);
+                            i == 0 ? st : side[i].stream, video_ready);
     }
     for (int i = 1; i < np; ++i)  // join even after a failed launch: the caller's stream must not run ahead of work already queued
         if (hipEventRecord(side[i].join, side[i].stream) != hipSuccess || hipStreamWaitEvent(st, side[i].join, 0) != hipSuccess) return RTFS_ERR_LAUNCH;

@@ -37,8 +37,8 @@ int rtfs_set_max_lds(const void* kernel, size_t bytes) {
 }
 
 
-// ---- side streams: slot 0 for the one full-resolution pass of a block that does not depend on the low-resolution chain (api.hip block_body
-// step 14), slots 1.. for the batch parts of the separator call (rtfs_separator_forward_f32).
+// ---- side streams: slots 1.. for the batch parts of the separator call (rtfs_separator_forward_f32), slot 15 for the video side of the CAF
+// (api.hip separator_part).  (Slot 0 carried a block's step-14 statistics pass until it moved into step 3's launch.)
 // One (stream, fork event, join event) triple per (device, caller stream, slot), created on first use and kept for the life of the process.
 namespace {
 struct SideEntry {
