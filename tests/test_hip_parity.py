@@ -450,8 +450,9 @@ def test_batch_split_per_call_argument():
 
 def test_launches_per_small_batch_forward():
     """A batch-1 forward is a chain of dependent launches at dispatch latency (test.py:51-62, inference.py:55 and infer_any_video.py:86 all run
-    one utterance per step): the library counts its launches, and the count of one RTFS-Net-4 forward must not creep up - 4 blocks x 16
-    + encoder 2 + bottleneck + head + 3 boundaries + tail + S3/taps + decoder + CAF video + VP block."""
+    one utterance per step): the library counts its launches, and the count of one RTFS-Net-4 forward must not creep up - 70 at the end of
+    round 3: 4 blocks x 15 (steps 3 and 14 share a launch) + STFT + encoder statistics + bottleneck / head + 3 boundaries + tail + iSTFT + CAF
+    video + VP block."""
     import rtfs_net_amd as R
     lib = R._lib.load()
     m = model()
@@ -463,7 +464,8 @@ def test_launches_per_small_batch_forward():
     m(w, e)
     torch.cuda.synchronize()
     n = lib.rtfs_debug_launch_count() - n0
-    assert 60 <= n <= 82, n
+    print(f"[launches] {n} per batch-1 forward")
+    assert 60 <= n <= 72, n
 
 
 def test_forward_can_be_captured_in_a_hip_graph():
